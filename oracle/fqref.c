@@ -1,0 +1,373 @@
+/* fqref.c — CPU oracle (TEST INFRASTRUCTURE ONLY, see fqref.h).
+ *
+ * Behavioural restatement in plain C of the reference crate's scan path.  Every function cites
+ * the reference lines it follows (paths relative to /root/reference).  No reference source is
+ * copied: the reference is Rust, this is an independent C program with the same observable
+ * behaviour (record boundaries, accessor slices, error kind and error point, buffer refill
+ * arithmetic including the 16-byte alignment of the next read).
+ */
+#include "fqref.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* Reader: std::io::Cursor<&[u8]> — read() copies min(dest.len(), remaining) bytes.            */
+/* max_read > 0 additionally caps one read() (a legal Read impl may return short reads).       */
+typedef struct {
+    const uint8_t *data;
+    uint64_t len, pos, max_read;
+} reader_t;
+
+static uint64_t reader_read(reader_t *r, uint8_t *dest, uint64_t n) {
+    uint64_t avail = r->len - r->pos;
+    if (n > avail) n = avail;
+    if (r->max_read && n > r->max_read) n = r->max_read;
+    if (n) memcpy(dest, r->data + r->pos, n);
+    r->pos += n;
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Buffer — src/buffer.rs:3-112                                                                */
+typedef struct {
+    uint8_t *data;
+    uint64_t cap, start, end;
+} buf_t;
+
+static void buf_init(buf_t *b, uint64_t size) { /* buffer.rs:10-16 */
+    b->data = (uint8_t *)calloc(size ? size : 1, 1);
+    b->cap = size;
+    b->start = b->end = 0;
+}
+static uint64_t buf_len(const buf_t *b) { return b->end - b->start; }     /* buffer.rs:18-20 */
+static uint64_t buf_n_free(const buf_t *b) { return b->cap - b->end; }    /* buffer.rs:22-24 */
+
+/* buffer.rs:51-72 — compact the unconsumed tail to the front so that the NEXT read lands on a
+ * 16-byte boundary: the tail is placed at [new_end - n, new_end) with new_end = roundup16(n).
+ * Nothing moves when start == 0 or when the move would not go towards the front. */
+static void buf_clean(buf_t *b) {
+    if (b->start == 0) return;
+    uint64_t n = buf_len(b);
+    uint64_t new_end = (n + 15) & ~(uint64_t)0x0f;
+    uint64_t new_start = new_end - n;
+    if (new_start >= b->start) return;
+    memmove(b->data + new_start, b->data + b->start, n);
+    b->start = new_start;
+    b->end = new_end;
+}
+
+/* buffer.rs:30-48 — swap in a fresh zeroed box, copying the tail to the aligned position.
+ * Returns the old storage (the caller owns it: it becomes the RecordSet's buffer). */
+static uint8_t *buf_replace(buf_t *b) {
+    uint64_t n = buf_len(b);
+    uint64_t new_end = (n + 15) & ~(uint64_t)0x0f;
+    uint64_t new_start = new_end - n;
+    uint8_t *fresh = (uint8_t *)calloc(b->cap ? b->cap : 1, 1);
+    /* assert!(buffer.len() >= new_end): holds because n <= cap and cap % 16 == 0 for both
+     * BUFSIZE values (69632 and 64). For other caps the reference would panic; we clamp. */
+    if (new_end > b->cap) { new_end = b->cap; new_start = new_end - n; }
+    memcpy(fresh + new_start, b->data + b->start, n);
+    uint8_t *old = b->data;
+    b->data = fresh;
+    b->start = new_start;
+    b->end = new_end;
+    return old;
+}
+
+/* buffer.rs:74-100 — one read() of a multiple of 4096 bytes (or all free space if < 4096).
+ * ErrorKind::Interrupted retry has no counterpart for an in-memory reader. */
+static uint64_t buf_read_into(buf_t *b, reader_t *r) {
+    uint64_t n_free = buf_n_free(b);
+    uint64_t num_read = n_free < 4096 ? n_free : n_free - n_free % 4096;
+    uint64_t n = reader_read(r, b->data + b->end, num_read);
+    b->end += n;
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* IdxRecord::from_buffer — src/records.rs:201-247 with read_header (:137-149), read_sep        */
+/* (:151-163).                                                                                  */
+enum { R_RECORD = 0, R_INCOMPLETE = 1, R_EMPTY = 2 };
+typedef struct { uint64_t head, seq, sep, qual, end; } rec_t; /* end = qual + 1 (data.1) */
+
+static int64_t find_nl(const uint8_t *p, uint64_t n) { /* memchr::memchr(b'\n', ..) */
+    if (n == 0) return -1;
+    const uint8_t *q = (const uint8_t *)memchr(p, '\n', n);
+    return q ? (int64_t)(q - p) : -1;
+}
+
+/* returns R_* and sets *err to FQREF_E_* (0 if none) */
+static int from_buffer(const uint8_t *buf, uint64_t n, rec_t *out, int *err) {
+    *err = 0;
+    if (n == 0) return R_EMPTY;                                      /* :202-204 */
+    /* read_header: first byte must be '@' BEFORE any newline search */
+    if (buf[0] != '@') { *err = FQREF_E_HEADER; return R_INCOMPLETE; } /* :138-147 */
+    int64_t k = find_nl(buf, n);
+    if (k < 0) return R_INCOMPLETE;                                  /* :206-209 */
+    uint64_t head_end = (uint64_t)k, pos = head_end + 1;
+    k = find_nl(buf + pos, n - pos);
+    if (k < 0) return R_INCOMPLETE;                                  /* :213-216 */
+    uint64_t seq_end = (uint64_t)k + pos;
+    pos = seq_end + 1;
+    /* read_sep: empty slice -> None -> Incomplete; wrong first byte -> Err */
+    if (pos >= n) return R_INCOMPLETE;                               /* :152-154, 220-222 */
+    if (buf[pos] != '+') { *err = FQREF_E_SEP; return R_INCOMPLETE; } /* :155-161 */
+    k = find_nl(buf + pos, n - pos);
+    if (k < 0) return R_INCOMPLETE;
+    uint64_t sep_end = (uint64_t)k + pos;
+    pos = sep_end + 1;
+    k = find_nl(buf + pos, n - pos);
+    if (k < 0) return R_INCOMPLETE;                                  /* :227-230 */
+    uint64_t qual_end = (uint64_t)k + pos;
+    /* raw line lengths (they include a possible '\r'): :233 */
+    if (qual_end - sep_end != seq_end - head_end) { *err = FQREF_E_LEN; return R_INCOMPLETE; }
+    out->head = head_end; out->seq = seq_end; out->sep = sep_end; out->qual = qual_end;
+    out->end = qual_end + 1;                                         /* :240-246 */
+    return R_RECORD;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Parser::each / RecordRefIter::advance — src/lib.rs:221-239, 255-303                         */
+void fqref_each(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
+                fqref_cb cb, void *user, fqref_result *res) {
+    reader_t rd = {data, len, 0, max_read};
+    buf_t b;
+    buf_init(&b, bufsize);
+    uint64_t consumed = 0; /* global offset of b.data[b.start] */
+    uint64_t cur_len = 0;  /* current_length.take() */
+    int have_cur = 0;
+    memset(res, 0, sizeof *res);
+    for (;;) {
+        /* advance() */
+        if (have_cur) { b.start += cur_len; consumed += cur_len; have_cur = 0; } /* :258-260 */
+        rec_t rec;
+        int got = 0, at_end = 0;
+        while (!got && !at_end) {
+            int err;
+            int r = from_buffer(b.data + b.start, buf_len(&b), &rec, &err);   /* :262 */
+            if (err) { res->status = err; goto done; }                         /* :263 */
+            if (r == R_EMPTY) {                                                /* :264-275 */
+                buf_clean(&b);
+                if (buf_read_into(&b, &rd) == 0) at_end = 1;
+            } else if (r == R_INCOMPLETE) {                                    /* :276-294 */
+                buf_clean(&b);
+                if (buf_n_free(&b) == 0) { res->status = FQREF_E_TOO_LONG; goto done; }
+                if (buf_read_into(&b, &rd) == 0) { res->status = FQREF_E_TRUNCATED; goto done; }
+            } else {                                                           /* :295-300 */
+                got = 1;
+            }
+        }
+        if (at_end) goto done;                 /* get() == None -> Ok(true)   :229 */
+        cur_len = rec.end; have_cur = 1;
+        fqref_idx idx = {consumed, rec.head, rec.seq, rec.sep, rec.qual};
+        res->n_records++;
+        res->bytes_consumed = consumed + rec.end;
+        if (cb && !cb(user, b.data + b.start, &idx)) { res->stopped = 1; goto done; } /* :231-234 */
+    }
+done:
+    free(b.data);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+void fqref_count(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
+                 fqref_result *res) {
+    fqref_each(data, len, bufsize, max_read, NULL, NULL, res);
+}
+
+typedef struct { fqref_idx *out; uint64_t cap, n; } idx_sink;
+static int idx_cb(void *u, const uint8_t *rec, const fqref_idx *idx) {
+    (void)rec;
+    idx_sink *s = (idx_sink *)u;
+    if (s->n < s->cap) s->out[s->n] = *idx;
+    s->n++;
+    return 1;
+}
+void fqref_index(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
+                 fqref_idx *out, uint64_t cap, fqref_result *res) {
+    idx_sink s = {out, cap, 0};
+    fqref_each(data, len, bufsize, max_read, idx_cb, &s, res);
+}
+
+typedef struct { uint64_t *out; uint64_t cap, n; } off_sink;
+static int off_cb(void *u, const uint8_t *rec, const fqref_idx *idx) {
+    (void)rec;
+    off_sink *s = (off_sink *)u;
+    if (s->n < s->cap) s->out[s->n] = idx->start;
+    s->n++;
+    return 1;
+}
+void fqref_offsets(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
+                   uint64_t *rec_start, uint64_t cap, fqref_result *res) {
+    off_sink s = {rec_start, cap, 0};
+    fqref_each(data, len, bufsize, max_read, off_cb, &s, res);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Accessors — src/records.rs:65-97.  trim_winline removes exactly ONE trailing '\r'.          */
+static uint64_t trim_winline(const uint8_t *p, uint64_t n) {
+    return (n && p[n - 1] == '\r') ? n - 1 : n;
+}
+void fqref_accessors(const uint8_t *rec, const fqref_idx *idx, uint64_t *head_off,
+                     uint64_t *head_len, uint64_t *seq_off, uint64_t *seq_len, uint64_t *qual_off,
+                     uint64_t *qual_len) {
+    *head_off = 1;                                            /* data[1..head]       :77-80 */
+    *head_len = trim_winline(rec + 1, idx->head - 1);
+    *seq_off = idx->head + 1;                                 /* data[head+1..seq]   :83-85 */
+    *seq_len = trim_winline(rec + *seq_off, idx->seq - *seq_off);
+    *qual_off = idx->sep + 1;                                 /* data[sep+1..qual]   :88-90 */
+    *qual_len = trim_winline(rec + *qual_off, idx->qual - *qual_off);
+}
+int fqref_validate_dna(const uint8_t *s, uint64_t n) {       /* records.rs:19-23 */
+    for (uint64_t i = 0; i < n; i++)
+        if (!(s[i] == 'A' || s[i] == 'C' || s[i] == 'T' || s[i] == 'G')) return 0;
+    return 1;
+}
+int fqref_validate_dnan(const uint8_t *s, uint64_t n) {      /* records.rs:29-33 */
+    for (uint64_t i = 0; i < n; i++)
+        if (!(s[i] == 'A' || s[i] == 'C' || s[i] == 'T' || s[i] == 'G' || s[i] == 'N')) return 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Per-read statistics — the "CPU loop over Record::qual/seq" of BASELINE.json configs[2].     */
+typedef struct { uint32_t lmax; uint64_t *qh, *bh, *sc; } stats_sink;
+static inline int base_class(uint8_t c) {
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+                 case 'N': return 4; default: return 5; }
+}
+static int stats_cb(void *u, const uint8_t *rec, const fqref_idx *idx) {
+    stats_sink *s = (stats_sink *)u;
+    uint64_t ho, hl, so, sl, qo, ql;
+    fqref_accessors(rec, idx, &ho, &hl, &so, &sl, &qo, &ql);
+    const uint8_t *seq = rec + so, *qual = rec + qo;
+    for (uint64_t p = 0; p < sl; p++) {
+        if (p < s->lmax) s->bh[p * 8 + base_class(seq[p])]++;
+        else s->sc[5]++;
+    }
+    for (uint64_t p = 0; p < ql; p++) {
+        if (p < s->lmax) s->qh[p * 256 + qual[p]]++;
+        else s->sc[6]++;
+    }
+    s->sc[0] += 1;
+    s->sc[1] += sl;
+    s->sc[2] += ql;
+    s->sc[3] += (uint64_t)fqref_validate_dna(seq, sl);
+    s->sc[4] += (uint64_t)fqref_validate_dnan(seq, sl);
+    return 1;
+}
+void fqref_stats(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
+                 uint32_t lmax, uint64_t *qual_hist, uint64_t *base_hist, uint64_t *scalars,
+                 fqref_result *res) {
+    stats_sink s = {lmax, qual_hist, base_hist, scalars};
+    fqref_each(data, len, bufsize, max_read, stats_cb, &s, res);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* RecordSetIter::next + parallel_each's deal — src/lib.rs:364-425, 521-548                    */
+void fqref_record_sets(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
+                       uint32_t n_threads, uint64_t *set_sizes, uint64_t cap_sets, uint64_t *n_sets,
+                       uint64_t *worker_counts, fqref_result *res) {
+    reader_t rd = {data, len, 0, max_read};
+    buf_t b;
+    buf_init(&b, bufsize);
+    memset(res, 0, sizeof *res);
+    uint64_t sets = 0, consumed = 0;
+    int reader_at_end = 0;
+    if (worker_counts) memset(worker_counts, 0, n_threads * sizeof(uint64_t));
+    while (!reader_at_end) {                                       /* next(): :365-367 */
+        uint64_t nrec = 0, set_consumed = consumed;
+        int yielded = 0;
+        while (!yielded) {
+            rec_t rec;
+            int err;
+            int r = from_buffer(b.data + b.start, buf_len(&b), &rec, &err);  /* :373 */
+            if (err) { res->status = err; goto done; }                        /* :375 */
+            if (r == R_EMPTY) {                                               /* :381-391 */
+                free(buf_replace(&b));
+                if (buf_read_into(&b, &rd) == 0) reader_at_end = 1;
+                yielded = 1;
+            } else if (r == R_INCOMPLETE) {                                   /* :392-414 */
+                free(buf_replace(&b));
+                if (buf_n_free(&b) == 0) { res->status = FQREF_E_TOO_LONG; goto done; }
+                if (buf_read_into(&b, &rd) == 0) { res->status = FQREF_E_TRUNCATED; goto done; }
+                yielded = 1;
+            } else {                                                          /* :415-422 */
+                nrec++;
+                b.start += rec.end;
+                set_consumed += rec.end;
+            }
+        }
+        /* Some(Ok(RecordSet)) — dealt to senders.iter().cycle(): lib.rs:535 */
+        if (sets < cap_sets && set_sizes) set_sizes[sets] = nrec;
+        if (worker_counts && n_threads) worker_counts[sets % n_threads] += nrec;
+        sets++;
+        consumed = set_consumed;
+        res->n_records += nrec;
+        res->bytes_consumed = consumed;
+    }
+done:
+    if (n_sets) *n_sets = sets;
+    free(b.data);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+const char *fqref_strerror(int status) {
+    switch (status) {
+    case FQREF_OK: return "ok";
+    case FQREF_E_HEADER: return "Fastq headers must start with '@'";
+    case FQREF_E_SEP: return "Sequence and quality not separated by +";
+    case FQREF_E_LEN: return "Sequence and quality length mismatch";
+    case FQREF_E_TRUNCATED: return "Possibly truncated input file";
+    case FQREF_E_TOO_LONG: return "Fastq record is too long";
+    default: return "unknown";
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Synthetic generator.  Counter-based: byte b of record i is a pure function of  */
+/* (seed, i, b).  The HIP generator in fastq-rs_amd/csrc/synth.hip implements the same map.    */
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+static inline uint64_t synth_hash(uint64_t seed, uint64_t rec, uint32_t stream, uint32_t p) {
+    return mix64(seed + rec * 0x9E3779B97F4A7C15ull +
+                 ((((uint64_t)stream) << 32 | p) + 1) * 0xD6E8FEB86659FD93ull);
+}
+static inline uint8_t synth_byte(uint64_t seed, uint64_t rec, uint32_t b) {
+    /* line 1: "@SYN." + 12-digit zero-padded decimal rec + " 1:N:0:1" + '\n'   (26 bytes) */
+    if (b < 26) {
+        static const char pre[] = "@SYN.", post[] = " 1:N:0:1\n";
+        if (b < 5) return (uint8_t)pre[b];
+        if (b < 17) {
+            uint64_t v = rec % 1000000000000ull;
+            for (uint32_t k = 16; k > b; k--) v /= 10;
+            return (uint8_t)('0' + v % 10);
+        }
+        return (uint8_t)post[b - 17];
+    }
+    if (b < 176) { /* line 2: 150 bases, N with prob 1/100 else uniform ACGT */
+        uint64_t h = synth_hash(seed, rec, 1, b - 26);
+        if ((uint32_t)(h >> 32) % 100u == 0) return 'N';
+        return (uint8_t)"ACGT"[h & 3];
+    }
+    if (b == 176) return '\n';
+    if (b == 177) return '+';
+    if (b == 178) return '\n';
+    if (b < 329) { /* line 4: 150 quals uniform in '#'..'I' (39 values; includes '+' and '@') */
+        uint64_t h = synth_hash(seed, rec, 2, b - 179);
+        return (uint8_t)('#' + (uint32_t)(h >> 32) % 39u);
+    }
+    return '\n';
+}
+void fqref_synth_range(uint8_t *out, uint64_t byte_off, uint64_t len, uint64_t seed) {
+    uint64_t rec = byte_off / FQREF_SYNTH_RECLEN;
+    uint32_t b = (uint32_t)(byte_off % FQREF_SYNTH_RECLEN);
+    for (uint64_t i = 0; i < len; i++) {
+        out[i] = synth_byte(seed, rec, b);
+        if (++b == FQREF_SYNTH_RECLEN) { b = 0; rec++; }
+    }
+}

@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the FASTQ record-scan path on MI355X.
+
+One "step" = one pass of the hot path (fqh_scan: byte-scan kernel -> tile prefix -> emit/validate ->
+summary) over one HBM-resident batch of synthetic 150 bp FASTQ.  N = 1: BASELINE.json configs[1],
+16 GiB (17 179 868 970 B = 52 060 209 records).  N > 1: the input is one file of N x 16 GiB cut by
+byte range at multiples of 2^34 (cuts fall inside records); every rank scans its own shard, the
+ranks exchange 7 words of carry, re-run only the emit step with the true carry, and all-reduce the
+counts (and histograms) over RCCL.  value = total bytes of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra keys: roofline (k_index, the dominant kernel, measured with
+HIP events on the launch stream inside the timed region), cpu_baseline (the oracle timed on the
+host cores, rank 0, N = 1 only), stats (the histogram pass on the same buffer, configs[2]).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RECLEN = 330
+SHARD = 1 << 34
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bytes", type=int, default=0, help="per-GPU bytes (default 16 GiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=4096)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as g
+    pkg = g.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == n_gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    shard = args.bytes if args.bytes else SHARD
+    total_records = (world * shard) // RECLEN
+    file_len = total_records * RECLEN
+    lo = rank * shard
+    hi = min((rank + 1) * shard, file_len)
+    nbytes = hi - lo
+
+    ctx = pkg.Ctx(dev.index, stream=torch.cuda.current_stream().cuda_stream)
+    buf = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+    ctx.synth_fill(buf.data_ptr(), lo, nbytes)
+    cap = nbytes // 300 + 16
+    rec_start = torch.empty(cap, dtype=torch.int64, device=dev)
+    is_last = rank == world - 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gather_in = torch.zeros(7, dtype=torch.int64, device=dev)
+    gather_out = [torch.zeros(7, dtype=torch.int64, device=dev) for _ in range(world)] if world > 1 else None
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    index_ms = []
+
+    def step():
+        if world == 1:
+            s, c, st = ctx.scan(buf.data_ptr(), nbytes, True, None, rec_start.data_ptr(), cap)
+            index_ms.append(ctx.timing().index_ms)
+            return s
+        # 1) shard-local byte scan (phase-free), 2) carry exchange, 3) emit with the true carry
+        s0, c0, _ = ctx.scan(buf.data_ptr(), nbytes, False, None, None, 0)
+        index_ms.append(ctx.timing().index_ms)
+        gather_in.copy_(torch.tensor([nbytes, s0.n_newlines, s0.n_line_starts] + list(c0.back),
+                                     dtype=torch.int64), non_blocking=False)
+        dist.all_gather(gather_out, gather_in)
+        rows = torch.stack(gather_out).cpu().numpy()
+        carry = None
+        for r in range(rank):
+            carry = pkg.carry_combine(carry, int(rows[r][0]), int(rows[r][1]), int(rows[r][2]),
+                                      [int(x) for x in rows[r][3:7]])
+        ctx.rescan_launch(is_last, carry, rec_start.data_ptr(), cap)
+        s, c, st = ctx.scan_finish()
+        counts[0] = s.n_records
+        counts[1] = 1 if s.parse_status != pkg.OK else 0
+        dist.all_reduce(counts)
+        return s
+
+    for _ in range(args.warmup):
+        s = step()
+    index_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        n_rec_total = int(counts[0].item())
+        n_err = int(counts[1].item())
+    else:
+        n_rec_total = int(s.n_records)
+        n_err = 0 if s.parse_status == pkg.OK else 1
+    assert n_err == 0, "scan reported a parse error on valid synthetic input"
+    assert n_rec_total == total_records, (n_rec_total, total_records)
+
+    ms_per_step = dt / args.steps * 1e3
+    gbs = file_len / 1e9 / (dt / args.steps)
+    k_ms = float(np.mean(index_ms))
+    achieved = nbytes / 1e9 / (k_ms / 1e3)
+
+    out = {
+        "metric": "GB/s FASTQ parsed (record-offset scan + count, 150 bp synthetic, HBM-resident)",
+        "value": round(gbs, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: %d x %.3f GiB synthetic 150 bp FASTQ resident in HBM, "
+                               "record-offset scan + count + validation" % (world, nbytes / 2**30),
+                   "bytes_per_gpu": nbytes, "records_total": total_records,
+                   "sharding": "byte-range, cuts at multiples of %d" % shard if world > 1 else "none"},
+        "records_per_s": round(total_records / (dt / args.steps), 1),
+        "hbm_roofline_frac_whole_step": round(gbs / world / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm", "kernel": "k_index", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel_ms": round(k_ms, 4),
+                     "algorithmic_bytes_per_launch": nbytes},
+    }
+
+    if rank == 0 and world == 1:
+        t = ctx.timing()
+        out["stage_ms"] = {"index": round(t.index_ms, 4), "prefix": round(t.prefix_ms, 4),
+                           "emit": round(t.emit_ms, 4), "total": round(t.total_ms, 4)}
+        cs, ms = ctx.read_ceiling(buf.data_ptr(), nbytes)
+        cs, ms2 = ctx.read_ceiling(buf.data_ptr(), nbytes)
+        out["read_ceiling_gbs"] = round(nbytes / 1e9 / (min(ms, ms2) / 1e3), 1)
+        if not args.no_stats:
+            qh = torch.zeros(150 * 256, dtype=torch.int64, device=dev)
+            bh = torch.zeros(150 * 8, dtype=torch.int64, device=dev)
+            sc = torch.zeros(8, dtype=torch.int64, device=dev)
+            best = None
+            for _ in range(3):
+                qh.zero_(); bh.zero_(); sc.zero_()
+                ctx.stats_launch(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+                ctx.stats_finish()
+                tt = ctx.timing()
+                best = tt.stats_ms if best is None else min(best, tt.stats_ms)
+            assert int(sc[0].item()) == total_records
+            assert int(qh.sum().item()) == total_records * 150 and int(bh.sum().item()) == total_records * 150
+            out["stats"] = {"workload": "configs[2]: per-position quality + base histograms, same buffer",
+                            "kernel": "k_stats_records", "kernel_ms": round(best, 3),
+                            "gbs": round(nbytes / 1e9 / (best / 1e3), 1),
+                            "frac_of_hbm_peak": round(nbytes / 1e9 / (best / 1e3) / HBM_PEAK_GBS, 4)}
+        if not args.no_cpu_baseline:
+            from oracle import fqref  # the oracle as timed CPU baseline (kind "port"), never the product
+            sample = min(nbytes, args.cpu_sample_mib << 20) // RECLEN * RECLEN
+            host = buf[:sample].cpu().numpy()
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                r = fqref.count(host)
+                d1 = time.perf_counter() - t1
+                best = d1 if best is None else min(best, d1)
+            assert r.status == 0 and r.n_records == sample // RECLEN
+            out["cpu_baseline"] = {"value": round(sample / 1e9 / best, 3), "unit": "GB/s", "cores": 1,
+                                   "kind": "port",
+                                   "sample": "oracle Parser::each count over the first %d MiB of the same "
+                                             "buffer, best of 3, 1 thread (the reference scan is "
+                                             "single-threaded); host has %d cores" % (sample >> 20, os.cpu_count())}
+            hs = min(sample, 512 << 20) // RECLEN * RECLEN
+            t1 = time.perf_counter()
+            fqref.stats(host[:hs], 150)
+            d1 = time.perf_counter() - t1
+            out["cpu_baseline"]["stats_gbs"] = round(hs / 1e9 / d1, 3)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,211 @@
+"""ctypes stub over libfastq_hip.so (include/fastq_hip.h).  Plumbing only: device memory comes from
+the caller (torch tensors -> data_ptr(), or fqh_dev_alloc); every call goes through the C ABI."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastq_hip.so")
+
+__all__ = ["LIB_PATH", "lib", "Ctx", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
+           "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "BUFSIZE", "NSCALARS", "EXPORTS"]
+
+OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY = range(10)
+BUFSIZE = 68 * 1024
+NSCALARS = 8
+
+# every symbol include/fastq_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
+    "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
+    "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_last_timing",
+    "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
+    "fqh_memcpy_d2h", "fqh_memset",
+]
+
+
+class Carry(C.Structure):
+    _fields_ = [("base_offset", C.c_uint64), ("nl_count", C.c_uint64), ("back", C.c_uint64 * 4)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("bytes_consumed", C.c_uint64),
+                ("parse_status", C.c_int32), ("reserved", C.c_int32),
+                ("err_record", C.c_uint64), ("err_offset", C.c_uint64),
+                ("n_newlines", C.c_uint64), ("tail_len", C.c_uint64),
+                ("max_record_len", C.c_uint64), ("n_line_starts", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("index_ms", C.c_float), ("prefix_ms", C.c_float),
+                ("emit_ms", C.c_float), ("stats_ms", C.c_float)]
+
+
+class IdxRecord(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("head", C.c_uint32), ("seq", C.c_uint32),
+                ("sep", C.c_uint32), ("qual", C.c_uint32)]
+
+
+class FqhError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("fqh status %d: %s" % (status, msg))
+        self.status = status
+
+
+_LIB = None
+
+
+def lib():
+    """Loads libfastq_hip.so.  No fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `make -C fastq-rs_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        L.fqh_create.argtypes = [i32, C.POINTER(vp)]
+        L.fqh_destroy.argtypes = [vp]
+        L.fqh_destroy.restype = None
+        L.fqh_strerror.argtypes = [i32]
+        L.fqh_strerror.restype = C.c_char_p
+        L.fqh_last_error.argtypes = [vp]
+        L.fqh_last_error.restype = C.c_char_p
+        L.fqh_set_stream.argtypes = [vp, vp]
+        L.fqh_set_bufsize.argtypes = [vp, u64]
+        L.fqh_scan.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), vp, u64, C.POINTER(Summary),
+                               C.POINTER(Carry)]
+        L.fqh_scan_launch.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), vp, u64]
+        L.fqh_scan_finish.argtypes = [vp, C.POINTER(Summary), C.POINTER(Carry)]
+        L.fqh_index_records.argtypes = [vp, vp, u64]
+        L.fqh_carry_combine.argtypes = [C.POINTER(Carry), u64, u64, u64, C.POINTER(u64 * 4),
+                                        C.POINTER(Carry)]
+        L.fqh_rescan_launch.argtypes = [vp, i32, C.POINTER(Carry), vp, u64]
+        L.fqh_invalidate.argtypes = [vp]
+        L.fqh_stats.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp,
+                                C.POINTER(Summary), C.POINTER(Carry)]
+        L.fqh_stats_launch.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
+        L.fqh_stats_finish.argtypes = [vp, C.POINTER(Summary), C.POINTER(Carry)]
+        L.fqh_last_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.fqh_synth_fill.argtypes = [vp, vp, u64, u64, u64]
+        L.fqh_read_ceiling.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(C.c_float)]
+        L.fqh_dev_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+        L.fqh_dev_free.argtypes = [vp, vp]
+        L.fqh_memcpy_h2d.argtypes = [vp, vp, vp, u64]
+        L.fqh_memcpy_d2h.argtypes = [vp, vp, vp, u64]
+        L.fqh_memset.argtypes = [vp, vp, i32, u64]
+        _LIB = L
+    return _LIB
+
+
+def strerror(status):
+    return lib().fqh_strerror(status).decode()
+
+
+def carry_combine(prev, length, n_newlines, n_line_starts, back_zero_carry):
+    """Folds one shard's zero-carry summary into the running carry (host-only, no GPU)."""
+    nxt = Carry()
+    arr = (C.c_uint64 * 4)(*[int(x) for x in back_zero_carry])
+    st = lib().fqh_carry_combine(C.byref(prev) if prev is not None else None, length, n_newlines,
+                                 n_line_starts, C.byref(arr), C.byref(nxt))
+    if st != OK:
+        raise FqhError(st, "fqh_carry_combine")
+    return nxt
+
+
+class Ctx:
+    """One fqh_ctx.  Pointers are raw device addresses (ints)."""
+
+    def __init__(self, device=0, stream=None, bufsize=None):
+        self._L = lib()
+        h = C.c_void_p()
+        st = self._L.fqh_create(device, C.byref(h))
+        if st != OK:
+            raise FqhError(st, "fqh_create failed (no GPU?)")
+        self._h = h
+        if stream is not None:
+            self._chk(self._L.fqh_set_stream(self._h, C.c_void_p(stream)))
+        if bufsize is not None:
+            self.set_bufsize(bufsize)
+
+    def close(self):
+        if self._h:
+            self._L.fqh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, allow=()):
+        if st != OK and st not in allow:
+            raise FqhError(st, self._L.fqh_last_error(self._h).decode() or strerror(st))
+        return st
+
+    def set_stream(self, stream):
+        self._chk(self._L.fqh_set_stream(self._h, C.c_void_p(stream or 0)))
+
+    def set_bufsize(self, bufsize):
+        self._chk(self._L.fqh_set_bufsize(self._h, bufsize))
+
+    def scan(self, d_buf, length, is_final=True, carry=None, d_rec_start=None, cap=0):
+        s, c = Summary(), Carry()
+        st = self._L.fqh_scan(self._h, d_buf, length, 1 if is_final else 0,
+                              C.byref(carry) if carry is not None else None,
+                              d_rec_start, cap, C.byref(s), C.byref(c))
+        self._chk(st, allow=(E_CAPACITY,))
+        return s, c, st
+
+    def scan_launch(self, d_buf, length, is_final=True, carry=None, d_rec_start=None, cap=0):
+        self._chk(self._L.fqh_scan_launch(self._h, d_buf, length, 1 if is_final else 0,
+                                          C.byref(carry) if carry is not None else None,
+                                          d_rec_start, cap))
+
+    def scan_finish(self):
+        s, c = Summary(), Carry()
+        st = self._L.fqh_scan_finish(self._h, C.byref(s), C.byref(c))
+        self._chk(st, allow=(E_CAPACITY,))
+        return s, c, st
+
+    def rescan_launch(self, is_final=True, carry=None, d_rec_start=None, cap=0):
+        self._chk(self._L.fqh_rescan_launch(self._h, 1 if is_final else 0,
+                                            C.byref(carry) if carry is not None else None,
+                                            d_rec_start, cap))
+
+    def invalidate(self):
+        self._chk(self._L.fqh_invalidate(self._h))
+
+    def index_records(self, d_index, cap):
+        self._chk(self._L.fqh_index_records(self._h, d_index, cap))
+
+    def stats(self, d_buf, length, lmax, d_qual, d_base, d_scalars, is_final=True, carry=None):
+        s, c = Summary(), Carry()
+        self._chk(self._L.fqh_stats(self._h, d_buf, length, 1 if is_final else 0,
+                                    C.byref(carry) if carry is not None else None, lmax,
+                                    d_qual, d_base, d_scalars, C.byref(s), C.byref(c)))
+        return s, c
+
+    def stats_launch(self, d_buf, length, lmax, d_qual, d_base, d_scalars, is_final=True, carry=None):
+        self._chk(self._L.fqh_stats_launch(self._h, d_buf, length, 1 if is_final else 0,
+                                           C.byref(carry) if carry is not None else None, lmax,
+                                           d_qual, d_base, d_scalars))
+
+    def stats_finish(self):
+        s, c = Summary(), Carry()
+        self._chk(self._L.fqh_stats_finish(self._h, C.byref(s), C.byref(c)))
+        return s, c
+
+    def timing(self):
+        t = Timing()
+        self._chk(self._L.fqh_last_timing(self._h, C.byref(t)))
+        return t
+
+    def synth_fill(self, d_out, byte_off, length, seed=0x5EEDF00D2026):
+        self._chk(self._L.fqh_synth_fill(self._h, d_out, byte_off, length, seed))
+
+    def read_ceiling(self, d_buf, length):
+        cs, ms = C.c_uint64(0), C.c_float(0)
+        self._chk(self._L.fqh_read_ceiling(self._h, d_buf, length, C.byref(cs), C.byref(ms)))
+        return cs.value, ms.value

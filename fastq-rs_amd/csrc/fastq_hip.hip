@@ -1,0 +1,658 @@
+// fastq_hip.hip — host side of libfastq_hip.so: the C ABI of include/fastq_hip.h.
+//
+// Owns the per-context workspace in HBM (line-start lists, tile counts/prefixes), enqueues the
+// kernels of scan_kernels.hip / stats_kernels.hip on one HIP stream, reads back one small struct
+// per scan and turns it into the reference's observable result (record count, error kind, error
+// record) — including the "Fastq record is too long" rule, which is a property of the reference's
+// 68 KiB Buffer (src/buffer.rs:51-100, src/lib.rs:276-283) and is resolved here by replaying that
+// buffer arithmetic over the record boundaries the GPU found.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fqh_internal.h"
+
+namespace fqh {
+void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
+void launch_prefix(hipStream_t, const uint32_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
+void launch_emit(hipStream_t, const ScanArgs &, DevOut *);
+void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
+void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_record *, uint64_t,
+                          uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
+void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
+void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *);
+}  // namespace fqh
+
+using namespace fqh;
+
+struct fqh_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t bufsize = FQH_BUFSIZE;
+    std::string err;
+
+    // workspace (grow-only)
+    uint16_t *list = nullptr;
+    size_t list_elems = 0;
+    uint32_t list_cap = LIST_CAP_DEFAULT;
+    uint32_t *tile_count = nullptr, *tile_prefix = nullptr;
+    uint64_t *block_prefix = nullptr;
+    size_t tiles_cap = 0;
+    DevOut *d_out = nullptr;      // [0] the scan's, [1] scratch for index-only emits
+    DevOut *h_out = nullptr;      // pinned
+    DevOut *h_init = nullptr;     // pinned reset image
+    uint64_t *d_misc = nullptr;   // 8 u64 of scratch
+    fqh_idx_record *idx = nullptr;
+    size_t idx_cap = 0;
+    uint64_t *tmp_rec = nullptr;
+    size_t tmp_rec_cap = 0;
+
+    hipEvent_t ev[8] = {};
+    fqh_timing timing = {};
+
+    // the scan in flight / last finished
+    bool pending = false;
+    bool last_valid = false;
+    ScanArgs args = {};
+    fqh_carry carry_in = {};
+    bool whole_file = false;
+    fqh_summary last_summary = {};
+    fqh_carry last_carry_out = {};
+    // stats in flight
+    bool stats_pending = false;
+};
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return FQH_E_DEVICE;                                                               \
+        }                                                                                      \
+    } while (0)
+
+static fqh_status fail(fqh_ctx *ctx, fqh_status s, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return s;
+}
+
+extern "C" {
+
+int fqh_abi_version(void) { return FQH_ABI_VERSION; }
+
+const char *fqh_strerror(fqh_status s) {
+    switch (s) {
+    case FQH_OK: return "ok";
+    case FQH_E_HEADER: return "Fastq headers must start with '@'";
+    case FQH_E_SEP: return "Sequence and quality not separated by +";
+    case FQH_E_LEN_MISMATCH: return "Sequence and quality length mismatch";
+    case FQH_E_TRUNCATED: return "Possibly truncated input file";
+    case FQH_E_TOO_LONG: return "Fastq record is too long";
+    case FQH_E_IO: return "i/o error";
+    case FQH_E_DEVICE: return "HIP device error";
+    case FQH_E_ARG: return "invalid argument";
+    case FQH_E_CAPACITY: return "output capacity too small";
+    }
+    return "unknown";
+}
+
+const char *fqh_last_error(fqh_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+fqh_status fqh_create(int device, fqh_ctx **out) {
+    if (!out) return FQH_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return FQH_E_DEVICE;
+    fqh_ctx *ctx = new (std::nothrow) fqh_ctx();
+    if (!ctx) return FQH_E_DEVICE;
+    ctx->device = device;
+    fqh_status st = FQH_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0)
+            ctx->n_cu = cu;
+        if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        ctx->stream = ctx->own_stream;
+        if (hipMalloc((void **)&ctx->d_out, 2 * sizeof(DevOut)) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        if (hipMalloc((void **)&ctx->d_misc, 64) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        if (hipHostMalloc((void **)&ctx->h_out, sizeof(DevOut), hipHostMallocDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        if (hipHostMalloc((void **)&ctx->h_init, sizeof(DevOut), hipHostMallocDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        memset(ctx->h_init, 0, sizeof(DevOut));
+        ctx->h_init->min_key = NOKEY;
+        ctx->h_init->first_long = NOKEY;
+        for (auto &e : ctx->ev)
+            if (hipEventCreate(&e) != hipSuccess) { st = FQH_E_DEVICE; break; }
+    } while (0);
+    if (st != FQH_OK) {
+        fqh_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return FQH_OK;
+}
+
+void fqh_destroy(fqh_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->list);
+    (void)hipFree(ctx->tile_count);
+    (void)hipFree(ctx->tile_prefix);
+    (void)hipFree(ctx->block_prefix);
+    (void)hipFree(ctx->d_out);
+    (void)hipFree(ctx->d_misc);
+    (void)hipFree(ctx->idx);
+    (void)hipFree(ctx->tmp_rec);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->h_init) (void)hipHostFree(ctx->h_init);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+fqh_status fqh_set_stream(fqh_ctx *ctx, void *hip_stream) {
+    if (!ctx) return FQH_E_ARG;
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is pending");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return FQH_OK;
+}
+
+fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize) {
+    if (!ctx) return FQH_E_ARG;
+    if (bufsize && (bufsize < 32 || bufsize % 16)) return fail(ctx, FQH_E_ARG, "bufsize must be 0 or a multiple of 16 >= 32");
+    ctx->bufsize = bufsize;
+    ctx->last_valid = false;
+    return FQH_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles) {
+    const size_t need_list = (size_t)n_tiles * ctx->list_cap;
+    if (need_list > ctx->list_elems) {
+        (void)hipFree(ctx->list);
+        ctx->list = nullptr;
+        ctx->list_elems = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->list, std::max<size_t>(need_list, 1) * sizeof(uint16_t)));
+        ctx->list_elems = need_list;
+    }
+    if (n_tiles > ctx->tiles_cap) {
+        (void)hipFree(ctx->tile_count);
+        (void)hipFree(ctx->tile_prefix);
+        (void)hipFree(ctx->block_prefix);
+        ctx->tile_count = ctx->tile_prefix = nullptr;
+        ctx->block_prefix = nullptr;
+        ctx->tiles_cap = 0;
+        const size_t nb = (n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->tile_count, n_tiles * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->tile_prefix, n_tiles * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
+        ctx->tiles_cap = n_tiles;
+    }
+    return FQH_OK;
+}
+
+static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index = false) {
+    ScanArgs &a = ctx->args;
+    hipStream_t s = ctx->stream;
+    fqh_status st = ensure_workspace(ctx, a.n_tiles);
+    if (st != FQH_OK) return st;
+    a.list = ctx->list;
+    a.list_cap = ctx->list_cap;
+    a.tile_count = ctx->tile_count;
+    a.tile_prefix = ctx->tile_prefix;
+    a.block_prefix = ctx->block_prefix;
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
+    if (!reuse_index)
+        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, a.n_tiles, &ctx->d_out[0]);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+    if (!reuse_index)
+        launch_prefix(s, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+    launch_emit(s, a, &ctx->d_out[0]);
+    launch_finalize(s, a, &ctx->d_out[0]);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, &ctx->d_out[0], sizeof(DevOut), hipMemcpyDeviceToHost, s));
+    return FQH_OK;
+}
+
+static bool carry_is_zero(const fqh_carry &c) {
+    return c.base_offset == 0 && c.nl_count == 0 && c.back[0] == 0 && c.back[1] == 0 && c.back[2] == 0 && c.back[3] == 0;
+}
+
+// Exact replay of Buffer (src/buffer.rs:51-100) inside RecordRefIter::advance (src/lib.rs:255-303)
+// at refill granularity, for a reader that always fills the request (std::io::Cursor, a plain
+// file).  rs[0..n] are the boundaries of the n valid records; `need` = bytes of the first
+// non-valid record that must be visible to report its own error (0 = it is a truncated tail,
+// UINT64_MAX = there is no such record).  Returns true and the record index if the reference would
+// report "Fastq record is too long" first.
+static bool replay_too_long(const uint64_t *rs, uint64_t n, uint64_t file_len, uint64_t need,
+                            uint64_t B, uint64_t *which) {
+    uint64_t start = 0, end = 0, fpos = rs[0], rd = rs[0], k = 0;
+    const uint64_t origin = rs[0];
+    (void)origin;
+    for (;;) {
+        // consume every complete valid record inside the window [fpos, rd)
+        const uint64_t *hi = std::upper_bound(rs + k, rs + n + 1, rd);
+        uint64_t j = (uint64_t)(hi - rs) - 1;
+        if (j > k) {
+            start += rs[j] - fpos;
+            fpos = rs[j];
+            k = j;
+        }
+        if (k == n) {
+            if (need == UINT64_MAX && fpos == file_len && start == end) return false;
+            if (need != UINT64_MAX && need != 0 && fpos + need <= rd) return false;
+        }
+        if (start == end) {  // EmptyBuffer: clean()
+            start = end = 0;
+        } else {             // Incomplete: clean(); n_free() == 0 => too long
+            if (start) {
+                const uint64_t m = end - start;
+                const uint64_t new_end = (m + 15) & ~(uint64_t)15;
+                const uint64_t new_start = new_end - m;
+                if (new_start < start) { start = new_start; end = new_end; }
+            }
+            if (B - end == 0) { *which = k; return true; }
+        }
+        const uint64_t n_free = B - end;
+        const uint64_t num = n_free < 4096 ? n_free : n_free - n_free % 4096;
+        const uint64_t got = std::min<uint64_t>(num, file_len - rd);
+        if (got == 0) return false;
+        end += got;
+        rd += got;
+    }
+}
+
+static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
+    const ScanArgs &a = ctx->args;
+    const DevOut &d = *ctx->h_out;
+    fqh_summary s = {};
+    const uint64_t r0 = a.nl_count >> 2;
+    s.n_records = d.n_records;
+    s.bytes_consumed = d.end_off > 0 ? (uint64_t)d.end_off : 0;
+    s.parse_status = FQH_OK;
+    s.n_newlines = d.n_newlines;
+    s.tail_len = d.tail_len;
+    s.max_record_len = d.max_len >= (1ull << 60) ? UINT64_MAX : d.max_len;
+    s.n_line_starts = d.total_entries + d.lastnl;
+    if (d.final_key != NOKEY) {
+        static const int32_t stage_status[4] = {FQH_E_HEADER, FQH_E_SEP, FQH_E_LEN_MISMATCH, FQH_E_TRUNCATED};
+        s.parse_status = stage_status[d.final_key & 3];
+        s.err_record = d.final_key >> 2;
+        s.err_offset = a.base_offset + (uint64_t)d.err_start;
+    }
+    // "Fastq record is too long" (src/lib.rs:278-283): only a whole-file scan can replay the
+    // reference's buffer alignment exactly; chunked callers resolve it in their driver.
+    if (ctx->bufsize && ctx->whole_file) {
+        const uint64_t B = ctx->bufsize;
+        bool cand = d.first_long != NOKEY && d.first_long < r0 + s.n_records;
+        uint64_t need = UINT64_MAX;
+        if (d.final_key != NOKEY) {
+            const uint32_t stage = (uint32_t)d.final_key & 3u;
+            if (stage == 3) {
+                need = 0;
+                if (a.len - (uint64_t)d.err_start + 15 >= B) cand = true;
+            } else {
+                need = d.err_need;
+                if (need + 15 > B) cand = true;
+            }
+        }
+        if (cand) {
+            // record boundaries on the host
+            const uint64_t n = s.n_records;
+            std::vector<uint64_t> rs(n + 1);
+            const uint64_t *src = a.rec_start;
+            if (!src || a.cap < n + 1) {
+                if (ctx->tmp_rec_cap < n + 1) {
+                    (void)hipFree(ctx->tmp_rec);
+                    ctx->tmp_rec = nullptr;
+                    ctx->tmp_rec_cap = 0;
+                    HIPCHK(ctx, hipMalloc((void **)&ctx->tmp_rec, (n + 1) * sizeof(uint64_t)));
+                    ctx->tmp_rec_cap = n + 1;
+                }
+                ScanArgs b = a;
+                b.rec_start = ctx->tmp_rec;
+                b.cap = n + 1;
+                b.idx = nullptr;
+                HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
+                launch_emit(ctx->stream, b, &ctx->d_out[1]);
+                launch_finalize(ctx->stream, b, &ctx->d_out[1]);
+                src = ctx->tmp_rec;
+            }
+            HIPCHK(ctx, hipMemcpyAsync(rs.data(), src, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            rs[n] = (uint64_t)(d.end_off > 0 ? d.end_off : 0);  // authoritative end of the last good record
+            uint64_t which = 0;
+            if (replay_too_long(rs.data(), n, a.len, need, B, &which)) {
+                s.parse_status = FQH_E_TOO_LONG;
+                s.n_records = which;
+                s.err_record = r0 + which;
+                s.err_offset = a.base_offset + rs[which];
+                s.bytes_consumed = rs[which];
+            }
+        }
+    }
+    if (a.rec_start && s.n_records + 1 > a.cap && s.parse_status == FQH_OK) {
+        ctx->last_summary = s;
+        if (out) *out = s;
+        return fail(ctx, FQH_E_CAPACITY, "d_rec_start capacity < n_records + 1");
+    }
+    fqh_carry c = {};
+    c.base_offset = a.base_offset + a.len;
+    c.nl_count = a.nl_count + d.n_newlines;
+    for (int i = 0; i < 4; ++i) {
+        long long v = (long long)a.len - d.recent[i];
+        uint64_t lim = a.base_offset + a.len;
+        c.back[i] = v < 0 ? 0 : ((uint64_t)v > lim ? lim : (uint64_t)v);
+    }
+    ctx->last_summary = s;
+    ctx->last_carry_out = c;
+    if (out) *out = s;
+    if (carry_out) *carry_out = c;
+    return FQH_OK;
+}
+
+static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                                 const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap,
+                                 bool reuse_index = false) {
+    if (!ctx) return FQH_E_ARG;
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
+    if (len && !d_buf) return fail(ctx, FQH_E_ARG, "d_buf is NULL");
+    if (len && ((uintptr_t)d_buf & 15)) return fail(ctx, FQH_E_ARG, "d_buf must be 16-byte aligned");
+    if (d_rec_start && cap == 0) return fail(ctx, FQH_E_ARG, "cap is 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->last_valid = false;
+    fqh_carry c = {};
+    if (in) c = *in;
+    for (int i = 0; i < 4; ++i)
+        if (c.back[i] > c.base_offset) return fail(ctx, FQH_E_ARG, "carry.back exceeds base_offset");
+    ctx->carry_in = c;
+    ctx->whole_file = is_final && carry_is_zero(c);
+    ScanArgs &a = ctx->args;
+    a = ScanArgs{};
+    a.buf = d_buf;
+    a.len = len;
+    a.base_offset = c.base_offset;
+    a.nl_count = c.nl_count;
+    for (int i = 0; i < 4; ++i) a.back[i] = c.back[i];
+    a.is_final = is_final ? 1 : 0;
+    a.v_start = (c.back[0] == 0 && len > 0) ? 1u : 0u;
+    a.bufsize = ctx->bufsize;
+    a.max_walk = ctx->bufsize ? (uint32_t)(ctx->bufsize / WT_BYTES + 3) : 0xFFFFFFFFu;
+    a.n_tiles = (len + WT_BYTES - 1) / WT_BYTES;
+    a.n_blocks = (a.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    a.rec_start = d_rec_start;
+    a.cap = d_rec_start ? cap : 0;
+    a.idx = nullptr;
+    a.idx_cap = 0;
+    fqh_status st = enqueue_scan(ctx, reuse_index);
+    if (st != FQH_OK) return st;
+    ctx->pending = true;
+    return FQH_OK;
+}
+
+static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
+    if (!ctx) return FQH_E_ARG;
+    if (!ctx->pending) return fail(ctx, FQH_E_ARG, "no scan pending");
+    ctx->pending = false;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_out->overflow) {
+        // a tile has more line starts than list_cap (average line < 8 bytes): rerun with lists that
+        // cannot overflow.  Never happens on real FASTQ.
+        ctx->list_cap = WT_BYTES;
+        fqh_status st = enqueue_scan(ctx);
+        if (st != FQH_OK) return st;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_out->overflow) return fail(ctx, FQH_E_DEVICE, "line list overflow after rerun");
+    }
+    float ms = 0;
+    ctx->timing = fqh_timing{};
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->timing.index_ms = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->timing.prefix_ms = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->timing.emit_ms = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) ctx->timing.total_ms = ms;
+    fqh_status st = resolve(ctx, out, carry_out);
+    ctx->last_valid = (st == FQH_OK || st == FQH_E_CAPACITY);
+    return st;
+}
+
+static bool same_scan(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in) {
+    if (!ctx->last_valid) return false;
+    fqh_carry c = {};
+    if (in) c = *in;
+    return ctx->args.buf == d_buf && ctx->args.len == len && ctx->args.is_final == (is_final ? 1 : 0) &&
+           memcmp(&c, &ctx->carry_in, sizeof c) == 0;
+}
+
+// index-only emit of the last scan into `dst` (device), local records [0, n)
+static fqh_status emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap) {
+    ScanArgs b = ctx->args;
+    b.rec_start = nullptr;
+    b.cap = 0;
+    b.idx = dst;
+    b.idx_cap = cap;
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
+    launch_emit(ctx->stream, b, &ctx->d_out[1]);
+    launch_finalize(ctx->stream, b, &ctx->d_out[1]);
+    HIPCHK(ctx, hipGetLastError());
+    return FQH_OK;
+}
+
+extern "C" {
+
+fqh_status fqh_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                           const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap) {
+    return do_scan_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap);
+}
+fqh_status fqh_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
+    return do_scan_finish(ctx, out, carry_out);
+}
+fqh_status fqh_scan(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                    uint64_t *d_rec_start, uint64_t cap, fqh_summary *out, fqh_carry *carry_out) {
+    fqh_status st = do_scan_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap);
+    if (st != FQH_OK) return st;
+    return do_scan_finish(ctx, out, carry_out);
+}
+
+fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, uint64_t *d_rec_start,
+                             uint64_t cap) {
+    if (!ctx) return FQH_E_ARG;
+    if (!ctx->last_valid) return fail(ctx, FQH_E_ARG, "no finished scan whose tile index could be reused");
+    const uint8_t *buf = ctx->args.buf;
+    const uint64_t len = ctx->args.len;
+    return do_scan_launch(ctx, buf, len, is_final, in, d_rec_start, cap, true);
+}
+
+fqh_status fqh_invalidate(fqh_ctx *ctx) {
+    if (!ctx) return FQH_E_ARG;
+    ctx->last_valid = false;
+    return FQH_OK;
+}
+
+fqh_status fqh_carry_combine(const fqh_carry *prev, uint64_t len, uint64_t n_newlines,
+                             uint64_t n_line_starts, const uint64_t back0[4], fqh_carry *next) {
+    if (!next || !back0) return FQH_E_ARG;
+    fqh_carry p = {};
+    if (prev) p = *prev;
+    fqh_carry n = {};
+    n.base_offset = p.base_offset + len;
+    n.nl_count = p.nl_count + n_newlines;
+    // most recent line starts <= end of the shard: first the ones inside the shard (offsets 1..len),
+    // then the one at shard offset 0 if the previous shard ended a line, then the previous carry's.
+    int k = 0;
+    for (; k < 4 && (uint64_t)k < n_line_starts; ++k) n.back[k] = back0[k];
+    int j = 0;
+    if (len == 0) {
+        for (int i = 0; i < 4; ++i) n.back[i] = p.back[i];
+    } else {
+        for (; k < 4; ++k, ++j) {
+            uint64_t v = p.back[j < 4 ? j : 3] + len;
+            n.back[k] = v > n.base_offset ? n.base_offset : v;
+        }
+    }
+    *next = n;
+    return FQH_OK;
+}
+
+fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap) {
+    if (!ctx || !d_index) return FQH_E_ARG;
+    if (!ctx->last_valid || ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "no finished scan to index");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = std::min<uint64_t>(ctx->last_summary.n_records, cap);
+    if (!n) return FQH_OK;
+    fqh_status st = emit_index(ctx, d_index, n);
+    if (st != FQH_OK) return st;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FQH_OK;
+}
+
+fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                            const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
+                            uint64_t *d_base_hist, uint64_t *d_scalars) {
+    if (!ctx) return FQH_E_ARG;
+    if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
+    fqh_status st;
+    if (!same_scan(ctx, d_buf, len, is_final, in)) {
+        st = do_scan_launch(ctx, d_buf, len, is_final, in, nullptr, 0);
+        if (st != FQH_OK) return st;
+        st = do_scan_finish(ctx, nullptr, nullptr);
+        if (st != FQH_OK) return st;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const fqh_timing scan_t = ctx->timing;
+    const uint64_t n = ctx->last_summary.n_records;
+    // the record in progress at the chunk start began in an earlier chunk: its bytes are not here
+    const uint64_t skip = (n && ctx->carry_in.back[ctx->carry_in.nl_count & 3] > 0) ? 1 : 0;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+    if (n > skip) {
+        if (ctx->idx_cap < n) {
+            (void)hipFree(ctx->idx);
+            ctx->idx = nullptr;
+            ctx->idx_cap = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->idx, n * sizeof(fqh_idx_record)));
+            ctx->idx_cap = n;
+        }
+        st = emit_index(ctx, ctx->idx, n);
+        if (st != FQH_OK) return st;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
+    if (n > skip)
+        launch_stats_records(s, d_buf, ctx->carry_in.base_offset, ctx->idx + skip, n - skip, lmax,
+                             d_qual_hist, d_base_hist, d_scalars, ctx->n_cu);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], s));
+    HIPCHK(ctx, hipGetLastError());
+    ctx->timing = scan_t;
+    ctx->stats_pending = true;
+    return FQH_OK;
+}
+
+fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
+    if (!ctx) return FQH_E_ARG;
+    if (!ctx->stats_pending) return fail(ctx, FQH_E_ARG, "no stats pending");
+    ctx->stats_pending = false;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->timing.emit_ms = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]) == hipSuccess) ctx->timing.stats_ms = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[6]) == hipSuccess) ctx->timing.total_ms = ms;
+    if (out) *out = ctx->last_summary;
+    if (carry_out) *carry_out = ctx->last_carry_out;
+    return FQH_OK;
+}
+
+fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                     uint32_t lmax, uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars,
+                     fqh_summary *out, fqh_carry *carry_out) {
+    fqh_status st = fqh_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars);
+    if (st != FQH_OK) return st;
+    return fqh_stats_finish(ctx, out, carry_out);
+}
+
+fqh_status fqh_last_timing(fqh_ctx *ctx, fqh_timing *out) {
+    if (!ctx || !out) return FQH_E_ARG;
+    *out = ctx->timing;
+    return FQH_OK;
+}
+
+fqh_status fqh_synth_fill(fqh_ctx *ctx, uint8_t *d_out, uint64_t byte_off, uint64_t len, uint64_t seed) {
+    if (!ctx || (len && !d_out)) return FQH_E_ARG;
+    if (len && ((uintptr_t)d_out & 15)) return fail(ctx, FQH_E_ARG, "d_out must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_synth(ctx->stream, d_out, byte_off, len, seed);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FQH_OK;
+}
+
+fqh_status fqh_read_ceiling(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t *checksum, float *ms) {
+    if (!ctx || (len && !d_buf)) return FQH_E_ARG;
+    if (len && ((uintptr_t)d_buf & 15)) return fail(ctx, FQH_E_ARG, "d_buf must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_misc, 0, 64, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[7], s));
+    launch_read_ceiling(s, d_buf, len, ctx->d_misc);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], s));
+    HIPCHK(ctx, hipGetLastError());
+    uint64_t sum = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&sum, ctx->d_misc, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    float t = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&t, ctx->ev[7], ctx->ev[6]));
+    if (checksum) *checksum = sum;
+    if (ms) *ms = t;
+    return FQH_OK;
+}
+
+fqh_status fqh_dev_alloc(fqh_ctx *ctx, uint64_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(d_ptr, bytes ? bytes : 16));
+    return FQH_OK;
+}
+fqh_status fqh_dev_free(fqh_ctx *ctx, void *d_ptr) {
+    if (!ctx) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipFree(d_ptr));
+    return FQH_OK;
+}
+fqh_status fqh_memcpy_h2d(fqh_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (!ctx) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FQH_OK;
+}
+fqh_status fqh_memcpy_d2h(fqh_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes) {
+    if (!ctx) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FQH_OK;
+}
+fqh_status fqh_memset(fqh_ctx *ctx, void *d_dst, int value, uint64_t bytes) {
+    if (!ctx) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FQH_OK;
+}
+
+}  // extern "C"

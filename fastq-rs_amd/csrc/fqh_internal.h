@@ -1,0 +1,74 @@
+// fqh_internal.h — layouts shared by the HIP kernels and the host side of libfastq_hip.so.
+//
+// Data layout in HBM:
+//   input        d_buf[len]                       caller-owned, 16-byte aligned
+//   wave tile    16 KiB of input = 16 pieces of 1 KiB; one wavefront owns one tile
+//   line list    u16 list[n_tiles][list_cap]      one entry per LINE START inside the tile
+//                bits 0..13 tile-relative offset, bit 14 byte=='@', bit 15 byte=='+'
+//   tile_count   u32 [n_tiles]                    entries of each tile (true count, may exceed cap)
+//   tile_prefix  u32 [n_tiles] + block_prefix u64 [n_tiles/2048 + 1]   exclusive scan of tile_count
+//   rec_start    u64 [n_records + 1]              caller-owned output
+//   index        fqh_idx_record [n_records]       optional (stats / RecordSet hand-back)
+#pragma once
+#include <stdint.h>
+
+#include "../../include/fastq_hip.h"
+
+namespace fqh {
+
+constexpr uint32_t WT_BYTES = 16384;    // bytes per wave tile
+constexpr uint32_t WT_SHIFT = 14;
+constexpr uint32_t PIECE_BYTES = 1024;  // one wave-wide 16-byte load
+constexpr uint32_t WT_PIECES = WT_BYTES / PIECE_BYTES;
+constexpr uint32_t LIST_CAP_DEFAULT = 2048;  // average line >= 8 bytes; rerun with WT_BYTES if not
+constexpr uint32_t SCAN_CHUNK = 2048;        // tiles per block of the tile-count scan
+constexpr uint32_t SCAN_SHIFT = 11;
+constexpr unsigned long long NOKEY = ~0ull;
+
+// Everything the emit / finalize kernels need to know about one scan call.
+struct ScanArgs {
+    const uint8_t *buf;
+    uint64_t len;
+    // carry-in (fqh_carry)
+    uint64_t base_offset, nl_count;
+    uint64_t back[4];
+    int32_t is_final;
+    uint32_t v_start;   // 1 if a line starts at chunk offset 0 (back[0]==0 && len>0)
+    uint64_t bufsize;   // 0 = unlimited
+    uint32_t max_walk;  // tiles a predecessor search may cross before the record is "too long"
+    // tile index
+    const uint16_t *list;
+    uint32_t list_cap;
+    const uint32_t *tile_count;
+    const uint32_t *tile_prefix;   // exclusive prefix inside its SCAN_CHUNK block
+    const uint64_t *block_prefix;  // exclusive prefix of block sums; [n_blocks] = total
+    uint64_t n_tiles;
+    uint64_t n_blocks;
+    // outputs
+    uint64_t *rec_start;
+    uint64_t cap;
+    fqh_idx_record *idx;
+    uint64_t idx_cap;
+};
+
+// Device-resident accumulators and the finalize kernel's results (one D2H copy per scan).
+struct DevOut {
+    // accumulated by k_index / k_emit with atomics; reset before every scan
+    unsigned long long min_key;     // min(record * 4 + stage) over violated predicates
+    unsigned long long first_long;  // min global record index with length >= bufsize - 15
+    unsigned long long max_len;     // longest complete record ending in the chunk
+    unsigned long long overflow;    // tiles whose list overflowed list_cap (=> rerun)
+    // written by k_finalize
+    unsigned long long total_entries;
+    unsigned long long lastnl;
+    long long recent[4];            // most recent line starts <= len, chunk-relative (may be < 0)
+    unsigned long long n_newlines;
+    unsigned long long final_key;   // min_key incl. the truncation rule; NOKEY if none
+    unsigned long long n_records;   // records ending in the chunk before the first error
+    long long end_off;              // chunk-relative end of the last good record (may be < 0)
+    long long err_start;            // chunk-relative start of the failing record
+    unsigned long long err_need;    // bytes of the failing record needed to see its error (0: n/a)
+    unsigned long long tail_len;
+};
+
+}  // namespace fqh

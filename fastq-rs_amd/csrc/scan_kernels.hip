@@ -1,0 +1,467 @@
+// scan_kernels.hip — gfx950 kernels of the record scan.
+//
+//   k_index     streaming byte-scan: one wavefront per 16 KiB tile, 16-byte coalesced loads,
+//               SWAR newline detection, ballot/mbcnt in-wave prefix, emits the tile's line-start
+//               list (replaces the memchr loop of src/records.rs:141,155,214,228).  Phase-free:
+//               needs no information from any other tile, shard or GPU.
+//   k_prefix_*  exclusive scan of the per-tile counts.
+//   k_emit      walks the line-start lists with the global line index known: record offsets,
+//               '@' / '+' / length checks in the order of src/records.rs:201-247.
+//   k_finalize  EOF rule (src/lib.rs:264-294), carry-out, summary.
+#include <hip/hip_runtime.h>
+
+#include "fqh_internal.h"
+
+namespace fqh {
+
+// ---------------------------------------------------------------------------------------------
+// byte-scan helpers
+// 0x80 in every byte of t that is zero (exact, no false positives)
+__device__ __forceinline__ uint32_t zero_flags(uint32_t t) {
+    return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+}
+// flags at bits 7,15,23,31 -> nibble
+__device__ __forceinline__ uint32_t nib(uint32_t m) {
+    m >>= 7;
+    m |= m >> 7;
+    m |= m >> 14;
+    return m & 0xFu;
+}
+// positional 16-bit mask: bit q set iff byte q of the 16-byte chunk equals the pattern byte
+__device__ __forceinline__ uint32_t eqmask16(const uint4 &v, uint32_t pat4) {
+    return nib(zero_flags(v.x ^ pat4)) | (nib(zero_flags(v.y ^ pat4)) << 4) |
+           (nib(zero_flags(v.z ^ pat4)) << 8) | (nib(zero_flags(v.w ^ pat4)) << 12);
+}
+// byte q (0..15) of a 16-byte chunk held in registers: pick the 8-byte half with two selects, then
+// v_perm_b32 pulls the byte out (selector 0x0C = constant zero).  Written this way so the compiler
+// does not turn it into an indexed vector extract through LDS.
+__device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t q) {
+    const uint32_t lo = q < 8 ? v.x : v.z;
+    const uint32_t hi = q < 8 ? v.y : v.w;
+    return __builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (q & 7u));
+}
+// 16 bytes at buf+off; bytes at or beyond len read as 0
+__device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ buf, uint64_t off, uint64_t len) {
+    if (off + 16 <= len) return *reinterpret_cast<const uint4 *>(buf + off);
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // no indexed array: it would be promoted to LDS
+    if (off < len) {
+        const uint32_t n = (uint32_t)(len - off);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t b = (uint32_t)buf[off + i] << ((i & 3u) * 8u);
+            if (i < 4) w0 |= b; else if (i < 8) w1 |= b; else if (i < 12) w2 |= b; else w3 |= b;
+        }
+    }
+    return make_uint4(w0, w1, w2, w3);
+}
+// exclusive prefix of small per-lane counts over the wavefront with ballots + mbcnt
+__device__ __forceinline__ uint32_t wave_prefix_small(uint32_t c, uint32_t &total) {
+    uint32_t pre = 0;
+    total = 0;
+    for (uint32_t k = 1;; ++k) {
+        unsigned long long b = __ballot(c >= k);
+        if (b == 0) break;
+        pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
+        total += (uint32_t)__popcll(b);
+    }
+    return pre;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_index: one wavefront per 16 KiB tile.
+__global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ buf, uint64_t len,
+                                               uint16_t *__restrict__ list, uint32_t list_cap,
+                                               uint32_t *__restrict__ tile_count, uint64_t n_tiles,
+                                               DevOut *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const uint64_t tbase = tile << WT_SHIFT;
+    uint16_t *__restrict__ tl = list + tile * list_cap;
+
+    uint32_t run = 0;
+    // Is the byte before the piece a newline?  Offset 0 of the chunk is never emitted here: whether
+    // a line starts there is carry information, handled by k_finalize.
+    uint32_t prev = 0;
+    if (tile > 0) prev = (buf[tbase - 1] == '\n') ? 1u : 0u;
+
+    // one 1 KiB piece: 16 bytes per lane, already in registers (by value: no indexed array, which
+    // the compiler would promote to LDS)
+    auto piece = [&](const uint4 v, const uint64_t off, const uint32_t pbase) {
+        const uint32_t M = eqmask16(v, 0x0A0A0A0Au);
+        const uint32_t up = __shfl_up(M >> 15, 1);
+        uint32_t LS = ((M << 1) | (lane ? up : prev)) & 0xFFFFu;
+        if (off + 16 > len) {  // a line start must be an existing byte
+            const uint32_t nvalid = off < len ? (uint32_t)(len - off) : 0u;
+            LS &= (1u << nvalid) - 1u;
+        }
+        prev = ((uint32_t)__builtin_amdgcn_readlane((int)M, 63)) >> 15;
+        uint32_t tot;
+        uint32_t idx = run + wave_prefix_small(__popc(LS), tot);
+        while (LS) {
+            const uint32_t q = __ffs(LS) - 1;
+            LS &= LS - 1;
+            const uint32_t b = byte_of(v, q);
+            const uint32_t e = (pbase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u);
+            if (idx < list_cap) tl[idx] = (uint16_t)e;
+            ++idx;
+        }
+        run += tot;
+    };
+#pragma unroll 1
+    for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
+        const uint64_t gbase = tbase + (uint64_t)g * 4 * PIECE_BYTES + lane * 16;
+        if (tbase + (uint64_t)g * 4 * PIECE_BYTES >= len) break;  // uniform
+        const uint4 v0 = load16(buf, gbase, len);
+        const uint4 v1 = load16(buf, gbase + PIECE_BYTES, len);
+        const uint4 v2 = load16(buf, gbase + 2 * PIECE_BYTES, len);
+        const uint4 v3 = load16(buf, gbase + 3 * PIECE_BYTES, len);
+        const uint32_t pb = g * 4 * PIECE_BYTES + lane * 16;
+        piece(v0, gbase, pb);
+        piece(v1, gbase + PIECE_BYTES, pb + PIECE_BYTES);
+        piece(v2, gbase + 2 * PIECE_BYTES, pb + 2 * PIECE_BYTES);
+        piece(v3, gbase + 3 * PIECE_BYTES, pb + 3 * PIECE_BYTES);
+    }
+    if (lane == 0) {
+        tile_count[tile] = run;
+        if (run > list_cap) atomicAdd(&out->overflow, 1ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of tile_count: per-block local prefix + block sums, then the block sums.
+__global__ __launch_bounds__(256) void k_prefix_local(const uint32_t *__restrict__ tile_count,
+                                                      uint32_t *__restrict__ tile_prefix,
+                                                      uint64_t *__restrict__ block_sum,
+                                                      uint64_t n_tiles) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t t0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)tid * 8;
+    uint32_t c[8];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c[i] = (t0 + i < n_tiles) ? tile_count[t0 + i] : 0u;
+        s += c[i];
+    }
+    // inclusive wave scan of s
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
+    uint32_t ex = wbase + inc - s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (t0 + i < n_tiles) tile_prefix[t0 + i] = ex;
+        ex += c[i];
+    }
+    if (tid == 255) block_sum[blockIdx.x] = (uint64_t)wbase + inc;
+}
+
+// single block: block_prefix[b] = exclusive prefix of block_sum, block_prefix[n_blocks] = total.
+// In place (block_sum == block_prefix is allowed: array has n_blocks + 1 slots).
+__global__ __launch_bounds__(1024) void k_prefix_top(uint64_t *__restrict__ block_prefix, uint64_t n_blocks) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n_blocks; base += 1024) {
+        const uint64_t i = base + tid;
+        unsigned long long s = (i < n_blocks) ? block_prefix[i] : 0ull;
+        unsigned long long inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long o = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long wbase = carry;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
+        if (i < n_blocks) block_prefix[i] = wbase + inc - s;
+        __syncthreads();
+        if (tid == 1023) carry = wbase + inc;
+        __syncthreads();
+    }
+    if (tid == 0) block_prefix[n_blocks] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers on the tile index
+__device__ __forceinline__ uint64_t tile_pref(const ScanArgs &a, uint64_t t) {
+    return a.block_prefix[t >> SCAN_SHIFT] + a.tile_prefix[t];
+}
+__device__ __forceinline__ uint32_t tile_cnt(const ScanArgs &a, uint64_t t) {
+    uint32_t c = a.tile_count[t];
+    return c < a.list_cap ? c : a.list_cap;
+}
+__device__ __forceinline__ long long entry_start(const ScanArgs &a, uint64_t t, uint32_t i) {
+    return (long long)((t << WT_SHIFT) + (a.list[t * a.list_cap + i] & 0x3FFFu));
+}
+
+// The (up to) four line starts that precede entry i of tile t, most recent first.  t == n_tiles,
+// i == 0 asks for the starts preceding the end of the chunk.  Starts before the chunk come from the
+// virtual start entry (offset 0) and the carry.  Returns false if the search crossed more than
+// max_walk tiles: then the enclosing record is longer than BUFSIZE and the rest is filled with a
+// far-away sentinel.
+__device__ bool collect_prev(const ScanArgs &a, uint64_t t, uint32_t i, long long out[4]) {
+    int n = 0;
+    long long ti = (long long)t;
+    long long ii = (long long)i - 1;
+    uint32_t walked = 0;
+    bool ok = true;
+    while (n < 4) {
+        if (ii >= 0) {
+            out[n++] = entry_start(a, (uint64_t)ti, (uint32_t)ii);
+            --ii;
+            continue;
+        }
+        --ti;
+        if (ti < 0) break;
+        if (++walked > a.max_walk) {
+            ok = false;
+            break;
+        }
+        ii = (long long)tile_cnt(a, (uint64_t)ti) - 1;
+    }
+    if (!ok) {
+        while (n < 4) out[n++] = -(1ll << 60);
+        return false;
+    }
+    if (n < 4) {
+        int j = 0;
+        if (a.v_start) {
+            out[n++] = 0;
+            j = 1;
+        }
+        while (n < 4) {
+            out[n++] = -(long long)a.back[j < 4 ? j : 3];
+            ++j;
+        }
+    }
+    return true;
+}
+
+struct Acc {
+    unsigned long long key, first_long, max_len;
+};
+
+// Checks of the record that ENDS right before the line start S (global line index l, l % 4 == 0):
+// length rule src/records.rs:233-238, record length for the too-long rule, index entry.
+__device__ __forceinline__ void close_record(const ScanArgs &a, uint64_t t, uint32_t i, long long S,
+                                             unsigned long long l, Acc &acc) {
+    long long p[4];
+    const bool ok = collect_prev(a, t, i, p);
+    const unsigned long long rec = (l >> 2) - 1;  // the record that just ended
+    unsigned long long reclen;
+    if (ok) {
+        // newlines: nl0=p[2]-1 nl1=p[1]-1 nl2=p[0]-1 nl3=S-1; raw line lengths nl3-nl2 vs nl1-nl0
+        if ((S - p[0]) != (p[1] - p[2])) {
+            unsigned long long k = rec * 4 + 2;
+            if (k < acc.key) acc.key = k;
+        }
+        reclen = (unsigned long long)(S - p[3]);
+    } else {
+        reclen = 1ull << 60;
+    }
+    if (reclen > acc.max_len) acc.max_len = reclen;
+    if (a.bufsize && reclen + 15 >= a.bufsize && rec < acc.first_long) acc.first_long = rec;
+    const unsigned long long r = (l >> 2) - (a.nl_count >> 2);  // local index of the NEXT record
+    if (a.idx && ok && r - 1 < a.idx_cap) {
+        fqh_idx_record ir;
+        ir.start = a.base_offset + (unsigned long long)p[3];
+        ir.head = (uint32_t)(p[2] - 1 - p[3]);
+        ir.seq = (uint32_t)(p[1] - 1 - p[3]);
+        ir.sep = (uint32_t)(p[0] - 1 - p[3]);
+        ir.qual = (uint32_t)(S - 1 - p[3]);
+        a.idx[r - 1] = ir;
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(v, d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_emit: one wavefront per tile, lanes stride over the tile's line-start entries.
+__global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.n_tiles) return;
+    const uint32_t cnt = tile_cnt(a, t);
+    if (cnt == 0) return;
+    const unsigned long long lbase = a.nl_count + 1 + tile_pref(a, t);
+    const unsigned long long r0 = a.nl_count >> 2;
+    Acc acc = {NOKEY, NOKEY, 0};
+    for (uint32_t i = lane; i < cnt; i += 64) {
+        const uint32_t e = a.list[t * a.list_cap + i];
+        const long long S = (long long)((t << WT_SHIFT) + (e & 0x3FFFu));
+        const unsigned long long l = lbase + i;
+        const uint32_t ph = (uint32_t)l & 3u;
+        if (ph == 0) {
+            if (!(e & 0x4000u)) {  // read_header: src/records.rs:138-147
+                unsigned long long k = (l >> 2) * 4 + 0;
+                if (k < acc.key) acc.key = k;
+            }
+            const unsigned long long r = (l >> 2) - r0;
+            if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + (unsigned long long)S;
+            close_record(a, t, i, S, l, acc);
+        } else if (ph == 2) {
+            if (!(e & 0x8000u)) {  // read_sep: src/records.rs:152-161
+                unsigned long long k = (l >> 2) * 4 + 1;
+                if (k < acc.key) acc.key = k;
+            }
+        }
+    }
+    const unsigned long long k = wave_min_u64(acc.key);
+    const unsigned long long fl = wave_min_u64(acc.first_long);
+    const unsigned long long ml = wave_max_u64(acc.max_len);
+    if (lane == 0) {
+        if (k != NOKEY) atomicMin(&out->min_key, k);
+        if (fl != NOKEY) atomicMin(&out->first_long, fl);
+        if (ml) atomicMax(&out->max_len, ml);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunk-relative start of global line L (must be one of: a line start before the chunk that the
+// carry still knows, the virtual start, a list entry, or the virtual end).
+__device__ long long start_of_line(const ScanArgs &a, unsigned long long L, unsigned long long E,
+                                   bool lastnl) {
+    if (L <= a.nl_count) {
+        unsigned long long j = a.nl_count - L;
+        if (j == 0 && a.v_start) return 0;
+        return -(long long)a.back[j < 4 ? j : 3];
+    }
+    unsigned long long e = L - (a.nl_count + 1);
+    if (e >= E) return (long long)a.len;  // virtual end (only asked for when lastnl)
+    // largest tile whose exclusive prefix is <= e
+    uint64_t lo = 0, hi = a.n_tiles;  // invariant: pref(lo) <= e
+    while (hi - lo > 1) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (tile_pref(a, mid) <= e) lo = mid; else hi = mid;
+    }
+    return entry_start(a, lo, (uint32_t)(e - tile_pref(a, lo)));
+}
+
+// k_finalize: one thread.  EOF rule of src/lib.rs:264-294, virtual entries at both chunk ends,
+// carry-out, summary.
+__global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
+    const bool lastnl = a.len > 0 && a.buf[a.len - 1] == '\n';
+    Acc acc = {out->min_key, out->first_long, out->max_len};
+    const unsigned long long r0 = a.nl_count >> 2;
+
+    // virtual start entry: a line starts at chunk offset 0
+    if (a.v_start) {
+        const unsigned long long l = a.nl_count;
+        const uint8_t b = a.buf[0];
+        if ((l & 3) == 0 && b != '@') { unsigned long long k = (l >> 2) * 4; if (k < acc.key) acc.key = k; }
+        if ((l & 3) == 2 && b != '+') { unsigned long long k = (l >> 2) * 4 + 1; if (k < acc.key) acc.key = k; }
+    }
+    // start of the record in progress at the chunk start
+    if (a.rec_start && a.cap > 0)
+        a.rec_start[0] = a.base_offset - a.back[a.nl_count & 3];
+
+    // line starts preceding the end of the chunk
+    long long p[4];
+    collect_prev(a, a.n_tiles, 0, p);
+    long long recent[4];
+    if (lastnl) {
+        // virtual end entry: a line would start at offset len
+        const unsigned long long l = a.nl_count + 1 + E;
+        if ((l & 3) == 0) {
+            close_record(a, a.n_tiles, 0, (long long)a.len, l, acc);
+            const unsigned long long r = (l >> 2) - r0;
+            if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + a.len;
+        }
+        recent[0] = (long long)a.len; recent[1] = p[0]; recent[2] = p[1]; recent[3] = p[2];
+    } else {
+        recent[0] = p[0]; recent[1] = p[1]; recent[2] = p[2]; recent[3] = p[3];
+    }
+    const unsigned long long n_newlines = a.len ? E + (lastnl ? 1 : 0) : 0;
+    const unsigned long long T = a.nl_count + n_newlines;
+    const unsigned long long col = (unsigned long long)((long long)a.len - recent[0]);
+    const bool tail = (T & 3) != 0 || col > 0;
+    if (a.is_final && tail) {  // "Possibly truncated input file", src/lib.rs:286-291
+        unsigned long long k = (T >> 2) * 4 + 3;
+        if (k < acc.key) acc.key = k;
+    }
+    const unsigned long long k_end = T >> 2;
+    unsigned long long n_good = k_end;
+    if (acc.key != NOKEY && (acc.key >> 2) < n_good) n_good = acc.key >> 2;
+    // end of the last good record = start of line 4 * n_good
+    long long end_off;
+    if (n_good == k_end) end_off = recent[T & 3];
+    else end_off = start_of_line(a, n_good * 4, E, lastnl);
+    long long err_start = end_off;
+    unsigned long long need = 0;
+    if (acc.key != NOKEY) {
+        const unsigned long long e = acc.key >> 2;
+        const uint32_t stage = (uint32_t)acc.key & 3u;
+        err_start = (e == k_end) ? recent[T & 3] : start_of_line(a, e * 4, E, lastnl);
+        if (stage == 0) need = 1;
+        else if (stage == 1) need = (unsigned long long)(start_of_line(a, e * 4 + 2, E, lastnl) + 1 - err_start);
+        else if (stage == 2) need = (unsigned long long)(start_of_line(a, e * 4 + 4, E, lastnl) - err_start);
+    }
+    out->min_key = acc.key;
+    out->first_long = acc.first_long;
+    out->max_len = acc.max_len;
+    out->total_entries = E;
+    out->lastnl = lastnl;
+    for (int i = 0; i < 4; ++i) out->recent[i] = recent[i];
+    out->n_newlines = n_newlines;
+    out->final_key = acc.key;
+    out->n_records = n_good - r0;
+    out->end_off = end_off;
+    out->err_start = err_start;
+    out->err_need = need;
+    out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (host)
+void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
+                  uint32_t *tile_count, uint64_t n_tiles, DevOut *out) {
+    if (!n_tiles) return;
+    const uint64_t blocks = (n_tiles + 3) / 4;
+    hipLaunchKernelGGL(k_index, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
+                       tile_count, n_tiles, out);
+}
+void launch_prefix(hipStream_t s, const uint32_t *tile_count, uint32_t *tile_prefix,
+                   uint64_t *block_prefix, uint64_t n_tiles, uint64_t n_blocks) {
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(k_prefix_local, dim3((uint32_t)n_blocks), dim3(256), 0, s, tile_count,
+                       tile_prefix, block_prefix, n_tiles);
+    hipLaunchKernelGGL(k_prefix_top, dim3(1), dim3(1024), 0, s, block_prefix, n_blocks);
+}
+void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out) {
+    if (!a.n_tiles) return;
+    const uint64_t blocks = (a.n_tiles + 3) / 4;
+    hipLaunchKernelGGL(k_emit, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+}
+void launch_finalize(hipStream_t s, const ScanArgs &a, DevOut *out) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, a, out);
+}
+
+}  // namespace fqh

@@ -1,0 +1,174 @@
+/* fastq_hip.h — C ABI of libfastq_hip.so: the MI355X (gfx950) FASTQ record-scan and per-read
+ * statistics path that sits behind the `fastq` crate's Parser / Record / parallel_each surface.
+ *
+ * The reference crate (aseyboldt/fastq-rs, fastq 0.6.0) has no FFI of its own; this header is the
+ * seam a Rust (or C/C++/Python) host binds.  Every entry point names the reference interface it
+ * replaces.  Plain C: opaque handle, plain pointers and sizes, status codes, no exceptions, no
+ * torch types.  Device pointers are raw HIP device addresses (hipMalloc / torch `data_ptr()`).
+ *
+ *   reference (CPU, one record at a time)                        this ABI (GPU, whole buffers)
+ *   ------------------------------------------------------------ ------------------------------
+ *   IdxRecord::from_buffer          src/records.rs:201-247        fqh_scan
+ *   read_header / read_sep          src/records.rs:137-163        fqh_scan (validation keys)
+ *   memchr('\n')                    src/records.rs:141,155,214,228 fqh_scan (byte-scan kernel)
+ *   RecordRefIter::advance / each   src/lib.rs:221-304            fqh_scan + fqh_summary
+ *   RecordSetIter::next             src/lib.rs:364-425            fqh_scan (record offsets) +
+ *                                                                 fqh_index_records
+ *   loop over Record::seq()/qual()  src/records.rs:75-90 (a8)     fqh_stats
+ *   validate_dna / validate_dnan    src/records.rs:19-33          fqh_stats (scalars 3,4)
+ *   Buffer                          src/buffer.rs:1-112           fqh_stream_* (pinned ring)
+ *   thread_reader                   src/thread_reader.rs:182-200  fqh_stream_* (copy stream)
+ *   parallel_each gather            src/lib.rs:553-559            fqh_reduce_* (RCCL/torch)
+ */
+#ifndef FASTQ_HIP_H
+#define FASTQ_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQH_ABI_VERSION 1
+#define FQH_BUFSIZE (68u * 1024u) /* BUFSIZE, src/lib.rs:128-129 */
+
+typedef struct fqh_ctx fqh_ctx; /* one per device and host thread; not thread-safe */
+
+typedef enum {
+    FQH_OK = 0,
+    FQH_E_HEADER = 1,       /* "Fastq headers must start with '@'"        src/records.rs:143-146 */
+    FQH_E_SEP = 2,          /* "Sequence and quality not separated by +"  src/records.rs:157-160 */
+    FQH_E_LEN_MISMATCH = 3, /* "Sequence and quality length mismatch"     src/records.rs:234-237 */
+    FQH_E_TRUNCATED = 4,    /* "Possibly truncated input file"            src/lib.rs:287-290     */
+    FQH_E_TOO_LONG = 5,     /* "Fastq record is too long"                 src/lib.rs:279-282     */
+    FQH_E_IO = 6,
+    FQH_E_DEVICE = 7,       /* HIP runtime error; fqh_last_error() has the text */
+    FQH_E_ARG = 8,
+    FQH_E_CAPACITY = 9      /* rec_start / index capacity too small; summary.n_records is exact */
+} fqh_status;
+
+/* Parser state at a byte boundary of the input: everything a scan of the NEXT chunk needs to be
+ * bit-exact without seeing earlier bytes.  All-zero = start of file.  (The reference keeps the same
+ * information implicitly in its 68 KiB window: src/lib.rs:255-303.) */
+typedef struct {
+    uint64_t base_offset; /* file offset of the chunk's first byte                               */
+    uint64_t nl_count;    /* '\n' seen before the chunk (nl_count % 4 = line phase, / 4 = record) */
+    uint64_t back[4];     /* back[i] = chunk_start - (i-th most recent line start <= chunk_start);
+                             back[0] is the column of the chunk's first byte; starts older than
+                             the file start are clamped to the file start                        */
+} fqh_carry;
+
+typedef struct {
+    uint64_t n_records;      /* records that END in this chunk, before the first error            */
+    uint64_t bytes_consumed; /* chunk-relative offset just past the last of them (0 if none)      */
+    int32_t parse_status;    /* FQH_OK or FQH_E_HEADER..FQH_E_TOO_LONG (is_final decides EOF rule)*/
+    int32_t reserved;
+    uint64_t err_record;     /* global index of the failing record (nl_count/4-based)             */
+    uint64_t err_offset;     /* file offset of the failing record's first byte                    */
+    uint64_t n_newlines;     /* '\n' in this chunk                                                */
+    uint64_t tail_len;       /* bytes after the last complete record (carried when !is_final)     */
+    uint64_t max_record_len; /* longest record ending in this chunk (bytes, incl. last '\n')      */
+    uint64_t n_line_starts;  /* line starts at chunk offsets 1..len (len counts if the last byte is
+                                '\n'): how many entries of carry_out.back[] lie inside this chunk  */
+} fqh_summary;
+
+/* One record of the index, the GPU-side counterpart of IdxRecord (src/records.rs:56-63):
+ * start = file offset of '@'; head/seq/sep/qual = offsets of the four '\n' relative to start. */
+typedef struct {
+    uint64_t start;
+    uint32_t head, seq, sep, qual;
+} fqh_idx_record;
+
+#define FQH_NSCALARS 8
+/* d_scalars layout of fqh_stats: [0] n_records [1] n_bases = sum len(seq()) [2] sum len(qual())
+ * [3] n_valid_dna [4] n_valid_dnan [5] seq bytes at position >= lmax [6] qual bytes >= lmax [7] 0 */
+
+fqh_status fqh_create(int device, fqh_ctx **out);
+void fqh_destroy(fqh_ctx *ctx);
+const char *fqh_strerror(fqh_status s); /* the reference's exact message strings for 1..5 */
+const char *fqh_last_error(fqh_ctx *ctx);
+int fqh_abi_version(void);
+
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+fqh_status fqh_set_stream(fqh_ctx *ctx, void *hip_stream);
+/* BUFSIZE used for the "record is too long" rule (default FQH_BUFSIZE; 64 = cfg(fuzzing),
+ * src/lib.rs:126-127; 0 = no limit). */
+fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
+
+/* Record scan.  d_buf[0..len) are device-resident bytes; `in` (NULL = start of file) describes
+ * where in the file they sit.  Writes d_rec_start[0..n_records]: [0] = file offset of the record in
+ * progress at the chunk start, [i] = file offset just past the i-th record that ends in this chunk
+ * (so record i of the chunk is [d_rec_start[i], d_rec_start[i+1])).  d_rec_start may be NULL
+ * (count + validate only); cap = its capacity in elements.  Blocking: returns with `out` filled. */
+fqh_status fqh_scan(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                    const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap, fqh_summary *out,
+                    fqh_carry *carry_out);
+
+/* Same scan split in two so a host can overlap the launch with other work (and so a benchmark can
+ * time the kernels alone): fqh_scan_launch enqueues every kernel and returns; fqh_scan_finish
+ * waits, resolves the summary.  Exactly one finish per launch. */
+fqh_status fqh_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                           const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap);
+fqh_status fqh_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
+
+/* Byte-range sharding: the byte scan of a shard needs nothing from other shards, only
+ * the emit step needs the carry.  So every rank first scans its shard as if it began the file
+ * (fqh_scan with in = NULL, is_final = 0, d_rec_start = NULL), the ranks exchange
+ * (len, summary.n_newlines, summary.n_line_starts, carry_out.back[4]) — 7 words — and fold them in
+ * rank order with fqh_carry_combine to get each shard's true carry-in; fqh_rescan_launch then redoes
+ * only the cheap emit/validate step on the tile index the first call left in the context (the
+ * buffer must be unchanged).  Finish with fqh_scan_finish. */
+fqh_status fqh_carry_combine(const fqh_carry *prev, uint64_t len, uint64_t n_newlines,
+                             uint64_t n_line_starts, const uint64_t back_zero_carry[4],
+                             fqh_carry *next);
+fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, uint64_t *d_rec_start,
+                             uint64_t cap);
+/* Forget the cached tile index (call after overwriting a buffer that was scanned). */
+fqh_status fqh_invalidate(fqh_ctx *ctx);
+
+/* Full IdxRecord-style index of the records found by the LAST fqh_scan on this context (same
+ * d_buf): d_index[0..n) with n = min(n_records, cap). */
+fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap);
+
+/* Per-position statistics over the records the scan delivers (everything before the first
+ * error): d_qual_hist[p*256 + qual()[p]] and d_base_hist[p*8 + class(seq()[p])] for p < lmax
+ * (classes A0 C1 G2 T3 N4 other5), d_scalars as above.  All are u64 device arrays that are ADDED
+ * to (zero them first).  Runs the scan itself unless the last fqh_scan on this context was on the
+ * same (d_buf, len, carry), in which case its tile index is reused. */
+fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                     const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
+                     uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out,
+                     fqh_carry *carry_out);
+fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                            const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
+                            uint64_t *d_base_hist, uint64_t *d_scalars);
+fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
+
+/* Timing of the kernels of the last launch/finish pair, measured with HIP events on the
+ * launch stream: total and per-kernel milliseconds (index, prefix, emit, stats). */
+typedef struct {
+    float total_ms, index_ms, prefix_ms, emit_ms, stats_ms;
+} fqh_timing;
+fqh_status fqh_last_timing(fqh_ctx *ctx, fqh_timing *out);
+
+/* Synthetic 150 bp FASTQ of SURVEY §8d, generated in HBM: bytes [byte_off, byte_off+len) of the
+ * infinite synthetic file (330 bytes per record, record i a pure function of (seed, i)). */
+fqh_status fqh_synth_fill(fqh_ctx *ctx, uint8_t *d_out, uint64_t byte_off, uint64_t len,
+                          uint64_t seed);
+
+/* Plain 16-byte-load read-reduction over d_buf: the measured streaming-read ceiling the roofline
+ * fraction is compared with.  *checksum receives the 64-bit sum of all dwords. */
+fqh_status fqh_read_ceiling(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t *checksum,
+                            float *ms);
+
+/* Device memory helpers for hosts without their own allocator (the C++ mirror, the CLI). */
+fqh_status fqh_dev_alloc(fqh_ctx *ctx, uint64_t bytes, void **d_ptr);
+fqh_status fqh_dev_free(fqh_ctx *ctx, void *d_ptr);
+fqh_status fqh_memcpy_h2d(fqh_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+fqh_status fqh_memcpy_d2h(fqh_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+fqh_status fqh_memset(fqh_ctx *ctx, void *d_dst, int value, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,342 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI (include/fastq_hip.h),
+against the CPU oracle on the same bytes — bit-exact record counts, offsets, index entries, error
+kind / error record, and integer histograms.  Mirrors the reference's own tests
+(src/lib.rs:611-811) plus the edge cases they do not pin."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fuzzgen
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_unit_tests.json")) as f:
+    GOLD = json.load(f)
+
+
+def build_input(parts):
+    out = bytearray()
+    for p in parts:
+        out += p[1].encode("latin-1") * (p[2] if p[0] == "rep" else 1)
+    return bytes(out)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(torch, pkg):
+    c = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+class Gpu:
+    """Small helper: host bytes -> device tensor -> fqh_scan / fqh_stats -> numpy."""
+
+    def __init__(self, torch, ctx, pkg):
+        self.t, self.ctx, self.pkg = torch, ctx, pkg
+        self.dev = torch.device("cuda:0")
+
+    def upload(self, data):
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        n = a.size
+        d = self.t.empty(max(n, 16), dtype=self.t.uint8, device=self.dev)
+        if n:
+            d[:n].copy_(self.t.from_numpy(a.copy()))
+        return d, n
+
+    def scan(self, data, is_final=True, carry=None, bufsize=None, want_offsets=True):
+        d, n = self.upload(data)
+        return self.scan_dev(d, n, is_final, carry, bufsize, want_offsets)
+
+    def scan_dev(self, d, n, is_final=True, carry=None, bufsize=None, want_offsets=True, off=0):
+        self.ctx.set_bufsize(self.pkg.BUFSIZE if bufsize is None else bufsize)
+        cap = n // 6 + 3
+        rs = self.t.zeros(cap, dtype=self.t.int64, device=self.dev) if want_offsets else None
+        s, c, st = self.ctx.scan(d.data_ptr() + off, n, is_final, carry,
+                                 rs.data_ptr() if want_offsets else None, cap if want_offsets else 0)
+        assert st == self.pkg.OK
+        offs = rs.cpu().numpy().astype(np.uint64)[: s.n_records + 1] if want_offsets else None
+        return s, c, offs
+
+    def stats(self, data, lmax, bufsize=None):
+        d, n = self.upload(data)
+        self.ctx.set_bufsize(self.pkg.BUFSIZE if bufsize is None else bufsize)
+        qh = self.t.zeros(lmax * 256, dtype=self.t.int64, device=self.dev)
+        bh = self.t.zeros(lmax * 8, dtype=self.t.int64, device=self.dev)
+        sc = self.t.zeros(8, dtype=self.t.int64, device=self.dev)
+        s, c = self.ctx.stats(d.data_ptr(), n, lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+        return (s, qh.cpu().numpy().astype(np.uint64).reshape(lmax, 256),
+                bh.cpu().numpy().astype(np.uint64).reshape(lmax, 8), sc.cpu().numpy().astype(np.uint64))
+
+
+@pytest.fixture(scope="module")
+def gpu(torch, ctx, pkg):
+    return Gpu(torch, ctx, pkg)
+
+
+def assert_scan_equal(fqref, gpu, data, bufsize=None):
+    B = fqref.BUFSIZE if bufsize is None else bufsize
+    res, idx = fqref.index(data, bufsize=B)
+    s, c, offs = gpu.scan(data, bufsize=B)
+    ctxt = (B, bytes(data[:200]), len(data))
+    assert s.parse_status == res.status, ctxt
+    assert s.n_records == res.n_records, ctxt
+    assert np.array_equal(offs[:-1], idx[:, 0]), ctxt
+    if res.n_records:
+        assert int(offs[-1]) == res.bytes_consumed == s.bytes_consumed, ctxt
+    if res.status != fqref.OK:
+        assert s.err_record == res.n_records, ctxt
+    return s, c, offs, res, idx
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [v["name"] for v in GOLD["vectors"]])
+def test_reference_unit_test_vectors(fqref, gpu, name):
+    """Every golden vector of the reference's own tests, through the HIP path."""
+    v = next(x for x in GOLD["vectors"] if x["name"] == name)
+    data = build_input(v["input"])
+    s, c, offs, res, idx = assert_scan_equal(fqref, gpu, data)
+    exp = v["expect"]
+    assert (s.parse_status == gpu.pkg.OK) == exp["ok"]
+    if "n_records" in exp:
+        assert s.n_records == exp["n_records"]
+    if "total_records" in exp:
+        assert s.n_records == exp["total_records"]
+    if "sum_of_worker_counts" in exp:
+        assert s.n_records == exp["sum_of_worker_counts"]
+
+
+def test_index_records_match_idxrecord(fqref, gpu, torch):
+    """fqh_index_records == IdxRecord{head,seq,sep,qual,data} of src/records.rs:240-246."""
+    rng = np.random.default_rng(5)
+    data = fuzzgen.valid_file(rng, 500, maxlen=120)
+    s, c, offs, res, idx = assert_scan_equal(fqref, gpu, data)
+    out = torch.zeros(res.n_records * 3, dtype=torch.int64, device=gpu.dev)  # 24 bytes per record
+    gpu.ctx.index_records(out.data_ptr(), res.n_records)
+    raw = out.cpu().numpy().view(np.uint8).reshape(res.n_records, 24)
+    start = raw[:, :8].copy().view(np.uint64)[:, 0]
+    rest = raw[:, 8:].copy().view(np.uint32)
+    assert np.array_equal(start, idx[:, 0])
+    assert np.array_equal(rest.astype(np.uint64), idx[:, 1:])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_scan_equals_oracle(fqref, gpu, seed):
+    for tag, data in fuzzgen.corpus(1000 + seed, 150):
+        assert_scan_equal(fqref, gpu, data)
+        assert_scan_equal(fqref, gpu, data, bufsize=64)  # cfg(fuzzing) BUFSIZE, src/lib.rs:126-127
+
+
+def test_edge_cases(fqref, gpu):
+    cases = [b"", b"\n", b"@", b"@\n", b"@a\nAC\n+\nII\n\n", b"@a\n\n+\n\n", b"@a\nAC\r\n+\nIII\n",
+             b"@a\nAC\n-\nII\n", b"@a\nAC\n", b"@a\nAC\n+", b"@a\nAC\nx", b"xa\nAC\n+\nII\n",
+             b"@a\nAC\n+\n@I\n@b\nGG\n+\n+@\n", b"@\n\n+\n\n" * 7, b"\n" * 40, b"@a\nAC\n+\nII",
+             b"@a\nACGT\n+\nIII\n@b\nAC\n+\nII\n"]
+    for d in cases:
+        assert_scan_equal(fqref, gpu, d)
+        assert_scan_equal(fqref, gpu, d, bufsize=64)
+
+
+def test_tile_and_piece_boundaries(fqref, gpu):
+    """Records placed so that newlines, '@' and '+' fall on 16 B / 1 KiB / 16 KiB boundaries."""
+    rng = np.random.default_rng(11)
+    for target in (16, 1024, 16384, 32768):
+        for delta in range(-3, 4):
+            pre = fuzzgen.valid_file(rng, 3, crlf=False)
+            pad = target + delta - len(pre) - 4  # "@" + pad*h + "\n" puts the header newline near target
+            if pad < 1:
+                pad += 16384
+            rec = b"@" + b"h" * pad + b"\nACGT\n+\nIIII\n"
+            data = pre + rec + fuzzgen.valid_file(rng, 3, crlf=False)
+            assert_scan_equal(fqref, gpu, data)
+            assert_scan_equal(fqref, gpu, data[: target + delta + 8])
+
+
+def test_too_long_band(fqref, gpu):
+    """<= B-15 always accepted, > B always rejected, alignment dependent in between."""
+    rng = np.random.default_rng(3)
+    B = fqref.BUFSIZE
+    statuses = set()
+    for trial in range(24):
+        parts = [fuzzgen.valid_record(rng, j) for j in range(int(rng.integers(0, 5)))]
+        L = B + int(rng.integers(-20, 3))
+        parts.append(b"@" + b"h" * (L - 9) + b"\nA\n+\nB\n")
+        parts += [fuzzgen.valid_record(rng, j) for j in range(int(rng.integers(0, 3)))]
+        data = b"".join(parts)
+        if trial % 4 == 3:
+            data = data[: len(data) - int(rng.integers(1, 12))]
+        s, *_ = assert_scan_equal(fqref, gpu, data)
+        statuses.add(s.parse_status)
+    assert gpu.pkg.E_TOO_LONG in statuses and gpu.pkg.OK in statuses
+
+
+def test_huge_line_without_newline(fqref, gpu):
+    data = b"@" + b"longid" * 200000  # 1.2 MB, no newline at all (huge_incomplete at scale)
+    s, *_ = assert_scan_equal(fqref, gpu, data)
+    assert s.parse_status == gpu.pkg.E_TOO_LONG
+
+
+def test_dense_newlines_force_list_rerun(fqref, gpu):
+    """More than 2048 line starts in one 16 KiB tile: the library reruns with full-size lists."""
+    data = b"@\n\n+\n\n" * 6000
+    s, *_ = assert_scan_equal(fqref, gpu, data)
+    assert s.n_records == 6000
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_stats_equal_oracle(fqref, gpu, seed):
+    for tag, data in fuzzgen.corpus(2000 + seed, 60):
+        for lmax in (8, 150):
+            r, qh, bh, sc = fqref.stats(data, lmax)
+            s, gq, gb, gs = gpu.stats(data, lmax)
+            assert (s.parse_status, s.n_records) == (r.status, r.n_records), data
+            assert np.array_equal(gq, qh) and np.array_equal(gb, bh) and np.array_equal(gs, sc), data
+
+
+def test_stats_long_reads_and_odd_bytes(fqref, gpu):
+    """Reads longer than the LDS-resident columns, quality bytes outside the LDS window, CRLF."""
+    rng = np.random.default_rng(9)
+    recs = []
+    for i in range(300):
+        n = int(rng.integers(0, 400))
+        seq = bytes(rng.choice(list(b"ACGTNacgtn*"), n).tolist())
+        qual = bytes(rng.integers(33, 127, n).astype(np.uint8).tolist()) if i % 3 else bytes([200]) * n
+        e = b"\r\n" if i % 5 == 0 else b"\n"
+        recs.append(b"@r" + e + seq + e + b"+" + e + qual + e)
+    data = b"".join(recs)
+    for lmax in (100, 300, 500):
+        r, qh, bh, sc = fqref.stats(data, lmax)
+        s, gq, gb, gs = gpu.stats(data, lmax)
+        assert s.n_records == r.n_records == 300
+        assert np.array_equal(gq, qh) and np.array_equal(gb, bh) and np.array_equal(gs, sc)
+
+
+def test_synth_generator_and_medium_parity(fqref, gpu, torch):
+    """64 MiB of the synthetic 150 bp workload: generator identical on CPU and GPU; offsets, count
+    and histograms bit-exact against the oracle."""
+    n = 64 * 1024 * 1024
+    d = torch.empty(n, dtype=torch.uint8, device=gpu.dev)
+    gpu.ctx.synth_fill(d.data_ptr(), 0, n)
+    host = d.cpu().numpy()
+    assert np.array_equal(host, fqref.synth(0, n))
+    res, off = fqref.offsets(host)
+    s, c, offs = gpu.scan_dev(d, n)
+    assert (s.parse_status, s.n_records) == (res.status, res.n_records)  # ends mid-record: truncated
+    assert np.array_equal(offs[:-1], off)
+    nrec = n // 330
+    full = nrec * 330
+    s, c, offs = gpu.scan_dev(d, full)
+    assert s.parse_status == gpu.pkg.OK and s.n_records == nrec
+    assert np.array_equal(offs, np.arange(nrec + 1, dtype=np.uint64) * 330)
+    qh = torch.zeros(150 * 256, dtype=torch.int64, device=gpu.dev)
+    bh = torch.zeros(150 * 8, dtype=torch.int64, device=gpu.dev)
+    sc = torch.zeros(8, dtype=torch.int64, device=gpu.dev)
+    gpu.ctx.stats(d.data_ptr(), full, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    r, oq, ob, osc = fqref.stats(host[:full], 150)
+    assert np.array_equal(qh.cpu().numpy().astype(np.uint64).reshape(150, 256), oq)
+    assert np.array_equal(bh.cpu().numpy().astype(np.uint64).reshape(150, 8), ob)
+    assert np.array_equal(sc.cpu().numpy().astype(np.uint64), osc)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_chunked_scan_with_carry(fqref, gpu, pkg, seed):
+    """Arbitrary byte cuts (the multi-GPU shard boundaries of SURVEY §8e): chaining fqh_scan with the
+    carry reproduces the whole-file scan exactly."""
+    rng = np.random.default_rng(40 + seed)
+    data = fuzzgen.valid_file(rng, 400, maxlen=60)
+    if seed == 3:
+        data = fuzzgen.mutate(rng, data, 1)
+    res, idx = fqref.index(data, bufsize=1 << 22)
+    gpu.ctx.set_bufsize(0)
+    ncut = int(rng.integers(1, 6))
+    cuts = sorted(set([0, len(data)] + [int(x) for x in rng.integers(0, len(data) + 1, ncut)]))
+    carry = None
+    starts = []
+    total = 0
+    status = pkg.OK
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        # device sub-buffers must be 16-byte aligned: upload each chunk separately
+        s, carry, offs = gpu.scan(data[a:b], is_final=(b == len(data)), carry=carry, bufsize=0)
+        if not starts:
+            starts.append(int(offs[0]))
+        starts += [int(x) for x in offs[1: s.n_records + 1]]
+        total += s.n_records
+        assert carry.base_offset == b
+        if s.parse_status != pkg.OK:
+            status = s.parse_status
+            break
+    assert status == res.status
+    assert total == res.n_records
+    assert starts[: res.n_records] == [int(x) for x in idx[:, 0]]
+
+
+def test_count_only_mode(fqref, gpu):
+    rng = np.random.default_rng(2)
+    data = fuzzgen.valid_file(rng, 300)
+    s, c, _ = gpu.scan(data, want_offsets=False)
+    r = fqref.count(data)
+    assert (s.parse_status, s.n_records, s.bytes_consumed) == (r.status, r.n_records, r.bytes_consumed)
+    bad = fuzzgen.mutate(rng, data, 2)
+    s, c, _ = gpu.scan(bad, want_offsets=False)
+    r = fqref.count(bad)
+    assert (s.parse_status, s.n_records) == (r.status, r.n_records)
+    if r.n_records:
+        assert s.bytes_consumed == r.bytes_consumed
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_sharded_two_stage_protocol(fqref, torch, pkg, seed):
+    """The multi-GPU protocol of bench.py on one GPU: every shard is byte-scanned with a zero carry,
+    the 7-word summaries are folded with fqh_carry_combine, and fqh_rescan_launch redoes only the
+    emit step with the true carry.  Result == whole-file oracle."""
+    rng = np.random.default_rng(70 + seed)
+    data = fuzzgen.valid_file(rng, 600, maxlen=80)
+    res, idx = fqref.index(data, bufsize=1 << 22)
+    nsh = 4
+    cuts = [0] + sorted(int(x) for x in rng.integers(1, len(data), nsh - 1)) + [len(data)]
+    dev = torch.device("cuda:0")
+    ctxs, bufs, sums = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream, bufsize=0)
+        n = b - a
+        d = torch.empty(max(n, 16), dtype=torch.uint8, device=dev)
+        if n:
+            d[:n].copy_(torch.from_numpy(np.frombuffer(data[a:b], dtype=np.uint8).copy()))
+        s0, c0, _ = c.scan(d.data_ptr(), n, False, None, None, 0)
+        ctxs.append(c); bufs.append((d, n)); sums.append((n, s0.n_newlines, s0.n_line_starts, list(c0.back)))
+    starts, total = [], 0
+    carry = None
+    for i, c in enumerate(ctxs):
+        d, n = bufs[i]
+        cap = n // 6 + 3
+        rs = torch.zeros(cap, dtype=torch.int64, device=dev)
+        c.rescan_launch(i == nsh - 1, carry, rs.data_ptr(), cap)
+        s, cout, st = c.scan_finish()
+        assert s.parse_status == pkg.OK
+        offs = rs.cpu().numpy()
+        if not starts:
+            starts.append(int(offs[0]))
+        starts += [int(x) for x in offs[1: s.n_records + 1]]
+        total += s.n_records
+        carry = pkg.carry_combine(carry, *sums[i])
+        assert (carry.base_offset, carry.nl_count, list(carry.back)) == \
+            (cout.base_offset, cout.nl_count, list(cout.back))
+        c.close()
+    assert total == res.n_records
+    assert starts[: res.n_records] == [int(x) for x in idx[:, 0]]

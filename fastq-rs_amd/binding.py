@@ -62,6 +62,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `make -C fastq-rs_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # When torch is used in the same process (tests, bench.py) it must be imported BEFORE this
+        # library is loaded: torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and the
+        # dynamic linker then resolves our NEEDED libamdhip64.so.7 to that one instance.  Loaded the
+        # other way round the process ends up with two HIP runtimes and fqh_create fails.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
         L.fqh_create.argtypes = [i32, C.POINTER(vp)]
@@ -121,7 +129,7 @@ class Ctx:
         h = C.c_void_p()
         st = self._L.fqh_create(device, C.byref(h))
         if st != OK:
-            raise FqhError(st, "fqh_create failed (no GPU?)")
+            raise FqhError(st, "fqh_create failed: " + self._L.fqh_last_error(None).decode())
         self._h = h
         if stream is not None:
             self._chk(self._L.fqh_set_stream(self._h, C.c_void_p(stream)))

@@ -103,17 +103,23 @@ const char *fqh_strerror(fqh_status s) {
     return "unknown";
 }
 
-const char *fqh_last_error(fqh_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+static std::string g_create_err = "no context";
+const char *fqh_last_error(fqh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 fqh_status fqh_create(int device, fqh_ctx **out) {
     if (!out) return FQH_E_ARG;
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return FQH_E_DEVICE;
+    hipError_t he = hipGetDeviceCount(&n);
+    if (he != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        g_create_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(he) + ", devices=" + std::to_string(n);
+        return FQH_E_DEVICE;
+    }
     fqh_ctx *ctx = new (std::nothrow) fqh_ctx();
     if (!ctx) return FQH_E_DEVICE;
     ctx->device = device;
     fqh_status st = FQH_OK;
+    g_create_err = "HIP resource creation failed";
     do {
         if (hipSetDevice(device) != hipSuccess) { st = FQH_E_DEVICE; break; }
         int cu = 0;

@@ -18,14 +18,14 @@
 #include "fqh_internal.h"
 
 namespace fqh {
-void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
+void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *, int);
 void launch_prefix(hipStream_t, const uint32_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
-void launch_emit(hipStream_t, const ScanArgs &, DevOut *);
+void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
 void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_record *, uint64_t,
                           uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
 void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
-void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *);
+void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
 }  // namespace fqh
 
 using namespace fqh;
@@ -221,12 +221,12 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index = false) {
     HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
     if (!reuse_index)
-        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, a.n_tiles, &ctx->d_out[0]);
+        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, a.n_tiles, &ctx->d_out[0], ctx->n_cu);
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     if (!reuse_index)
         launch_prefix(s, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    launch_emit(s, a, &ctx->d_out[0]);
+    launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
     launch_finalize(s, a, &ctx->d_out[0]);
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     HIPCHK(ctx, hipGetLastError());
@@ -334,7 +334,7 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
                 b.cap = n + 1;
                 b.idx = nullptr;
                 HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
-                launch_emit(ctx->stream, b, &ctx->d_out[1]);
+                launch_emit(ctx->stream, b, &ctx->d_out[1], ctx->n_cu);
                 launch_finalize(ctx->stream, b, &ctx->d_out[1]);
                 src = ctx->tmp_rec;
             }
@@ -452,7 +452,7 @@ static fqh_status emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap) {
     b.idx = dst;
     b.idx_cap = cap;
     HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
-    launch_emit(ctx->stream, b, &ctx->d_out[1]);
+    launch_emit(ctx->stream, b, &ctx->d_out[1], ctx->n_cu);
     launch_finalize(ctx->stream, b, &ctx->d_out[1]);
     HIPCHK(ctx, hipGetLastError());
     return FQH_OK;
@@ -614,7 +614,7 @@ fqh_status fqh_read_ceiling(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, ui
     hipStream_t s = ctx->stream;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_misc, 0, 64, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], s));
-    launch_read_ceiling(s, d_buf, len, ctx->d_misc);
+    launch_read_ceiling(s, d_buf, len, ctx->d_misc, ctx->n_cu);
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], s));
     HIPCHK(ctx, hipGetLastError());
     uint64_t sum = 0;

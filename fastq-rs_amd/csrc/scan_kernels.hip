@@ -41,8 +41,15 @@ __device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t q) {
     return __builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (q & 7u));
 }
 // 16 bytes at buf+off; bytes at or beyond len read as 0
+// The input is read exactly once: non-temporal loads keep it from displacing useful lines and are
+// worth ~12 % of HBM read rate on MI355X (tools/readbw.hip: 5.8 -> 6.5 TB/s).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load16_nt(const uint8_t *p) {
+    const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
 __device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ buf, uint64_t off, uint64_t len) {
-    if (off + 16 <= len) return *reinterpret_cast<const uint4 *>(buf + off);
+    if (off + 16 <= len) return load16_nt(buf + off);
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // no indexed array: it would be promoted to LDS
     if (off < len) {
         const uint32_t n = (uint32_t)(len - off);
@@ -53,78 +60,97 @@ __device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ buf, uint64_
     }
     return make_uint4(w0, w1, w2, w3);
 }
-// exclusive prefix of small per-lane counts over the wavefront with ballots + mbcnt
-__device__ __forceinline__ uint32_t wave_prefix_small(uint32_t c, uint32_t &total) {
-    uint32_t pre = 0;
-    total = 0;
-    for (uint32_t k = 1;; ++k) {
-        unsigned long long b = __ballot(c >= k);
-        if (b == 0) break;
-        pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
-        total += (uint32_t)__popcll(b);
-    }
-    return pre;
+// ---------------------------------------------------------------------------------------------
+// k_index: persistent grid, a wavefront takes 16 KiB tiles round-robin.
+//
+// lane-1's value (lane 0 gets `first`): DPP wave_shr:1, no LDS crossbar round trip
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xF, 0xF, false);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_index: one wavefront per 16 KiB tile.
+// One 1 KiB piece: 16 bytes per lane, already in registers.  FULL: every byte of the piece exists.
+template <bool FULL>
+__device__ __forceinline__ void index_piece(const uint4 v, const uint64_t off, const uint64_t len,
+                                            const uint32_t pbase, const uint32_t lane,
+                                            uint32_t &prev, uint32_t &run,
+                                            uint16_t *__restrict__ tl, const uint32_t list_cap) {
+    const uint32_t M = eqmask16(v, 0x0A0A0A0Au);
+    uint32_t LS = ((M << 1) | wave_shr1(M >> 15, prev)) & 0xFFFFu;
+    if (!FULL && off + 16 > len) {  // a line start must be an existing byte
+        const uint32_t nvalid = off < len ? (uint32_t)(len - off) : 0u;
+        LS &= (1u << nvalid) - 1u;
+    }
+    prev = ((uint32_t)__builtin_amdgcn_readlane((int)M, 63)) >> 15;
+    // exclusive prefix of popc(LS) over the wave: two ballot levels cover FASTQ ("\n+\n" puts two
+    // line starts in one 16-byte chunk); deeper levels only for pathological input
+    const uint32_t c = __popc(LS);
+    const unsigned long long b1 = __ballot(c >= 1), b2 = __ballot(c >= 2);
+    uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
+    pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
+    uint32_t tot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    if (__ballot(c >= 3)) {
+        for (uint32_t k = 3;; ++k) {
+            const unsigned long long b = __ballot(c >= k);
+            if (!b) break;
+            pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
+            tot += (uint32_t)__popcll(b);
+        }
+    }
+    if (run + tot <= list_cap) {  // uniform: no per-entry bound check
+        uint16_t *__restrict__ dst = tl + run + pre;
+        while (LS) {
+            const uint32_t q = __ffs(LS) - 1;
+            LS &= LS - 1;
+            const uint32_t b = byte_of(v, q);
+            *dst++ = (uint16_t)((pbase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+        }
+    }
+    run += tot;
+}
+
 __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ buf, uint64_t len,
                                                uint16_t *__restrict__ list, uint32_t list_cap,
                                                uint32_t *__restrict__ tile_count, uint64_t n_tiles,
                                                DevOut *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    const uint64_t tbase = tile << WT_SHIFT;
-    uint16_t *__restrict__ tl = list + tile * list_cap;
-
-    uint32_t run = 0;
-    // Is the byte before the piece a newline?  Offset 0 of the chunk is never emitted here: whether
-    // a line starts there is carry information, handled by k_finalize.
-    uint32_t prev = 0;
-    if (tile > 0) prev = (buf[tbase - 1] == '\n') ? 1u : 0u;
-
-    // one 1 KiB piece: 16 bytes per lane, already in registers (by value: no indexed array, which
-    // the compiler would promote to LDS)
-    auto piece = [&](const uint4 v, const uint64_t off, const uint32_t pbase) {
-        const uint32_t M = eqmask16(v, 0x0A0A0A0Au);
-        const uint32_t up = __shfl_up(M >> 15, 1);
-        uint32_t LS = ((M << 1) | (lane ? up : prev)) & 0xFFFFu;
-        if (off + 16 > len) {  // a line start must be an existing byte
-            const uint32_t nvalid = off < len ? (uint32_t)(len - off) : 0u;
-            LS &= (1u << nvalid) - 1u;
-        }
-        prev = ((uint32_t)__builtin_amdgcn_readlane((int)M, 63)) >> 15;
-        uint32_t tot;
-        uint32_t idx = run + wave_prefix_small(__popc(LS), tot);
-        while (LS) {
-            const uint32_t q = __ffs(LS) - 1;
-            LS &= LS - 1;
-            const uint32_t b = byte_of(v, q);
-            const uint32_t e = (pbase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u);
-            if (idx < list_cap) tl[idx] = (uint16_t)e;
-            ++idx;
-        }
-        run += tot;
-    };
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    uint32_t n_over = 0;
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += nwaves) {
+        const uint64_t tbase = tile << WT_SHIFT;
+        uint16_t *__restrict__ tl = list + tile * list_cap;
+        uint32_t run = 0;
+        // Is the byte before the piece a newline?  Offset 0 of the chunk is never emitted here:
+        // whether a line starts there is carry information, handled by k_finalize.
+        uint32_t prev = 0;
+        if (tile > 0) prev = (buf[tbase - 1] == '\n') ? 1u : 0u;
+        const uint32_t lo = lane * 16;
+        if (tbase + WT_BYTES <= len) {
+            const uint8_t *p = buf + tbase + lo;
 #pragma unroll 1
-    for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
-        const uint64_t gbase = tbase + (uint64_t)g * 4 * PIECE_BYTES + lane * 16;
-        if (tbase + (uint64_t)g * 4 * PIECE_BYTES >= len) break;  // uniform
-        const uint4 v0 = load16(buf, gbase, len);
-        const uint4 v1 = load16(buf, gbase + PIECE_BYTES, len);
-        const uint4 v2 = load16(buf, gbase + 2 * PIECE_BYTES, len);
-        const uint4 v3 = load16(buf, gbase + 3 * PIECE_BYTES, len);
-        const uint32_t pb = g * 4 * PIECE_BYTES + lane * 16;
-        piece(v0, gbase, pb);
-        piece(v1, gbase + PIECE_BYTES, pb + PIECE_BYTES);
-        piece(v2, gbase + 2 * PIECE_BYTES, pb + 2 * PIECE_BYTES);
-        piece(v3, gbase + 3 * PIECE_BYTES, pb + 3 * PIECE_BYTES);
+            for (uint32_t g = 0; g < WT_PIECES / 4; ++g, p += 4 * PIECE_BYTES) {
+                const uint4 v0 = load16_nt(p);
+                const uint4 v1 = load16_nt(p + PIECE_BYTES);
+                const uint4 v2 = load16_nt(p + 2 * PIECE_BYTES);
+                const uint4 v3 = load16_nt(p + 3 * PIECE_BYTES);
+                const uint32_t pb = g * 4 * PIECE_BYTES + lo;
+                index_piece<true>(v0, 0, 0, pb, lane, prev, run, tl, list_cap);
+                index_piece<true>(v1, 0, 0, pb + PIECE_BYTES, lane, prev, run, tl, list_cap);
+                index_piece<true>(v2, 0, 0, pb + 2 * PIECE_BYTES, lane, prev, run, tl, list_cap);
+                index_piece<true>(v3, 0, 0, pb + 3 * PIECE_BYTES, lane, prev, run, tl, list_cap);
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t j = 0; j < WT_PIECES; ++j) {
+                const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
+                if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
+                const uint4 v = load16(buf, off, len);
+                index_piece<false>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
+            }
+        }
+        if (lane == 0) tile_count[tile] = run;
+        if (run > list_cap) ++n_over;
     }
-    if (lane == 0) {
-        tile_count[tile] = run;
-        if (run > list_cap) atomicAdd(&out->overflow, 1ull);
-    }
+    if (lane == 0 && n_over) atomicAdd(&out->overflow, (unsigned long long)n_over);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -302,36 +328,75 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_emit: one wavefront per tile, lanes stride over the tile's line-start entries.
+// k_emit: one wavefront per tile.  The tile's line-start list is staged in LDS (coalesced 2-byte
+// loads), so the three predecessor starts every record needs are LDS reads; only the first four
+// entries of a tile look into earlier tiles (collect_prev).
+constexpr uint32_t EMIT_STAGE = 2048;  // entries staged per wave (lists longer than this: global)
 __global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ out) {
+    __shared__ uint16_t stage[4][EMIT_STAGE];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= a.n_tiles) return;
-    const uint32_t cnt = tile_cnt(a, t);
-    if (cnt == 0) return;
-    const unsigned long long lbase = a.nl_count + 1 + tile_pref(a, t);
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const unsigned long long r0 = a.nl_count >> 2;
     Acc acc = {NOKEY, NOKEY, 0};
-    for (uint32_t i = lane; i < cnt; i += 64) {
-        const uint32_t e = a.list[t * a.list_cap + i];
-        const long long S = (long long)((t << WT_SHIFT) + (e & 0x3FFFu));
-        const unsigned long long l = lbase + i;
-        const uint32_t ph = (uint32_t)l & 3u;
-        if (ph == 0) {
-            if (!(e & 0x4000u)) {  // read_header: src/records.rs:138-147
-                unsigned long long k = (l >> 2) * 4 + 0;
-                if (k < acc.key) acc.key = k;
-            }
-            const unsigned long long r = (l >> 2) - r0;
-            if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + (unsigned long long)S;
-            close_record(a, t, i, S, l, acc);
-        } else if (ph == 2) {
-            if (!(e & 0x8000u)) {  // read_sep: src/records.rs:152-161
-                unsigned long long k = (l >> 2) * 4 + 1;
-                if (k < acc.key) acc.key = k;
+    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wv; t < a.n_tiles; t += nwaves) {
+        const uint32_t cnt = tile_cnt(a, t);
+        if (cnt == 0) continue;
+        const uint16_t *__restrict__ tl = a.list + t * a.list_cap;
+        const uint32_t nst = cnt < EMIT_STAGE ? cnt : EMIT_STAGE;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < nst; i += 64) stage[wv][i] = tl[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long lbase = a.nl_count + 1 + tile_pref(a, t);
+        const long long tb = (long long)(t << WT_SHIFT);
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const uint32_t e = i < EMIT_STAGE ? stage[wv][i] : tl[i];
+            const long long S = tb + (e & 0x3FFFu);
+            const unsigned long long l = lbase + i;
+            const uint32_t ph = (uint32_t)l & 3u;
+            if (ph == 0) {
+                if (!(e & 0x4000u)) {  // read_header: src/records.rs:138-147
+                    unsigned long long k = (l >> 2) * 4 + 0;
+                    if (k < acc.key) acc.key = k;
+                }
+                const unsigned long long r = (l >> 2) - r0;
+                if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + (unsigned long long)S;
+                if (i >= 4 && i < EMIT_STAGE) {
+                    // fast path: the whole record lies in this tile
+                    const long long p0 = tb + (stage[wv][i - 1] & 0x3FFFu);
+                    const long long p1 = tb + (stage[wv][i - 2] & 0x3FFFu);
+                    const long long p2 = tb + (stage[wv][i - 3] & 0x3FFFu);
+                    const long long p3 = tb + (stage[wv][i - 4] & 0x3FFFu);
+                    const unsigned long long rec = (l >> 2) - 1;
+                    if ((S - p0) != (p1 - p2)) {  // src/records.rs:233-238
+                        unsigned long long k = rec * 4 + 2;
+                        if (k < acc.key) acc.key = k;
+                    }
+                    const unsigned long long reclen = (unsigned long long)(S - p3);
+                    if (reclen > acc.max_len) acc.max_len = reclen;
+                    if (a.bufsize && reclen + 15 >= a.bufsize && rec < acc.first_long) acc.first_long = rec;
+                    if (a.idx && r - 1 < a.idx_cap) {
+                        fqh_idx_record ir;
+                        ir.start = a.base_offset + (unsigned long long)p3;
+                        ir.head = (uint32_t)(p2 - 1 - p3);
+                        ir.seq = (uint32_t)(p1 - 1 - p3);
+                        ir.sep = (uint32_t)(p0 - 1 - p3);
+                        ir.qual = (uint32_t)(S - 1 - p3);
+                        a.idx[r - 1] = ir;
+                    }
+                } else {
+                    close_record(a, t, i, S, l, acc);
+                }
+            } else if (ph == 2) {
+                if (!(e & 0x8000u)) {  // read_sep: src/records.rs:152-161
+                    unsigned long long k = (l >> 2) * 4 + 1;
+                    if (k < acc.key) acc.key = k;
+                }
             }
         }
     }
+    // one set of atomics per wavefront of the persistent grid
     const unsigned long long k = wave_min_u64(acc.key);
     const unsigned long long fl = wave_min_u64(acc.first_long);
     const unsigned long long ml = wave_max_u64(acc.max_len);
@@ -441,10 +506,15 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 
 // ---------------------------------------------------------------------------------------------
 // launchers (host)
+static uint32_t persistent_blocks(uint64_t n_tiles, int n_cu) {
+    uint64_t blocks = (n_tiles + 3) / 4;
+    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * 8;
+    return (uint32_t)(blocks < maxb ? blocks : maxb);
+}
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
-                  uint32_t *tile_count, uint64_t n_tiles, DevOut *out) {
+                  uint32_t *tile_count, uint64_t n_tiles, DevOut *out, int n_cu) {
     if (!n_tiles) return;
-    const uint64_t blocks = (n_tiles + 3) / 4;
+    const uint64_t blocks = persistent_blocks(n_tiles, n_cu);
     hipLaunchKernelGGL(k_index, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
                        tile_count, n_tiles, out);
 }
@@ -455,9 +525,9 @@ void launch_prefix(hipStream_t s, const uint32_t *tile_count, uint32_t *tile_pre
                        tile_prefix, block_prefix, n_tiles);
     hipLaunchKernelGGL(k_prefix_top, dim3(1), dim3(1024), 0, s, block_prefix, n_blocks);
 }
-void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out) {
+void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     if (!a.n_tiles) return;
-    const uint64_t blocks = (a.n_tiles + 3) / 4;
+    const uint64_t blocks = persistent_blocks(a.n_tiles, n_cu);
     hipLaunchKernelGGL(k_emit, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
 }
 void launch_finalize(hipStream_t s, const ScanArgs &a, DevOut *out) {

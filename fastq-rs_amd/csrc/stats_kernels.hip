@@ -174,36 +174,48 @@ void launch_synth(hipStream_t s, uint8_t *out, uint64_t byte_off, uint64_t len, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streaming-read ceiling: the same access pattern as k_index (one wavefront per 16 KiB tile, four
-// 16-byte loads in flight per lane) with only an integer sum as work.
+// Streaming-read ceiling: the same access pattern as k_index (a wavefront reads a 16 KiB tile as
+// 1 KiB pieces, four 16-byte loads in flight per lane) with only an integer sum as work.  Persistent
+// grid so that the final atomics do not serialise.
 __global__ __launch_bounds__(256) void k_read_ceiling(const uint8_t *__restrict__ buf, uint64_t len,
                                                       unsigned long long *__restrict__ sum) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t tbase = tile << WT_SHIFT;
+    const uint64_t n_tiles = (len + WT_BYTES - 1) >> WT_SHIFT;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     unsigned long long acc = 0;
-    if (tbase + WT_BYTES <= len) {
+    for (uint64_t tile = wave0; tile < n_tiles; tile += nwaves) {
+        const uint64_t tbase = tile << WT_SHIFT;
+        if (tbase + WT_BYTES <= len) {
 #pragma unroll 1
-        for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
-            uint4 v[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j)
-                v[j] = *reinterpret_cast<const uint4 *>(buf + tbase + (g * 4 + j) * PIECE_BYTES + lane * 16);
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) acc += (unsigned long long)v[j].x + v[j].y + v[j].z + v[j].w;
+            for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
+                const uint8_t *p = buf + tbase + g * 4 * PIECE_BYTES + lane * 16;
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+                const u32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + PIECE_BYTES));
+                const u32x4 v2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + 2 * PIECE_BYTES));
+                const u32x4 v3 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + 3 * PIECE_BYTES));
+                acc += (unsigned long long)v0.x + v0.y + v0.z + v0.w;
+                acc += (unsigned long long)v1.x + v1.y + v1.z + v1.w;
+                acc += (unsigned long long)v2.x + v2.y + v2.z + v2.w;
+                acc += (unsigned long long)v3.x + v3.y + v3.z + v3.w;
+            }
+        } else {
+            for (uint64_t o = tbase + lane * 4; o + 4 <= len && o < tbase + WT_BYTES; o += 256)
+                acc += *reinterpret_cast<const uint32_t *>(buf + o);
         }
-    } else {
-        for (uint64_t o = tbase + lane * 4; o + 4 <= len && o < tbase + WT_BYTES; o += 256)
-            acc += *reinterpret_cast<const uint32_t *>(buf + o);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if (lane == 0 && acc) atomicAdd(sum, acc);
 }
-void launch_read_ceiling(hipStream_t s, const uint8_t *buf, uint64_t len, uint64_t *sum) {
+void launch_read_ceiling(hipStream_t s, const uint8_t *buf, uint64_t len, uint64_t *sum, int n_cu) {
     const uint64_t n_tiles = (len + WT_BYTES - 1) / WT_BYTES;
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_read_ceiling, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), 0, s, buf, len,
+    uint64_t blocks = (n_tiles + 3) / 4;
+    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * 8;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(k_read_ceiling, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len,
                        (unsigned long long *)sum);
 }
 

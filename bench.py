@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=4096)
+    ap.add_argument("--variants", default="", help="tuning: comma list of k_index variants to A/B (interleaved rounds)")
     args = ap.parse_args()
 
     import numpy as np
@@ -105,6 +106,23 @@ def main():
         dist.all_reduce(counts)
         return s
 
+    if args.variants:
+        vs = [int(x) for x in args.variants.split(",")]
+        res = {v: [] for v in vs}
+        for rnd in range(6):
+            for v in vs:
+                pkg.lib().fqh_debug_set_index_variant(v)
+                for _ in range(3):
+                    ctx.scan(buf.data_ptr(), nbytes, True, None, rec_start.data_ptr(), cap)
+                    t = ctx.timing()
+                    res[v].append((t.index_ms, t.emit_ms))
+        ceil = sorted(ctx.read_ceiling(buf.data_ptr(), nbytes)[1] for _ in range(6))
+        print("read ceiling: min %.3f med %.3f ms (%.0f GB/s at min)" % (ceil[0], ceil[3], nbytes / 1e6 / ceil[0]))
+        for v in vs:
+            im = sorted(x[0] for x in res[v]); em = sorted(x[1] for x in res[v])
+            print("variant %d: index min %.3f med %.3f ms (%.0f GB/s at min) | emit min %.3f med %.3f" %
+                  (v, im[0], im[len(im) // 2], nbytes / 1e6 / im[0], em[0], em[len(em) // 2]), flush=True)
+        return
     for _ in range(args.warmup):
         s = step()
     index_ms.clear()

@@ -26,6 +26,7 @@ void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_
                           uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
 void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
 void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
+extern int g_index_variant;
 }  // namespace fqh
 
 using namespace fqh;
@@ -482,6 +483,9 @@ fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, ui
     const uint64_t len = ctx->args.len;
     return do_scan_launch(ctx, buf, len, is_final, in, d_rec_start, cap, true);
 }
+
+// tuning hook, not part of the public header: selects the k_index code variant for A/B runs
+extern "C" void fqh_debug_set_index_variant(int v) { fqh::g_index_variant = v; }
 
 fqh_status fqh_invalidate(fqh_ctx *ctx) {
     if (!ctx) return FQH_E_ARG;

@@ -10,6 +10,8 @@
 //   k_finalize  EOF rule (src/lib.rs:264-294), carry-out, summary.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fqh_internal.h"
 
 namespace fqh {
@@ -20,17 +22,28 @@ namespace fqh {
 __device__ __forceinline__ uint32_t zero_flags(uint32_t t) {
     return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
 }
-// flags at bits 7,15,23,31 -> nibble
+// positional 16-bit mask: bit q set iff byte q of the 16-byte chunk equals the pattern byte.
+// MASKV 0: shift/or nibble gather.  MASKV 1: v_dot4_u32_u8 gathers the four 0x80 flags of a dword
+// in ONE instruction (byte weights 1,2,4,8 give nibble << 7; the next dword's weights 16..128 add
+// its nibble four bits higher).
 __device__ __forceinline__ uint32_t nib(uint32_t m) {
     m >>= 7;
     m |= m >> 7;
     m |= m >> 14;
     return m & 0xFu;
 }
-// positional 16-bit mask: bit q set iff byte q of the 16-byte chunk equals the pattern byte
+template <int MASKV>
 __device__ __forceinline__ uint32_t eqmask16(const uint4 &v, uint32_t pat4) {
-    return nib(zero_flags(v.x ^ pat4)) | (nib(zero_flags(v.y ^ pat4)) << 4) |
-           (nib(zero_flags(v.z ^ pat4)) << 8) | (nib(zero_flags(v.w ^ pat4)) << 12);
+    if (MASKV == 0) {
+        return nib(zero_flags(v.x ^ pat4)) | (nib(zero_flags(v.y ^ pat4)) << 4) |
+               (nib(zero_flags(v.z ^ pat4)) << 8) | (nib(zero_flags(v.w ^ pat4)) << 12);
+    } else {
+        const uint32_t lo = __builtin_amdgcn_udot4(zero_flags(v.y ^ pat4), 0x80402010u,
+                            __builtin_amdgcn_udot4(zero_flags(v.x ^ pat4), 0x08040201u, 0u, false), false);
+        const uint32_t hi = __builtin_amdgcn_udot4(zero_flags(v.w ^ pat4), 0x80402010u,
+                            __builtin_amdgcn_udot4(zero_flags(v.z ^ pat4), 0x08040201u, 0u, false), false);
+        return (lo >> 7) | (hi << 1);
+    }
 }
 // byte q (0..15) of a 16-byte chunk held in registers: pick the 8-byte half with two selects, then
 // v_perm_b32 pulls the byte out (selector 0x0C = constant zero).  Written this way so the compiler
@@ -69,12 +82,12 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t first) {
 }
 
 // One 1 KiB piece: 16 bytes per lane, already in registers.  FULL: every byte of the piece exists.
-template <bool FULL>
+template <bool FULL, int MASKV>
 __device__ __forceinline__ void index_piece(const uint4 v, const uint64_t off, const uint64_t len,
                                             const uint32_t pbase, const uint32_t lane,
                                             uint32_t &prev, uint32_t &run,
                                             uint16_t *__restrict__ tl, const uint32_t list_cap) {
-    const uint32_t M = eqmask16(v, 0x0A0A0A0Au);
+    const uint32_t M = eqmask16<MASKV>(v, 0x0A0A0A0Au);
     uint32_t LS = ((M << 1) | wave_shr1(M >> 15, prev)) & 0xFFFFu;
     if (!FULL && off + 16 > len) {  // a line start must be an existing byte
         const uint32_t nvalid = off < len ? (uint32_t)(len - off) : 0u;
@@ -108,6 +121,9 @@ __device__ __forceinline__ void index_piece(const uint4 v, const uint64_t off, c
     run += tot;
 }
 
+// MASKV: mask gather variant.  PF: 1 = the next 4 KiB group is requested before the current one
+// is processed (register double buffer).
+template <int MASKV, int PF>
 __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ buf, uint64_t len,
                                                uint16_t *__restrict__ list, uint32_t list_cap,
                                                uint32_t *__restrict__ tile_count, uint64_t n_tiles,
@@ -126,17 +142,36 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ buf, 
         const uint32_t lo = lane * 16;
         if (tbase + WT_BYTES <= len) {
             const uint8_t *p = buf + tbase + lo;
+            if (PF == 0) {
 #pragma unroll 1
-            for (uint32_t g = 0; g < WT_PIECES / 4; ++g, p += 4 * PIECE_BYTES) {
-                const uint4 v0 = load16_nt(p);
-                const uint4 v1 = load16_nt(p + PIECE_BYTES);
-                const uint4 v2 = load16_nt(p + 2 * PIECE_BYTES);
-                const uint4 v3 = load16_nt(p + 3 * PIECE_BYTES);
-                const uint32_t pb = g * 4 * PIECE_BYTES + lo;
-                index_piece<true>(v0, 0, 0, pb, lane, prev, run, tl, list_cap);
-                index_piece<true>(v1, 0, 0, pb + PIECE_BYTES, lane, prev, run, tl, list_cap);
-                index_piece<true>(v2, 0, 0, pb + 2 * PIECE_BYTES, lane, prev, run, tl, list_cap);
-                index_piece<true>(v3, 0, 0, pb + 3 * PIECE_BYTES, lane, prev, run, tl, list_cap);
+                for (uint32_t g = 0; g < WT_PIECES / 4; ++g, p += 4 * PIECE_BYTES) {
+                    const uint4 v0 = load16_nt(p);
+                    const uint4 v1 = load16_nt(p + PIECE_BYTES);
+                    const uint4 v2 = load16_nt(p + 2 * PIECE_BYTES);
+                    const uint4 v3 = load16_nt(p + 3 * PIECE_BYTES);
+                    const uint32_t pb = g * 4 * PIECE_BYTES + lo;
+                    index_piece<true, MASKV>(v0, 0, 0, pb, lane, prev, run, tl, list_cap);
+                    index_piece<true, MASKV>(v1, 0, 0, pb + PIECE_BYTES, lane, prev, run, tl, list_cap);
+                    index_piece<true, MASKV>(v2, 0, 0, pb + 2 * PIECE_BYTES, lane, prev, run, tl, list_cap);
+                    index_piece<true, MASKV>(v3, 0, 0, pb + 3 * PIECE_BYTES, lane, prev, run, tl, list_cap);
+                }
+            } else {
+                uint4 n0 = load16_nt(p), n1 = load16_nt(p + PIECE_BYTES);
+                uint4 n2 = load16_nt(p + 2 * PIECE_BYTES), n3 = load16_nt(p + 3 * PIECE_BYTES);
+#pragma unroll
+                for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
+                    const uint4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
+                    if (g + 1 < WT_PIECES / 4) {
+                        p += 4 * PIECE_BYTES;
+                        n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
+                        n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
+                    }
+                    const uint32_t pb = g * 4 * PIECE_BYTES + lo;
+                    index_piece<true, MASKV>(v0, 0, 0, pb, lane, prev, run, tl, list_cap);
+                    index_piece<true, MASKV>(v1, 0, 0, pb + PIECE_BYTES, lane, prev, run, tl, list_cap);
+                    index_piece<true, MASKV>(v2, 0, 0, pb + 2 * PIECE_BYTES, lane, prev, run, tl, list_cap);
+                    index_piece<true, MASKV>(v3, 0, 0, pb + 3 * PIECE_BYTES, lane, prev, run, tl, list_cap);
+                }
             }
         } else {
 #pragma unroll 1
@@ -144,7 +179,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ buf, 
                 const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
                 if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
                 const uint4 v = load16(buf, off, len);
-                index_piece<false>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
+                index_piece<false, MASKV>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
             }
         }
         if (lane == 0) tile_count[tile] = run;
@@ -339,16 +374,36 @@ __global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ o
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const unsigned long long r0 = a.nl_count >> 2;
     Acc acc = {NOKEY, NOKEY, 0};
-    for (uint64_t t = (uint64_t)blockIdx.x * 4 + wv; t < a.n_tiles; t += nwaves) {
-        const uint32_t cnt = tile_cnt(a, t);
+    // Software pipeline over the wave's tiles: the next tile's count, prefix and first 256 list
+    // entries are requested (unconditionally: list_cap >= 256) before the current tile is
+    // processed, so one memory latency is exposed per tile instead of three dependent ones.
+    struct Pre { uint32_t cnt, tp; unsigned long long bp; uint16_t e[4]; };
+    auto fetch = [&](uint64_t t, Pre &p) {
+        if (t < a.n_tiles) {
+            p.cnt = a.tile_count[t];
+            p.tp = a.tile_prefix[t];
+            p.bp = a.block_prefix[t >> SCAN_SHIFT];
+            const uint16_t *tl = a.list + t * a.list_cap + lane;
+            p.e[0] = tl[0]; p.e[1] = tl[64]; p.e[2] = tl[128]; p.e[3] = tl[192];
+        }
+    };
+    Pre nx;
+    uint64_t t = (uint64_t)blockIdx.x * 4 + wv;
+    fetch(t, nx);
+    for (; t < a.n_tiles; t += nwaves) {
+        const Pre cur = nx;
+        fetch(t + nwaves, nx);
+        const uint32_t cnt = cur.cnt < a.list_cap ? cur.cnt : a.list_cap;
         if (cnt == 0) continue;
         const uint16_t *__restrict__ tl = a.list + t * a.list_cap;
         const uint32_t nst = cnt < EMIT_STAGE ? cnt : EMIT_STAGE;
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < nst; i += 64) stage[wv][i] = tl[i];
+        stage[wv][lane] = cur.e[0]; stage[wv][lane + 64] = cur.e[1];
+        stage[wv][lane + 128] = cur.e[2]; stage[wv][lane + 192] = cur.e[3];
+        for (uint32_t i = lane + 256; i < nst; i += 64) stage[wv][i] = tl[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long lbase = a.nl_count + 1 + tile_pref(a, t);
+        const unsigned long long lbase = a.nl_count + 1 + cur.bp + cur.tp;
         const long long tb = (long long)(t << WT_SHIFT);
         for (uint32_t i = lane; i < cnt; i += 64) {
             const uint32_t e = i < EMIT_STAGE ? stage[wv][i] : tl[i];
@@ -506,6 +561,117 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 
 // ---------------------------------------------------------------------------------------------
 // launchers (host)
+// ---------------------------------------------------------------------------------------------
+// k_index_t: same job as k_index, LDS-transposed.  A wavefront still fetches its tile with
+// coalesced 16-byte loads (lane-strided, 1 KiB per instruction), but stages each 4 KiB group in
+// LDS and reads it back so that lane l owns the 64 CONTIGUOUS bytes [64 l, 64 l + 64): one in-wave
+// prefix, one boundary shuffle and ~3 emit-loop iterations per 4 KiB instead of per 1 KiB.
+// LDS image: logical 16-byte chunk c of the group lives in slot c ^ ((c >> 4) & 3) — conflict-free
+// for the lane-strided ds_write_b128 and for the lane-contiguous ds_read_b128 (MI355X LDS services
+// b128 reads in 16-lane groups over a 16-slot bank row).
+template <int PF>
+__global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf, uint64_t len,
+                                                 uint16_t *__restrict__ list, uint32_t list_cap,
+                                                 uint32_t *__restrict__ tile_count, uint64_t n_tiles,
+                                                 DevOut *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *const lds = lds_all[threadIdx.x >> 6];
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    uint32_t n_over = 0;
+    // per-lane constants of the LDS image
+    const uint32_t wslot = lane ^ ((lane >> 4) & 3u);        // write: chunk 64 j + lane -> slot 64 j + wslot
+    const uint32_t s4 = ((lane >> 2) & 3u) << 4;              // read:  byte Q of the lane at 64 lane + (Q ^ s4)
+    uint8_t *const wptr = lds + wslot * 16;
+    const uint8_t *const rptr = lds + lane * 64;
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += nwaves) {
+        const uint64_t tbase = tile << WT_SHIFT;
+        uint16_t *__restrict__ tl = list + tile * list_cap;
+        uint32_t run = 0;
+        uint32_t prev = 0;
+        if (tile > 0) prev = (buf[tbase - 1] == '\n') ? 1u : 0u;
+        const uint32_t lo = lane * 16;
+        if (tbase + WT_BYTES <= len) {
+            const uint8_t *p = buf + tbase + lo;
+            uint4 n0 = load16_nt(p), n1 = load16_nt(p + PIECE_BYTES);
+            uint4 n2 = load16_nt(p + 2 * PIECE_BYTES), n3 = load16_nt(p + 3 * PIECE_BYTES);
+#pragma unroll 1
+            for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
+                __builtin_amdgcn_wave_barrier();
+                *reinterpret_cast<uint4 *>(wptr) = n0;
+                *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
+                *reinterpret_cast<uint4 *>(wptr + 2048) = n2;
+                *reinterpret_cast<uint4 *>(wptr + 3072) = n3;
+                if (PF && g + 1 < WT_PIECES / 4) {
+                    p += 4 * PIECE_BYTES;
+                    n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
+                    n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + (0u ^ s4));
+                const uint4 d1 = *reinterpret_cast<const uint4 *>(rptr + (16u ^ s4));
+                const uint4 d2 = *reinterpret_cast<const uint4 *>(rptr + (32u ^ s4));
+                const uint4 d3 = *reinterpret_cast<const uint4 *>(rptr + (48u ^ s4));
+                const uint32_t m_lo = eqmask16<1>(d0, 0x0A0A0A0Au) | (eqmask16<1>(d1, 0x0A0A0A0Au) << 16);
+                const uint32_t m_hi = eqmask16<1>(d2, 0x0A0A0A0Au) | (eqmask16<1>(d3, 0x0A0A0A0Au) << 16);
+                // line starts: the byte after a newline
+                uint32_t ls_lo = (m_lo << 1) | wave_shr1(m_hi >> 31, prev);
+                uint32_t ls_hi = __builtin_amdgcn_alignbit(m_hi, m_lo, 31);
+                prev = ((uint32_t)__builtin_amdgcn_readlane((int)m_hi, 63)) >> 31;
+                const uint32_t c = __popc(ls_lo) + __popc(ls_hi);
+                const unsigned long long b1 = __ballot(c >= 1), b2 = __ballot(c >= 2), b3 = __ballot(c >= 3);
+                uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
+                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
+                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, pre));
+                uint32_t tot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2) + (uint32_t)__popcll(b3);
+                if (__ballot(c >= 4)) {
+                    for (uint32_t k = 4;; ++k) {
+                        const unsigned long long b = __ballot(c >= k);
+                        if (!b) break;
+                        pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
+                        tot += (uint32_t)__popcll(b);
+                    }
+                }
+                if (run + tot <= list_cap) {  // uniform
+                    uint16_t *__restrict__ dst = tl + run + pre;
+                    const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
+                    while (ls_lo) {
+                        const uint32_t q = __ffs(ls_lo) - 1;
+                        ls_lo &= ls_lo - 1;
+                        const uint32_t b = rptr[q ^ s4];
+                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    }
+                    while (ls_hi) {
+                        const uint32_t q = __ffs(ls_hi) + 31;
+                        ls_hi &= ls_hi - 1;
+                        const uint32_t b = rptr[q ^ s4];
+                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    }
+                }
+                run += tot;
+                if (!PF && g + 1 < WT_PIECES / 4) {
+                    p += 4 * PIECE_BYTES;
+                    n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
+                    n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t j = 0; j < WT_PIECES; ++j) {
+                const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
+                if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
+                const uint4 v = load16(buf, off, len);
+                index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
+            }
+        }
+        if (lane == 0) tile_count[tile] = run;
+        if (run > list_cap) ++n_over;
+    }
+    if (lane == 0 && n_over) atomicAdd(&out->overflow, (unsigned long long)n_over);
+}
+
+int g_index_variant = -1;  // tuning hook (bench.py --variants); -1 = FQH_INDEX_VARIANT or default
 static uint32_t persistent_blocks(uint64_t n_tiles, int n_cu) {
     uint64_t blocks = (n_tiles + 3) / 4;
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * 8;
@@ -514,8 +680,25 @@ static uint32_t persistent_blocks(uint64_t n_tiles, int n_cu) {
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
                   uint32_t *tile_count, uint64_t n_tiles, DevOut *out, int n_cu) {
     if (!n_tiles) return;
-    const uint64_t blocks = persistent_blocks(n_tiles, n_cu);
-    hipLaunchKernelGGL(k_index, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
+    static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 0;
+    static const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;
+    typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
+    static const kern_t kerns[6] = {k_index<0, 0>, k_index<1, 0>, k_index<0, 1>, k_index<1, 1>,
+                                    k_index_t<0>, k_index_t<1>};
+    static int occ[6] = {0, 0, 0, 0, 0, 0};
+    int v = g_index_variant >= 0 ? g_index_variant : variant;
+    if (v < 0 || v > 5) v = 0;
+    if (!occ[v]) {
+        // persistent grid = exactly the blocks that are resident at once: a static round-robin of
+        // tiles over a grid with one non-resident block per CU would run that block as a tail
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kerns[v], 256, 0) != hipSuccess || o < 1) o = 4;
+        occ[v] = o > 8 ? 8 : o;
+    }
+    uint64_t blocks = (n_tiles + 3) / 4;
+    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_env > 0 ? bpc_env : occ[v]);
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(kerns[v], dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
                        tile_count, n_tiles, out);
 }
 void launch_prefix(hipStream_t s, const uint32_t *tile_count, uint32_t *tile_prefix,
@@ -527,7 +710,15 @@ void launch_prefix(hipStream_t s, const uint32_t *tile_count, uint32_t *tile_pre
 }
 void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     if (!a.n_tiles) return;
-    const uint64_t blocks = persistent_blocks(a.n_tiles, n_cu);
+    static int occ = 0;
+    if (!occ) {
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_emit, 256, 0) != hipSuccess || o < 1) o = 4;
+        occ = o > 8 ? 8 : o;
+    }
+    uint64_t blocks = (a.n_tiles + 3) / 4;
+    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ;
+    if (blocks > maxb) blocks = maxb;
     hipLaunchKernelGGL(k_emit, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
 }
 void launch_finalize(hipStream_t s, const ScanArgs &a, DevOut *out) {

@@ -18,9 +18,12 @@ namespace fqh {
 
 // ---------------------------------------------------------------------------------------------
 // byte-scan helpers
-// 0x80 in every byte of t that is zero (exact, no false positives)
-__device__ __forceinline__ uint32_t zero_flags(uint32_t t) {
-    return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+// 0x80 in every byte of x that equals the (7-bit) pattern byte — exact, no false positives, three
+// VALU ops: ((x & 0x7F..) ^ pat) in one v_bitop3; + 0x7F.. carries into bit 7 iff the low 7 bits
+// differ; bit 7 of x itself must be clear as well: ~(a | x) & 0x80.. in one v_bitop3.
+__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t pat4) {
+    const uint32_t a = ((x & 0x7F7F7F7Fu) ^ pat4) + 0x7F7F7F7Fu;
+    return ~(a | x) & 0x80808080u;
 }
 // positional 16-bit mask: bit q set iff byte q of the 16-byte chunk equals the pattern byte.
 // MASKV 0: shift/or nibble gather.  MASKV 1: v_dot4_u32_u8 gathers the four 0x80 flags of a dword
@@ -35,13 +38,13 @@ __device__ __forceinline__ uint32_t nib(uint32_t m) {
 template <int MASKV>
 __device__ __forceinline__ uint32_t eqmask16(const uint4 &v, uint32_t pat4) {
     if (MASKV == 0) {
-        return nib(zero_flags(v.x ^ pat4)) | (nib(zero_flags(v.y ^ pat4)) << 4) |
-               (nib(zero_flags(v.z ^ pat4)) << 8) | (nib(zero_flags(v.w ^ pat4)) << 12);
+        return nib(eq_flags(v.x, pat4)) | (nib(eq_flags(v.y, pat4)) << 4) |
+               (nib(eq_flags(v.z, pat4)) << 8) | (nib(eq_flags(v.w, pat4)) << 12);
     } else {
-        const uint32_t lo = __builtin_amdgcn_udot4(zero_flags(v.y ^ pat4), 0x80402010u,
-                            __builtin_amdgcn_udot4(zero_flags(v.x ^ pat4), 0x08040201u, 0u, false), false);
-        const uint32_t hi = __builtin_amdgcn_udot4(zero_flags(v.w ^ pat4), 0x80402010u,
-                            __builtin_amdgcn_udot4(zero_flags(v.z ^ pat4), 0x08040201u, 0u, false), false);
+        const uint32_t lo = __builtin_amdgcn_udot4(eq_flags(v.y, pat4), 0x80402010u,
+                            __builtin_amdgcn_udot4(eq_flags(v.x, pat4), 0x08040201u, 0u, false), false);
+        const uint32_t hi = __builtin_amdgcn_udot4(eq_flags(v.w, pat4), 0x80402010u,
+                            __builtin_amdgcn_udot4(eq_flags(v.z, pat4), 0x08040201u, 0u, false), false);
         return (lo >> 7) | (hi << 1);
     }
 }
@@ -363,94 +366,178 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_emit: one wavefront per tile.  The tile's line-start list is staged in LDS (coalesced 2-byte
-// loads), so the three predecessor starts every record needs are LDS reads; only the first four
-// entries of a tile look into earlier tiles (collect_prev).
-constexpr uint32_t EMIT_STAGE = 2048;  // entries staged per wave (lists longer than this: global)
+// k_emit: persistent grid, a wavefront takes tiles round-robin.
+//
+// Per tile: the line-start list (u16 entries) is staged in LDS behind a 4-entry header holding the
+// last four entries of the PREVIOUS tile, so a record-start entry finds its four predecessor line
+// starts with LDS reads even when the record began in the previous tile.  '@'/'+' bits are checked
+// while staging (one lane per entry); the per-record work (offset store, length rule of
+// src/records.rs:233-238, record length) runs one lane per RECORD in 32-bit tile-relative
+// arithmetic.  Everything 64-bit (error keys, generic predecessor search for tiles whose
+// predecessor has fewer than four entries) sits behind wave-uniform rare branches.
+// A three-stage software pipeline (counts -> list entries -> process) keeps two tiles of loads in
+// flight per wavefront, so no memory latency is exposed per tile.
+constexpr uint32_t EMIT_STAGE = 2048;  // entries staged per wave; longer lists take the generic path
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// generic (slow) per-entry processing of one tile: any list length, any predecessor situation
+__device__ void emit_tile_generic(const ScanArgs &a, uint64_t t, uint32_t cnt, unsigned long long lbase,
+                                  uint32_t lane, Acc &acc) {
+    const unsigned long long r0 = a.nl_count >> 2;
+    const uint16_t *__restrict__ tl = a.list + t * a.list_cap;
+    for (uint32_t i = lane; i < cnt; i += 64) {
+        const uint32_t e = tl[i];
+        const long long S = (long long)((t << WT_SHIFT) + (e & 0x3FFFu));
+        const unsigned long long l = lbase + i;
+        const uint32_t ph = (uint32_t)l & 3u;
+        if (ph == 0) {
+            if (!(e & 0x4000u)) {  // read_header: src/records.rs:138-147
+                unsigned long long k = (l >> 2) * 4 + 0;
+                if (k < acc.key) acc.key = k;
+            }
+            const unsigned long long r = (l >> 2) - r0;
+            if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + (unsigned long long)S;
+            close_record(a, t, i, S, l, acc);
+        } else if (ph == 2) {
+            if (!(e & 0x8000u)) {  // read_sep: src/records.rs:152-161
+                unsigned long long k = (l >> 2) * 4 + 1;
+                if (k < acc.key) acc.key = k;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ out) {
-    __shared__ uint16_t stage[4][EMIT_STAGE];
+    __shared__ uint16_t stage_all[4][EMIT_STAGE + 8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
+    uint16_t *const st = stage_all[wv] + 4;  // st[-4..-1]: tail of the previous tile
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const unsigned long long r0 = a.nl_count >> 2;
+    const uint32_t bufsize32 = a.bufsize > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)a.bufsize;
     Acc acc = {NOKEY, NOKEY, 0};
-    // Software pipeline over the wave's tiles: the next tile's count, prefix and first 256 list
-    // entries are requested (unconditionally: list_cap >= 256) before the current tile is
-    // processed, so one memory latency is exposed per tile instead of three dependent ones.
-    struct Pre { uint32_t cnt, tp; unsigned long long bp; uint16_t e[4]; };
-    auto fetch = [&](uint64_t t, Pre &p) {
+    uint32_t maxlen32 = 0;
+
+    struct StageA { uint32_t cnt, tp, cprev; unsigned long long bp; };
+    struct StageB { uint32_t cnt, tp, cprev; unsigned long long bp; uint32_t e0, e1, e2, e3, tail; };
+    auto fetchA = [&](uint64_t t, StageA &p) {
         if (t < a.n_tiles) {
             p.cnt = a.tile_count[t];
             p.tp = a.tile_prefix[t];
             p.bp = a.block_prefix[t >> SCAN_SHIFT];
-            const uint16_t *tl = a.list + t * a.list_cap + lane;
-            p.e[0] = tl[0]; p.e[1] = tl[64]; p.e[2] = tl[128]; p.e[3] = tl[192];
+            p.cprev = t ? a.tile_count[t - 1] : 0u;
         }
     };
-    Pre nx;
+    auto fetchB = [&](uint64_t t, const StageA &q, StageB &p) {
+        if (t < a.n_tiles) {
+            p.cnt = q.cnt; p.tp = q.tp; p.cprev = q.cprev; p.bp = q.bp;
+            const uint16_t *tl = a.list + t * a.list_cap + lane;  // list_cap >= 256: always in bounds
+            p.e0 = tl[0]; p.e1 = tl[64]; p.e2 = tl[128]; p.e3 = tl[192];
+            const uint32_t cp = q.cprev < a.list_cap ? q.cprev : a.list_cap;
+            p.tail = (lane < 4 && cp >= 4) ? (uint32_t)a.list[(t - 1) * a.list_cap + cp - 4 + lane] : 0u;
+        }
+    };
     uint64_t t = (uint64_t)blockIdx.x * 4 + wv;
-    fetch(t, nx);
+    StageA sa;
+    StageB sb;
+    fetchA(t, sa);
+    fetchB(t, sa, sb);
+    fetchA(t + nwaves, sa);
     for (; t < a.n_tiles; t += nwaves) {
-        const Pre cur = nx;
-        fetch(t + nwaves, nx);
-        const uint32_t cnt = cur.cnt < a.list_cap ? cur.cnt : a.list_cap;
+        const StageB cur = sb;
+        fetchB(t + nwaves, sa, sb);
+        fetchA(t + 2 * nwaves, sa);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur.cnt < a.list_cap ? cur.cnt : a.list_cap));
         if (cnt == 0) continue;
-        const uint16_t *__restrict__ tl = a.list + t * a.list_cap;
-        const uint32_t nst = cnt < EMIT_STAGE ? cnt : EMIT_STAGE;
+        const unsigned long long lbase = a.nl_count + 1 + uniform64(cur.bp) +
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.tp);
+        const uint32_t cprev = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.cprev);
+        const bool have_tail = t > 0 && cprev >= 4;
+        if (cnt > EMIT_STAGE || !have_tail) {
+            // dense tile, first tile of the chunk, or a predecessor tile with < 4 line starts
+            emit_tile_generic(a, t, cnt, lbase, lane, acc);
+            continue;
+        }
+        const uint32_t lb3 = (uint32_t)lbase & 3u;
+        // ---- stage the list in LDS; check '@' (phase 0) and '+' (phase 2) on the way
         __builtin_amdgcn_wave_barrier();
-        stage[wv][lane] = cur.e[0]; stage[wv][lane + 64] = cur.e[1];
-        stage[wv][lane + 128] = cur.e[2]; stage[wv][lane + 192] = cur.e[3];
-        for (uint32_t i = lane + 256; i < nst; i += 64) stage[wv][i] = tl[i];
+        uint32_t bad = 0;
+        auto put = [&](uint32_t i, uint32_t e) {
+            st[i] = (uint16_t)e;
+            const uint32_t ph = (lb3 + i) & 3u;
+            const bool b = i < cnt && ((ph == 0 && !(e & 0x4000u)) || (ph == 2 && !(e & 0x8000u)));
+            bad |= b ? 1u : 0u;
+        };
+        put(lane, cur.e0); put(lane + 64, cur.e1); put(lane + 128, cur.e2); put(lane + 192, cur.e3);
+        if (cnt > 256) {
+            const uint16_t *__restrict__ tl = a.list + t * a.list_cap;
+            for (uint32_t i = lane + 256; i < cnt; i += 64) put(i, tl[i]);
+        }
+        if (lane < 4) st[(int)lane - 4] = (uint16_t)cur.tail;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long lbase = a.nl_count + 1 + cur.bp + cur.tp;
-        const long long tb = (long long)(t << WT_SHIFT);
-        for (uint32_t i = lane; i < cnt; i += 64) {
-            const uint32_t e = i < EMIT_STAGE ? stage[wv][i] : tl[i];
-            const long long S = tb + (e & 0x3FFFu);
-            const unsigned long long l = lbase + i;
-            const uint32_t ph = (uint32_t)l & 3u;
-            if (ph == 0) {
-                if (!(e & 0x4000u)) {  // read_header: src/records.rs:138-147
-                    unsigned long long k = (l >> 2) * 4 + 0;
-                    if (k < acc.key) acc.key = k;
-                }
-                const unsigned long long r = (l >> 2) - r0;
-                if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + (unsigned long long)S;
-                if (i >= 4 && i < EMIT_STAGE) {
-                    // fast path: the whole record lies in this tile
-                    const long long p0 = tb + (stage[wv][i - 1] & 0x3FFFu);
-                    const long long p1 = tb + (stage[wv][i - 2] & 0x3FFFu);
-                    const long long p2 = tb + (stage[wv][i - 3] & 0x3FFFu);
-                    const long long p3 = tb + (stage[wv][i - 4] & 0x3FFFu);
-                    const unsigned long long rec = (l >> 2) - 1;
-                    if ((S - p0) != (p1 - p2)) {  // src/records.rs:233-238
-                        unsigned long long k = rec * 4 + 2;
-                        if (k < acc.key) acc.key = k;
-                    }
-                    const unsigned long long reclen = (unsigned long long)(S - p3);
-                    if (reclen > acc.max_len) acc.max_len = reclen;
-                    if (a.bufsize && reclen + 15 >= a.bufsize && rec < acc.first_long) acc.first_long = rec;
-                    if (a.idx && r - 1 < a.idx_cap) {
-                        fqh_idx_record ir;
-                        ir.start = a.base_offset + (unsigned long long)p3;
-                        ir.head = (uint32_t)(p2 - 1 - p3);
-                        ir.seq = (uint32_t)(p1 - 1 - p3);
-                        ir.sep = (uint32_t)(p0 - 1 - p3);
-                        ir.qual = (uint32_t)(S - 1 - p3);
-                        a.idx[r - 1] = ir;
-                    }
-                } else {
-                    close_record(a, t, i, S, l, acc);
-                }
-            } else if (ph == 2) {
-                if (!(e & 0x8000u)) {  // read_sep: src/records.rs:152-161
-                    unsigned long long k = (l >> 2) * 4 + 1;
+        if (__ballot(bad)) {  // rare: some header / separator byte is wrong -> error keys
+            for (uint32_t i = lane; i < cnt; i += 64) {
+                const uint32_t e = st[i];
+                const unsigned long long l = lbase + i;
+                const uint32_t ph = (uint32_t)l & 3u;
+                if (ph == 0 && !(e & 0x4000u)) { unsigned long long k = (l >> 2) * 4; if (k < acc.key) acc.key = k; }
+                if (ph == 2 && !(e & 0x8000u)) { unsigned long long k = (l >> 2) * 4 + 1; if (k < acc.key) acc.key = k; }
+            }
+        }
+        // ---- one lane per record: entry i0 + 4 m starts record m of the tile and closes the one before
+        const uint32_t i0 = (4u - lb3) & 3u;
+        if (i0 >= cnt) continue;
+        const uint32_t nrec = (cnt - i0 + 3) >> 2;
+        const unsigned long long rbase = ((lbase + i0) >> 2) - r0;  // local index of the tile's first record start
+        const unsigned long long vbase = a.base_offset + (t << WT_SHIFT);
+        const bool cap_ok = rbase + nrec <= a.cap;
+        uint32_t mism = 0;
+        for (uint32_t m = lane; m < nrec; m += 64) {
+            const int i = (int)(i0 + 4 * m);
+            const int o = st[i] & 0x3FFF;
+            const int o1 = (st[i - 1] & 0x3FFF) - (i < 1 ? (int)WT_BYTES : 0);
+            const int o2 = (st[i - 2] & 0x3FFF) - (i < 2 ? (int)WT_BYTES : 0);
+            const int o3 = (st[i - 3] & 0x3FFF) - (i < 3 ? (int)WT_BYTES : 0);
+            const int o4 = (st[i - 4] & 0x3FFF) - (i < 4 ? (int)WT_BYTES : 0);
+            if (a.rec_start && (cap_ok || rbase + m < a.cap)) a.rec_start[rbase + m] = vbase + (uint32_t)o;
+            mism |= ((o - o1) != (o2 - o3)) ? 1u : 0u;  // src/records.rs:233-238
+            const uint32_t reclen = (uint32_t)(o - o4);
+            maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+            if (bufsize32 && reclen + 15 >= bufsize32) {
+                const unsigned long long rec = r0 + rbase + m - 1;
+                if (rec < acc.first_long) acc.first_long = rec;
+            }
+            if (a.idx && rbase + m - 1 < a.idx_cap) {
+                fqh_idx_record ir;
+                ir.start = vbase + (unsigned long long)(long long)o4;
+                ir.head = (uint32_t)(o3 - 1 - o4);
+                ir.seq = (uint32_t)(o2 - 1 - o4);
+                ir.sep = (uint32_t)(o1 - 1 - o4);
+                ir.qual = (uint32_t)(o - 1 - o4);
+                a.idx[rbase + m - 1] = ir;
+            }
+        }
+        if (__ballot(mism)) {  // rare: a length mismatch -> error keys
+            for (uint32_t m = lane; m < nrec; m += 64) {
+                const int i = (int)(i0 + 4 * m);
+                const int o = st[i] & 0x3FFF;
+                const int o1 = (st[i - 1] & 0x3FFF) - (i < 1 ? (int)WT_BYTES : 0);
+                const int o2 = (st[i - 2] & 0x3FFF) - (i < 2 ? (int)WT_BYTES : 0);
+                const int o3 = (st[i - 3] & 0x3FFF) - (i < 3 ? (int)WT_BYTES : 0);
+                if ((o - o1) != (o2 - o3)) {
+                    const unsigned long long k = (r0 + rbase + m - 1) * 4 + 2;
                     if (k < acc.key) acc.key = k;
                 }
             }
         }
     }
+    if (maxlen32 > acc.max_len) acc.max_len = maxlen32;
     // one set of atomics per wavefront of the persistent grid
     const unsigned long long k = wave_min_u64(acc.key);
     const unsigned long long fl = wave_min_u64(acc.first_long);
@@ -672,21 +759,18 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
 }
 
 int g_index_variant = -1;  // tuning hook (bench.py --variants); -1 = FQH_INDEX_VARIANT or default
-static uint32_t persistent_blocks(uint64_t n_tiles, int n_cu) {
-    uint64_t blocks = (n_tiles + 3) / 4;
-    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * 8;
-    return (uint32_t)(blocks < maxb ? blocks : maxb);
-}
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
                   uint32_t *tile_count, uint64_t n_tiles, DevOut *out, int n_cu) {
     if (!n_tiles) return;
-    static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 0;
+    static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 5;
     static const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;
     typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
     static const kern_t kerns[6] = {k_index<0, 0>, k_index<1, 0>, k_index<0, 1>, k_index<1, 1>,
                                     k_index_t<0>, k_index_t<1>};
     static int occ[6] = {0, 0, 0, 0, 0, 0};
     int v = g_index_variant >= 0 ? g_index_variant : variant;
+    const int bpc_dbg = v / 100;  // tuning: variant + 100 * blocks-per-CU
+    v %= 100;
     if (v < 0 || v > 5) v = 0;
     if (!occ[v]) {
         // persistent grid = exactly the blocks that are resident at once: a static round-robin of
@@ -696,7 +780,7 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
         occ[v] = o > 8 ? 8 : o;
     }
     uint64_t blocks = (n_tiles + 3) / 4;
-    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_env > 0 ? bpc_env : occ[v]);
+    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occ[v]);
     if (blocks > maxb) blocks = maxb;
     hipLaunchKernelGGL(kerns[v], dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
                        tile_count, n_tiles, out);

@@ -377,7 +377,6 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // predecessor has fewer than four entries) sits behind wave-uniform rare branches.
 // A three-stage software pipeline (counts -> list entries -> process) keeps two tiles of loads in
 // flight per wavefront, so no memory latency is exposed per tile.
-constexpr uint32_t EMIT_STAGE = 2048;  // entries staged per wave; longer lists take the generic path
 
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -412,124 +411,161 @@ __device__ void emit_tile_generic(const ScanArgs &a, uint64_t t, uint32_t cnt, u
     }
 }
 
+// A wavefront handles a SUPER-TILE of four consecutive tiles (64 KiB of input, ~800 line starts,
+// ~200 records) per iteration: the four lists are compacted into one LDS array (their exclusive
+// prefixes give the slots), which amortises the per-tile scalar overhead and fills the lanes of the
+// record pass.  LDS word: bits 0..16 = offset relative to the super-tile + 16384 (so the tail of the
+// previous tile, at negative offsets, needs no special case), bit 17 = '@', bit 18 = '+'.
+constexpr uint32_t EMIT_G = 4;
+constexpr uint32_t EMIT_WORDS = 1280;  // staged entries per wave; more -> generic path
+
 __global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ out) {
-    __shared__ uint16_t stage_all[4][EMIT_STAGE + 8];
+    __shared__ uint32_t stage_all[4][EMIT_WORDS + 4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    uint16_t *const st = stage_all[wv] + 4;  // st[-4..-1]: tail of the previous tile
+    uint32_t *const st = stage_all[wv] + 4;  // st[-4..-1]: tail of the previous tile
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t n_super = (a.n_tiles + EMIT_G - 1) / EMIT_G;
     const unsigned long long r0 = a.nl_count >> 2;
     const uint32_t bufsize32 = a.bufsize > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)a.bufsize;
     Acc acc = {NOKEY, NOKEY, 0};
     uint32_t maxlen32 = 0;
 
-    struct StageA { uint32_t cnt, tp, cprev; unsigned long long bp; };
-    struct StageB { uint32_t cnt, tp, cprev; unsigned long long bp; uint32_t e0, e1, e2, e3, tail; };
-    auto fetchA = [&](uint64_t t, StageA &p) {
-        if (t < a.n_tiles) {
-            p.cnt = a.tile_count[t];
-            p.tp = a.tile_prefix[t];
-            p.bp = a.block_prefix[t >> SCAN_SHIFT];
-            p.cprev = t ? a.tile_count[t - 1] : 0u;
+    struct StageA { uint32_t cnt[4], tp[4], cprev; unsigned long long bp; };
+    struct StageB { StageA h; uint32_t e[4][4]; uint32_t tail; };
+    auto fetchA = [&](uint64_t sidx, StageA &p) {
+        if (sidx < n_super) {
+            const uint64_t t0 = sidx * EMIT_G;
+#pragma unroll
+            for (uint32_t k = 0; k < EMIT_G; ++k) {
+                const bool in = t0 + k < a.n_tiles;
+                p.cnt[k] = in ? a.tile_count[t0 + k] : 0u;
+                p.tp[k] = in ? a.tile_prefix[t0 + k] : 0u;
+            }
+            p.bp = a.block_prefix[t0 >> SCAN_SHIFT];
+            p.cprev = t0 ? a.tile_count[t0 - 1] : 0u;
         }
     };
-    auto fetchB = [&](uint64_t t, const StageA &q, StageB &p) {
-        if (t < a.n_tiles) {
-            p.cnt = q.cnt; p.tp = q.tp; p.cprev = q.cprev; p.bp = q.bp;
-            const uint16_t *tl = a.list + t * a.list_cap + lane;  // list_cap >= 256: always in bounds
-            p.e0 = tl[0]; p.e1 = tl[64]; p.e2 = tl[128]; p.e3 = tl[192];
+    auto fetchB = [&](uint64_t sidx, const StageA &q, StageB &p) {
+        if (sidx < n_super) {
+            const uint64_t t0 = sidx * EMIT_G;
+            p.h = q;
+#pragma unroll
+            for (uint32_t k = 0; k < EMIT_G; ++k) {
+                // list_cap >= 256: always inside the workspace (a partial last super-tile re-reads tile n-1)
+                const uint64_t tk = t0 + k < a.n_tiles ? t0 + k : a.n_tiles - 1;
+                const uint16_t *tl = a.list + tk * a.list_cap + lane;
+                p.e[k][0] = tl[0]; p.e[k][1] = tl[64]; p.e[k][2] = tl[128]; p.e[k][3] = tl[192];
+            }
             const uint32_t cp = q.cprev < a.list_cap ? q.cprev : a.list_cap;
-            p.tail = (lane < 4 && cp >= 4) ? (uint32_t)a.list[(t - 1) * a.list_cap + cp - 4 + lane] : 0u;
+            p.tail = (lane < 4 && cp >= 4) ? (uint32_t)a.list[(t0 - 1) * a.list_cap + cp - 4 + lane] : 0u;
         }
     };
-    uint64_t t = (uint64_t)blockIdx.x * 4 + wv;
+    uint64_t sidx = (uint64_t)blockIdx.x * 4 + wv;
     StageA sa;
     StageB sb;
-    fetchA(t, sa);
-    fetchB(t, sa, sb);
-    fetchA(t + nwaves, sa);
-    for (; t < a.n_tiles; t += nwaves) {
+    fetchA(sidx, sa);
+    fetchB(sidx, sa, sb);
+    fetchA(sidx + nwaves, sa);
+    for (; sidx < n_super; sidx += nwaves) {
         const StageB cur = sb;
-        fetchB(t + nwaves, sa, sb);
-        fetchA(t + 2 * nwaves, sa);
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur.cnt < a.list_cap ? cur.cnt : a.list_cap));
-        if (cnt == 0) continue;
-        const unsigned long long lbase = a.nl_count + 1 + uniform64(cur.bp) +
-                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.tp);
-        const uint32_t cprev = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.cprev);
-        const bool have_tail = t > 0 && cprev >= 4;
-        if (cnt > EMIT_STAGE || !have_tail) {
-            // dense tile, first tile of the chunk, or a predecessor tile with < 4 line starts
-            emit_tile_generic(a, t, cnt, lbase, lane, acc);
+        fetchB(sidx + nwaves, sa, sb);
+        fetchA(sidx + 2 * nwaves, sa);
+        const uint64_t t0 = sidx * EMIT_G;
+        uint32_t cnt[EMIT_G], slot[EMIT_G];
+        uint32_t total = 0;
+        bool capped = false;
+#pragma unroll
+        for (uint32_t k = 0; k < EMIT_G; ++k) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.cnt[k]);
+            capped |= c > a.list_cap;
+            cnt[k] = c < a.list_cap ? c : a.list_cap;
+            slot[k] = total;
+            total += cnt[k];
+        }
+        if (total == 0) continue;
+        const unsigned long long lbase = a.nl_count + 1 + uniform64(cur.h.bp) +
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.tp[0]);
+        const uint32_t cprev = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.h.cprev);
+        if (total > EMIT_WORDS || capped || t0 == 0 || cprev < 4) {
+            // dense tiles, first tiles of the chunk, or a predecessor tile with < 4 line starts
+            unsigned long long lb = lbase;
+            for (uint32_t k = 0; k < EMIT_G; ++k) {
+                if (cnt[k]) emit_tile_generic(a, t0 + k, cnt[k], lb, lane, acc);
+                lb += cnt[k];
+            }
             continue;
         }
         const uint32_t lb3 = (uint32_t)lbase & 3u;
-        // ---- stage the list in LDS; check '@' (phase 0) and '+' (phase 2) on the way
+        // ---- compact the four lists into LDS; check '@' (phase 0) and '+' (phase 2) on the way
         __builtin_amdgcn_wave_barrier();
         uint32_t bad = 0;
-        auto put = [&](uint32_t i, uint32_t e) {
-            st[i] = (uint16_t)e;
-            const uint32_t ph = (lb3 + i) & 3u;
-            const bool b = i < cnt && ((ph == 0 && !(e & 0x4000u)) || (ph == 2 && !(e & 0x8000u)));
-            bad |= b ? 1u : 0u;
+        auto put = [&](uint32_t k, uint32_t i, uint32_t e) {
+            if (i < cnt[k]) {
+                const uint32_t j = slot[k] + i;
+                st[j] = ((e & 0x3FFFu) + (k << WT_SHIFT) + WT_BYTES) | ((e & 0xC000u) << 3);
+                const uint32_t ph = (lb3 + j) & 3u;
+                bad |= ((ph == 0 && !(e & 0x4000u)) || (ph == 2 && !(e & 0x8000u))) ? 1u : 0u;
+            }
         };
-        put(lane, cur.e0); put(lane + 64, cur.e1); put(lane + 128, cur.e2); put(lane + 192, cur.e3);
-        if (cnt > 256) {
-            const uint16_t *__restrict__ tl = a.list + t * a.list_cap;
-            for (uint32_t i = lane + 256; i < cnt; i += 64) put(i, tl[i]);
+#pragma unroll
+        for (uint32_t k = 0; k < EMIT_G; ++k) {
+            put(k, lane, cur.e[k][0]); put(k, lane + 64, cur.e[k][1]);
+            put(k, lane + 128, cur.e[k][2]); put(k, lane + 192, cur.e[k][3]);
+            if (cnt[k] > 256) {
+                const uint16_t *__restrict__ tl = a.list + (t0 + k) * a.list_cap;
+                for (uint32_t i = lane + 256; i < cnt[k]; i += 64) put(k, i, tl[i]);
+            }
         }
-        if (lane < 4) st[(int)lane - 4] = (uint16_t)cur.tail;
+        if (lane < 4) st[(int)lane - 4] = (cur.tail & 0x3FFFu);  // previous tile: offset - 16384, biased + 16384
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (__ballot(bad)) {  // rare: some header / separator byte is wrong -> error keys
-            for (uint32_t i = lane; i < cnt; i += 64) {
-                const uint32_t e = st[i];
-                const unsigned long long l = lbase + i;
+            for (uint32_t j = lane; j < total; j += 64) {
+                const uint32_t v = st[j];
+                const unsigned long long l = lbase + j;
                 const uint32_t ph = (uint32_t)l & 3u;
-                if (ph == 0 && !(e & 0x4000u)) { unsigned long long k = (l >> 2) * 4; if (k < acc.key) acc.key = k; }
-                if (ph == 2 && !(e & 0x8000u)) { unsigned long long k = (l >> 2) * 4 + 1; if (k < acc.key) acc.key = k; }
+                if (ph == 0 && !(v & 0x20000u)) { unsigned long long k = (l >> 2) * 4; if (k < acc.key) acc.key = k; }
+                if (ph == 2 && !(v & 0x40000u)) { unsigned long long k = (l >> 2) * 4 + 1; if (k < acc.key) acc.key = k; }
             }
         }
-        // ---- one lane per record: entry i0 + 4 m starts record m of the tile and closes the one before
+        // ---- one lane per record: entry i0 + 4 m starts record m of the super-tile, closes the one before
         const uint32_t i0 = (4u - lb3) & 3u;
-        if (i0 >= cnt) continue;
-        const uint32_t nrec = (cnt - i0 + 3) >> 2;
-        const unsigned long long rbase = ((lbase + i0) >> 2) - r0;  // local index of the tile's first record start
-        const unsigned long long vbase = a.base_offset + (t << WT_SHIFT);
+        if (i0 >= total) continue;
+        const uint32_t nrec = (total - i0 + 3) >> 2;
+        const unsigned long long rbase = ((lbase + i0) >> 2) - r0;  // local index of the first record start
+        const unsigned long long vbase = a.base_offset + (t0 << WT_SHIFT) - WT_BYTES;  // minus the bias
         const bool cap_ok = rbase + nrec <= a.cap;
+        uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rbase : nullptr;
+        fqh_idx_record *__restrict__ ix = a.idx ? a.idx + (rbase - 1) : nullptr;
         uint32_t mism = 0;
         for (uint32_t m = lane; m < nrec; m += 64) {
-            const int i = (int)(i0 + 4 * m);
-            const int o = st[i] & 0x3FFF;
-            const int o1 = (st[i - 1] & 0x3FFF) - (i < 1 ? (int)WT_BYTES : 0);
-            const int o2 = (st[i - 2] & 0x3FFF) - (i < 2 ? (int)WT_BYTES : 0);
-            const int o3 = (st[i - 3] & 0x3FFF) - (i < 3 ? (int)WT_BYTES : 0);
-            const int o4 = (st[i - 4] & 0x3FFF) - (i < 4 ? (int)WT_BYTES : 0);
-            if (a.rec_start && (cap_ok || rbase + m < a.cap)) a.rec_start[rbase + m] = vbase + (uint32_t)o;
+            const int j = (int)(i0 + 4 * m);
+            const uint32_t o = st[j] & 0x1FFFFu, o1 = st[j - 1] & 0x1FFFFu, o2 = st[j - 2] & 0x1FFFFu;
+            const uint32_t o3 = st[j - 3] & 0x1FFFFu, o4 = st[j - 4] & 0x1FFFFu;
+            if (rs && (cap_ok || rbase + m < a.cap)) rs[m] = vbase + o;
             mism |= ((o - o1) != (o2 - o3)) ? 1u : 0u;  // src/records.rs:233-238
-            const uint32_t reclen = (uint32_t)(o - o4);
+            const uint32_t reclen = o - o4;
             maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
             if (bufsize32 && reclen + 15 >= bufsize32) {
                 const unsigned long long rec = r0 + rbase + m - 1;
                 if (rec < acc.first_long) acc.first_long = rec;
             }
-            if (a.idx && rbase + m - 1 < a.idx_cap) {
+            if (ix && rbase + m - 1 < a.idx_cap) {
                 fqh_idx_record ir;
-                ir.start = vbase + (unsigned long long)(long long)o4;
-                ir.head = (uint32_t)(o3 - 1 - o4);
-                ir.seq = (uint32_t)(o2 - 1 - o4);
-                ir.sep = (uint32_t)(o1 - 1 - o4);
-                ir.qual = (uint32_t)(o - 1 - o4);
-                a.idx[rbase + m - 1] = ir;
+                ir.start = vbase + o4;
+                ir.head = o3 - 1 - o4;
+                ir.seq = o2 - 1 - o4;
+                ir.sep = o1 - 1 - o4;
+                ir.qual = o - 1 - o4;
+                ix[m] = ir;
             }
         }
         if (__ballot(mism)) {  // rare: a length mismatch -> error keys
             for (uint32_t m = lane; m < nrec; m += 64) {
-                const int i = (int)(i0 + 4 * m);
-                const int o = st[i] & 0x3FFF;
-                const int o1 = (st[i - 1] & 0x3FFF) - (i < 1 ? (int)WT_BYTES : 0);
-                const int o2 = (st[i - 2] & 0x3FFF) - (i < 2 ? (int)WT_BYTES : 0);
-                const int o3 = (st[i - 3] & 0x3FFF) - (i < 3 ? (int)WT_BYTES : 0);
+                const int j = (int)(i0 + 4 * m);
+                const uint32_t o = st[j] & 0x1FFFFu, o1 = st[j - 1] & 0x1FFFFu, o2 = st[j - 2] & 0x1FFFFu;
+                const uint32_t o3 = st[j - 3] & 0x1FFFFu;
                 if ((o - o1) != (o2 - o3)) {
                     const unsigned long long k = (r0 + rbase + m - 1) * 4 + 2;
                     if (k < acc.key) acc.key = k;
@@ -800,7 +836,7 @@ void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_emit, 256, 0) != hipSuccess || o < 1) o = 4;
         occ = o > 8 ? 8 : o;
     }
-    uint64_t blocks = (a.n_tiles + 3) / 4;
+    uint64_t blocks = ((a.n_tiles + EMIT_G - 1) / EMIT_G + 3) / 4;
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ;
     if (blocks > maxb) blocks = maxb;
     hipLaunchKernelGGL(k_emit, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);

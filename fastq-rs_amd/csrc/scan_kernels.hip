@@ -692,14 +692,20 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 // LDS image: logical 16-byte chunk c of the group lives in slot c ^ ((c >> 4) & 3) — conflict-free
 // for the lane-strided ds_write_b128 and for the lane-contiguous ds_read_b128 (MI355X LDS services
 // b128 reads in 16-lane groups over a 16-slot bank row).
-template <int PF>
+// LSTAGE: the tile's list entries are collected in LDS and written to HBM once per tile with
+// 8-byte coalesced stores, so the emit loops issue no global stores: on gfx950 stores share the
+// vmcnt counter with loads, and scattered 2-byte stores between the prefetch loads and their
+// s_waitcnt would put store acknowledgements on the critical path of the next 4 KiB group.
+constexpr uint32_t LSTAGE_ENTRIES = 512;
+template <int PF, int LSTAGE>
 __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf, uint64_t len,
                                                  uint16_t *__restrict__ list, uint32_t list_cap,
                                                  uint32_t *__restrict__ tile_count, uint64_t n_tiles,
                                                  DevOut *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + (LSTAGE ? LSTAGE_ENTRIES * 2 : 0)];
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *const lds = lds_all[threadIdx.x >> 6];
+    uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + 4096);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     uint32_t n_over = 0;
     // per-lane constants of the LDS image
@@ -711,6 +717,7 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
         const uint64_t tbase = tile << WT_SHIFT;
         uint16_t *__restrict__ tl = list + tile * list_cap;
         uint32_t run = 0;
+        uint32_t nstaged = 0;  // entries [0, nstaged) of this tile live in LDS until the tile ends
         uint32_t prev = 0;
         if (tile > 0) prev = (buf[tbase - 1] == '\n') ? 1u : 0u;
         const uint32_t lo = lane * 16;
@@ -756,9 +763,24 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                         tot += (uint32_t)__popcll(b);
                     }
                 }
-                if (run + tot <= list_cap) {  // uniform
+                const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
+                if (LSTAGE && run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
+                    uint16_t *dst = lst + run + pre;
+                    while (ls_lo) {
+                        const uint32_t q = __ffs(ls_lo) - 1;
+                        ls_lo &= ls_lo - 1;
+                        const uint32_t b = rptr[q ^ s4];
+                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    }
+                    while (ls_hi) {
+                        const uint32_t q = __ffs(ls_hi) + 31;
+                        ls_hi &= ls_hi - 1;
+                        const uint32_t b = rptr[q ^ s4];
+                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    }
+                    nstaged = run + tot;
+                } else if (run + tot <= list_cap) {  // uniform
                     uint16_t *__restrict__ dst = tl + run + pre;
-                    const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
                     while (ls_lo) {
                         const uint32_t q = __ffs(ls_lo) - 1;
                         ls_lo &= ls_lo - 1;
@@ -788,6 +810,18 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                 index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
             }
         }
+        if (LSTAGE && nstaged) {  // flush the staged list: 4 entries (8 bytes) per lane and store
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane * 4; i < nstaged; i += 256) {
+                if (i + 4 <= nstaged) {
+                    *reinterpret_cast<uint2 *>(tl + i) = *reinterpret_cast<const uint2 *>(lst + i);
+                } else {  // never write past the staged part: later entries may already be in HBM
+                    for (uint32_t k = i; k < nstaged; ++k) tl[k] = lst[k];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         if (lane == 0) tile_count[tile] = run;
         if (run > list_cap) ++n_over;
     }
@@ -801,13 +835,13 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
     static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 5;
     static const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;
     typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
-    static const kern_t kerns[6] = {k_index<0, 0>, k_index<1, 0>, k_index<0, 1>, k_index<1, 1>,
-                                    k_index_t<0>, k_index_t<1>};
-    static int occ[6] = {0, 0, 0, 0, 0, 0};
+    static const kern_t kerns[7] = {k_index<0, 0>, k_index<1, 0>, k_index<0, 1>, k_index<1, 1>,
+                                    k_index_t<0, 0>, k_index_t<1, 0>, k_index_t<1, 1>};
+    static int occ[7] = {0, 0, 0, 0, 0, 0, 0};
     int v = g_index_variant >= 0 ? g_index_variant : variant;
     const int bpc_dbg = v / 100;  // tuning: variant + 100 * blocks-per-CU
     v %= 100;
-    if (v < 0 || v > 5) v = 0;
+    if (v < 0 || v > 6) v = 0;
     if (!occ[v]) {
         // persistent grid = exactly the blocks that are resident at once: a static round-robin of
         // tiles over a grid with one non-resident block per CU would run that block as a tail

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -24,6 +25,8 @@ void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
 void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_record *, uint64_t,
                           uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
+size_t stats_lines_scratch_bytes(uint32_t, int);
+hipError_t launch_stats_lines(hipStream_t, StatsArgs, int);
 void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
 void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
 extern int g_index_variant;
@@ -54,6 +57,8 @@ struct fqh_ctx {
     size_t idx_cap = 0;
     uint64_t *tmp_rec = nullptr;
     size_t tmp_rec_cap = 0;
+    uint32_t *stats_scratch = nullptr;
+    size_t stats_scratch_bytes = 0;
 
     hipEvent_t ev[8] = {};
     fqh_timing timing = {};
@@ -160,6 +165,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->d_misc);
     (void)hipFree(ctx->idx);
     (void)hipFree(ctx->tmp_rec);
+    (void)hipFree(ctx->stats_scratch);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->h_init) (void)hipHostFree(ctx->h_init);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -549,8 +555,11 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
     // the record in progress at the chunk start began in an earlier chunk: its bytes are not here
     const uint64_t skip = (n && ctx->carry_in.back[ctx->carry_in.nl_count & 3] > 0) ? 1 : 0;
     hipStream_t s = ctx->stream;
+    static const int stats_variant = getenv("FQH_STATS_VARIANT") ? atoi(getenv("FQH_STATS_VARIANT")) : 1;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
-    if (n > skip) {
+    if (n > skip && stats_variant == 0) {
+        // first implementation (one lane per record over an index of records): kept as a second,
+        // independent statement of the histogram for cross-checks
         if (ctx->idx_cap < n) {
             (void)hipFree(ctx->idx);
             ctx->idx = nullptr;
@@ -562,9 +571,39 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
         if (st != FQH_OK) return st;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
-    if (n > skip)
+    if (n > skip && stats_variant == 0) {
         launch_stats_records(s, d_buf, ctx->carry_in.base_offset, ctx->idx + skip, n - skip, lmax,
                              d_qual_hist, d_base_hist, d_scalars, ctx->n_cu);
+    } else if (n > skip) {
+        const size_t need = stats_lines_scratch_bytes(lmax, ctx->n_cu);
+        if (need > ctx->stats_scratch_bytes) {
+            (void)hipFree(ctx->stats_scratch);
+            ctx->stats_scratch = nullptr;
+            ctx->stats_scratch_bytes = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->stats_scratch, need));
+            ctx->stats_scratch_bytes = need;
+        }
+        const uint64_t r0 = ctx->carry_in.nl_count >> 2;
+        StatsArgs sa = {};
+        sa.buf = d_buf;
+        sa.len = len;
+        sa.valid_end = ctx->last_summary.bytes_consumed;
+        sa.nl_count = ctx->carry_in.nl_count;
+        sa.line_lo = 4 * (r0 + skip);
+        sa.line_hi = 4 * (r0 + n);
+        sa.list = ctx->list;
+        sa.list_cap = ctx->list_cap;
+        sa.tile_count = ctx->tile_count;
+        sa.tile_prefix = ctx->tile_prefix;
+        sa.block_prefix = ctx->block_prefix;
+        sa.n_tiles = ctx->args.n_tiles;
+        sa.lmax = lmax;
+        sa.scratch = ctx->stats_scratch;
+        sa.qual_hist = (unsigned long long *)d_qual_hist;
+        sa.base_hist = (unsigned long long *)d_base_hist;
+        sa.scalars = (unsigned long long *)d_scalars;
+        HIPCHK(ctx, launch_stats_lines(s, sa, ctx->n_cu));
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], s));
     HIPCHK(ctx, hipGetLastError());
     ctx->timing = scan_t;

@@ -51,6 +51,24 @@ struct ScanArgs {
     uint64_t idx_cap;
 };
 
+// Arguments of the line-parallel histogram kernel (stats_kernels.hip: k_stats_lines).
+struct StatsArgs {
+    const uint8_t *buf;
+    uint64_t len;
+    uint64_t valid_end;          // chunk-relative end of the last delivered record
+    uint64_t nl_count;           // carry-in: newlines before the chunk
+    uint64_t line_lo, line_hi;   // global line indices [lo, hi): lines of the records that count
+    const uint16_t *list;
+    uint32_t list_cap;
+    const uint32_t *tile_count;
+    const uint32_t *tile_prefix;
+    const uint64_t *block_prefix;
+    uint64_t n_tiles;
+    uint32_t lmax, lc;           // lc = columns kept in LDS
+    uint32_t *scratch;           // [gridDim.x][lc * 128] per-block partial histograms
+    unsigned long long *qual_hist, *base_hist, *scalars;
+};
+
 // Device-resident accumulators and the finalize kernel's results (one D2H copy per scan).
 struct DevOut {
     // accumulated by k_index / k_emit with atomics; reset before every scan

@@ -102,6 +102,237 @@ void launch_stats_records(hipStream_t s, const uint8_t *buf, uint64_t base_offse
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_stats_lines — the production histogram kernel.
+//
+// Unit of parallelism = one LINE per lane.  The scan's tile index already lists every line start,
+// and the tile prefix gives each line its global index, hence its role (index % 4 == 1: sequence,
+// == 3: quality).  A wavefront takes a 16 KiB tile, its lanes take that tile's sequence/quality
+// lines (~100), and all 64 lanes walk their lines in lock step, four columns per iteration: one
+// unaligned dword load per lane, a SWAR validity test, four LDS atomic adds on row p..p+3 of the
+// block's histogram.  Both histograms use 64-word rows so sequence and quality lanes share the
+// code: quality bin = byte - 33 (window '!'..'`'); sequence bin = byte & 7 (A1 C3 T4 N6 G7, distinct)
+// replicated in 8 copies (copy = lane & 7) so that the four hot letters spread over all 32 banks.
+// Anything outside the fast case (bytes outside the window / alphabet, columns beyond the LDS rows,
+// the last partial dword of a line) goes through an exact per-byte path.  Counters are integers:
+// the result is bit-exact whatever the order.
+constexpr uint32_t SL_THREADS = 1024;
+constexpr uint32_t SL_WAVES = SL_THREADS / 64;
+constexpr uint32_t SL_LC_MAX = 256;  // 256 rows * 128 words * 4 B = 128 KiB of LDS
+
+__device__ __forceinline__ uint32_t seq_expected(uint32_t w) {
+    // byte-wise: the alphabet letter whose (byte & 7) equals this byte's, 0xFF where there is none
+    return __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, w & 0x07070707u);
+}
+__device__ __forceinline__ uint32_t bin_to_class(uint32_t bin) {  // A0 C1 G2 T3 N4 other5
+    return bin == 1 ? 0u : bin == 3 ? 1u : bin == 7 ? 2u : bin == 4 ? 3u : bin == 6 ? 4u : 5u;
+}
+
+// 16 bytes at p (any alignment); bytes at or beyond `end` read as 0
+__device__ __forceinline__ uint4 load16_any(const uint8_t *__restrict__ p, const uint8_t *__restrict__ end) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p + 16 <= end) {
+        __builtin_memcpy(&v, p, 16);
+    } else {
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        for (uint32_t i = 0; p + i < end && i < 16; ++i) {
+            const uint32_t b = (uint32_t)p[i] << ((i & 3u) * 8u);
+            if (i < 4) w0 |= b; else if (i < 8) w1 |= b; else if (i < 12) w2 |= b; else w3 |= b;
+        }
+        v = make_uint4(w0, w1, w2, w3);
+    }
+    return v;
+}
+
+// One dword (columns p..p+3) of one line per lane.  IS_SEQ is wave-uniform: a wave iteration takes
+// either sequence lines or quality lines, so there is no divergence between the two alphabets.
+template <bool IS_SEQ>
+__device__ __forceinline__ void stats_dword(const StatsArgs &a, uint32_t w, uint32_t p, uint32_t len,
+                                            uint32_t lc, uint32_t *__restrict__ row0, uint32_t *__restrict__ qh,
+                                            uint32_t *__restrict__ sh, uint32_t copy8, uint32_t &any_n,
+                                            uint32_t &any_inv, uint32_t &ovf) {
+    if (p >= len) return;
+    const uint32_t nb = len - p < 4 ? len - p : 4u;
+    bool fast = nb == 4 && p + 4 <= lc;
+    uint32_t bins;
+    if (IS_SEQ) {
+        fast = fast && w == seq_expected(w);
+        bins = w & 0x07070707u;
+    } else {
+        const uint32_t lo7 = w & 0x7F7F7F7Fu;
+        const uint32_t ge33 = lo7 + 0x5F5F5F5Fu, ge97 = lo7 + 0x1F1F1F1Fu;
+        fast = fast && ((ge33 & ~ge97 & ~w) & 0x80808080u) == 0x80808080u;
+        bins = w - 0x21212121u;
+    }
+    if (fast) {
+        if (IS_SEQ) any_n |= ~((((w & 0x7F7F7F7Fu) ^ 0x4E4E4E4Eu) + 0x7F7F7F7Fu) | w) & 0x80808080u;
+        uint32_t *r = row0 + p * 64;
+        atomicAdd(r + (bins & 0xFFu), 1u);
+        atomicAdd(r + 64 + ((bins >> 8) & 0xFFu), 1u);
+        atomicAdd(r + 128 + ((bins >> 16) & 0xFFu), 1u);
+        atomicAdd(r + 192 + (bins >> 24), 1u);
+    } else {
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t b = (w >> (8 * j)) & 0xFFu;
+            const uint32_t col = p + j;
+            if (IS_SEQ) {
+                const bool valid = b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N';
+                const uint32_t bin = valid ? (b & 7u) : 0u;
+                any_inv |= valid ? 0u : 1u;
+                any_n |= b == 'N' ? 1u : 0u;
+                if (col < lc) atomicAdd(sh + col * 64 + copy8 + bin, 1u);
+                else if (col < a.lmax) atomicAdd(&a.base_hist[(uint64_t)col * 8 + bin_to_class(bin)], 1ull);
+                else ++ovf;
+            } else {
+                if (col < lc && b - 33u < 64u) atomicAdd(qh + col * 64 + (b - 33u), 1u);
+                else if (col < a.lmax) atomicAdd(&a.qual_hist[(uint64_t)col * 256 + b], 1ull);
+                else ++ovf;
+            }
+        }
+    }
+}
+
+struct StatsAcc {
+    unsigned long long rec, bases, qual, dna, dnan, oseq, oqual;
+};
+
+// All sequence lines (IS_SEQ) or all quality lines of one tile: entries i == i0 (mod 4).
+template <bool IS_SEQ>
+__device__ __forceinline__ void stats_tile_lines(const StatsArgs &a, uint32_t lane, uint32_t i0, uint32_t cnt,
+                                                 unsigned long long lbase, uint64_t tb, uint64_t next_first,
+                                                 const uint16_t *__restrict__ tl, uint32_t lc, uint32_t *qh,
+                                                 uint32_t *sh, uint32_t copy8, StatsAcc &acc) {
+    if (i0 >= cnt) return;
+    const uint32_t nitems = (cnt - i0 + 3) >> 2;
+    const uint8_t *const bend = a.buf + a.len;
+    uint32_t *const row0 = IS_SEQ ? sh + copy8 : qh;
+    for (uint32_t kk = 0; kk < nitems; kk += 64) {
+        const uint32_t k = kk + lane;
+        const uint32_t i = i0 + 4 * k;
+        const unsigned long long L = lbase + i;
+        const bool act = k < nitems && L >= a.line_lo && L < a.line_hi;
+        uint64_t S = 0;
+        uint32_t len = 0;
+        if (act) {
+            S = tb + (tl[i] & 0x3FFFu);
+            uint64_t nextS = (i + 1 < cnt) ? tb + (tl[i + 1] & 0x3FFFu) : next_first;
+            if (nextS > a.valid_end) nextS = a.valid_end;
+            len = (uint32_t)(nextS - 1 - S);                      // raw line, without its '\n'
+            if (len && a.buf[S + len - 1] == '\r') --len;          // trim_winline, src/records.rs:66-73
+        }
+        const uint8_t *__restrict__ lp = a.buf + S;
+        uint32_t any_n = 0, any_inv = 0, ovf = 0;
+        uint4 cur = len ? load16_any(lp, bend) : make_uint4(0, 0, 0, 0);
+        for (uint32_t p = 0; __ballot(p < len) != 0; p += 16) {
+            const uint4 nxt = p + 16 < len ? load16_any(lp + p + 16, bend) : make_uint4(0, 0, 0, 0);
+            stats_dword<IS_SEQ>(a, cur.x, p, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+            stats_dword<IS_SEQ>(a, cur.y, p + 4, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+            stats_dword<IS_SEQ>(a, cur.z, p + 8, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+            stats_dword<IS_SEQ>(a, cur.w, p + 12, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+            cur = nxt;
+        }
+        if (act) {
+            if (IS_SEQ) {
+                ++acc.rec;
+                acc.bases += len;
+                acc.dna += (any_n | any_inv) ? 0 : 1;
+                acc.dnan += any_inv ? 0 : 1;
+                acc.oseq += ovf;
+            } else {
+                acc.qual += len;
+                acc.oqual += ovf;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SL_THREADS) void k_stats_lines(StatsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // [lc][64] quality, [lc][64] sequence
+    const uint32_t lc = a.lc;
+    uint32_t *const qh = hist;
+    uint32_t *const sh = hist + lc * 64;
+    for (uint32_t i = threadIdx.x; i < lc * 128; i += SL_THREADS) hist[i] = 0;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t copy8 = (lane & 7u) * 8u;
+    StatsAcc acc = {0, 0, 0, 0, 0, 0, 0};
+
+    for (uint64_t tile = (uint64_t)blockIdx.x * SL_WAVES + wv; tile < a.n_tiles;
+         tile += (uint64_t)gridDim.x * SL_WAVES) {
+        uint32_t cnt = a.tile_count[tile];
+        cnt = cnt < a.list_cap ? cnt : a.list_cap;
+        if (cnt == 0) continue;
+        const unsigned long long lbase = a.nl_count + 1 + a.block_prefix[tile >> SCAN_SHIFT] + a.tile_prefix[tile];
+        if (lbase >= a.line_hi || lbase + cnt <= a.line_lo) continue;
+        const uint16_t *__restrict__ tl = a.list + tile * a.list_cap;
+        const uint64_t tb = tile << WT_SHIFT;
+        // start of the first line after this tile (ends the tile's last line)
+        uint64_t next_first = a.valid_end;
+        for (uint64_t t2 = tile + 1; t2 < a.n_tiles; ++t2) {
+            if (a.tile_count[t2]) { next_first = (t2 << WT_SHIFT) + (a.list[t2 * a.list_cap] & 0x3FFFu); break; }
+        }
+        const uint32_t lb3 = (uint32_t)lbase & 3u;
+        stats_tile_lines<true>(a, lane, (1u - lb3) & 3u, cnt, lbase, tb, next_first, tl, lc, qh, sh, copy8, acc);
+        stats_tile_lines<false>(a, lane, (3u - lb3) & 3u, cnt, lbase, tb, next_first, tl, lc, qh, sh, copy8, acc);
+    }
+    __syncthreads();
+    uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * lc * 128;
+    for (uint32_t i = threadIdx.x; i < lc * 128; i += SL_THREADS) dst[i] = hist[i];
+    unsigned long long sc[7] = {acc.rec, acc.bases, acc.qual, acc.dna, acc.dnan, acc.oseq, acc.oqual};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        unsigned long long v = sc[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0 && v) atomicAdd(&a.scalars[j], v);
+    }
+}
+
+// Sum the per-block partial histograms into the caller's u64 arrays (plain adds: one thread per bin).
+__global__ __launch_bounds__(256) void k_stats_reduce(const uint32_t *__restrict__ scratch, uint32_t n_blocks,
+                                                      uint32_t lc, unsigned long long *__restrict__ qual_hist,
+                                                      unsigned long long *__restrict__ base_hist) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nq = lc * 64, ns = lc * 8;
+    const uint64_t stride = (uint64_t)lc * 128;
+    if (id < nq) {
+        unsigned long long s = 0;
+        for (uint32_t b = 0; b < n_blocks; ++b) s += scratch[b * stride + id];
+        if (s) qual_hist[(uint64_t)(id / 64) * 256 + 33 + (id % 64)] += s;
+    } else if (id < nq + ns) {
+        const uint32_t j = id - nq, row = j / 8, bin = j % 8;
+        unsigned long long s = 0;
+        for (uint32_t b = 0; b < n_blocks; ++b)
+            for (uint32_t c = 0; c < 8; ++c) s += scratch[b * stride + nq + row * 64 + c * 8 + bin];
+        if (s) atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+    }
+}
+
+uint32_t stats_lines_lc(uint32_t lmax) { return lmax < SL_LC_MAX ? lmax : SL_LC_MAX; }
+uint32_t stats_lines_blocks(int n_cu) { return (uint32_t)(n_cu > 0 ? n_cu : 256); }
+size_t stats_lines_scratch_bytes(uint32_t lmax, int n_cu) {
+    return (size_t)stats_lines_blocks(n_cu) * stats_lines_lc(lmax) * 128 * sizeof(uint32_t);
+}
+hipError_t launch_stats_lines(hipStream_t s, StatsArgs a, int n_cu) {
+    a.lc = stats_lines_lc(a.lmax);
+    const size_t lds = (size_t)a.lc * 128 * sizeof(uint32_t);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_lines),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    const uint32_t blocks = stats_lines_blocks(n_cu);
+    hipLaunchKernelGGL(k_stats_lines, dim3(blocks), dim3(SL_THREADS), lds, s, a);
+    const uint32_t nred = a.lc * 72;
+    hipLaunchKernelGGL(k_stats_reduce, dim3((nred + 255) / 256), dim3(256), 0, s, a.scratch, blocks, a.lc,
+                       a.qual_hist, a.base_hist);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic 150 bp FASTQ: byte b of record i is a pure function of (seed, i, b); the
 // tests regenerate any sub-range on the CPU from the same map.
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfastq_hip.so")
 
-__all__ = ["LIB_PATH", "lib", "Ctx", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
+__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
            "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "BUFSIZE", "NSCALARS", "EXPORTS"]
 
@@ -19,7 +19,8 @@ EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
     "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_last_timing",
-    "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
+    "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_acquire", "fqh_stream_submit",
+    "fqh_stream_collect", "fqh_stream_release", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
 ]
 
@@ -44,6 +45,17 @@ class Timing(C.Structure):
 class IdxRecord(C.Structure):
     _fields_ = [("start", C.c_uint64), ("head", C.c_uint32), ("seq", C.c_uint32),
                 ("sep", C.c_uint32), ("qual", C.c_uint32)]
+
+
+class Chunk(C.Structure):
+    _fields_ = [("parse_status", C.c_int32), ("is_final", C.c_int32), ("n_records", C.c_uint64),
+                ("base_offset", C.c_uint64), ("data_len", C.c_uint64), ("lead_len", C.c_uint64),
+                ("h_data", C.c_void_p), ("h_index", C.c_void_p), ("h_rec_start", C.c_void_p),
+                ("d_data", C.c_void_p), ("d_rec_start", C.c_void_p),
+                ("err_record", C.c_uint64), ("err_offset", C.c_uint64)]
+
+
+STREAM_INDEX = 1
 
 
 class FqhError(RuntimeError):
@@ -95,6 +107,13 @@ def lib():
         L.fqh_stats_launch.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
         L.fqh_stats_finish.argtypes = [vp, C.POINTER(Summary), C.POINTER(Carry)]
         L.fqh_last_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.fqh_stream_create.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
+        L.fqh_stream_destroy.argtypes = [vp]
+        L.fqh_stream_destroy.restype = None
+        L.fqh_stream_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+        L.fqh_stream_submit.argtypes = [vp, u64, i32]
+        L.fqh_stream_collect.argtypes = [vp, C.POINTER(Chunk)]
+        L.fqh_stream_release.argtypes = [vp]
         L.fqh_synth_fill.argtypes = [vp, vp, u64, u64, u64]
         L.fqh_read_ceiling.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(C.c_float)]
         L.fqh_dev_alloc.argtypes = [vp, u64, C.POINTER(vp)]
@@ -217,3 +236,39 @@ class Ctx:
         cs, ms = C.c_uint64(0), C.c_float(0)
         self._chk(self._L.fqh_read_ceiling(self._h, d_buf, length, C.byref(cs), C.byref(ms)))
         return cs.value, ms.value
+
+
+class Stream:
+    """fqh_stream_*: pinned ring + overlapped H2D in front of the scan (single producer/consumer)."""
+
+    def __init__(self, ctx, slot_bytes, n_slots=3, flags=STREAM_INDEX):
+        self.ctx = ctx
+        self._L = ctx._L
+        h = C.c_void_p()
+        ctx._chk(self._L.fqh_stream_create(ctx._h, slot_bytes, n_slots, flags, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._L.fqh_stream_destroy(self._h)
+            self._h = None
+
+    def acquire(self):
+        """-> (host address, capacity) or None when the ring is full."""
+        p, cap = C.c_void_p(), C.c_uint64()
+        st = self._L.fqh_stream_acquire(self._h, C.byref(p), C.byref(cap))
+        if st == E_CAPACITY:
+            return None
+        self.ctx._chk(st)
+        return p.value, cap.value
+
+    def submit(self, nbytes, is_final):
+        self.ctx._chk(self._L.fqh_stream_submit(self._h, nbytes, 1 if is_final else 0))
+
+    def collect(self):
+        c = Chunk()
+        self.ctx._chk(self._L.fqh_stream_collect(self._h, C.byref(c)))
+        return c
+
+    def release(self):
+        self.ctx._chk(self._L.fqh_stream_release(self._h))

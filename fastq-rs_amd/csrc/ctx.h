@@ -1,0 +1,83 @@
+// ctx.h — the library-internal definition of fqh_ctx, shared by fastq_hip.hip and stream.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "fqh_internal.h"
+#include "replay.h"
+
+namespace fqh {
+void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *, int);
+void launch_prefix(hipStream_t, const uint32_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
+void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
+void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
+void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_record *, uint64_t,
+                          uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
+size_t stats_lines_scratch_bytes(uint32_t, int);
+hipError_t launch_stats_lines(hipStream_t, StatsArgs, int);
+void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
+void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
+extern int g_index_variant;
+}  // namespace fqh
+
+using namespace fqh;
+
+struct fqh_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t bufsize = FQH_BUFSIZE;
+    std::string err;
+
+    // workspace (grow-only)
+    uint16_t *list = nullptr;
+    size_t list_elems = 0;
+    uint32_t list_cap = LIST_CAP_DEFAULT;
+    uint32_t *tile_count = nullptr, *tile_prefix = nullptr;
+    uint64_t *block_prefix = nullptr;
+    size_t tiles_cap = 0;
+    DevOut *d_out = nullptr;      // [0] the scan's, [1] scratch for index-only emits
+    DevOut *h_out = nullptr;      // pinned
+    DevOut *h_init = nullptr;     // pinned reset image
+    uint64_t *d_misc = nullptr;   // 8 u64 of scratch
+    fqh_idx_record *idx = nullptr;
+    size_t idx_cap = 0;
+    uint64_t *tmp_rec = nullptr;
+    size_t tmp_rec_cap = 0;
+    uint32_t *stats_scratch = nullptr;
+    size_t stats_scratch_bytes = 0;
+
+    hipEvent_t ev[8] = {};
+    fqh_timing timing = {};
+
+    // the scan in flight / last finished
+    bool pending = false;
+    bool last_valid = false;
+    ScanArgs args = {};
+    fqh_carry carry_in = {};
+    bool whole_file = false;
+    fqh_summary last_summary = {};
+    fqh_carry last_carry_out = {};
+    // stats in flight
+    bool stats_pending = false;
+};
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return FQH_E_DEVICE;                                                               \
+        }                                                                                      \
+    } while (0)
+
+
+// internal entry points shared between translation units
+fqh_status fqh_internal_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                                    const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap, bool reuse_index);
+fqh_status fqh_internal_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
+fqh_status fqh_internal_emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap);
+// error visibility of the failing record of the last finished scan (BufferReplay::step's `need`)
+uint64_t fqh_internal_last_need(const fqh_ctx *ctx);

@@ -16,73 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "fqh_internal.h"
-
-namespace fqh {
-void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *, int);
-void launch_prefix(hipStream_t, const uint32_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
-void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
-void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
-void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_record *, uint64_t,
-                          uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
-size_t stats_lines_scratch_bytes(uint32_t, int);
-hipError_t launch_stats_lines(hipStream_t, StatsArgs, int);
-void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
-void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
-extern int g_index_variant;
-}  // namespace fqh
-
-using namespace fqh;
-
-struct fqh_ctx {
-    int device = 0;
-    int n_cu = 256;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    uint64_t bufsize = FQH_BUFSIZE;
-    std::string err;
-
-    // workspace (grow-only)
-    uint16_t *list = nullptr;
-    size_t list_elems = 0;
-    uint32_t list_cap = LIST_CAP_DEFAULT;
-    uint32_t *tile_count = nullptr, *tile_prefix = nullptr;
-    uint64_t *block_prefix = nullptr;
-    size_t tiles_cap = 0;
-    DevOut *d_out = nullptr;      // [0] the scan's, [1] scratch for index-only emits
-    DevOut *h_out = nullptr;      // pinned
-    DevOut *h_init = nullptr;     // pinned reset image
-    uint64_t *d_misc = nullptr;   // 8 u64 of scratch
-    fqh_idx_record *idx = nullptr;
-    size_t idx_cap = 0;
-    uint64_t *tmp_rec = nullptr;
-    size_t tmp_rec_cap = 0;
-    uint32_t *stats_scratch = nullptr;
-    size_t stats_scratch_bytes = 0;
-
-    hipEvent_t ev[8] = {};
-    fqh_timing timing = {};
-
-    // the scan in flight / last finished
-    bool pending = false;
-    bool last_valid = false;
-    ScanArgs args = {};
-    fqh_carry carry_in = {};
-    bool whole_file = false;
-    fqh_summary last_summary = {};
-    fqh_carry last_carry_out = {};
-    // stats in flight
-    bool stats_pending = false;
-};
-
-#define HIPCHK(ctx, call)                                                                      \
-    do {                                                                                       \
-        hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess) {                                                                \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
-            return FQH_E_DEVICE;                                                               \
-        }                                                                                      \
-    } while (0)
+#include "ctx.h"
 
 static fqh_status fail(fqh_ctx *ctx, fqh_status s, const char *msg) {
     if (ctx) ctx->err = msg;
@@ -245,50 +179,6 @@ static bool carry_is_zero(const fqh_carry &c) {
     return c.base_offset == 0 && c.nl_count == 0 && c.back[0] == 0 && c.back[1] == 0 && c.back[2] == 0 && c.back[3] == 0;
 }
 
-// Exact replay of Buffer (src/buffer.rs:51-100) inside RecordRefIter::advance (src/lib.rs:255-303)
-// at refill granularity, for a reader that always fills the request (std::io::Cursor, a plain
-// file).  rs[0..n] are the boundaries of the n valid records; `need` = bytes of the first
-// non-valid record that must be visible to report its own error (0 = it is a truncated tail,
-// UINT64_MAX = there is no such record).  Returns true and the record index if the reference would
-// report "Fastq record is too long" first.
-static bool replay_too_long(const uint64_t *rs, uint64_t n, uint64_t file_len, uint64_t need,
-                            uint64_t B, uint64_t *which) {
-    uint64_t start = 0, end = 0, fpos = rs[0], rd = rs[0], k = 0;
-    const uint64_t origin = rs[0];
-    (void)origin;
-    for (;;) {
-        // consume every complete valid record inside the window [fpos, rd)
-        const uint64_t *hi = std::upper_bound(rs + k, rs + n + 1, rd);
-        uint64_t j = (uint64_t)(hi - rs) - 1;
-        if (j > k) {
-            start += rs[j] - fpos;
-            fpos = rs[j];
-            k = j;
-        }
-        if (k == n) {
-            if (need == UINT64_MAX && fpos == file_len && start == end) return false;
-            if (need != UINT64_MAX && need != 0 && fpos + need <= rd) return false;
-        }
-        if (start == end) {  // EmptyBuffer: clean()
-            start = end = 0;
-        } else {             // Incomplete: clean(); n_free() == 0 => too long
-            if (start) {
-                const uint64_t m = end - start;
-                const uint64_t new_end = (m + 15) & ~(uint64_t)15;
-                const uint64_t new_start = new_end - m;
-                if (new_start < start) { start = new_start; end = new_end; }
-            }
-            if (B - end == 0) { *which = k; return true; }
-        }
-        const uint64_t n_free = B - end;
-        const uint64_t num = n_free < 4096 ? n_free : n_free - n_free % 4096;
-        const uint64_t got = std::min<uint64_t>(num, file_len - rd);
-        if (got == 0) return false;
-        end += got;
-        rd += got;
-    }
-}
-
 static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
     const ScanArgs &a = ctx->args;
     const DevOut &d = *ctx->h_out;
@@ -349,7 +239,9 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             rs[n] = (uint64_t)(d.end_off > 0 ? d.end_off : 0);  // authoritative end of the last good record
             uint64_t which = 0;
-            if (replay_too_long(rs.data(), n, a.len, need, B, &which)) {
+            BufferReplay rp;
+            rp.reset(B);
+            if (rp.step(rs.data(), 0, n, a.len, true, need == UINT64_MAX ? BufferReplay::NO_BAD : need, &which)) {
                 s.parse_status = FQH_E_TOO_LONG;
                 s.n_records = which;
                 s.err_record = r0 + which;
@@ -463,6 +355,20 @@ static fqh_status emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap) {
     launch_finalize(ctx->stream, b, &ctx->d_out[1]);
     HIPCHK(ctx, hipGetLastError());
     return FQH_OK;
+}
+
+fqh_status fqh_internal_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                                    const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap, bool reuse_index) {
+    return do_scan_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap, reuse_index);
+}
+fqh_status fqh_internal_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
+    return do_scan_finish(ctx, out, carry_out);
+}
+fqh_status fqh_internal_emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap) { return emit_index(ctx, dst, cap); }
+uint64_t fqh_internal_last_need(const fqh_ctx *ctx) {
+    const DevOut &d = *ctx->h_out;
+    if (d.final_key == NOKEY) return BufferReplay::NO_BAD;
+    return ((uint32_t)d.final_key & 3u) == 3 ? 0 : d.err_need;
 }
 
 extern "C" {

@@ -1,0 +1,98 @@
+// replay.h — host-side replay of the reference's 68 KiB Buffer, used to decide "Fastq record is
+// too long" exactly as the crate does.
+//
+// The rule (src/lib.rs:276-283) fires when IdxRecord::from_buffer returns Incomplete and the buffer
+// has no free space after Buffer::clean() (src/buffer.rs:51-72).  clean() re-aligns the unconsumed
+// tail so that the NEXT read is 16-byte aligned, and reads are multiples of 4096 bytes
+// (src/buffer.rs:74-100), so whether a record of 69 618..69 632 bytes fits depends on where the
+// previous refills happened to end.  That is pure integer arithmetic over record boundaries, which
+// the GPU scan provides; no input byte is touched here.  The replay is incremental so that a
+// streamed input (fqh_stream_*) can feed it chunk by chunk.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace fqh {
+
+struct BufferReplay {
+    static constexpr uint64_t NO_BAD = UINT64_MAX;  // no non-valid record known (yet)
+    uint64_t B = 0;
+    uint64_t start = 0, end = 0;  // Buffer::start / Buffer::end
+    uint64_t fpos = 0;            // file offset of buffer[start]
+    uint64_t rd = 0;              // file offset of buffer[end] (bytes the reader has delivered)
+    uint64_t k = 0;               // global index of the record boundary at fpos
+    uint64_t kbase = 0;           // global index of pend[0]
+    std::vector<uint64_t> pend;   // boundaries not yet consumed, pend[0] is boundary kbase
+
+    void reset(uint64_t bufsize) {
+        B = bufsize;
+        start = end = fpos = rd = k = kbase = 0;
+        pend.assign(1, 0);
+    }
+
+    // New information: boundaries rs[0..n] of the records that end in the latest chunk (rs[0] is the
+    // boundary the previous chunk ended with, global index k0); bytes [0, known_end) of the file exist;
+    // eof: known_end is the end of the file.  `need`: if the record starting at rs[n] is not valid,
+    // the number of its bytes that must be visible to report its own error (0: it is a truncated
+    // tail, reported only at EOF); NO_BAD otherwise.  Returns true (and *which) as soon as the
+    // reference would report "too long" for record *which.
+    bool step(const uint64_t *rs, uint64_t k0, uint64_t n, uint64_t known_end, bool eof, uint64_t need,
+              uint64_t *which) {
+        if (B == 0) return false;
+        // append the new boundaries after the pending ones
+        const uint64_t have_last = kbase + pend.size() - 1;  // global index of the last pending boundary
+        for (uint64_t i = 0; i <= n; ++i)
+            if (k0 + i > have_last) pend.push_back(rs[i]);
+        const uint64_t klast = kbase + pend.size() - 1;  // boundary index where the non-valid record starts
+        bool tripped = false;
+        for (;;) {
+            // consume every complete valid record inside the window [fpos, rd)
+            const uint64_t *b = pend.data();
+            const uint64_t *hi = std::upper_bound(b + (k - kbase), b + pend.size(), rd);
+            const uint64_t j = kbase + (uint64_t)(hi - b) - 1;
+            if (j > k) {
+                start += b[j - kbase] - fpos;
+                fpos = b[j - kbase];
+                k = j;
+            }
+            if (k == klast) {
+                if (eof && need == NO_BAD && fpos == known_end && start == end) break;  // clean EOF
+                if (need != NO_BAD && need != 0 && fpos + need <= rd) break;            // its own error shows
+            }
+            if (start == end) {  // EmptyBuffer: clean()
+                start = end = 0;
+            } else {             // Incomplete: clean(); n_free() == 0 => "Fastq record is too long"
+                if (start) {
+                    const uint64_t m = end - start;
+                    const uint64_t new_end = (m + 15) & ~(uint64_t)15;
+                    const uint64_t new_start = new_end - m;
+                    if (new_start < start) { start = new_start; end = new_end; }
+                }
+                if (B - end == 0) {
+                    *which = k;
+                    tripped = true;
+                    break;
+                }
+            }
+            const uint64_t n_free = B - end;
+            const uint64_t num = n_free < 4096 ? n_free : n_free - n_free % 4096;
+            uint64_t got;
+            if (rd + num <= known_end) got = num;
+            else if (eof) got = known_end - rd;
+            else break;  // the reader would block: wait for the next chunk (this iteration is idempotent)
+            if (got == 0) break;  // EOF: Ok(end) or "truncated", the caller's status stands
+            end += got;
+            rd += got;
+        }
+        // drop boundaries behind the window
+        if (k > kbase) {
+            pend.erase(pend.begin(), pend.begin() + (k - kbase));
+            kbase = k;
+        }
+        return tripped;
+    }
+};
+
+}  // namespace fqh

@@ -1,0 +1,237 @@
+// stream.hip — fqh_stream_*: pinned-host ring + side-stream hipMemcpyAsync in front of the scan.
+// Replaces the reference's Buffer (src/buffer.rs) and thread_reader (src/thread_reader.rs) for the
+// GPU path: ingest of slot c+1 overlaps the scan of slot c and the caller's walk over slot c-1.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ctx.h"
+
+struct fqh_stream {
+    fqh_ctx *ctx = nullptr;
+    uint32_t n_slots = 0, flags = 0;
+    uint64_t slot_bytes = 0, reserve = 0;
+    hipStream_t copy_stream = nullptr;
+    struct Slot {
+        uint8_t *h = nullptr;   // pinned: [reserve][slot_bytes]
+        uint8_t *d = nullptr;   // device: [slot_bytes + 16]
+        uint64_t *d_rec = nullptr, *h_rec = nullptr;
+        uint64_t rec_cap = 0;
+        fqh_idx_record *d_idx = nullptr, *h_idx = nullptr;
+        uint64_t idx_cap = 0;
+        hipEvent_t copied = nullptr;
+        uint64_t n_new = 0, lead = 0;
+        int is_final = 0;
+        int state = 0;  // 0 free, 1 acquired, 2 submitted, 3 collected (held by the caller)
+    };
+    std::vector<Slot> slots;
+    uint64_t head = 0, sub = 0, col = 0;  // next slot to acquire / submit / collect (monotone counters)
+    fqh_carry carry = {};
+    uint64_t records_done = 0;
+    bool ended = false;
+    fqh::BufferReplay replay;
+};
+
+static fqh_status grow_rec(fqh_stream *st, fqh_stream::Slot &s, uint64_t need) {
+    fqh_ctx *ctx = st->ctx;
+    if (s.rec_cap >= need) return FQH_OK;
+    (void)hipFree(s.d_rec);
+    if (s.h_rec) (void)hipHostFree(s.h_rec);
+    s.d_rec = nullptr; s.h_rec = nullptr; s.rec_cap = 0;
+    HIPCHK(ctx, hipMalloc((void **)&s.d_rec, need * sizeof(uint64_t)));
+    HIPCHK(ctx, hipHostMalloc((void **)&s.h_rec, need * sizeof(uint64_t), hipHostMallocDefault));
+    s.rec_cap = need;
+    return FQH_OK;
+}
+static fqh_status grow_idx(fqh_stream *st, fqh_stream::Slot &s, uint64_t need) {
+    fqh_ctx *ctx = st->ctx;
+    if (s.idx_cap >= need) return FQH_OK;
+    (void)hipFree(s.d_idx);
+    if (s.h_idx) (void)hipHostFree(s.h_idx);
+    s.d_idx = nullptr; s.h_idx = nullptr; s.idx_cap = 0;
+    HIPCHK(ctx, hipMalloc((void **)&s.d_idx, need * sizeof(fqh_idx_record)));
+    HIPCHK(ctx, hipHostMalloc((void **)&s.h_idx, need * sizeof(fqh_idx_record), hipHostMallocDefault));
+    s.idx_cap = need;
+    return FQH_OK;
+}
+
+extern "C" {
+
+void fqh_stream_destroy(fqh_stream *st) {
+    if (!st) return;
+    (void)hipSetDevice(st->ctx->device);
+    if (st->copy_stream) (void)hipStreamSynchronize(st->copy_stream);
+    (void)hipStreamSynchronize(st->ctx->stream);
+    for (auto &s : st->slots) {
+        if (s.h) (void)hipHostFree(s.h);
+        (void)hipFree(s.d);
+        (void)hipFree(s.d_rec);
+        if (s.h_rec) (void)hipHostFree(s.h_rec);
+        (void)hipFree(s.d_idx);
+        if (s.h_idx) (void)hipHostFree(s.h_idx);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+    }
+    if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
+    delete st;
+}
+
+fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots, uint32_t flags,
+                             fqh_stream **out) {
+    if (!ctx || !out || n_slots < 2 || slot_bytes < 4096) return FQH_E_ARG;
+    *out = nullptr;
+    fqh_stream *st = new (std::nothrow) fqh_stream();
+    if (!st) return FQH_E_DEVICE;
+    st->ctx = ctx;
+    st->n_slots = n_slots;
+    st->flags = flags;
+    st->slot_bytes = (slot_bytes + 15) & ~(uint64_t)15;
+    // room for the partial trailing record of the previous slot: a record longer than BUFSIZE is an
+    // error in the reference, so two BUFSIZEs always suffice
+    st->reserve = 2 * (uint64_t)FQH_BUFSIZE;
+    st->slots.resize(n_slots);
+    st->replay.reset(ctx->bufsize);
+    fqh_status rc = FQH_OK;
+    do {
+        if (hipSetDevice(ctx->device) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+        for (auto &s : st->slots) {
+            if (hipHostMalloc((void **)&s.h, st->reserve + st->slot_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc((void **)&s.d, st->slot_bytes + 16) != hipSuccess ||
+                hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+            if (grow_rec(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
+            if ((flags & FQH_STREAM_INDEX) && grow_idx(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
+        }
+    } while (0);
+    if (rc != FQH_OK) {
+        ctx->err = "fqh_stream_create: allocation failed";
+        fqh_stream_destroy(st);
+        return rc;
+    }
+    *out = st;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap) {
+    if (!st || !h_dst || !cap) return FQH_E_ARG;
+    fqh_stream::Slot &s = st->slots[st->head % st->n_slots];
+    if (st->head != st->sub || s.state != 0) return FQH_E_CAPACITY;  // previous acquire not submitted, or ring full
+    s.state = 1;
+    *h_dst = s.h + st->reserve;
+    *cap = st->slot_bytes;
+    ++st->head;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final) {
+    if (!st) return FQH_E_ARG;
+    if (st->sub + 1 != st->head) return FQH_E_ARG;  // nothing acquired
+    fqh_stream::Slot &s = st->slots[st->sub % st->n_slots];
+    if (s.state != 1 || nbytes > st->slot_bytes) return FQH_E_ARG;
+    fqh_ctx *ctx = st->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    s.n_new = nbytes;
+    s.is_final = is_final ? 1 : 0;
+    if (nbytes) HIPCHK(ctx, hipMemcpyAsync(s.d, s.h + st->reserve, nbytes, hipMemcpyHostToDevice, st->copy_stream));
+    HIPCHK(ctx, hipEventRecord(s.copied, st->copy_stream));
+    s.state = 2;
+    ++st->sub;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
+    if (!st || !out) return FQH_E_ARG;
+    if (st->col >= st->sub) return FQH_E_ARG;  // nothing submitted
+    if (st->ended) return FQH_E_ARG;
+    fqh_stream::Slot &s = st->slots[st->col % st->n_slots];
+    if (s.state != 2) return FQH_E_ARG;
+    fqh_ctx *ctx = st->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    fqh_summary sum = {};
+    fqh_carry cout = {};
+    fqh_status rc;
+    for (int attempt = 0;; ++attempt) {
+        rc = fqh_internal_scan_launch(ctx, s.d, s.n_new, s.is_final, &st->carry, s.d_rec, s.rec_cap, attempt > 0);
+        if (rc != FQH_OK) return rc;
+        rc = fqh_internal_scan_finish(ctx, &sum, &cout);
+        if (rc == FQH_E_CAPACITY && attempt == 0) {
+            rc = grow_rec(st, s, sum.n_records + 16);
+            if (rc != FQH_OK) return rc;
+            continue;
+        }
+        if (rc != FQH_OK) return rc;
+        break;
+    }
+    const uint64_t n = sum.n_records;
+    // boundaries (and index) back to the host
+    HIPCHK(ctx, hipMemcpyAsync(s.h_rec, s.d_rec, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((st->flags & FQH_STREAM_INDEX) && n) {
+        rc = grow_idx(st, s, n);
+        if (rc != FQH_OK) return rc;
+        rc = fqh_internal_emit_index(ctx, s.d_idx, n);
+        if (rc != FQH_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(s.h_idx, s.d_idx, n * sizeof(fqh_idx_record), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+
+    fqh_chunk c = {};
+    c.parse_status = sum.parse_status;
+    c.is_final = s.is_final;
+    c.n_records = n;
+    c.base_offset = st->carry.base_offset;
+    c.data_len = s.n_new;
+    c.lead_len = s.lead;
+    c.h_data = s.h + st->reserve;
+    c.h_index = (st->flags & FQH_STREAM_INDEX) ? s.h_idx : nullptr;
+    c.h_rec_start = s.h_rec;
+    c.d_data = s.d;
+    c.d_rec_start = s.d_rec;
+    c.err_record = sum.err_record;
+    c.err_offset = sum.err_offset;
+
+    // "Fastq record is too long": replay the reference's buffer over the boundaries seen so far
+    const uint64_t known_end = c.base_offset + s.n_new;
+    uint64_t which = 0;
+    const bool bad_here = sum.parse_status != FQH_OK;
+    const uint64_t need = bad_here ? fqh_internal_last_need(ctx) : fqh::BufferReplay::NO_BAD;
+    if (ctx->bufsize &&
+        st->replay.step(s.h_rec, st->records_done, n, known_end, s.is_final || bad_here, need, &which)) {
+        c.parse_status = FQH_E_TOO_LONG;
+        c.err_record = which;
+        c.n_records = which >= st->records_done ? which - st->records_done : 0;
+        c.err_offset = s.h_rec[c.n_records];
+    }
+    // the partial trailing record goes in front of the next slot's data
+    const uint64_t tail = known_end - s.h_rec[n];
+    if (c.parse_status == FQH_OK && !s.is_final) {
+        if (tail > st->reserve) {
+            c.parse_status = FQH_E_TOO_LONG;  // cannot be kept contiguous; the reference rejects it as well
+            c.err_record = st->records_done + n;
+            c.err_offset = s.h_rec[n];
+        } else {
+            fqh_stream::Slot &nx = st->slots[(st->col + 1) % st->n_slots];
+            if (tail) memcpy(nx.h + st->reserve - tail, s.h + st->reserve + s.n_new - tail, tail);
+            nx.lead = tail;
+        }
+    }
+    if (c.parse_status != FQH_OK || s.is_final) st->ended = true;
+    st->records_done += n;
+    st->carry = cout;
+    s.state = 3;
+    ++st->col;
+    *out = c;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_release(fqh_stream *st) {
+    if (!st || st->col == 0) return FQH_E_ARG;
+    fqh_stream::Slot &s = st->slots[(st->col - 1) % st->n_slots];
+    if (s.state != 3) return FQH_E_ARG;
+    s.state = 0;
+    s.lead = 0;
+    return FQH_OK;
+}
+
+}  // extern "C"

@@ -144,6 +144,41 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
                             uint64_t *d_base_hist, uint64_t *d_scalars);
 fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
 
+/* ---- Streaming ingest: the GPU counterpart of Buffer + thread_reader --------------------------
+ * src/buffer.rs keeps one 68 KiB window and memmoves the partial trailing record to its front;
+ * src/thread_reader.rs fills two 4 MiB boxes in a background thread.  Here the window is a ring of
+ * pinned host slots (MiBs each) with a device twin per slot: fqh_stream_submit starts the
+ * host-to-device copy on a side stream and returns; fqh_stream_collect scans the oldest submitted
+ * slot (carry chained from the previous one, so slots may end anywhere), brings the record index
+ * back and copies the partial trailing record in front of the next slot, so every record is
+ * contiguous in host memory when the caller walks it.  Copies of later slots overlap the scan and
+ * the caller's work on earlier ones.  Single producer/consumer, one thread. */
+typedef struct fqh_stream fqh_stream;
+typedef struct {
+    int32_t parse_status;  /* FQH_OK or FQH_E_HEADER..FQH_E_TOO_LONG; an error ends the stream         */
+    int32_t is_final;
+    uint64_t n_records;    /* records that END in this chunk (before the first error)                  */
+    uint64_t base_offset;  /* file offset of the chunk's first new byte                                */
+    uint64_t data_len;     /* new bytes in the chunk                                                   */
+    uint64_t lead_len;     /* bytes of the record in progress available in front of h_data             */
+    const uint8_t *h_data; /* pinned host memory: byte at base_offset; h_data[-lead_len..] is valid    */
+    const fqh_idx_record *h_index; /* n_records entries, `start` = file offset; NULL without FQH_STREAM_INDEX */
+    const uint64_t *h_rec_start;   /* n_records + 1 boundaries (file offsets)                          */
+    const uint8_t *d_data;         /* device twin of the new bytes                                     */
+    const uint64_t *d_rec_start;   /* device copy of the boundaries                                    */
+    uint64_t err_record, err_offset;
+} fqh_chunk;
+#define FQH_STREAM_INDEX 1u /* also build + download the IdxRecord-style index per chunk */
+fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots, uint32_t flags,
+                             fqh_stream **out);
+void fqh_stream_destroy(fqh_stream *st);
+/* Where to put the next input bytes (pinned host memory, *cap bytes).  FQH_E_CAPACITY if every slot
+ * is submitted or held by the caller. */
+fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap);
+fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final);
+fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out);
+fqh_status fqh_stream_release(fqh_stream *st); /* done with the chunk of the last collect */
+
 /* Timing of the kernels of the last launch/finish pair, measured with HIP events on the
  * launch stream: total and per-kernel milliseconds (index, prefix, emit, stats). */
 typedef struct {

@@ -52,7 +52,7 @@ class Chunk(C.Structure):
                 ("base_offset", C.c_uint64), ("data_len", C.c_uint64), ("lead_len", C.c_uint64),
                 ("h_data", C.c_void_p), ("h_index", C.c_void_p), ("h_rec_start", C.c_void_p),
                 ("d_data", C.c_void_p), ("d_rec_start", C.c_void_p),
-                ("err_record", C.c_uint64), ("err_offset", C.c_uint64)]
+                ("err_record", C.c_uint64), ("err_offset", C.c_uint64), ("err_need", C.c_uint64)]
 
 
 STREAM_INDEX = 1

@@ -25,11 +25,19 @@ struct BufferReplay {
     uint64_t k = 0;               // global index of the record boundary at fpos
     uint64_t kbase = 0;           // global index of pend[0]
     std::vector<uint64_t> pend;   // boundaries not yet consumed, pend[0] is boundary kbase
+    // sets == true replays RecordSetIter::next (src/lib.rs:364-425) instead of RecordRefIter::advance:
+    // every refill goes through Buffer::replace_buffer (src/buffer.rs:30-48), which ALWAYS re-aligns,
+    // and ends one RecordSet.  set_sizes receives the number of records of every set that a step
+    // completes (the first one is empty: lib.rs:381-391).
+    bool sets = false;
+    uint64_t set_first = 0;       // global index of the first record of the set under construction
 
-    void reset(uint64_t bufsize) {
+    void reset(uint64_t bufsize, bool record_sets = false) {
         B = bufsize;
         start = end = fpos = rd = k = kbase = 0;
         pend.assign(1, 0);
+        sets = record_sets;
+        set_first = 0;
     }
 
     // New information: boundaries rs[0..n] of the records that end in the latest chunk (rs[0] is the
@@ -39,7 +47,8 @@ struct BufferReplay {
     // tail, reported only at EOF); NO_BAD otherwise.  Returns true (and *which) as soon as the
     // reference would report "too long" for record *which.
     bool step(const uint64_t *rs, uint64_t k0, uint64_t n, uint64_t known_end, bool eof, uint64_t need,
-              uint64_t *which) {
+              uint64_t *which, std::vector<uint64_t> *set_sizes = nullptr, bool *finished = nullptr) {
+        if (finished) *finished = false;
         if (B == 0) return false;
         // append the new boundaries after the pending ones
         const uint64_t have_last = kbase + pend.size() - 1;  // global index of the last pending boundary
@@ -58,31 +67,50 @@ struct BufferReplay {
                 k = j;
             }
             if (k == klast) {
-                if (eof && need == NO_BAD && fpos == known_end && start == end) break;  // clean EOF
-                if (need != NO_BAD && need != 0 && fpos + need <= rd) break;            // its own error shows
-            }
-            if (start == end) {  // EmptyBuffer: clean()
-                start = end = 0;
-            } else {             // Incomplete: clean(); n_free() == 0 => "Fastq record is too long"
-                if (start) {
-                    const uint64_t m = end - start;
-                    const uint64_t new_end = (m + 15) & ~(uint64_t)15;
-                    const uint64_t new_start = new_end - m;
-                    if (new_start < start) { start = new_start; end = new_end; }
+                if (!sets && eof && need == NO_BAD && fpos == known_end && start == end) {  // clean EOF
+                    if (finished) *finished = true;
+                    break;
                 }
-                if (B - end == 0) {
+                if (need != NO_BAD && need != 0 && fpos + need <= rd) {  // its own error shows
+                    if (finished) *finished = true;
+                    break;
+                }
+            }
+            uint64_t nstart = start, nend = end;
+            if (start == end) {  // EmptyBuffer: clean() / replace_buffer() of nothing
+                nstart = nend = 0;
+            } else {             // Incomplete
+                const uint64_t m = end - start;
+                const uint64_t new_end = (m + 15) & ~(uint64_t)15;
+                const uint64_t new_start = new_end - m;
+                if (sets || (start && new_start < start)) { nstart = new_start; nend = new_end; }
+                if (B - nend == 0) {  // n_free() == 0 => "Fastq record is too long"
+                    start = nstart; end = nend;
                     *which = k;
                     tripped = true;
                     break;
                 }
             }
-            const uint64_t n_free = B - end;
+            const uint64_t n_free = B - nend;
             const uint64_t num = n_free < 4096 ? n_free : n_free - n_free % 4096;
             uint64_t got;
             if (rd + num <= known_end) got = num;
             else if (eof) got = known_end - rd;
-            else break;  // the reader would block: wait for the next chunk (this iteration is idempotent)
-            if (got == 0) break;  // EOF: Ok(end) or "truncated", the caller's status stands
+            else break;  // the reader would block: wait for the next chunk; nothing was committed
+            start = nstart; end = nend;
+            const bool was_empty = start == end;
+            if (got == 0 && !(sets && was_empty)) {  // EOF inside a record: "truncated", caller's status stands
+                if (finished) *finished = true;
+                break;
+            }
+            if (sets) {  // this refill ends a RecordSet (lib.rs:381-415)
+                if (set_sizes) set_sizes->push_back(k - set_first);
+                set_first = k;
+            }
+            if (got == 0) {  // EmptyBuffer at EOF: reader_at_end, the last set was just yielded
+                if (finished) *finished = true;
+                break;
+            }
             end += got;
             rd += got;
         }

@@ -190,6 +190,7 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     c.d_rec_start = s.d_rec;
     c.err_record = sum.err_record;
     c.err_offset = sum.err_offset;
+    c.err_need = sum.parse_status != FQH_OK ? fqh_internal_last_need(ctx) : UINT64_MAX;
 
     // "Fastq record is too long": replay the reference's buffer over the boundaries seen so far
     const uint64_t known_end = c.base_offset + s.n_new;

@@ -1,0 +1,575 @@
+// fastq.hpp — C++17 mirror of the `fastq` crate's public surface (aseyboldt/fastq-rs 0.6.0) on top
+// of the C ABI of libfastq_hip.so.  Same names, argument meaning and error behaviour as the crate,
+// so the reference's own tests read the same here (tests/host_tests.cpp):
+//
+//   crate (src/lib.rs, src/records.rs, src/thread_reader.rs)        here
+//   --------------------------------------------------------------- -------------------------------
+//   trait Record { head seq qual write validate_dna validate_dnan } fastq::RefRecord / OwnedRecord
+//   RefRecord::to_owned_record, OwnedRecord                         RefRecord::to_owned_record()
+//   Parser::new(reader)                                             fastq::Parser<Reader>(reader)
+//   Parser::each(FnMut(RefRecord)->bool) -> io::Result<bool>        Parser::each(f) -> bool, throws Error
+//   Parser::ref_iter() / RecordRefIter::{advance,get}               Parser::ref_iter() -> RecordRefIter
+//   Parser::record_sets() (crate-private) / RecordSet::{iter,len}   Parser::record_sets(f) / RecordSet
+//   Parser::parallel_each(n, Fn(iterator<RecordSet>) -> O)          Parser::parallel_each<O>(n, f)
+//   each_zipped(p1, p2, callback)                                   fastq::each_zipped
+//   parse_path(Option<path>, FnOnce(Parser))                        fastq::parse_path (plain input only)
+//   thread_reader(bufsize, queuelen, reader, f)                     fastq::thread_reader
+//   io::Error(InvalidData, msg)                                     fastq::Error{kind(), what()}
+//
+// What runs where: bytes go reader -> pinned ring slot -> (hipMemcpyAsync on a side stream) -> HBM;
+// record boundaries, the four newline offsets of every record and all syntax checks come from the
+// HIP kernels; this header only walks the index the GPU produced and replays the reference's
+// 68 KiB Buffer arithmetic (csrc/replay.h) to reproduce "record too long" and the RecordSet
+// boundaries exactly.  A Reader is anything with `size_t read(uint8_t *dst, size_t n)` returning 0
+// at end of input (std::io::Read); it may throw.
+#pragma once
+#include <stdint.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <vector>
+
+#include "../../include/fastq_hip.h"
+#include "../csrc/replay.h"
+
+namespace fastq {
+
+constexpr size_t BUFSIZE = FQH_BUFSIZE;  // src/lib.rs:128-129
+
+enum class ErrorKind { InvalidData, BrokenPipe, Other };
+
+class Error : public std::runtime_error {
+  public:
+    Error(ErrorKind k, const std::string &m) : std::runtime_error(m), kind_(k) {}
+    ErrorKind kind() const { return kind_; }
+
+  private:
+    ErrorKind kind_;
+};
+
+using bytes_view = std::basic_string_view<uint8_t>;
+
+inline bytes_view trim_winline(bytes_view line) {  // src/records.rs:66-73
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    return line;
+}
+inline bool all_of_alphabet(bytes_view s, bool allow_n) {  // src/records.rs:19-33
+    for (uint8_t x : s)
+        if (!(x == 'A' || x == 'C' || x == 'T' || x == 'G' || (allow_n && x == 'N'))) return false;
+    return true;
+}
+
+struct OwnedRecord {  // src/records.rs:47-54, 99-129
+    std::string head, seq, qual;
+    std::optional<std::string> sep;
+    size_t write(std::ostream &w) const {
+        w.put('@'); w << head; w.put('\n'); w << seq; w.put('\n');
+        if (sep) w << *sep; else w.put('+');
+        w.put('\n'); w << qual; w.put('\n');
+        return 1 + head.size() + 1 + seq.size() + 1 + (sep ? sep->size() : 1) + 1 + qual.size() + 1;
+    }
+    bool validate_dna() const { return all_of_alphabet({(const uint8_t *)seq.data(), seq.size()}, false); }
+    bool validate_dnan() const { return all_of_alphabet({(const uint8_t *)seq.data(), seq.size()}, true); }
+};
+
+// A record that borrows its bytes (src/records.rs:36-45): data = the raw record including the final
+// '\n'; head/seq/sep/qual = offsets of the four newlines, exactly IdxRecord's fields.
+class RefRecord {
+  public:
+    RefRecord(const uint8_t *d, size_t n, uint32_t h, uint32_t s, uint32_t p, uint32_t q)
+        : data_(d), len_(n), head_(h), seq_(s), sep_(p), qual_(q) {}
+    bytes_view head() const { return trim_winline({data_ + 1, (size_t)head_ - 1}); }            // :77-80
+    bytes_view seq() const { return trim_winline({data_ + head_ + 1, (size_t)(seq_ - head_ - 1)}); }   // :83-85
+    bytes_view qual() const { return trim_winline({data_ + sep_ + 1, (size_t)(qual_ - sep_ - 1)}); }   // :88-90
+    bytes_view data() const { return {data_, len_}; }
+    size_t write(std::ostream &w) const {                                                        // :93-96
+        w.write((const char *)data_, (std::streamsize)len_);
+        return len_;
+    }
+    bool validate_dna() const { return all_of_alphabet(seq(), false); }
+    bool validate_dnan() const { return all_of_alphabet(seq(), true); }
+    OwnedRecord to_owned_record() const {                                                        // :167-174
+        auto str = [](bytes_view v) { return std::string((const char *)v.data(), v.size()); };
+        OwnedRecord o;
+        o.head = str(head()); o.seq = str(seq()); o.qual = str(qual());
+        o.sep = str(trim_winline({data_ + seq_ + 1, (size_t)(sep_ - seq_ - 1)}));
+        return o;
+    }
+
+  private:
+    const uint8_t *data_;
+    size_t len_;
+    uint32_t head_, seq_, sep_, qual_;
+};
+
+// An owned batch of records (src/lib.rs:306-353): one byte buffer + the index into it.
+class RecordSet {
+  public:
+    struct Idx { uint64_t start; uint32_t head, seq, sep, qual; };
+    size_t len() const { return idx_.size(); }
+    bool is_empty() const { return idx_.empty(); }
+    RefRecord at(size_t i) const {
+        const Idx &r = idx_[i];
+        return RefRecord(buf_.data() + r.start, (size_t)r.qual + 1, r.head, r.seq, r.sep, r.qual);
+    }
+    class iterator {
+      public:
+        iterator(const RecordSet *s, size_t i) : s_(s), i_(i) {}
+        RefRecord operator*() const { return s_->at(i_); }
+        iterator &operator++() { ++i_; return *this; }
+        bool operator!=(const iterator &o) const { return i_ != o.i_; }
+      private:
+        const RecordSet *s_;
+        size_t i_;
+    };
+    iterator begin() const { return iterator(this, 0); }
+    iterator end() const { return iterator(this, idx_.size()); }
+    const RecordSet &iter() const { return *this; }
+    void push(const uint8_t *rec, const fqh_idx_record &r) {
+        Idx x{buf_.size(), r.head, r.seq, r.sep, r.qual};
+        buf_.insert(buf_.end(), rec, rec + (size_t)r.qual + 1);
+        idx_.push_back(x);
+    }
+    // records [a, b) as a set of their own (their bytes are contiguous in buf_)
+    RecordSet slice(size_t a, size_t b) const {
+        RecordSet out;
+        if (b > a) {
+            const uint64_t lo = idx_[a].start, hi = idx_[b - 1].start + idx_[b - 1].qual + 1;
+            out.buf_.assign(buf_.begin() + (ptrdiff_t)lo, buf_.begin() + (ptrdiff_t)hi);
+            out.idx_.assign(idx_.begin() + (ptrdiff_t)a, idx_.begin() + (ptrdiff_t)b);
+            for (auto &x : out.idx_) x.start -= lo;
+        }
+        return out;
+    }
+    void clear() { buf_.clear(); idx_.clear(); }
+
+  private:
+    std::vector<uint8_t> buf_;
+    std::vector<Idx> idx_;
+};
+
+struct Options {
+    int device = 0;
+    uint64_t slot_bytes = 32ull << 20;  // pinned ring slot (the GPU-side "BUFSIZE")
+    uint32_t n_slots = 3;
+    uint64_t bufsize = BUFSIZE;         // the reference's BUFSIZE, for its "too long" rule (64 = cfg(fuzzing))
+};
+
+namespace detail {
+inline const char *message(int status, bool sets) {
+    // the crate words two errors differently in RecordSetIter::next (lib.rs:399-402, 407-410)
+    if (sets && status == FQH_E_TOO_LONG) return "Fastq record is too long.";
+    if (sets && status == FQH_E_TRUNCATED) return "Truncated input file.";
+    return fqh_strerror((fqh_status)status);
+}
+struct Handles {
+    fqh_ctx *ctx = nullptr;
+    fqh_stream *st = nullptr;
+    ~Handles() {
+        if (st) fqh_stream_destroy(st);
+        if (ctx) fqh_destroy(ctx);
+    }
+};
+}  // namespace detail
+
+template <class Reader>
+class RecordRefIter;
+
+template <class Reader>
+class Parser {
+  public:
+    explicit Parser(Reader reader, Options opt = Options()) : reader_(std::move(reader)), opt_(opt) {}
+
+    // Parser::each (src/lib.rs:221-239): true if the input was exhausted, false if f stopped it.
+    template <class F>
+    bool each(F f) {
+        open(false);
+        for (;;) {
+            Chunk c = next_chunk();
+            for (uint64_t i = 0; i < c.n; ++i)
+                if (!f(c.record(i))) { release(); return false; }
+            const int status = c.status;
+            const bool fin = c.is_final;
+            release();
+            if (status != FQH_OK) throw Error(ErrorKind::InvalidData, detail::message(status, false));
+            if (fin) return true;
+        }
+    }
+
+    RecordRefIter<Reader> ref_iter() { return RecordRefIter<Reader>(this); }
+
+    // Parser::record_sets (src/lib.rs:428-436): f(RecordSet&&) -> bool (false stops).  Sets have the
+    // same boundaries as the crate's (one per 68 KiB refill, the first one empty).  Throws on a parse
+    // error; like the crate, records of the set under construction are dropped with the error.
+    template <class F>
+    void record_sets(F f) {
+        open(true);
+        RecordSet pend;       // records scanned but not yet assigned to a set (the replay lags by < BUFSIZE)
+        size_t pend_off = 0;  // records of pend already handed out
+        std::vector<uint64_t> sizes;
+        for (;;) {
+            Chunk c = next_chunk(&sizes);
+            for (uint64_t i = 0; i < c.n; ++i) pend.push(c.record_ptr(i), c.idx[i]);
+            const int status = c.status;
+            const bool fin = c.is_final;
+            release();
+            for (uint64_t want : sizes) {  // one RecordSet per refill of the reference's buffer
+                RecordSet out = pend.slice(pend_off, pend_off + (size_t)want);
+                pend_off += (size_t)want;
+                if (!f(std::move(out))) return;
+            }
+            sizes.clear();
+            if (pend_off == pend.len()) { pend.clear(); pend_off = 0; }
+            else if (pend_off > 4096) { pend = pend.slice(pend_off, pend.len()); pend_off = 0; }
+            if (status != FQH_OK) throw Error(ErrorKind::InvalidData, detail::message(status, true));
+            if (fin) return;
+        }
+    }
+
+    // Parser::parallel_each (src/lib.rs:509-565): n_threads workers, each fed RecordSets round-robin
+    // through a bounded queue of 10; the worker closure gets a pull function (the crate's iterator):
+    // `std::optional<RecordSet> next()`.  Returns the workers' results in worker order; on a parse
+    // error the results are discarded and the error is thrown after all workers have finished.
+    template <class O, class F>
+    std::vector<O> parallel_each(size_t n_threads, F func) {
+        struct Queue {
+            std::mutex m;
+            std::condition_variable cv_put, cv_get;
+            std::deque<RecordSet> q;
+            bool closed = false, consumer_gone = false;
+        };
+        std::vector<std::unique_ptr<Queue>> qs;
+        for (size_t i = 0; i < n_threads; ++i) qs.emplace_back(new Queue());
+        std::vector<O> results(n_threads);
+        std::vector<std::exception_ptr> panics(n_threads);
+        std::vector<std::thread> threads;
+        for (size_t i = 0; i < n_threads; ++i) {
+            threads.emplace_back([&, i] {
+                Queue &q = *qs[i];
+                auto next = [&q]() -> std::optional<RecordSet> {
+                    std::unique_lock<std::mutex> lk(q.m);
+                    q.cv_get.wait(lk, [&] { return !q.q.empty() || q.closed; });
+                    if (q.q.empty()) return std::nullopt;
+                    RecordSet s = std::move(q.q.front());
+                    q.q.pop_front();
+                    q.cv_put.notify_one();
+                    return s;
+                };
+                try { results[i] = func(next); } catch (...) { panics[i] = std::current_exception(); }
+                std::lock_guard<std::mutex> lk(q.m);
+                q.consumer_gone = true;
+                q.q.clear();
+                q.cv_put.notify_all();
+            });
+        }
+        std::exception_ptr io_error;
+        size_t turn = 0;
+        try {
+            if (n_threads) {
+                record_sets([&](RecordSet &&s) {
+                    Queue &q = *qs[turn % n_threads];  // senders.iter().cycle(), lib.rs:535
+                    ++turn;
+                    std::unique_lock<std::mutex> lk(q.m);
+                    q.cv_put.wait(lk, [&] { return q.q.size() < 10 || q.consumer_gone; });  // sync_channel(10)
+                    if (q.consumer_gone) return false;  // send error: stop parsing (lib.rs:538-543)
+                    q.q.push_back(std::move(s));
+                    q.cv_get.notify_one();
+                    return true;
+                });
+            }
+        } catch (...) {
+            io_error = std::current_exception();
+        }
+        for (auto &q : qs) {  // drop(senders)
+            std::lock_guard<std::mutex> lk(q->m);
+            q->closed = true;
+            q->cv_get.notify_all();
+        }
+        for (auto &t : threads) t.join();
+        for (auto &p : panics)
+            if (p) std::rethrow_exception(p);  // "Panic in worker thread"
+        if (io_error) std::rethrow_exception(io_error);
+        return results;
+    }
+
+  private:
+    friend class RecordRefIter<Reader>;
+    struct Chunk {
+        uint64_t n = 0;
+        int status = FQH_OK;
+        bool is_final = false;
+        const uint8_t *h_data = nullptr;
+        uint64_t base = 0;
+        const fqh_idx_record *idx = nullptr;
+        const uint8_t *record_ptr(uint64_t i) const { return h_data + (int64_t)(idx[i].start - base); }
+        RefRecord record(uint64_t i) const {
+            const fqh_idx_record &r = idx[i];
+            return RefRecord(record_ptr(i), (size_t)r.qual + 1, r.head, r.seq, r.sep, r.qual);
+        }
+    };
+
+    void open(bool sets) {
+        if (h_.ctx) throw Error(ErrorKind::Other, "parser already consumed");
+        if (fqh_create(opt_.device, &h_.ctx) != FQH_OK)
+            throw Error(ErrorKind::Other, std::string("fqh_create: ") + fqh_last_error(nullptr));
+        fqh_set_bufsize(h_.ctx, 0);  // the "too long" rule is replayed here, mode-exact (each vs record sets)
+        if (fqh_stream_create(h_.ctx, opt_.slot_bytes, opt_.n_slots, FQH_STREAM_INDEX, &h_.st) != FQH_OK)
+            throw Error(ErrorKind::Other, std::string("fqh_stream_create: ") + fqh_last_error(h_.ctx));
+        replay_.reset(opt_.bufsize, sets);
+        sets_ = sets;
+    }
+
+    void fill() {  // keep the ring busy: read -> pinned slot -> async H2D
+        while (!eof_) {
+            uint8_t *dst;
+            uint64_t cap;
+            fqh_status st = fqh_stream_acquire(h_.st, &dst, &cap);
+            if (st == FQH_E_CAPACITY) return;
+            if (st != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
+            uint64_t n = 0;
+            while (n < cap) {
+                size_t got = reader_.read(dst + n, (size_t)(cap - n));
+                if (got == 0) { eof_ = true; break; }
+                n += got;
+            }
+            if (fqh_stream_submit(h_.st, n, eof_ ? 1 : 0) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
+            ++in_flight_;
+        }
+    }
+
+    Chunk next_chunk(std::vector<uint64_t> *set_sizes = nullptr) {
+        fill();
+        fqh_chunk c;
+        if (fqh_stream_collect(h_.st, &c) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
+        --in_flight_;
+        held_ = true;
+        Chunk out;
+        out.n = c.n_records;
+        out.status = c.parse_status;
+        out.is_final = c.is_final != 0;
+        out.h_data = c.h_data;
+        out.base = c.base_offset;
+        out.idx = c.h_index;
+        // the reference's Buffer, replayed over the boundaries: "too long" and (sets) the set cuts
+        uint64_t which = 0;
+        bool finished = false;
+        const bool bad = c.parse_status != FQH_OK;
+        const uint64_t known_end = c.base_offset + c.data_len;
+        if (replay_.step(c.h_rec_start, records_done_, c.n_records, known_end, out.is_final || bad,
+                         bad ? c.err_need : fqh::BufferReplay::NO_BAD, &which, set_sizes, &finished)) {
+            out.status = FQH_E_TOO_LONG;
+            out.n = which >= records_done_ ? which - records_done_ : 0;
+            out.is_final = true;
+        }
+        records_done_ += c.n_records;
+        return out;
+    }
+
+    void release() {
+        if (held_) fqh_stream_release(h_.st);
+        held_ = false;
+    }
+
+    Reader reader_;
+    Options opt_;
+    detail::Handles h_;
+    fqh::BufferReplay replay_;
+    bool sets_ = false, eof_ = false, held_ = false;
+    uint64_t records_done_ = 0;
+    int in_flight_ = 0;
+};
+
+// RecordRefIter (src/lib.rs:241-304): advance() then get(); get() is empty at end of input.
+template <class Reader>
+class RecordRefIter {
+  public:
+    explicit RecordRefIter(Parser<Reader> *p) : p_(p) {}
+    void advance() {
+        if (!opened_) { p_->open(false); opened_ = true; }
+        ++i_;
+        while (!have_ || i_ >= c_.n) {
+            if (have_) {
+                const int status = c_.status;
+                const bool fin = c_.is_final;
+                p_->release();
+                have_ = false;
+                if (status != FQH_OK) throw Error(ErrorKind::InvalidData, detail::message(status, false));
+                if (fin) { done_ = true; return; }
+            }
+            if (done_) return;
+            c_ = p_->next_chunk();
+            have_ = true;
+            i_ = 0;
+        }
+    }
+    std::optional<RefRecord> get() const {
+        if (done_ || !have_ || i_ >= c_.n) return std::nullopt;
+        return c_.record(i_);
+    }
+
+  private:
+    Parser<Reader> *p_;
+    typename Parser<Reader>::Chunk c_;
+    bool opened_ = false, have_ = false, done_ = false;
+    uint64_t i_ = (uint64_t)-1;
+};
+
+// each_zipped (src/lib.rs:577-609)
+template <class R1, class R2, class F>
+std::pair<bool, bool> each_zipped(Parser<R1> &p1, Parser<R2> &p2, F callback) {
+    auto it1 = p1.ref_iter();
+    auto it2 = p2.ref_iter();
+    std::pair<bool, bool> finished{false, false};
+    it1.advance();
+    it2.advance();
+    for (;;) {
+        auto v1 = finished.first ? std::nullopt : it1.get();
+        auto v2 = finished.second ? std::nullopt : it2.get();
+        finished = {!v1.has_value(), !v2.has_value()};
+        std::pair<bool, bool> adv = callback(v1, v2);
+        if ((!adv.first && !adv.second) || (finished.first && finished.second)) return finished;
+        if (adv.first && !finished.first) it1.advance();
+        if (adv.second && !finished.second) it2.advance();
+    }
+}
+
+// Readers ---------------------------------------------------------------------------------------
+class MemReader {  // std::io::Cursor<&[u8]>
+  public:
+    MemReader(const uint8_t *d, size_t n) : d_(d), n_(n) {}
+    explicit MemReader(const std::string &s) : d_((const uint8_t *)s.data()), n_(s.size()) {}
+    size_t read(uint8_t *dst, size_t n) {
+        size_t k = n < n_ - pos_ ? n : n_ - pos_;
+        if (k) memcpy(dst, d_ + pos_, k);
+        pos_ += k;
+        return k;
+    }
+  private:
+    const uint8_t *d_;
+    size_t n_, pos_ = 0;
+};
+
+class FileReader {  // std::fs::File / stdin
+  public:
+    explicit FileReader(FILE *f, bool own) : f_(f), own_(own) {}
+    FileReader(FileReader &&o) noexcept : f_(o.f_), own_(o.own_) { o.f_ = nullptr; }
+    FileReader(const FileReader &) = delete;
+    ~FileReader() { if (f_ && own_) fclose(f_); }
+    size_t read(uint8_t *dst, size_t n) {
+        size_t k = fread(dst, 1, n, f_);
+        if (k == 0 && ferror(f_)) throw Error(ErrorKind::Other, "read error");
+        return k;
+    }
+  private:
+    FILE *f_;
+    bool own_;
+};
+
+// thread_reader (src/thread_reader.rs:182-200): `queuelen` recycled buffers of `bufsize` bytes are
+// filled by a background thread; the consumer sees a Reader.  A reader exception is rethrown in the
+// consumer as BrokenPipe-style Error after the thread has been joined.
+template <class Reader>
+class ThreadReader {
+  public:
+    ThreadReader(Reader r, size_t bufsize, size_t queuelen) : reader_(std::move(r)), bufsize_(bufsize) {
+        for (size_t i = 0; i < (queuelen ? queuelen : 1); ++i) empty_.push_back(std::vector<uint8_t>(bufsize));
+        th_ = std::thread([this] { serve(); });
+    }
+    ~ThreadReader() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    size_t read(uint8_t *dst, size_t n) {
+        if (cur_pos_ == cur_len_) {
+            std::unique_lock<std::mutex> lk(m_);
+            if (have_cur_) { empty_.push_back(std::move(cur_)); have_cur_ = false; cv_.notify_all(); }
+            cv_.wait(lk, [&] { return !full_.empty() || failed_; });
+            if (full_.empty()) throw Error(ErrorKind::BrokenPipe, "reader thread died");
+            auto m = std::move(full_.front());
+            full_.pop_front();
+            cur_ = std::move(m.first);
+            cur_len_ = m.second;
+            cur_pos_ = 0;
+            have_cur_ = true;
+            if (cur_len_ == 0) return 0;  // a read() of 0 bytes is forwarded (thread_reader.rs:40-50)
+        }
+        size_t k = n < cur_len_ - cur_pos_ ? n : cur_len_ - cur_pos_;
+        memcpy(dst, cur_.data() + cur_pos_, k);
+        cur_pos_ += k;
+        return k;
+    }
+  private:
+    void serve() {
+        for (;;) {
+            std::vector<uint8_t> b;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !empty_.empty() || stop_; });
+                if (stop_) return;
+                b = std::move(empty_.front());
+                empty_.pop_front();
+            }
+            size_t got = 0;
+            try { got = reader_.read(b.data(), bufsize_); } catch (...) {
+                std::lock_guard<std::mutex> lk(m_);
+                failed_ = true;
+                cv_.notify_all();
+                return;
+            }
+            std::lock_guard<std::mutex> lk(m_);
+            full_.emplace_back(std::move(b), got);
+            cv_.notify_all();
+            if (got == 0) { /* keep serving: the consumer may poll EOF again */ }
+        }
+    }
+    Reader reader_;
+    size_t bufsize_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::vector<uint8_t>> empty_;
+    std::deque<std::pair<std::vector<uint8_t>, size_t>> full_;
+    std::vector<uint8_t> cur_;
+    size_t cur_len_ = 0, cur_pos_ = 0;
+    bool have_cur_ = false, stop_ = false, failed_ = false;
+    std::thread th_;
+};
+
+template <class Reader, class F>
+auto thread_reader(size_t bufsize, size_t queuelen, Reader reader, F func) {
+    ThreadReader<Reader> tr(std::move(reader), bufsize, queuelen);
+    struct Ref {  // the closure gets a `&mut ThreadReader`
+        ThreadReader<Reader> *t;
+        size_t read(uint8_t *d, size_t n) { return t->read(d, n); }
+    };
+    return func(Ref{&tr});
+}
+
+// parse_path (src/lib.rs:167-196), plain (uncompressed) input only: compression sniffing is the
+// niffler crate's job in the reference and is out of scope here.  nullopt / "-" = stdin.
+template <class F>
+auto parse_path(const std::optional<std::string> &path, F func, Options opt = Options()) {
+    FILE *f = stdin;
+    bool own = false;
+    if (path && *path != "-") {
+        f = fopen(path->c_str(), "rb");
+        if (!f) throw Error(ErrorKind::Other, "cannot open " + *path);
+        own = true;
+    }
+    Parser<FileReader> p(FileReader(f, own), opt);
+    return func(p);
+}
+
+}  // namespace fastq

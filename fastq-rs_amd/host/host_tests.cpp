@@ -1,0 +1,199 @@
+// host_tests — the reference's unit tests (src/lib.rs:611-811) and doc-test (src/lib.rs:474-508)
+// written against the C++ mirror, same names and assertions, plus a differential mode used by
+// tests/test_gpu_host_mirror.py:   host_tests --dump FILE THREADS BUFSIZE
+// prints status, record count, RecordSet sizes and per-worker counts for comparison with the oracle.
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+
+#include "fastq.hpp"
+
+using namespace fastq;
+
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); exit(1); } } while (0)
+
+static std::string sv(bytes_view v) { return std::string((const char *)v.data(), v.size()); }
+static Options small() { Options o; o.slot_bytes = 1 << 20; return o; }
+
+static void correct() {  // lib.rs:616-652
+    std::string d = "@hi\nNN\n+\n++\n@hallo\nTCC\n+\nabc\n";
+    Parser<MemReader> p(MemReader(d), small());
+    int i = 0;
+    bool ok = p.each([&](const RefRecord &r) {
+        if (i == 0) {
+            CHECK(sv(r.head()) == "hi" && sv(r.seq()) == "NN" && sv(r.qual()) == "++");
+            OwnedRecord o = r.to_owned_record();
+            CHECK(o.head == "hi" && o.seq == "NN" && o.qual == "++");
+            std::ostringstream out;
+            CHECK(o.write(out) == 12 && out.str() == "@hi\nNN\n+\n++\n");
+        } else {
+            CHECK(sv(r.head()) == "hallo" && sv(r.seq()) == "TCC" && sv(r.qual()) == "abc");
+            std::ostringstream out;
+            CHECK(r.to_owned_record().write(out) == 17 && out.str() == "@hallo\nTCC\n+\nabc\n");
+        }
+        CHECK(i < 2);
+        ++i;
+        return true;
+    });
+    CHECK(ok && i == 2);
+}
+static void empty_id() {  // lib.rs:654-666
+    std::string d = "@\nNN\n+\n++\n";
+    Parser<MemReader> p(MemReader(d), small());
+    p.each([&](const RefRecord &r) { CHECK(sv(r.head()) == "" && sv(r.seq()) == "NN" && sv(r.qual()) == "++"); return true; });
+}
+static void missing_lines() {  // lib.rs:668-686
+    std::string d = "@hi\nNN\n+\n++\n@hi\nNN";
+    Parser<MemReader> p(MemReader(d), small());
+    int seen = 0;
+    try {
+        p.each([&](const RefRecord &r) { CHECK(sv(r.head()) == "hi"); ++seen; return true; });
+        CHECK(!"should fail");
+    } catch (const Error &e) { CHECK(e.kind() == ErrorKind::InvalidData && seen == 1); }
+}
+static void truncated() {  // lib.rs:688-697
+    std::string d = "@hi\nNN\n+\n++";
+    Parser<MemReader> p(MemReader(d), small());
+    try { p.each([&](const RefRecord &) { CHECK(false); return true; }); CHECK(false); } catch (const Error &) {}
+}
+static void second_idline() {  // lib.rs:699-714
+    std::string d = "@hi\nNN\n+hi\n++\n@hi\nNN\n+hi\n++\n";
+    Parser<MemReader> p(MemReader(d), small());
+    p.each([&](const RefRecord &r) {
+        std::ostringstream out;
+        CHECK(r.write(out) == 14 && out.str() == "@hi\nNN\n+hi\n++\n");
+        return true;
+    });
+}
+static void windows_lineend() {  // lib.rs:716-727
+    std::string d = "@hi\r\nNN\r\n+\r\n++\r\n@hi\r\nNN\r\n+\r\n++\r\n";
+    Parser<MemReader> p(MemReader(d), small());
+    int n = 0;
+    p.each([&](const RefRecord &r) { CHECK(sv(r.head()) == "hi" && sv(r.seq()) == "NN" && sv(r.qual()) == "++"); ++n; return true; });
+    CHECK(n == 2);
+}
+static void length_mismatch() {  // lib.rs:729-738
+    std::string d = "@hi\nNN\n+\n+\n";
+    Parser<MemReader> p(MemReader(d), small());
+    try { p.each([&](const RefRecord &) { CHECK(false); return true; }); CHECK(false); }
+    catch (const Error &e) { CHECK(std::string(e.what()) == "Sequence and quality length mismatch"); }
+}
+static std::string huge() { std::string d = "@"; for (size_t i = 0; i < BUFSIZE; ++i) d += "longid"; return d; }
+static void huge_incomplete() {  // lib.rs:740-750
+    std::string d = huge();
+    Parser<MemReader> p(MemReader(d), small());
+    try { p.each([&](const RefRecord &) { return true; }); CHECK(false); }
+    catch (const Error &e) { CHECK(std::string(e.what()) == "Fastq record is too long"); }
+}
+static void bufflen() {  // lib.rs:752-774
+    std::string d = "@" + std::string(BUFSIZE - 8, 'a') + "\nA\n+\nB\n";
+    Parser<MemReader> p(MemReader(d), small());
+    auto vals = p.parallel_each<uint64_t>(2, [](auto next) { uint64_t c = 0; while (auto s = next()) for (auto r : s->iter()) { (void)r; ++c; } return c; });
+    CHECK(vals.size() == 2 && vals[0] + vals[1] == 1);
+}
+static void refset() {  // lib.rs:776-791
+    std::string d = "@hi\nNN\n+\n++\n@hi\nNN\n+\n++\n";
+    Parser<MemReader> p(MemReader(d), small());
+    size_t count = 0, sets = 0;
+    bool first_empty = false;
+    p.record_sets([&](RecordSet &&s) {
+        if (sets++ == 0) first_empty = s.is_empty();
+        for (auto r : s.iter()) { ++count; CHECK(sv(r.head()) == "hi" && sv(r.seq()) == "NN" && sv(r.qual()) == "++"); }
+        return true;
+    });
+    CHECK(count == 2 && first_empty);
+}
+static void refset_incomplete() {  // lib.rs:793-798
+    std::string d = "@hi\nNN\n+\n++\n@hi\nNN\n+\n++";
+    Parser<MemReader> p(MemReader(d), small());
+    try { p.record_sets([&](RecordSet &&) { return true; }); CHECK(false); }
+    catch (const Error &e) { CHECK(std::string(e.what()) == "Truncated input file."); }
+}
+static void refset_huge_incomplete() {  // lib.rs:800-810
+    std::string d = huge();
+    Parser<MemReader> p(MemReader(d), small());
+    try { p.record_sets([&](RecordSet &&) { return true; }); CHECK(false); }
+    catch (const Error &e) { CHECK(std::string(e.what()) == "Fastq record is too long."); }
+}
+static void doctest_parallel_each() {  // lib.rs:474-508
+    std::string d = "@hi\nATTAATTAATTA\n+\n++++++++++++\n";
+    Parser<MemReader> p(MemReader(d), small());
+    auto res = p.parallel_each<std::optional<std::string>>(4, [](auto next) -> std::optional<std::string> {
+        while (auto set = next())
+            for (auto r : set->iter())
+                if (sv(r.seq()).rfind("ATTAATTA", 0) == 0) return sv(r.seq());
+        return std::nullopt;
+    });
+    int found = 0;
+    for (auto &r : res) if (r) { CHECK(*r == "ATTAATTAATTA"); ++found; }
+    CHECK(found == 1);
+}
+static void zipped_and_thread_reader() {  // each_zipped lib.rs:577-609, thread_reader.rs:182-200
+    std::string a = "@a1\nAC\n+\nII\n@a2\nGG\n+\nII\n", b = "@b1\nTT\n+\nII\n";
+    Parser<MemReader> p1(MemReader(a), small()), p2(MemReader(b), small());
+    std::vector<std::string> seen;
+    auto fin = each_zipped(p1, p2, [&](std::optional<RefRecord> x, std::optional<RefRecord> y) {
+        seen.push_back((x ? sv(x->head()) : "-") + "/" + (y ? sv(y->head()) : "-"));
+        return std::make_pair(true, true);
+    });
+    CHECK(fin.first && fin.second);
+    CHECK(seen.size() == 3 && seen[0] == "a1/b1" && seen[1] == "a2/-" && seen[2] == "-/-");
+    std::string big;
+    for (int i = 0; i < 20000; ++i) big += "@r" + std::to_string(i) + "\nACGTN\n+\nIIIII\n";
+    size_t n = thread_reader(1 << 16, 2, MemReader(big), [&](auto reader) {
+        Parser<decltype(reader)> p(reader, small());
+        size_t c = 0;
+        p.each([&](const RefRecord &r) { c += r.validate_dnan() && !r.validate_dna(); return true; });
+        return c;
+    });
+    CHECK(n == 20000);
+}
+
+static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) {
+    std::ifstream f(file, std::ios::binary);
+    std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    Options o;
+    o.bufsize = bufsize;
+    o.slot_bytes = slot;
+    {   // each
+        Parser<MemReader> p(MemReader(d), o);
+        size_t n = 0, bases = 0;
+        std::string err = "ok";
+        try { p.each([&](const RefRecord &r) { ++n; bases += r.seq().size(); return true; }); }
+        catch (const Error &e) { err = e.what(); }
+        printf("each %zu %zu %s\n", n, bases, err.c_str());
+    }
+    {   // record_sets
+        Parser<MemReader> p(MemReader(d), o);
+        std::string err = "ok", sizes;
+        try { p.record_sets([&](RecordSet &&s) { sizes += std::to_string(s.len()) + ","; return true; }); }
+        catch (const Error &e) { err = e.what(); }
+        printf("sets %s %s\n", sizes.empty() ? "-" : sizes.c_str(), err.c_str());
+    }
+    {   // parallel_each
+        Parser<MemReader> p(MemReader(d), o);
+        std::string err = "ok", counts;
+        try {
+            auto res = p.parallel_each<size_t>((size_t)threads, [](auto next) { size_t c = 0; while (auto s = next()) c += s->len(); return c; });
+            for (size_t c : res) counts += std::to_string(c) + ",";
+        } catch (const Error &e) { err = e.what(); }
+        printf("workers %s %s\n", counts.empty() ? "-" : counts.c_str(), err.c_str());
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 5 && !strcmp(argv[1], "--dump"))
+        return dump(argv[2], atoi(argv[3]), strtoull(argv[4], 0, 0), argc > 5 ? strtoull(argv[5], 0, 0) : (1 << 20));
+#define RUN(t) do { t(); printf("ok %s\n", #t); fflush(stdout); } while (0)
+    RUN(correct); RUN(empty_id); RUN(missing_lines); RUN(truncated); RUN(second_idline); RUN(windows_lineend);
+    RUN(length_mismatch); RUN(huge_incomplete); RUN(bufflen); RUN(refset); RUN(refset_incomplete);
+    RUN(refset_huge_incomplete); RUN(doctest_parallel_each); RUN(zipped_and_thread_reader);
+    printf("all host tests passed\n");
+    return 0;
+}

@@ -167,6 +167,9 @@ typedef struct {
     const uint8_t *d_data;         /* device twin of the new bytes                                     */
     const uint64_t *d_rec_start;   /* device copy of the boundaries                                    */
     uint64_t err_record, err_offset;
+    uint64_t err_need;     /* bytes of the failing record that must be visible to report its error
+                              (0: truncated tail, reported at EOF only; UINT64_MAX: no failing record):
+                              input of a host-side replay of the reference's Buffer                   */
 } fqh_chunk;
 #define FQH_STREAM_INDEX 1u /* also build + download the IdxRecord-style index per chunk */
 fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots, uint32_t flags,

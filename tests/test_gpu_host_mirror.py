@@ -1,0 +1,100 @@
+"""The C++ mirror of the crate API (fastq-rs_amd/host/fastq.hpp) on the GPU: the reference's own
+unit tests ported one-to-one (host_tests), and a differential check of Parser::each, record_sets
+(set boundaries!) and parallel_each (per-worker counts) against the oracle on random files."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fuzzgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "fastq-rs_amd", "host", "bin")
+
+
+@pytest.fixture(scope="module")
+def gpu_ok():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if not os.path.exists(os.path.join(BIN, "host_tests")):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_reference_unit_tests_against_cpp_mirror(gpu_ok):
+    out = subprocess.run([os.path.join(BIN, "host_tests")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all host tests passed" in out.stdout
+    for t in ("correct", "empty_id", "missing_lines", "truncated", "second_idline", "windows_lineend",
+              "length_mismatch", "huge_incomplete", "bufflen", "refset", "refset_incomplete",
+              "refset_huge_incomplete", "doctest_parallel_each"):
+        assert "ok %s\n" % t in out.stdout
+
+
+SETS_MSG = {4: "Truncated input file.", 5: "Fastq record is too long."}
+
+
+def run_dump(path, threads, bufsize, slot):
+    out = subprocess.run([os.path.join(BIN, "host_tests"), "--dump", path, str(threads), str(bufsize), str(slot)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in out.stdout.strip().split("\n")}
+    return lines
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_each_sets_parallel_each_equal_oracle(gpu_ok, fqref, tmp_path, seed):
+    rng = np.random.default_rng(500 + seed)
+    if seed < 3:
+        data = fuzzgen.valid_file(rng, 4000, maxlen=150)
+    elif seed == 3:
+        data = fuzzgen.mutate(rng, fuzzgen.valid_file(rng, 2000, maxlen=150), 1)
+    elif seed == 4:
+        B = fqref.BUFSIZE
+        data = fuzzgen.valid_file(rng, 300) + b"@" + b"h" * (B - 12) + b"\nA\n+\nB\n" + fuzzgen.valid_file(rng, 300)
+    else:
+        data = fuzzgen.valid_file(rng, 1500, maxlen=150)[:-7]
+    path = tmp_path / "in.fq"
+    path.write_bytes(data)
+    threads = 3
+    for bufsize, slot in ((fqref.BUFSIZE, 1 << 20), (fqref.BUFSIZE, 1 << 16), (64, 1 << 16)):
+        if bufsize == 64 and seed != 3:
+            data2 = fuzzgen.valid_file(rng, 200, maxlen=8)
+            path.write_bytes(data2)
+        else:
+            data2 = data
+        got = run_dump(str(path), threads, bufsize, slot)
+        r = fqref.count(data2, bufsize=bufsize)
+        _, idx = fqref.index(data2, bufsize=bufsize)
+        bases = sum(len(fqref.accessors(data2, row)[1]) for row in idx)
+        each = got["each"].split(" ", 2)
+        assert (int(each[0]), int(each[1])) == (r.n_records, bases)
+        assert each[2] == (fqref.strerror(r.status) if r.status else "ok")
+        rs, sizes, workers = fqref.record_sets(data2, n_threads=threads, bufsize=bufsize)
+        s_sizes, s_err = got["sets"].rsplit(" ", 1) if got["sets"].endswith("ok") else got["sets"].split(" ", 1)
+        want_sizes = ",".join(str(int(x)) for x in sizes) + ","
+        assert s_sizes == want_sizes, (bufsize, slot)
+        want_err = "ok" if rs.status == 0 else SETS_MSG.get(rs.status, fqref.strerror(rs.status))
+        assert s_err == want_err
+        w_counts, w_err = got["workers"].rsplit(" ", 1) if got["workers"].endswith("ok") else got["workers"].split(" ", 1)
+        assert w_err == want_err
+        if rs.status == 0:
+            assert w_counts == ",".join(str(int(x)) for x in workers) + ","
+
+
+def test_fastq_count_cli(gpu_ok, fqref, tmp_path):
+    """examples/fastq-count.rs behaviour: decimal count on stdout; failure on an invalid file."""
+    d = bytes(fqref.synth(0, 330 * 20000))
+    p = tmp_path / "a.fq"
+    p.write_bytes(d)
+    exe = os.path.join(BIN, "fastq_count")
+    assert subprocess.run([exe, str(p)], capture_output=True, text=True).stdout.strip() == "20000"
+    assert subprocess.run([exe, "--threads", "2", str(p)], capture_output=True, text=True).stdout.strip() == "20000"
+    with open(p, "rb") as fh:
+        assert subprocess.run([exe, "-"], stdin=fh, capture_output=True, text=True).stdout.strip() == "20000"
+    p.write_bytes(d[:-5])
+    bad = subprocess.run([exe, str(p)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Possibly truncated input file" in bad.stderr

@@ -83,13 +83,13 @@ c = torch.tensor([mine[1]], dtype=torch.int64)
 dist.all_reduce(c)
 assert int(c) == data.count(b"\n")
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join({out!r}, "ok_%d" % rank), "w").write("ok")
 '''
 
 
 def test_two_rank_gloo_carry_exchange(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -99,4 +99,4 @@ def test_two_rank_gloo_carry_exchange(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), out.stdout + out.stderr

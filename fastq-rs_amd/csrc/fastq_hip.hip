@@ -316,13 +316,15 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->h_out->overflow) {
-        // a tile has more line starts than list_cap (average line < 8 bytes): rerun with lists that
-        // cannot overflow.  Never happens on real FASTQ.
-        ctx->list_cap = WT_BYTES;
-        fqh_status st = enqueue_scan(ctx);
-        if (st != FQH_OK) return st;
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->h_out->overflow) return fail(ctx, FQH_E_DEVICE, "line list overflow after rerun");
+        // a tile has more line starts than list_cap (lines shorter than 32 bytes on average): rerun
+        // with longer lists; the setting sticks to the context, so steady state stays single-pass.
+        while (ctx->h_out->overflow) {
+            if (ctx->list_cap >= WT_BYTES) return fail(ctx, FQH_E_DEVICE, "line list overflow with full-size lists");
+            ctx->list_cap = ctx->list_cap < 2048 ? 2048 : WT_BYTES;
+            fqh_status st = enqueue_scan(ctx);
+            if (st != FQH_OK) return st;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     float ms = 0;
     ctx->timing = fqh_timing{};

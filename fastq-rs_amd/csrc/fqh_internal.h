@@ -20,7 +20,8 @@ constexpr uint32_t WT_BYTES = 16384;    // bytes per wave tile
 constexpr uint32_t WT_SHIFT = 14;
 constexpr uint32_t PIECE_BYTES = 1024;  // one wave-wide 16-byte load
 constexpr uint32_t WT_PIECES = WT_BYTES / PIECE_BYTES;
-constexpr uint32_t LIST_CAP_DEFAULT = 2048;  // average line >= 8 bytes; rerun with WT_BYTES if not
+constexpr uint32_t LIST_CAP_DEFAULT = 512;   // entries per tile list (average line >= 32 bytes); a scan that
+                                             // overflows reruns with 2048, then 16384, and the context keeps it
 constexpr uint32_t SCAN_CHUNK = 2048;        // tiles per block of the tile-count scan
 constexpr uint32_t SCAN_SHIFT = 11;
 constexpr unsigned long long NOKEY = ~0ull;

@@ -49,14 +49,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
+    # FQH_BENCH_BACKEND=gloo + FQH_BENCH_ONE_GPU=1: run the N > 1 protocol with every rank on cuda:0
+    # (functional check of the sharded path on a 1-GPU box; the driver's runs use RCCL, one GPU per rank)
+    backend = os.environ.get("FQH_BENCH_BACKEND", "nccl")
+    one_gpu = os.environ.get("FQH_BENCH_ONE_GPU", "0") == "1"
+    dev_index = 0 if (world == 1 or one_gpu) else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == n_gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     shard = args.bytes if args.bytes else SHARD
@@ -89,10 +97,9 @@ def main():
             index_ms.append(ctx.timing().index_ms)
             return s
         # 1) shard-local byte scan (phase-free), 2) carry exchange, 3) emit with the true carry
-        s0, c0, _ = ctx.scan(buf.data_ptr(), nbytes, False, None, None, 0)
+        nn, ns, back0 = ctx.shard_prescan(buf.data_ptr(), nbytes)
         index_ms.append(ctx.timing().index_ms)
-        gather_in.copy_(torch.tensor([nbytes, s0.n_newlines, s0.n_line_starts] + list(c0.back),
-                                     dtype=torch.int64), non_blocking=False)
+        gather_in.copy_(torch.tensor([nbytes, nn, ns] + back0, dtype=torch.int64), non_blocking=False)
         dist.all_gather(gather_out, gather_in)
         rows = torch.stack(gather_out).cpu().numpy()
         carry = None

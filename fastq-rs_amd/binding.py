@@ -18,7 +18,7 @@ NSCALARS = 8
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
-    "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_last_timing",
+    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
@@ -101,6 +101,7 @@ def lib():
         L.fqh_carry_combine.argtypes = [C.POINTER(Carry), u64, u64, u64, C.POINTER(u64 * 4),
                                         C.POINTER(Carry)]
         L.fqh_rescan_launch.argtypes = [vp, i32, C.POINTER(Carry), vp, u64]
+        L.fqh_shard_prescan.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64 * 4)]
         L.fqh_invalidate.argtypes = [vp]
         L.fqh_stats.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp,
                                 C.POINTER(Summary), C.POINTER(Carry)]
@@ -195,6 +196,12 @@ class Ctx:
         st = self._L.fqh_scan_finish(self._h, C.byref(s), C.byref(c))
         self._chk(st, allow=(E_CAPACITY,))
         return s, c, st
+
+    def shard_prescan(self, d_buf, length):
+        """-> (n_newlines, n_line_starts, back[4]) of the shard scanned as if it began the file."""
+        nn, ns, back = C.c_uint64(), C.c_uint64(), (C.c_uint64 * 4)()
+        self._chk(self._L.fqh_shard_prescan(self._h, d_buf, length, C.byref(nn), C.byref(ns), C.byref(back)))
+        return nn.value, ns.value, [int(x) for x in back]
 
     def rescan_launch(self, is_final=True, carry=None, d_rec_start=None, cap=0):
         self._chk(self._L.fqh_rescan_launch(self._h, 1 if is_final else 0,

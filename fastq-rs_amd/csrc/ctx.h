@@ -58,6 +58,7 @@ struct fqh_ctx {
     ScanArgs args = {};
     fqh_carry carry_in = {};
     bool whole_file = false;
+    bool skip_emit = false;  // shard prescan: only the byte scan, the prefix and the chunk-end summary
     fqh_summary last_summary = {};
     fqh_carry last_carry_out = {};
     // stats in flight

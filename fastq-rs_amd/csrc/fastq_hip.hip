@@ -167,7 +167,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index = false) {
     if (!reuse_index)
         launch_prefix(s, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
+    if (!ctx->skip_emit) launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
     launch_finalize(s, a, &ctx->d_out[0]);
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     HIPCHK(ctx, hipGetLastError());
@@ -387,6 +387,25 @@ fqh_status fqh_scan(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_fin
     fqh_status st = do_scan_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap);
     if (st != FQH_OK) return st;
     return do_scan_finish(ctx, out, carry_out);
+}
+
+fqh_status fqh_shard_prescan(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t *n_newlines,
+                             uint64_t *n_line_starts, uint64_t back0[4]) {
+    if (!ctx || !n_newlines || !n_line_starts || !back0) return FQH_E_ARG;
+    ctx->skip_emit = true;
+    fqh_status st = do_scan_launch(ctx, d_buf, len, 0, nullptr, nullptr, 0);
+    ctx->skip_emit = false;
+    if (st != FQH_OK) return st;
+    fqh_summary s;
+    fqh_carry c;
+    ctx->skip_emit = true;  // an overflow rerun inside finish must skip the emit as well
+    st = do_scan_finish(ctx, &s, &c);
+    ctx->skip_emit = false;
+    if (st != FQH_OK) return st;
+    *n_newlines = s.n_newlines;
+    *n_line_starts = s.n_line_starts;
+    for (int i = 0; i < 4; ++i) back0[i] = c.back[i];
+    return FQH_OK;
 }
 
 fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, uint64_t *d_rec_start,

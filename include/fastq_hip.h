@@ -118,6 +118,11 @@ fqh_status fqh_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out)
  * rank order with fqh_carry_combine to get each shard's true carry-in; fqh_rescan_launch then redoes
  * only the cheap emit/validate step on the tile index the first call left in the context (the
  * buffer must be unchanged).  Finish with fqh_scan_finish. */
+/* Step 1 of that recipe without the (wasted) emit pass: byte scan + tile prefix only.  Leaves the
+ * tile index in the context for fqh_rescan_launch.  back_zero_carry[i] = len - (i-th most recent line
+ * start inside the shard), meaningful for i < n_line_starts. */
+fqh_status fqh_shard_prescan(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t *n_newlines,
+                             uint64_t *n_line_starts, uint64_t back_zero_carry[4]);
 fqh_status fqh_carry_combine(const fqh_carry *prev, uint64_t len, uint64_t n_newlines,
                              uint64_t n_line_starts, const uint64_t back_zero_carry[4],
                              fqh_carry *next);

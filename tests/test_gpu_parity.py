@@ -318,8 +318,13 @@ def test_sharded_two_stage_protocol(fqref, torch, pkg, seed):
         d = torch.empty(max(n, 16), dtype=torch.uint8, device=dev)
         if n:
             d[:n].copy_(torch.from_numpy(np.frombuffer(data[a:b], dtype=np.uint8).copy()))
-        s0, c0, _ = c.scan(d.data_ptr(), n, False, None, None, 0)
-        ctxs.append(c); bufs.append((d, n)); sums.append((n, s0.n_newlines, s0.n_line_starts, list(c0.back)))
+        if seed == 0:
+            s0, c0, _ = c.scan(d.data_ptr(), n, False, None, None, 0)
+            summ = (n, s0.n_newlines, s0.n_line_starts, list(c0.back))
+        else:
+            nn, ns, back0 = c.shard_prescan(d.data_ptr(), n)  # same numbers without the emit pass
+            summ = (n, nn, ns, back0)
+        ctxs.append(c); bufs.append((d, n)); sums.append(summ)
     starts, total = [], 0
     carry = None
     for i, c in enumerate(ctxs):

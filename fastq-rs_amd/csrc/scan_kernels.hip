@@ -1,9 +1,9 @@
 // scan_kernels.hip — gfx950 kernels of the record scan.
 //
-//   k_index     streaming byte-scan: one wavefront per 16 KiB tile, 16-byte coalesced loads,
-//               SWAR newline detection, ballot/mbcnt in-wave prefix, emits the tile's line-start
-//               list (replaces the memchr loop of src/records.rs:141,155,214,228).  Phase-free:
-//               needs no information from any other tile, shard or GPU.
+//   k_index_t   streaming byte-scan: a wavefront owns a 16 KiB tile, 16-byte coalesced loads,
+//               LDS transposition, SWAR newline detection, ballot/mbcnt in-wave prefix, emits the
+//               tile's line-start list (replaces the memchr loop of src/records.rs:141,155,214,228).
+//               Phase-free: needs no information from any other tile, shard or GPU.
 //   k_prefix_*  exclusive scan of the per-tile counts.
 //   k_emit      walks the line-start lists with the global line index known: record offsets,
 //               '@' / '+' / length checks in the order of src/records.rs:201-247.
@@ -77,8 +77,7 @@ __device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ buf, uint64_
     return make_uint4(w0, w1, w2, w3);
 }
 // ---------------------------------------------------------------------------------------------
-// k_index: persistent grid, a wavefront takes 16 KiB tiles round-robin.
-//
+// helpers of the index kernel (k_index_t below)
 // lane-1's value (lane 0 gets `first`): DPP wave_shr:1, no LDS crossbar round trip
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t first) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xF, 0xF, false);
@@ -122,73 +121,6 @@ __device__ __forceinline__ void index_piece(const uint4 v, const uint64_t off, c
         }
     }
     run += tot;
-}
-
-// MASKV: mask gather variant.  PF: 1 = the next 4 KiB group is requested before the current one
-// is processed (register double buffer).
-template <int MASKV, int PF>
-__global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ buf, uint64_t len,
-                                               uint16_t *__restrict__ list, uint32_t list_cap,
-                                               uint32_t *__restrict__ tile_count, uint64_t n_tiles,
-                                               DevOut *__restrict__ out) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    uint32_t n_over = 0;
-    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += nwaves) {
-        const uint64_t tbase = tile << WT_SHIFT;
-        uint16_t *__restrict__ tl = list + tile * list_cap;
-        uint32_t run = 0;
-        // Is the byte before the piece a newline?  Offset 0 of the chunk is never emitted here:
-        // whether a line starts there is carry information, handled by k_finalize.
-        uint32_t prev = 0;
-        if (tile > 0) prev = (buf[tbase - 1] == '\n') ? 1u : 0u;
-        const uint32_t lo = lane * 16;
-        if (tbase + WT_BYTES <= len) {
-            const uint8_t *p = buf + tbase + lo;
-            if (PF == 0) {
-#pragma unroll 1
-                for (uint32_t g = 0; g < WT_PIECES / 4; ++g, p += 4 * PIECE_BYTES) {
-                    const uint4 v0 = load16_nt(p);
-                    const uint4 v1 = load16_nt(p + PIECE_BYTES);
-                    const uint4 v2 = load16_nt(p + 2 * PIECE_BYTES);
-                    const uint4 v3 = load16_nt(p + 3 * PIECE_BYTES);
-                    const uint32_t pb = g * 4 * PIECE_BYTES + lo;
-                    index_piece<true, MASKV>(v0, 0, 0, pb, lane, prev, run, tl, list_cap);
-                    index_piece<true, MASKV>(v1, 0, 0, pb + PIECE_BYTES, lane, prev, run, tl, list_cap);
-                    index_piece<true, MASKV>(v2, 0, 0, pb + 2 * PIECE_BYTES, lane, prev, run, tl, list_cap);
-                    index_piece<true, MASKV>(v3, 0, 0, pb + 3 * PIECE_BYTES, lane, prev, run, tl, list_cap);
-                }
-            } else {
-                uint4 n0 = load16_nt(p), n1 = load16_nt(p + PIECE_BYTES);
-                uint4 n2 = load16_nt(p + 2 * PIECE_BYTES), n3 = load16_nt(p + 3 * PIECE_BYTES);
-#pragma unroll
-                for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
-                    const uint4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
-                    if (g + 1 < WT_PIECES / 4) {
-                        p += 4 * PIECE_BYTES;
-                        n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
-                        n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
-                    }
-                    const uint32_t pb = g * 4 * PIECE_BYTES + lo;
-                    index_piece<true, MASKV>(v0, 0, 0, pb, lane, prev, run, tl, list_cap);
-                    index_piece<true, MASKV>(v1, 0, 0, pb + PIECE_BYTES, lane, prev, run, tl, list_cap);
-                    index_piece<true, MASKV>(v2, 0, 0, pb + 2 * PIECE_BYTES, lane, prev, run, tl, list_cap);
-                    index_piece<true, MASKV>(v3, 0, 0, pb + 3 * PIECE_BYTES, lane, prev, run, tl, list_cap);
-                }
-            }
-        } else {
-#pragma unroll 1
-            for (uint32_t j = 0; j < WT_PIECES; ++j) {
-                const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
-                if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
-                const uint4 v = load16(buf, off, len);
-                index_piece<false, MASKV>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
-            }
-        }
-        if (lane == 0) tile_count[tile] = run;
-        if (run > list_cap) ++n_over;
-    }
-    if (lane == 0 && n_over) atomicAdd(&out->overflow, (unsigned long long)n_over);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -685,7 +617,7 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 // ---------------------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------------------
-// k_index_t: same job as k_index, LDS-transposed.  A wavefront still fetches its tile with
+// k_index_t: persistent grid, a wavefront takes 16 KiB tiles round-robin.  It fetches its tile with
 // coalesced 16-byte loads (lane-strided, 1 KiB per instruction), but stages each 4 KiB group in
 // LDS and reads it back so that lane l owns the 64 CONTIGUOUS bytes [64 l, 64 l + 64): one in-wave
 // prefix, one boundary shuffle and ~3 emit-loop iterations per 4 KiB instead of per 1 KiB.
@@ -835,7 +767,8 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
     static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 5;
     static const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;
     typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
-    static const kern_t kerns[7] = {k_index<0, 0>, k_index<1, 0>, k_index<0, 1>, k_index<1, 1>,
+    // 4: no prefetch, 5: production (register prefetch of the next 4 KiB group), 6: list staged in LDS
+    static const kern_t kerns[7] = {k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>,
                                     k_index_t<0, 0>, k_index_t<1, 0>, k_index_t<1, 1>};
     static int occ[7] = {0, 0, 0, 0, 0, 0, 0};
     int v = g_index_variant >= 0 ? g_index_variant : variant;

@@ -221,13 +221,55 @@ __device__ __forceinline__ void stats_tile_lines(const StatsArgs &a, uint32_t la
         }
         const uint8_t *__restrict__ lp = a.buf + S;
         uint32_t any_n = 0, any_inv = 0, ovf = 0;
+        // longest line of this wave iteration (uniform loop bound)
+        uint32_t maxlen = len;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(maxlen, d);
+            maxlen = o > maxlen ? o : maxlen;
+        }
+        maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxlen);
         uint4 cur = len ? load16_any(lp, bend) : make_uint4(0, 0, 0, 0);
-        for (uint32_t p = 0; __ballot(p < len) != 0; p += 16) {
+        for (uint32_t p = 0; p < maxlen; p += 16) {
             const uint4 nxt = p + 16 < len ? load16_any(lp + p + 16, bend) : make_uint4(0, 0, 0, 0);
-            stats_dword<IS_SEQ>(a, cur.x, p, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
-            stats_dword<IS_SEQ>(a, cur.y, p + 4, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
-            stats_dword<IS_SEQ>(a, cur.z, p + 8, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
-            stats_dword<IS_SEQ>(a, cur.w, p + 12, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+            const bool in = p < len;
+            // Fast step (wave-uniform): every lane still inside its line has 16 more bytes, all of
+            // them in the alphabet / quality window, and the 16 rows are LDS-resident.
+            bool ok = len >= p + 16;
+            uint4 bins;
+            if (IS_SEQ) {
+                ok = ok && ((cur.x ^ seq_expected(cur.x)) | (cur.y ^ seq_expected(cur.y)) |
+                            (cur.z ^ seq_expected(cur.z)) | (cur.w ^ seq_expected(cur.w))) == 0;
+                bins = make_uint4(cur.x & 0x07070707u, cur.y & 0x07070707u, cur.z & 0x07070707u, cur.w & 0x07070707u);
+            } else {
+                auto win = [](uint32_t w) {  // 0x80 per byte inside ['!', '`']
+                    const uint32_t lo7 = w & 0x7F7F7F7Fu;
+                    return (lo7 + 0x5F5F5F5Fu) & ~(lo7 + 0x1F1F1F1Fu) & ~w;
+                };
+                ok = ok && ((win(cur.x) & win(cur.y) & win(cur.z) & win(cur.w)) & 0x80808080u) == 0x80808080u;
+                bins = make_uint4(cur.x - 0x21212121u, cur.y - 0x21212121u, cur.z - 0x21212121u, cur.w - 0x21212121u);
+            }
+            if (p + 16 <= lc && __ballot(in && !ok) == 0) {
+                if (in) {
+                    if (IS_SEQ) {
+                        auto isn = [](uint32_t w) { return ~((((w & 0x7F7F7F7Fu) ^ 0x4E4E4E4Eu) + 0x7F7F7F7Fu) | w); };
+                        any_n |= (isn(cur.x) | isn(cur.y) | isn(cur.z) | isn(cur.w)) & 0x80808080u;
+                    }
+                    uint32_t *r = row0 + p * 64;
+#define FQH_ADD4(w, base)                                     \
+                    atomicAdd(r + (base) + ((w) & 0xFFu), 1u);               \
+                    atomicAdd(r + (base) + 64 + (((w) >> 8) & 0xFFu), 1u);   \
+                    atomicAdd(r + (base) + 128 + (((w) >> 16) & 0xFFu), 1u); \
+                    atomicAdd(r + (base) + 192 + ((w) >> 24), 1u);
+                    FQH_ADD4(bins.x, 0) FQH_ADD4(bins.y, 256) FQH_ADD4(bins.z, 512) FQH_ADD4(bins.w, 768)
+#undef FQH_ADD4
+                }
+            } else {
+                stats_dword<IS_SEQ>(a, cur.x, p, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+                stats_dword<IS_SEQ>(a, cur.y, p + 4, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+                stats_dword<IS_SEQ>(a, cur.z, p + 8, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+                stats_dword<IS_SEQ>(a, cur.w, p + 12, len, lc, row0, qh, sh, copy8, any_n, any_inv, ovf);
+            }
             cur = nxt;
         }
         if (act) {

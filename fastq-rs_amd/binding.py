@@ -108,6 +108,8 @@ def lib():
         L.fqh_stats_launch.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
         L.fqh_stats_finish.argtypes = [vp, C.POINTER(Summary), C.POINTER(Carry)]
         L.fqh_last_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.fqh_debug_last_scan_fast.argtypes = [vp]
+        L.fqh_debug_set_spec.argtypes = [vp, i32]
         L.fqh_stream_create.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
         L.fqh_stream_destroy.argtypes = [vp]
         L.fqh_stream_destroy.restype = None
@@ -230,6 +232,14 @@ class Ctx:
         s, c = Summary(), Carry()
         self._chk(self._L.fqh_stats_finish(self._h, C.byref(s), C.byref(c)))
         return s, c
+
+    def last_scan_fast(self):
+        """Test hook: did the last scan complete on the fast path (no exact rerun)?"""
+        return bool(self._L.fqh_debug_last_scan_fast(self._h))
+
+    def set_spec(self, on):
+        """Test hook: (re-)enable or disable the fast path for this context."""
+        self._L.fqh_debug_set_spec(self._h, 1 if on else 0)
 
     def timing(self):
         t = Timing()

@@ -8,7 +8,9 @@
 #include "replay.h"
 
 namespace fqh {
-void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *, int);
+void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint8_t *, uint64_t, DevOut *, int, bool);
+void launch_emit_fast(hipStream_t, const ScanArgs &, DevOut *, int);
+void launch_finalize_fast(hipStream_t, const ScanArgs &, DevOut *);
 void launch_prefix(hipStream_t, const uint32_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
 void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
@@ -36,6 +38,7 @@ struct fqh_ctx {
     size_t list_elems = 0;
     uint32_t list_cap = LIST_CAP_DEFAULT;
     uint32_t *tile_count = nullptr, *tile_prefix = nullptr;
+    uint8_t *tile_hyp = nullptr;
     uint64_t *block_prefix = nullptr;
     size_t tiles_cap = 0;
     DevOut *d_out = nullptr;      // [0] the scan's, [1] scratch for index-only emits
@@ -59,6 +62,10 @@ struct fqh_ctx {
     fqh_carry carry_in = {};
     bool whole_file = false;
     bool skip_emit = false;  // shard prescan: only the byte scan, the prefix and the chunk-end summary
+    // fast path: prove validity with a quarter of the list traffic; any doubt -> exact rerun
+    bool spec_enabled = true;   // switched off for good once an input needed the exact path
+    bool index_full = true;     // the tile index in the workspace holds complete line lists
+    bool used_spec = false;     // the scan in flight runs the fast path
     fqh_summary last_summary = {};
     fqh_carry last_carry_out = {};
     // stats in flight

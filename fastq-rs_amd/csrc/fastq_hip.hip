@@ -81,6 +81,7 @@ fqh_status fqh_create(int device, fqh_ctx **out) {
         fqh_destroy(ctx);
         return st;
     }
+    if (const char *e = getenv("FQH_SPEC")) ctx->spec_enabled = atoi(e) != 0;  // tuning hook: 0 = exact path only
     *out = ctx;
     return FQH_OK;
 }
@@ -94,6 +95,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->list);
     (void)hipFree(ctx->tile_count);
     (void)hipFree(ctx->tile_prefix);
+    (void)hipFree(ctx->tile_hyp);
     (void)hipFree(ctx->block_prefix);
     (void)hipFree(ctx->d_out);
     (void)hipFree(ctx->d_misc);
@@ -136,20 +138,24 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles) {
     if (n_tiles > ctx->tiles_cap) {
         (void)hipFree(ctx->tile_count);
         (void)hipFree(ctx->tile_prefix);
+        (void)hipFree(ctx->tile_hyp);
         (void)hipFree(ctx->block_prefix);
         ctx->tile_count = ctx->tile_prefix = nullptr;
+        ctx->tile_hyp = nullptr;
         ctx->block_prefix = nullptr;
         ctx->tiles_cap = 0;
         const size_t nb = (n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_count, n_tiles * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_prefix, n_tiles * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->tile_hyp, n_tiles));
         HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
         ctx->tiles_cap = n_tiles;
     }
     return FQH_OK;
 }
 
-static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index = false) {
+// fast == true: the speculative path (k_index_t<.,2> + k_emit_fast + k_finalize_fast)
+static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     ScanArgs &a = ctx->args;
     hipStream_t s = ctx->stream;
     fqh_status st = ensure_workspace(ctx, a.n_tiles);
@@ -157,23 +163,35 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index = false) {
     a.list = ctx->list;
     a.list_cap = ctx->list_cap;
     a.tile_count = ctx->tile_count;
+    a.tile_hyp = ctx->tile_hyp;
     a.tile_prefix = ctx->tile_prefix;
     a.block_prefix = ctx->block_prefix;
+    ctx->used_spec = fast;
     HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
-    if (!reuse_index)
-        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, a.n_tiles, &ctx->d_out[0], ctx->n_cu);
+    if (!reuse_index) {
+        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->tile_hyp, a.n_tiles,
+                     &ctx->d_out[0], ctx->n_cu, fast);
+        ctx->index_full = !fast;
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     if (!reuse_index)
         launch_prefix(s, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    if (!ctx->skip_emit) launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
-    launch_finalize(s, a, &ctx->d_out[0]);
+    if (fast) {
+        if (!ctx->skip_emit) launch_emit_fast(s, a, &ctx->d_out[0], ctx->n_cu);
+        launch_finalize_fast(s, a, &ctx->d_out[0]);  // a prescan still needs the newline count and the carry
+    } else {
+        if (!ctx->skip_emit) launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
+        launch_finalize(s, a, &ctx->d_out[0]);
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, &ctx->d_out[0], sizeof(DevOut), hipMemcpyDeviceToHost, s));
     return FQH_OK;
 }
+
+static fqh_status ensure_full_index(fqh_ctx *ctx);
 
 static bool carry_is_zero(const fqh_carry &c) {
     return c.base_offset == 0 && c.nl_count == 0 && c.back[0] == 0 && c.back[1] == 0 && c.back[2] == 0 && c.back[3] == 0;
@@ -226,7 +244,9 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
                     HIPCHK(ctx, hipMalloc((void **)&ctx->tmp_rec, (n + 1) * sizeof(uint64_t)));
                     ctx->tmp_rec_cap = n + 1;
                 }
-                ScanArgs b = a;
+                fqh_status fst = ensure_full_index(ctx);
+                if (fst != FQH_OK) return fst;
+                ScanArgs b = ctx->args;
                 b.rec_start = ctx->tmp_rec;
                 b.cap = n + 1;
                 b.idx = nullptr;
@@ -303,7 +323,10 @@ static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     a.cap = d_rec_start ? cap : 0;
     a.idx = nullptr;
     a.idx_cap = 0;
-    fqh_status st = enqueue_scan(ctx, reuse_index);
+    // fast path: when the caller does not need full line lists and no earlier input needed the exact
+    // path; a rescan on a retained index uses whichever kind of index is there
+    const bool fast = reuse_index ? !ctx->index_full : (ctx->spec_enabled && ctx->list_cap >= LIST_CAP_DEFAULT);
+    fqh_status st = enqueue_scan(ctx, reuse_index, fast);
     if (st != FQH_OK) return st;
     ctx->pending = true;
     return FQH_OK;
@@ -315,13 +338,22 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     ctx->pending = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->used_spec && ctx->h_out->spec_fail) {
+        // the fast path could not prove the input valid (a real error, lines longer than a few KiB,
+        // or a degenerate layout): run the exact path, and stay on it for later scans of this context
+        ctx->spec_enabled = false;
+        fqh_status st = enqueue_scan(ctx, false, false);
+        if (st != FQH_OK) return st;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // (ctx->used_spec now tells whether the result in h_out came from the fast path)
     if (ctx->h_out->overflow) {
         // a tile has more line starts than list_cap (lines shorter than 32 bytes on average): rerun
         // with longer lists; the setting sticks to the context, so steady state stays single-pass.
         while (ctx->h_out->overflow) {
             if (ctx->list_cap >= WT_BYTES) return fail(ctx, FQH_E_DEVICE, "line list overflow with full-size lists");
             ctx->list_cap = ctx->list_cap < 2048 ? 2048 : WT_BYTES;
-            fqh_status st = enqueue_scan(ctx);
+            fqh_status st = enqueue_scan(ctx, false, false);
             if (st != FQH_OK) return st;
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
@@ -346,7 +378,36 @@ static bool same_scan(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
 }
 
 // index-only emit of the last scan into `dst` (device), local records [0, n)
+// (re)build complete line lists for the buffer of the last scan (after a fast-path scan)
+static fqh_status ensure_full_index(fqh_ctx *ctx) {
+    if (ctx->index_full) return FQH_OK;
+    const ScanArgs &a = ctx->args;
+    for (;;) {
+        fqh_status st = ensure_workspace(ctx, a.n_tiles);
+        if (st != FQH_OK) return st;
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
+        launch_index(ctx->stream, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->tile_hyp,
+                     a.n_tiles, &ctx->d_out[1], ctx->n_cu, false);
+        launch_prefix(ctx->stream, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
+        DevOut tmp;
+        HIPCHK(ctx, hipMemcpyAsync(&tmp, &ctx->d_out[1], sizeof(DevOut), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!tmp.overflow) break;
+        if (ctx->list_cap >= WT_BYTES) return fail(ctx, FQH_E_DEVICE, "line list overflow with full-size lists");
+        ctx->list_cap = ctx->list_cap < 2048 ? 2048 : WT_BYTES;
+    }
+    ctx->index_full = true;
+    ctx->args.list = ctx->list;
+    ctx->args.list_cap = ctx->list_cap;
+    ctx->args.tile_count = ctx->tile_count;
+    ctx->args.tile_prefix = ctx->tile_prefix;
+    ctx->args.block_prefix = ctx->block_prefix;
+    return FQH_OK;
+}
+
 static fqh_status emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap) {
+    fqh_status fst = ensure_full_index(ctx);
+    if (fst != FQH_OK) return fst;
     ScanArgs b = ctx->args;
     b.rec_start = nullptr;
     b.cap = 0;
@@ -417,6 +478,9 @@ fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, ui
     return do_scan_launch(ctx, buf, len, is_final, in, d_rec_start, cap, true);
 }
 
+// test hooks, not part of the public header
+extern "C" int fqh_debug_last_scan_fast(fqh_ctx *ctx) { return ctx && ctx->used_spec ? 1 : 0; }
+extern "C" void fqh_debug_set_spec(fqh_ctx *ctx, int on) { if (ctx) ctx->spec_enabled = on != 0; }
 // tuning hook, not part of the public header: selects the k_index code variant for A/B runs
 extern "C" void fqh_debug_set_index_variant(int v) { fqh::g_index_variant = v; }
 
@@ -477,6 +541,8 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
         if (st != FQH_OK) return st;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    st = ensure_full_index(ctx);  // the histogram kernel walks complete line lists
+    if (st != FQH_OK) return st;
     const fqh_timing scan_t = ctx->timing;
     const uint64_t n = ctx->last_summary.n_records;
     // the record in progress at the chunk start began in an earlier chunk: its bytes are not here

@@ -41,6 +41,7 @@ struct ScanArgs {
     const uint16_t *list;
     uint32_t list_cap;
     const uint32_t *tile_count;
+    const uint8_t *tile_hyp;       // fast path only: index (0..3) of the tile's first record-start entry
     const uint32_t *tile_prefix;   // exclusive prefix inside its SCAN_CHUNK block
     const uint64_t *block_prefix;  // exclusive prefix of block sums; [n_blocks] = total
     uint64_t n_tiles;
@@ -77,6 +78,7 @@ struct DevOut {
     unsigned long long first_long;  // min global record index with length >= bufsize - 15
     unsigned long long max_len;     // longest complete record ending in the chunk
     unsigned long long overflow;    // tiles whose list overflowed list_cap (=> rerun)
+    unsigned long long spec_fail;   // fast path: some tile could not be proven valid (=> exact rerun)
     // written by k_finalize
     unsigned long long total_entries;
     unsigned long long lastnl;

@@ -629,12 +629,21 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 // vmcnt counter with loads, and scattered 2-byte stores between the prefetch loads and their
 // s_waitcnt would put store acknowledgements on the critical path of the next 4 KiB group.
 constexpr uint32_t LSTAGE_ENTRIES = 512;
+// LSTAGE == 2, the FAST PATH: the tile's list is staged in LDS and NOT written out.
+// The wavefront checks every 4-line group that lies completely inside the tile under each of the
+// four possible alignments ('@' on line i, '+' on line i+2, equal raw lengths of lines i+1 and
+// i+3); if exactly one alignment is consistent it writes only what k_emit_fast needs: the offsets
+// of that alignment's record starts and the tile's first and last four entries (for the records that
+// straddle tiles) — a quarter of the bytes.  Nothing is assumed: the alignment is verified against the
+// true line index after the prefix scan, and any tile that cannot be proven valid makes the library
+// fall back to the exact path, which also produces the precise error.
 template <int PF, int LSTAGE>
 __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf, uint64_t len,
                                                  uint16_t *__restrict__ list, uint32_t list_cap,
-                                                 uint32_t *__restrict__ tile_count, uint64_t n_tiles,
+                                                 uint32_t *__restrict__ tile_count,
+                                                 uint8_t *__restrict__ tile_hyp, uint64_t n_tiles,
                                                  DevOut *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + (LSTAGE ? LSTAGE_ENTRIES * 2 : 0)];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + (LSTAGE ? LSTAGE_ENTRIES * 2 + 16 : 0)];
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *const lds = lds_all[threadIdx.x >> 6];
     uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + 4096);
@@ -696,7 +705,9 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                     }
                 }
                 const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
-                if (LSTAGE && run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
+                if (LSTAGE == 2 && (run != nstaged || run + tot > LSTAGE_ENTRIES)) {
+                    // fast path: a tile with more than 512 line starts is left to the exact path
+                } else if (LSTAGE && run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
                     uint16_t *dst = lst + run + pre;
                     while (ls_lo) {
                         const uint32_t q = __ffs(ls_lo) - 1;
@@ -739,8 +750,44 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                 const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
                 if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
                 const uint4 v = load16(buf, off, len);
-                index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
+                if (LSTAGE == 2) index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, LSTAGE_ENTRIES);
+                else index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
             }
+            if (LSTAGE == 2) nstaged = run <= LSTAGE_ENTRIES ? run : 0;
+        }
+        if (LSTAGE == 2) {
+            uint32_t hyp = 7;
+            if (nstaged == run && run >= 8) {  // uniform
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint32_t bad = 0, have = 0;  // bit r: some / some failing complete group starting at i == r (mod 4)
+                for (uint32_t i = lane; i + 4 < run; i += 64) {
+                    const uint32_t e0 = lst[i], e1 = lst[i + 1], e2 = lst[i + 2], e3 = lst[i + 3], e4 = lst[i + 4];
+                    const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
+                                    ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
+                    have |= 1u << (i & 3u);
+                    bad |= ok ? 0u : 1u << (i & 3u);
+                }
+                uint32_t cons = 0;
+#pragma unroll
+                for (uint32_t r = 0; r < 4; ++r)
+                    if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
+                if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
+            }
+            if (hyp < 4) {
+                // [0..3] first four entries, [4..7] last four, [8..] offsets of the record starts
+                if (lane < 4) tl[lane] = lst[lane];
+                else if (lane < 8) tl[lane] = lst[run - 8 + lane];
+                for (uint32_t j = lane; hyp + 4 * j < run; j += 64) tl[8 + j] = lst[hyp + 4 * j] & 0x3FFFu;
+            } else {
+                ++n_over;  // counted into spec_fail below
+            }
+            if (lane == 0) {
+                tile_count[tile] = run;
+                tile_hyp[tile] = (uint8_t)hyp;
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
         if (LSTAGE && nstaged) {  // flush the staged list: 4 entries (8 bytes) per lane and store
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -757,24 +804,243 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
         if (lane == 0) tile_count[tile] = run;
         if (run > list_cap) ++n_over;
     }
-    if (lane == 0 && n_over) atomicAdd(&out->overflow, (unsigned long long)n_over);
+    if (lane == 0 && n_over) atomicAdd(LSTAGE == 2 ? &out->spec_fail : &out->overflow, (unsigned long long)n_over);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_emit_fast: the fast path's emit.  Per tile: verify the tile's alignment against the true line
+// index, store the record starts, and validate the one record that straddles into the tile from
+// the previous one (its five line starts are in the two tiles' edge entries).  Any doubt sets
+// spec_fail; error keys are never produced here.
+__global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const unsigned long long r0 = a.nl_count >> 2;
+    const uint32_t bufsize32 = a.bufsize > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)a.bufsize;
+    unsigned long long first_long = NOKEY;
+    uint32_t maxlen32 = 0, fail = 0;
+    struct Pre { uint32_t cnt, tp, cprev, hyp; unsigned long long bp; uint32_t e0, e1, edge, pedge; };
+    auto fetch = [&](uint64_t t, Pre &p) {
+        if (t < a.n_tiles) {
+            p.cnt = a.tile_count[t];
+            p.tp = a.tile_prefix[t];
+            p.bp = a.block_prefix[t >> SCAN_SHIFT];
+            p.hyp = a.tile_hyp[t];
+            p.cprev = t ? a.tile_count[t - 1] : 0u;
+            const uint16_t *tl = a.list + t * a.list_cap;
+            p.e0 = tl[8 + lane];           // record starts (list_cap >= 512: always in bounds)
+            p.e1 = tl[8 + 64 + lane];
+            p.edge = lane < 8 ? tl[lane] : 0u;
+            p.pedge = (t && lane < 4) ? (uint32_t)a.list[(t - 1) * a.list_cap + 4 + lane] : 0u;
+        }
+    };
+    // four tiles of loads in flight per wavefront: the per-tile work is tiny, memory latency is not
+    Pre q0, q1, q2, q3;
+    uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    fetch(t, q0);
+    fetch(t + nwaves, q1);
+    fetch(t + 2 * nwaves, q2);
+    fetch(t + 3 * nwaves, q3);
+    for (; t < a.n_tiles; t += nwaves) {
+        const Pre cur = q0;
+        q0 = q1; q1 = q2; q2 = q3;
+        fetch(t + 4 * nwaves, q3);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.cnt);
+        if (n == 0) continue;
+        const unsigned long long lbase = a.nl_count + 1 + uniform64(cur.bp) +
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.tp);
+        const uint32_t hyp = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.hyp);
+        const uint32_t r = (4u - ((uint32_t)lbase & 3u)) & 3u;  // entry index of the first record start
+        if (hyp != r) { fail = 1; continue; }
+        const uint32_t nrs = (n - r + 3) >> 2;
+        const unsigned long long rbase = ((lbase + r) >> 2) - r0;
+        const unsigned long long vbase = a.base_offset + (t << WT_SHIFT);
+        const bool cap_ok = rbase + nrs <= a.cap;
+        uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rbase : nullptr;
+        const uint16_t *__restrict__ tl = a.list + t * a.list_cap + 8;
+        uint32_t carry = 0;  // offset of record start mb - 1 (last lane of the previous group of 64)
+        for (uint32_t mb = 0; mb < nrs; mb += 64) {
+            const uint32_t m = mb + lane;
+            const uint32_t o = mb == 0 ? cur.e0 : mb == 64 ? cur.e1 : (m < nrs ? (uint32_t)tl[m] : 0u);
+            const uint32_t oprev = wave_shr1(o, carry);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)o, 63);
+            if (m < nrs) {
+                if (rs && (cap_ok || rbase + m < a.cap)) rs[m] = vbase + o;
+                if (m) {  // record m-1 of the tile lies inside it: its length
+                    const uint32_t reclen = o - oprev;
+                    maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+                    if (bufsize32 && reclen + 15 >= bufsize32) {
+                        const unsigned long long rec = r0 + rbase + m - 1;
+                        if (rec < first_long) first_long = rec;
+                    }
+                }
+            }
+        }
+        // the record that ends at entry r started in the previous tile (tile 0: k_finalize_fast)
+        if (t) {
+            const uint32_t cprev = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.cprev);
+            if (cprev < 4 || n < 4) { fail = 1; continue; }
+            // entries r-4 .. r: negative indices are the previous tile's last four (offset - 16 KiB)
+            uint32_t ev[5];
+            int ov[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int j = (int)r - 4 + k;
+                const uint32_t e = j >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)cur.edge, j)
+                                          : (uint32_t)__builtin_amdgcn_readlane((int)cur.pedge, 4 + j);
+                ev[k] = e;
+                ov[k] = (int)(e & 0x3FFFu) - (j >= 0 ? 0 : (int)WT_BYTES);
+            }
+            const bool ok = (ev[0] & 0x4000u) && (ev[2] & 0x8000u) && (ov[2] - ov[1]) == (ov[4] - ov[3]);
+            if (!ok) { fail = 1; continue; }
+            const uint32_t reclen = (uint32_t)(ov[4] - ov[0]);
+            maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+            if (bufsize32 && reclen + 15 >= bufsize32) {
+                const unsigned long long rec = r0 + rbase - 1;
+                if (rec < first_long) first_long = rec;
+            }
+        }
+    }
+    const unsigned long long fl = wave_min_u64(first_long);
+    const unsigned long long ml = wave_max_u64(maxlen32);
+    if (lane == 0) {
+        if (fl != NOKEY) atomicMin(&out->first_long, fl);
+        if (ml) atomicMax(&out->max_len, ml);
+    }
+    if (__ballot(fail) && lane == 0) atomicAdd(&out->spec_fail, 1ull);
+}
+
+// k_finalize_fast: one thread.  Everything k_emit_fast leaves out: the record in progress at the
+// chunk start (validated with the carry), the lines after the last complete in-tile group, the EOF
+// rule, carry-out and summary.  Needs at least four line starts in the first and in the last tile;
+// otherwise, or on any violation, it sets spec_fail.
+__global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool fail = out->spec_fail != 0 || a.n_tiles == 0;
+    const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
+    const bool lastnl = a.len > 0 && a.buf[a.len - 1] == '\n';
+    const uint64_t tl_last = a.n_tiles ? a.n_tiles - 1 : 0;
+    if (!fail && (a.tile_count[0] < 4 || a.tile_count[tl_last] < 4 || E < 8)) fail = true;
+    unsigned long long max_len = out->max_len, first_long = out->first_long;
+    const unsigned long long r0 = a.nl_count >> 2;
+    long long recent[4] = {0, 0, 0, 0};
+    unsigned long long n_newlines = 0, T = a.nl_count;
+    if (!fail) {
+        // ---- chunk start: the virtual line start at offset 0 and the record in progress
+        const unsigned long long lbase0 = a.nl_count + 1;
+        if (a.v_start) {
+            const unsigned long long l = a.nl_count;
+            const uint8_t b = a.buf[0];
+            if (((l & 3) == 0 && b != '@') || ((l & 3) == 2 && b != '+')) fail = true;
+        }
+        const uint32_t rr = (4u - ((uint32_t)lbase0 & 3u)) & 3u;  // first entry of tile 0 that starts a record
+        long long S[5];   // line starts rr-4 .. rr of tile 0, chunk-relative
+        uint32_t cls[5];  // bit 0 '@', bit 1 '+' where known from this chunk (entries); 3 = not checkable here
+        for (int k = 0; k < 5; ++k) {
+            const int j = (int)rr - 4 + k;
+            if (j >= 0) {
+                const uint32_t e = a.list[j];
+                S[k] = (long long)(e & 0x3FFFu);
+                cls[k] = ((e & 0x4000u) ? 1u : 0u) | ((e & 0x8000u) ? 2u : 0u);
+            } else {
+                // line starts before entry 0, most recent first: the virtual start at offset 0 (if a
+                // line starts there), then the carry's
+                const int idx = -j - 1;
+                S[k] = (a.v_start && idx == 0) ? 0 : -(long long)a.back[idx < 4 ? idx : 3];
+                cls[k] = 3;
+            }
+        }
+        // class checks of the entries 0..rr (lines of the record in progress that start in this chunk)
+        for (int k = 0; k < 5; ++k) {
+            const int j = (int)rr - 4 + k;
+            if (j < 0) continue;
+            const unsigned long long l = lbase0 + j;
+            if ((l & 3) == 0 && !(cls[k] & 1u)) fail = true;
+            if ((l & 3) == 2 && !(cls[k] & 2u)) fail = true;
+        }
+        // length rule and length of the record that ends at entry rr (needs >= 1 earlier record line)
+        if (lbase0 + rr >= 4) {
+            if ((S[4] - S[3]) != (S[2] - S[1])) fail = true;
+            const unsigned long long reclen = (unsigned long long)(S[4] - S[0]);
+            if (reclen > max_len) max_len = reclen;
+            const unsigned long long rec = ((lbase0 + rr) >> 2) - 1;
+            if (a.bufsize && reclen + 15 >= a.bufsize && rec < first_long) first_long = rec;
+        }
+        if (a.rec_start && a.cap > 0) a.rec_start[0] = a.base_offset - a.back[a.nl_count & 3];
+
+        // ---- chunk end: the last four entries (with their class bits)
+        const uint16_t *el = a.list + tl_last * a.list_cap + 4;
+        uint32_t le[4];
+        long long ls[4];
+        for (int k = 0; k < 4; ++k) {  // k = 0: most recent
+            le[k] = el[3 - k];
+            ls[k] = (long long)((tl_last << WT_SHIFT) + (le[k] & 0x3FFFu));
+        }
+        n_newlines = E + (lastnl ? 1 : 0);
+        T = a.nl_count + n_newlines;
+        // global line index of the most recent entry
+        const unsigned long long l_last = a.nl_count + E;  // entries are lines nl_count+1 .. nl_count+E
+        // entries after the last complete in-tile group were not class-checked: the last group start g
+        // (largest line index == 0 mod 4 among the last four entries) and what follows it
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long l = l_last - k;
+            // a group starting at l was validated in its tile only if its fifth line start exists as an entry
+            const bool group_done = (l & 3) == 0 ? (l + 4 <= l_last) : ((l & ~3ull) + 4 <= l_last);
+            if (group_done) continue;
+            if ((l & 3) == 0 && !(le[k] & 0x4000u)) fail = true;
+            if ((l & 3) == 2 && !(le[k] & 0x8000u)) fail = true;
+        }
+        if (lastnl) {
+            const unsigned long long lv = a.nl_count + 1 + E;  // a line would start at offset len
+            if ((lv & 3) == 0) {  // a record ends exactly at the chunk end: lines lv-4 .. lv-1 = the last four entries
+                if ((((long long)a.len - ls[0]) != (ls[1] - ls[2]))) fail = true;
+                const unsigned long long reclen = (unsigned long long)((long long)a.len - ls[3]);
+                if (reclen > max_len) max_len = reclen;
+                const unsigned long long rec = (lv >> 2) - 1;
+                if (a.bufsize && reclen + 15 >= a.bufsize && rec < first_long) first_long = rec;
+                const unsigned long long r = (lv >> 2) - r0;
+                if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + a.len;
+            }
+            recent[0] = (long long)a.len; recent[1] = ls[0]; recent[2] = ls[1]; recent[3] = ls[2];
+        } else {
+            recent[0] = ls[0]; recent[1] = ls[1]; recent[2] = ls[2]; recent[3] = ls[3];
+        }
+        const unsigned long long col = (unsigned long long)((long long)a.len - recent[0]);
+        if (a.is_final && ((T & 3) != 0 || col > 0)) fail = true;  // truncated: the exact path reports it
+    }
+    out->spec_fail = fail ? 1 : 0;
+    out->min_key = NOKEY;
+    out->first_long = first_long;
+    out->max_len = max_len;
+    out->total_entries = E;
+    out->lastnl = lastnl;
+    for (int i = 0; i < 4; ++i) out->recent[i] = recent[i];
+    out->n_newlines = n_newlines;
+    out->final_key = NOKEY;
+    out->n_records = (T >> 2) - r0;
+    out->end_off = recent[T & 3];
+    out->err_start = recent[T & 3];
+    out->err_need = 0;
+    out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
 }
 
 int g_index_variant = -1;  // tuning hook (bench.py --variants); -1 = FQH_INDEX_VARIANT or default
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
-                  uint32_t *tile_count, uint64_t n_tiles, DevOut *out, int n_cu) {
+                  uint32_t *tile_count, uint8_t *tile_hyp, uint64_t n_tiles, DevOut *out, int n_cu, bool fast) {
     if (!n_tiles) return;
     static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 5;
     static const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;
-    typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
-    // 4: no prefetch, 5: production (register prefetch of the next 4 KiB group), 6: list staged in LDS
-    static const kern_t kerns[7] = {k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>,
-                                    k_index_t<0, 0>, k_index_t<1, 0>, k_index_t<1, 1>};
-    static int occ[7] = {0, 0, 0, 0, 0, 0, 0};
+    typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint8_t *, uint64_t, DevOut *);
+    // 4: no prefetch, 5: production exact (register prefetch of the next 4 KiB group), 6: list staged
+    // in LDS, 7: fast path (record starts + tile edges only)
+    static const kern_t kerns[8] = {k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>,
+                                    k_index_t<0, 0>, k_index_t<1, 0>, k_index_t<1, 1>, k_index_t<1, 2>};
+    static int occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int v = g_index_variant >= 0 ? g_index_variant : variant;
     const int bpc_dbg = v / 100;  // tuning: variant + 100 * blocks-per-CU
     v %= 100;
-    if (v < 0 || v > 6) v = 0;
+    if (v < 0 || v > 6) v = 5;
+    if (fast) v = 7;
     if (!occ[v]) {
         // persistent grid = exactly the blocks that are resident at once: a static round-robin of
         // tiles over a grid with one non-resident block per CU would run that block as a tail
@@ -786,7 +1052,24 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occ[v]);
     if (blocks > maxb) blocks = maxb;
     hipLaunchKernelGGL(kerns[v], dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
-                       tile_count, n_tiles, out);
+                       tile_count, tile_hyp, n_tiles, out);
+}
+void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
+    if (a.n_tiles) {
+        static int occ = 0;
+        if (!occ) {
+            int o = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_emit_fast, 256, 0) != hipSuccess || o < 1) o = 4;
+            occ = o > 8 ? 8 : o;
+        }
+        uint64_t blocks = (a.n_tiles + 3) / 4;
+        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ;
+        if (blocks > maxb) blocks = maxb;
+        hipLaunchKernelGGL(k_emit_fast, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+    }
+}
+void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {
+    hipLaunchKernelGGL(k_finalize_fast, dim3(1), dim3(64), 0, s, a, out);
 }
 void launch_prefix(hipStream_t s, const uint32_t *tile_count, uint32_t *tile_prefix,
                    uint64_t *block_prefix, uint64_t n_tiles, uint64_t n_blocks) {

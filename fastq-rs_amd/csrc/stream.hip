@@ -92,6 +92,7 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
     st->reserve = 2 * (uint64_t)FQH_BUFSIZE;
     st->slots.resize(n_slots);
     st->replay.reset(ctx->bufsize);
+    if (flags & FQH_STREAM_INDEX) ctx->spec_enabled = false;  // every chunk needs complete line lists
     fqh_status rc = FQH_OK;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = FQH_E_DEVICE; break; }

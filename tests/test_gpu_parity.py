@@ -345,3 +345,44 @@ def test_sharded_two_stage_protocol(fqref, torch, pkg, seed):
         c.close()
     assert total == res.n_records
     assert starts[: res.n_records] == [int(x) for x in idx[:, 0]]
+
+
+def test_fast_path_is_taken_and_falls_back_exactly(fqref, torch, pkg):
+    """The fast path (record starts + tile edges only) must (a) really run on valid
+    multi-tile input and (b) hand every input it cannot prove valid to the exact path: same status,
+    count, offsets and error record as the oracle either way, with the fast path re-enabled per input."""
+    rng = np.random.default_rng(909)
+    dev = torch.device("cuda:0")
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    taken = fell = 0
+    for trial in range(60):
+        nrec = int(rng.integers(300, 3000))
+        data = fuzzgen.valid_file(rng, nrec, seqlen=int(rng.choice([20, 100, 150, 300])), crlf=bool(trial % 7 == 0))
+        kind = trial % 4
+        if kind == 1:
+            data = fuzzgen.mutate(rng, data, 1)
+        elif kind == 2:   # damage exactly at a tile boundary region
+            b = bytearray(data)
+            pos = min(len(b) - 1, 16384 * int(rng.integers(1, max(2, len(b) // 16384))) + int(rng.integers(-3, 4)))
+            b[pos] = int(rng.choice(list(b"\n@+x")))
+            data = bytes(b)
+        elif kind == 3:
+            data = data[: len(data) - int(rng.integers(0, 40))]
+        ctx.set_spec(True)
+        d = torch.empty(max(len(data), 16), dtype=torch.uint8, device=dev)
+        d[: len(data)].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()))
+        cap = len(data) // 6 + 3
+        rs = torch.zeros(cap, dtype=torch.int64, device=dev)
+        s, c, st = ctx.scan(d.data_ptr(), len(data), True, None, rs.data_ptr(), cap)
+        res, idx = fqref.index(data)
+        assert (s.parse_status, s.n_records) == (res.status, res.n_records), (trial, kind)
+        assert np.array_equal(rs.cpu().numpy().astype(np.uint64)[: res.n_records], idx[:, 0])
+        if ctx.last_scan_fast():
+            taken += 1
+            assert res.status == fqref.OK
+        else:
+            fell += 1
+        if res.status != fqref.OK:
+            assert s.err_record == res.n_records
+    assert taken >= 10 and fell >= 10, (taken, fell)
+    ctx.close()

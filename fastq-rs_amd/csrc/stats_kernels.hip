@@ -331,21 +331,25 @@ __global__ __launch_bounds__(SL_THREADS) void k_stats_lines(StatsArgs a) {
     }
 }
 
-// Sum the per-block partial histograms into the caller's u64 arrays (plain adds: one thread per bin).
+// Sum the per-block partial histograms into the caller's u64 arrays.  blockIdx.y splits the partial
+// histograms into groups so that no thread walks more than 32 of them; one atomic per (bin, group).
+constexpr uint32_t RED_GROUP = 32;
 __global__ __launch_bounds__(256) void k_stats_reduce(const uint32_t *__restrict__ scratch, uint32_t n_blocks,
                                                       uint32_t lc, unsigned long long *__restrict__ qual_hist,
                                                       unsigned long long *__restrict__ base_hist) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nq = lc * 64, ns = lc * 8;
     const uint64_t stride = (uint64_t)lc * 128;
+    const uint32_t b0 = blockIdx.y * RED_GROUP;
+    const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
     if (id < nq) {
         unsigned long long s = 0;
-        for (uint32_t b = 0; b < n_blocks; ++b) s += scratch[b * stride + id];
-        if (s) qual_hist[(uint64_t)(id / 64) * 256 + 33 + (id % 64)] += s;
+        for (uint32_t b = b0; b < b1; ++b) s += scratch[b * stride + id];
+        if (s) atomicAdd(&qual_hist[(uint64_t)(id / 64) * 256 + 33 + (id % 64)], s);
     } else if (id < nq + ns) {
         const uint32_t j = id - nq, row = j / 8, bin = j % 8;
         unsigned long long s = 0;
-        for (uint32_t b = 0; b < n_blocks; ++b)
+        for (uint32_t b = b0; b < b1; ++b)
             for (uint32_t c = 0; c < 8; ++c) s += scratch[b * stride + nq + row * 64 + c * 8 + bin];
         if (s) atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
     }
@@ -369,8 +373,8 @@ hipError_t launch_stats_lines(hipStream_t s, StatsArgs a, int n_cu) {
     const uint32_t blocks = stats_lines_blocks(n_cu);
     hipLaunchKernelGGL(k_stats_lines, dim3(blocks), dim3(SL_THREADS), lds, s, a);
     const uint32_t nred = a.lc * 72;
-    hipLaunchKernelGGL(k_stats_reduce, dim3((nred + 255) / 256), dim3(256), 0, s, a.scratch, blocks, a.lc,
-                       a.qual_hist, a.base_hist);
+    hipLaunchKernelGGL(k_stats_reduce, dim3((nred + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0,
+                       s, a.scratch, blocks, a.lc, a.qual_hist, a.base_hist);
     return hipGetLastError();
 }
 

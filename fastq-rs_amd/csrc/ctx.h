@@ -18,6 +18,8 @@ void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_
                           uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
 size_t stats_lines_scratch_bytes(uint32_t, int);
 hipError_t launch_stats_lines(hipStream_t, StatsArgs, int);
+size_t stats_oct_scratch_bytes(uint32_t, int);
+hipError_t launch_stats_oct(hipStream_t, StatsArgs, int);
 void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
 void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
 extern int g_index_variant;

@@ -548,7 +548,7 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
     // the record in progress at the chunk start began in an earlier chunk: its bytes are not here
     const uint64_t skip = (n && ctx->carry_in.back[ctx->carry_in.nl_count & 3] > 0) ? 1 : 0;
     hipStream_t s = ctx->stream;
-    static const int stats_variant = getenv("FQH_STATS_VARIANT") ? atoi(getenv("FQH_STATS_VARIANT")) : 1;
+    static const int stats_variant = getenv("FQH_STATS_VARIANT") ? atoi(getenv("FQH_STATS_VARIANT")) : 2;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     if (n > skip && stats_variant == 0) {
         // first implementation (one lane per record over an index of records): kept as a second,
@@ -568,7 +568,8 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
         launch_stats_records(s, d_buf, ctx->carry_in.base_offset, ctx->idx + skip, n - skip, lmax,
                              d_qual_hist, d_base_hist, d_scalars, ctx->n_cu);
     } else if (n > skip) {
-        const size_t need = stats_lines_scratch_bytes(lmax, ctx->n_cu);
+        const size_t need = stats_variant == 1 ? stats_lines_scratch_bytes(lmax, ctx->n_cu)
+                                                 : stats_oct_scratch_bytes(lmax, ctx->n_cu);
         if (need > ctx->stats_scratch_bytes) {
             (void)hipFree(ctx->stats_scratch);
             ctx->stats_scratch = nullptr;
@@ -595,7 +596,7 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
         sa.qual_hist = (unsigned long long *)d_qual_hist;
         sa.base_hist = (unsigned long long *)d_base_hist;
         sa.scalars = (unsigned long long *)d_scalars;
-        HIPCHK(ctx, launch_stats_lines(s, sa, ctx->n_cu));
+        HIPCHK(ctx, stats_variant == 1 ? launch_stats_lines(s, sa, ctx->n_cu) : launch_stats_oct(s, sa, ctx->n_cu));
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], s));
     HIPCHK(ctx, hipGetLastError());

@@ -379,6 +379,408 @@ hipError_t launch_stats_lines(hipStream_t s, StatsArgs a, int n_cu) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_stats_oct — eight lanes per line, conflict-free LDS atomics.
+//
+// What bounds a histogram of random bytes on a CU is the LDS atomic unit and the instruction issue
+// around it.  A ds_add_u32 costs 4 LDS cycles per wave when its 2 x 32 lanes hit 32 distinct banks
+// and N x that with N-way bank or address collisions (tools/ldsatom.hip; binned instrument
+// qualities give 9x).  Here the bank is a function of the LANE only, so no input can collide:
+//   * a line is walked by 8 consecutive lanes, one dword (4 columns) each, 32 columns per step;
+//     a wave walks 8 lines at once (a "batch");
+//   * the histogram is bin-major: byte address = region | rb << (8 + binbits) | bin << 8 | slot << 2
+//     with rb = row / 64 and slot = a 6-bit rearrangement of row % 64 (so_slot);
+//   * at the k-th atomic of a step, lane (line slot g, dword m) adds the byte j = k ^ (g & 3) of
+//     its dword: row = 32 u + 4 m + j, slot = m + 8 j + 32 (u & 1), bank = m + 8 j — the 32 lanes
+//     of a group (4 line slots x 8 dwords) are on 32 distinct banks whatever the bins are;
+//   * the bin sits in byte 1 of the address, so one v_perm_b32 (bytes 0, 2, 3 of the lane's address
+//     register, byte 1 from the bins) is the whole address computation.
+// A wave stages its tile's line-start list in LDS.  64 lines at a time, one lane per line works out
+// where the line starts, how long it is and whether it ends in '\r'; batches then pick that up with
+// ds_bpermute.  The loads of batch b+1 (every step of the line at once, unconditional, plus the
+// dword that holds the line's partial tail) are in flight while batch b is counted.  Whole dwords
+// of in-window bytes cost 1 VALU + 1 DS per byte; a line's last 1-3 columns are added by lanes 0-2
+// of its group; bytes outside the window / alphabet and columns beyond the LDS rows take the exact
+// per-byte path.  Quality bins: byte - 33 (0..63); sequence bins: byte & 7.
+constexpr uint32_t SO_THREADS = 1024;
+constexpr uint32_t SO_WAVES = SO_THREADS / 64;
+constexpr uint32_t SO_LC_MAX = 256;           // rows kept in LDS
+constexpr uint32_t SO_QBYTES = 4 * 64 * 256;  // quality region: 4 row blocks x 64 bins x 64 slots x 4 B
+constexpr uint32_t SO_SBYTES = 4 * 8 * 256;   // sequence region
+constexpr uint32_t SO_WORDS = (SO_QBYTES + SO_SBYTES) / 4;
+constexpr uint32_t SO_LISTW = 512;            // list entries staged in LDS per wave (u16 each)
+
+__device__ __forceinline__ uint32_t so_slot(uint32_t r) {  // r = row % 64
+    return ((r >> 2) & 7u) | ((r & 3u) << 3) | (r & 32u);
+}
+__device__ __forceinline__ uint32_t so_row6(uint32_t slot) {
+    return ((slot & 7u) << 2) | ((slot >> 3) & 3u) | (slot & 32u);
+}
+// word index of (bin, row): quality bins 0..63, sequence bins 0..7
+template <bool IS_SEQ>
+__device__ __forceinline__ uint32_t so_word(uint32_t bin, uint32_t row) {
+    const uint32_t rb = row >> 6, slot = so_slot(row & 63u);
+    return IS_SEQ ? SO_QBYTES / 4 + ((rb << 9) | (bin << 6) | slot) : ((rb << 12) | (bin << 6) | slot);
+}
+__device__ __forceinline__ uint32_t load4_any(const uint8_t *__restrict__ p, const uint8_t *__restrict__ end) {
+    uint32_t v = 0;
+    if (p + 4 <= end) {
+        __builtin_memcpy(&v, p, 4);
+    } else {
+        for (uint32_t i = 0; p + i < end && i < 4; ++i) v |= (uint32_t)p[i] << (i * 8u);
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t load4_fast(const uint8_t *__restrict__ p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+struct SoLane {          // per-lane constants of the bank schedule
+    uint32_t sel[4];     // v_perm selector of the k-th atomic: bytes 0, 2, 3 of the address register,
+                         // byte 1 = byte k ^ (g & 3) of the bins
+    uint32_t A[4];       // address registers: LDS byte address of slot m + 8 (k ^ g) in the region of
+                         // the kind being counted, byte 1 (the bin) zero
+};
+
+// ds_add_u32 with the u & 1 half of the slot (128 bytes) as the instruction's immediate offset.
+// No return value; the kernel waits for lgkmcnt(0) before the barrier that precedes the read-out.
+template <uint32_t OFF>
+__device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v) {
+    asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF));
+}
+
+// Step U of a batch: the lanes whose dword (columns 32 U + 4 m .. +3) lies entirely inside the
+// line and the LDS rows count it (`full`); the others add 0 at a harmless address.  Returns false
+// (wave-uniform) when a counted dword holds a byte outside the window / alphabet; nothing has been
+// counted then.
+template <bool IS_SEQ, uint32_t U>
+__device__ __forceinline__ bool so_fast_step(uint32_t w, bool full, const SoLane &c, uint32_t &any_n) {
+    const uint32_t wf = full ? w : (IS_SEQ ? 0x41414141u : 0x21212121u);
+    const uint32_t inc = full ? 1u : 0u;
+    bool ok;
+    uint32_t bins;
+    if (IS_SEQ) {
+        bins = wf & 0x07070707u;
+        ok = wf == __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins);
+    } else {
+        const uint32_t lo7 = wf & 0x7F7F7F7Fu;
+        ok = (((lo7 + 0x5F5F5F5Fu) & ~(lo7 + 0x1F1F1F1Fu) & ~wf) & 0x80808080u) == 0x80808080u;
+        bins = wf - 0x21212121u;
+    }
+    if (__ballot(!ok) != 0) return false;
+    if (IS_SEQ) any_n |= __builtin_amdgcn_perm(0x00800000u, 0u, bins);  // bin 6 = 'N'
+    constexpr uint32_t RB = U >> 1;
+    const uint32_t pb = bins + (IS_SEQ ? 0x08080808u : 0x40404040u) * RB;  // row block into the bin byte
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds_add<128u * (U & 1u)>(__builtin_amdgcn_perm(c.A[k], pb, c.sel[k]), inc);
+    return true;
+}
+
+// The exact per-byte statement: columns pos .. of a line of `len` columns held in w.
+template <bool IS_SEQ>
+__device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, uint32_t pos, uint32_t len, uint32_t lc,
+                                              uint32_t *hist, uint32_t &any_n, uint32_t &any_inv, uint32_t &ovf) {
+    const int rem = (int)len - (int)pos;
+    const uint32_t nb = rem >= 4 ? 4u : (uint32_t)(rem > 0 ? rem : 0);
+    for (uint32_t j = 0; j < nb; ++j) {
+        const uint32_t b = (w >> (8 * j)) & 0xFFu;
+        const uint32_t col = pos + j;
+        if (IS_SEQ) {
+            const bool valid = b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N';
+            const uint32_t bin = valid ? (b & 7u) : 0u;
+            any_inv |= valid ? 0u : 1u;
+            any_n |= b == 'N' ? 1u : 0u;
+            if (col < lc) atomicAdd(hist + so_word<true>(bin, col), 1u);
+            else if (col < a.lmax) atomicAdd(&a.base_hist[(uint64_t)col * 8 + bin_to_class(bin)], 1ull);
+            else ++ovf;
+        } else {
+            if (col < lc && b - 33u < 64u) atomicAdd(hist + so_word<false>(b - 33u, col), 1u);
+            else if (col < a.lmax) atomicAdd(&a.qual_hist[(uint64_t)col * 256 + b], 1ull);
+            else ++ovf;
+        }
+    }
+}
+
+template <uint32_t NSL>
+struct SoBatch {                 // one batch in flight: 8 lines, this lane's dword of each step
+    const uint8_t *line;         // first byte of this lane's line
+    uint32_t meta;               // bit 31: the slot holds a line that counts; bits 0..30: its length
+    uint32_t wt;                 // the dword at column (min(len, lc) & ~3): the line's partial tail
+    uint32_t w[NSL];
+};
+
+// Count one batch (its loads were issued one batch earlier).
+template <bool IS_SEQ, uint32_t NSL>
+__device__ __forceinline__ void so_count(const StatsArgs &a, const SoBatch<NSL> &B, uint32_t lane, uint32_t lc,
+                                         uint32_t *hist, const SoLane &c, StatsAcc &acc) {
+    const uint32_t m = lane & 7u, m4 = m * 4u;
+    const uint8_t *const bend = a.buf + a.len;
+    const bool act = (B.meta >> 31) != 0;
+    const uint32_t len = B.meta & 0x7FFFFFFFu;
+    const uint32_t lenc = len <= lc ? len : (lc & ~3u);
+    const uint32_t nfull4 = lenc & ~3u;                             // columns covered by whole dwords
+    const int tt = (int)nfull4 - (int)m4;
+    uint32_t any_n = 0, any_inv = 0, ovf = 0;
+    uint32_t slow = 0;  // wave-uniform: steps left to the exact path
+    do {
+#define FQH_SO_STEP(U)                                                                   \
+        if (U < NSL) {                                                                   \
+            const bool full = tt > (int)(32u * U);                                       \
+            if (__ballot(full) == 0) break;                                              \
+            if (!so_fast_step<IS_SEQ, U>(B.w[U < NSL ? U : 0], full, c, any_n)) slow |= 1u << U; \
+        }
+        FQH_SO_STEP(0) FQH_SO_STEP(1) FQH_SO_STEP(2) FQH_SO_STEP(3)
+        FQH_SO_STEP(4) FQH_SO_STEP(5) FQH_SO_STEP(6) FQH_SO_STEP(7)
+#undef FQH_SO_STEP
+    } while (0);
+    // the partial last dword: column nfull4 + m is added by lane m (< 3) of the line's group
+    bool tail_exact = false;
+    if (__ballot(nfull4 < lenc) != 0) {
+        const bool has = nfull4 + m < lenc;
+        const uint32_t b = (B.wt >> (8u * (m & 3u))) & 0xFFu;
+        uint32_t bin;
+        bool ok;
+        if (IS_SEQ) {
+            bin = b & 7u;
+            ok = (b | 0xFFFFFF00u) == __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bin);
+        } else {
+            bin = b - 33u;
+            ok = bin < 64u;
+        }
+        if (__ballot(has && !ok) != 0) {
+            tail_exact = true;
+        } else if (has) {
+            if (IS_SEQ) any_n |= b == 'N' ? 1u : 0u;
+            atomicAdd(hist + so_word<IS_SEQ>(bin, nfull4 + m), 1u);
+        }
+    }
+    // exact work: refused steps, a refused tail, and everything from column nfull4 on in lines
+    // longer than the LDS rows
+    const bool longs = __ballot(len > lc) != 0;
+    if (__builtin_amdgcn_readfirstlane((int)(slow | (tail_exact ? 256u : 0u) | (longs ? 512u : 0u))) != 0) {
+        bool tail = tail_exact || longs;
+        for (uint32_t ul = lc >> 5;;) {
+            uint32_t pos, le;
+            if (slow) {
+                const uint32_t u = (uint32_t)__builtin_ctz(slow);
+                slow &= slow - 1;
+                pos = m4 + 32 * u;
+                le = nfull4;
+            } else if (tail) {
+                tail = false;
+                pos = nfull4;
+                le = (m == 0 && (tail_exact || len > lc)) ? len : 0u;
+            } else {
+                if (!longs) break;
+                pos = m4 + 32 * ul++;
+                if (__ballot(pos < len) == 0) break;
+                le = (len > lc && pos > nfull4) ? len : 0u;
+            }
+            const uint32_t wl = pos < le ? load4_any(B.line + pos, bend) : 0u;
+            so_exact_step<IS_SEQ>(a, wl, pos, le, lc, hist, any_n, any_inv, ovf);
+        }
+    }
+    // per-line scalars: the 8 lanes of a line OR their flags through two ballots
+    const unsigned long long bn = __ballot(any_n != 0), bi = __ballot(any_inv != 0);
+    unsigned long long so = ovf;
+    if (__ballot(ovf != 0) != 0) {
+        so += __shfl_xor(so, 1);
+        so += __shfl_xor(so, 2);
+        so += __shfl_xor(so, 4);
+    }
+    if (act && m == 0) {
+        const bool gn = ((bn >> (lane & 56u)) & 0xFFu) != 0, gi = ((bi >> (lane & 56u)) & 0xFFu) != 0;
+        if (IS_SEQ) {
+            ++acc.rec;
+            acc.bases += len;
+            acc.dna += (gn || gi) ? 0 : 1;
+            acc.dnan += gi ? 0 : 1;
+            acc.oseq += so;
+        } else {
+            acc.qual += len;
+            acc.oqual += so;
+        }
+    }
+}
+
+template <uint32_t NSL>
+__global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // quality + sequence regions, then the staged lists
+    const uint32_t lc = a.lc;
+    for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) hist[i] = 0;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t m4 = (lane & 7u) * 4u, g8 = lane >> 3;
+    uint16_t *const wl = reinterpret_cast<uint16_t *>(hist + SO_WORDS) + wv * SO_LISTW;  // this wave's staged list
+    // The address registers assume the histogram starts at LDS address 0 (it is the kernel's only
+    // LDS object); a shared-memory pointer is its LDS address in the low 32 bits.
+    if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();
+    SoLane c;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t j = k ^ (g8 & 3u);
+        c.sel[k] = 0x07060004u | (j << 8);
+        c.A[k] = ((lane & 7u) + 8u * j) * 4u;
+    }
+    const uint8_t *const last4 = a.buf + (a.len >= 4 ? a.len - 4 : 0);  // a record has at least 6 bytes
+    StatsAcc acc = {0, 0, 0, 0, 0, 0, 0};
+
+    for (uint64_t tile = (uint64_t)blockIdx.x * SO_WAVES + wv; tile < a.n_tiles && a.len >= 4;
+         tile += (uint64_t)gridDim.x * SO_WAVES) {
+        uint32_t cnt = a.tile_count[tile];
+        cnt = cnt < a.list_cap ? cnt : a.list_cap;
+        if (cnt == 0) continue;
+        const unsigned long long lbase = a.nl_count + 1 + a.block_prefix[tile >> SCAN_SHIFT] + a.tile_prefix[tile];
+        if (lbase >= a.line_hi || lbase + cnt <= a.line_lo) continue;
+        const uint16_t *__restrict__ tl = a.list + tile * a.list_cap;
+        const uint64_t tb = tile << WT_SHIFT;
+        // stage the list (4 entries = 8 bytes per lane and round)
+        const uint32_t nst = cnt < SO_LISTW ? cnt : SO_LISTW;
+        for (uint32_t e = lane * 4; e < nst; e += 256)
+            *reinterpret_cast<uint2 *>(wl + e) = *reinterpret_cast<const uint2 *>(tl + e);
+        // start of the first line after this tile (ends the tile's last line), tile-relative
+        uint64_t next_first = a.valid_end;
+        for (uint64_t t2 = tile + 1; t2 < a.n_tiles; ++t2) {
+            if (a.tile_count[t2]) { next_first = (t2 << WT_SHIFT) + (a.list[t2 * a.list_cap] & 0x3FFFu); break; }
+        }
+        const uint64_t vend = a.valid_end > tb ? a.valid_end - tb : 0;
+        const uint32_t vend_rel = vend < 0x7FFFFFFFull ? (uint32_t)vend : 0x7FFFFFFFu;
+        const uint64_t nf = next_first > tb ? next_first - tb : 0;
+        const uint32_t nf_rel = nf < 0x7FFFFFFFull ? (uint32_t)nf : 0x7FFFFFFFu;
+        // entries of this tile whose lines count: global line index in [line_lo, line_hi)
+        const uint32_t e_lo = a.line_lo > lbase ? (uint32_t)(a.line_lo - lbase) : 0u;
+        const uint32_t e_hi = a.line_hi - lbase < cnt ? (uint32_t)(a.line_hi - lbase) : cnt;
+        const uint32_t lb3 = (uint32_t)lbase & 3u;
+        const uint8_t *const tbase = a.buf + tb;
+        // every unconditional load of a line that starts in this tile stays inside the buffer
+        const bool safe = tb + WT_BYTES + 32u * NSL + 8u <= a.len;
+
+        for (uint32_t kind = 0; kind < 2; ++kind) {        // 0: sequence lines, 1: quality lines
+            const uint32_t i0 = ((kind ? 3u : 1u) - lb3) & 3u;
+            if (i0 >= cnt) continue;
+            const uint32_t nlines = (cnt - i0 + 3) >> 2;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) c.A[k] = (c.A[k] & 0xFFu) | (kind ? 0u : SO_QBYTES);  // region
+            for (uint32_t sb = 0; sb < nlines; sb += 64) {
+                // one lane per line: start, length, '\r' trim
+                uint32_t my_s = 0, my_meta = 0;
+                {
+                    const uint32_t i = i0 + 4u * (sb + lane);
+                    if (sb + lane < nlines && i >= e_lo && i < e_hi) {
+                        my_s = (i < SO_LISTW ? wl[i] : tl[i]) & 0x3FFFu;
+                        uint32_t n_rel = i + 1 < cnt ? ((i + 1 < SO_LISTW ? wl[i + 1] : tl[i + 1]) & 0x3FFFu) : nf_rel;
+                        n_rel = n_rel < vend_rel ? n_rel : vend_rel;
+                        uint32_t len = n_rel - 1 - my_s;                               // raw line, without its '\n'
+                        if (len && tbase[my_s + len - 1] == '\r') --len;               // trim_winline, src/records.rs:66-73
+                        my_meta = 0x80000000u | len;
+                    }
+                }
+                const uint32_t nbat = ((nlines - sb < 64 ? nlines - sb : 64u) + 7) >> 3;
+                SoBatch<NSL> cur, nxt;
+                auto fetch = [&](uint32_t b, SoBatch<NSL> &B) {
+                    const uint32_t src = 8u * b + g8;
+                    B.meta = (uint32_t)__shfl((int)my_meta, (int)src);
+                    B.line = tbase + (uint32_t)__shfl((int)my_s, (int)src);
+                    const uint32_t len = B.meta & 0x7FFFFFFFu;
+                    const uint32_t nf4 = (len <= lc ? len : lc) & ~3u;
+                    const uint8_t *const lp = B.line + m4;
+                    if (safe) {
+#pragma unroll
+                        for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(lp + 32 * u);
+                        B.wt = load4_fast(B.line + nf4);
+                    } else {
+                        // near the end of the buffer: a counted dword lies inside its line, hence
+                        // inside the buffer, so clamping the address only changes dwords nobody counts;
+                        // the tail dword may straddle the end and is shifted back into place
+#pragma unroll
+                        for (uint32_t u = 0; u < NSL; ++u) {
+                            const uint8_t *p = lp + 32 * u;
+                            B.w[u] = load4_fast(p < last4 ? p : last4);
+                        }
+                        const uint8_t *pt = B.line + nf4;
+                        const uint32_t over = pt > last4 ? (uint32_t)(pt - last4) : 0u;
+                        B.wt = over < 4 ? load4_fast(pt - over) >> (8u * over) : 0u;
+                    }
+                };
+                fetch(0, nxt);
+                for (uint32_t b = 0; b < nbat; ++b) {
+                    cur = nxt;
+                    if (b + 1 < nbat) fetch(b + 1, nxt);
+                    if (kind == 0) so_count<true, NSL>(a, cur, lane, lc, hist, c, acc);
+                    else so_count<false, NSL>(a, cur, lane, lc, hist, c, acc);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the inline ds_add of lds_add
+    __syncthreads();
+    uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * SO_WORDS;
+    for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) dst[i] = hist[i];
+    unsigned long long sc[7] = {acc.rec, acc.bases, acc.qual, acc.dna, acc.dnan, acc.oseq, acc.oqual};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        unsigned long long v = sc[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0 && v) atomicAdd(&a.scalars[j], v);
+    }
+}
+
+// Sum the per-block partial histograms into the caller's u64 arrays (coalesced reads).
+__global__ __launch_bounds__(256) void k_stats_reduce_oct(const uint32_t *__restrict__ scratch, uint32_t n_blocks,
+                                                          uint32_t lc, unsigned long long *__restrict__ qual_hist,
+                                                          unsigned long long *__restrict__ base_hist) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= SO_WORDS) return;
+    const bool isq = id < SO_QBYTES / 4;
+    const uint32_t r = isq ? id : id - SO_QBYTES / 4;
+    const uint32_t rb = isq ? r >> 12 : r >> 9, bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
+    const uint32_t row = rb * 64 + so_row6(r & 63u);
+    if (row >= lc) return;
+    const uint32_t b0 = blockIdx.y * RED_GROUP;
+    const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
+    unsigned long long s = 0;
+    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * SO_WORDS + id];
+    if (!s) return;
+    if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
+    else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+}
+
+uint32_t stats_oct_lc(uint32_t lmax) { return lmax < SO_LC_MAX ? lmax : SO_LC_MAX; }
+size_t stats_oct_scratch_bytes(uint32_t, int n_cu) {
+    return (size_t)stats_lines_blocks(n_cu) * SO_WORDS * sizeof(uint32_t);
+}
+template <uint32_t NSL>
+static hipError_t launch_stats_oct_n(hipStream_t s, const StatsArgs &a, uint32_t blocks, size_t lds) {
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_oct<NSL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        set = true;
+    }
+    hipLaunchKernelGGL(k_stats_oct<NSL>, dim3(blocks), dim3(SO_THREADS), lds, s, a);
+    return hipSuccess;
+}
+hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
+    a.lc = stats_oct_lc(a.lmax);
+    const size_t lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * SO_LISTW * sizeof(uint16_t);
+    const uint32_t blocks = stats_lines_blocks(n_cu);
+    const uint32_t nsl = (a.lc + 31) / 32;  // steps that hold LDS rows
+    hipError_t e = nsl <= 2   ? launch_stats_oct_n<2>(s, a, blocks, lds)
+                   : nsl <= 4 ? launch_stats_oct_n<4>(s, a, blocks, lds)
+                   : nsl <= 5 ? launch_stats_oct_n<5>(s, a, blocks, lds)
+                              : launch_stats_oct_n<8>(s, a, blocks, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stats_reduce_oct, dim3((SO_WORDS + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP),
+                       dim3(256), 0, s, a.scratch, blocks, a.lc, a.qual_hist, a.base_hist);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic 150 bp FASTQ: byte b of record i is a pure function of (seed, i, b); the
 // tests regenerate any sub-range on the CPU from the same map.
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {

@@ -256,7 +256,7 @@ def main():
             assert int(sc[0].item()) == total_records
             assert int(qh.sum().item()) == total_records * 150 and int(bh.sum().item()) == total_records * 150
             out["stats"] = {"workload": "configs[2]: per-position quality + base histograms, same buffer",
-                            "kernel": "k_stats_lines", "kernel_ms": round(best, 3),
+                            "kernel": "k_stats_oct", "kernel_ms": round(best, 3),
                             "gbs": round(nbytes / 1e9 / (best / 1e3), 1),
                             "frac_of_hbm_peak": round(nbytes / 1e9 / (best / 1e3) / HBM_PEAK_GBS, 4)}
         if not args.no_cpu_baseline:

@@ -450,37 +450,11 @@ __device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v) {
     asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF));
 }
 
-// Step U of a batch: the lanes whose dword (columns 32 U + 4 m .. +3) lies entirely inside the
-// line and the LDS rows count it (`full`); the others add 0 at a harmless address.  Returns false
-// (wave-uniform) when a counted dword holds a byte outside the window / alphabet; nothing has been
-// counted then.
-template <bool IS_SEQ, uint32_t U>
-__device__ __forceinline__ bool so_fast_step(uint32_t w, bool full, const SoLane &c, uint32_t &any_n) {
-    const uint32_t wf = full ? w : (IS_SEQ ? 0x41414141u : 0x21212121u);
-    const uint32_t inc = full ? 1u : 0u;
-    bool ok;
-    uint32_t bins;
-    if (IS_SEQ) {
-        bins = wf & 0x07070707u;
-        ok = wf == __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins);
-    } else {
-        const uint32_t lo7 = wf & 0x7F7F7F7Fu;
-        ok = (((lo7 + 0x5F5F5F5Fu) & ~(lo7 + 0x1F1F1F1Fu) & ~wf) & 0x80808080u) == 0x80808080u;
-        bins = wf - 0x21212121u;
-    }
-    if (__ballot(!ok) != 0) return false;
-    if (IS_SEQ) any_n |= __builtin_amdgcn_perm(0x00800000u, 0u, bins);  // bin 6 = 'N'
-    constexpr uint32_t RB = U >> 1;
-    const uint32_t pb = bins + (IS_SEQ ? 0x08080808u : 0x40404040u) * RB;  // row block into the bin byte
-#pragma unroll
-    for (int k = 0; k < 4; ++k) lds_add<128u * (U & 1u)>(__builtin_amdgcn_perm(c.A[k], pb, c.sel[k]), inc);
-    return true;
-}
-
 // The exact per-byte statement: columns pos .. of a line of `len` columns held in w.
 template <bool IS_SEQ>
 __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, uint32_t pos, uint32_t len, uint32_t lc,
-                                              uint32_t *hist, uint32_t &any_n, uint32_t &any_inv, uint32_t &ovf) {
+                                              uint32_t *hist, uint32_t &any_n, uint32_t &any_inv,
+                                              unsigned long long &ovf) {
     const int rem = (int)len - (int)pos;
     const uint32_t nb = rem >= 4 ? 4u : (uint32_t)(rem > 0 ? rem : 0);
     for (uint32_t j = 0; j < nb; ++j) {
@@ -502,42 +476,99 @@ __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, ui
     }
 }
 
+// What one lane knows about one line (worked out by one lane per line, 64 lines at a time).
+constexpr uint32_t SO_P_NBT = 9, SO_P_LONG = 11, SO_P_ACT = 12, SO_P_SREL = 16;
+__device__ __forceinline__ uint32_t so_pack(uint32_t s_rel, uint32_t len, uint32_t lc) {
+    const uint32_t lenc = len <= lc ? len : (lc & ~3u);        // columns the whole-dword steps and the tail cover
+    return (lenc & ~3u) | ((lenc & 3u) << SO_P_NBT) | ((len > lc ? 1u : 0u) << SO_P_LONG) | (1u << SO_P_ACT) |
+           (s_rel << SO_P_SREL);
+}
+
 template <uint32_t NSL>
 struct SoBatch {                 // one batch in flight: 8 lines, this lane's dword of each step
-    const uint8_t *line;         // first byte of this lane's line
-    uint32_t meta;               // bit 31: the slot holds a line that counts; bits 0..30: its length
-    uint32_t wt;                 // the dword at column (min(len, lc) & ~3): the line's partial tail
+    uint32_t P;                  // so_pack() of this lane's line (0: no line in this slot)
+    uint32_t wt;                 // the dword at the line's column nfull4: its partial tail
     uint32_t w[NSL];
 };
 
-// Count one batch (its loads were issued one batch earlier).
+// Wave-uniform per-wave totals that need no vector registers.
+struct SoTotals {
+    uint32_t not_dna;            // sequence lines with an 'N' or a byte outside the alphabet
+    uint32_t not_dnan;           // sequence lines with a byte outside the alphabet
+};
+__device__ __forceinline__ uint32_t so_groups(unsigned long long lanes) {  // 8-lane groups with a lane set
+    lanes |= lanes >> 4;
+    lanes |= lanes >> 2;
+    lanes |= lanes >> 1;
+    return (uint32_t)__builtin_popcountll(lanes & 0x0101010101010101ull);
+}
+
+// Count one batch (its loads were issued one batch earlier).  Pass 1 checks every whole dword the
+// batch counts (lanes without one get a filler), pass 2 adds them: one v_perm_b32 and one ds_add
+// per byte, no divergence.  A byte outside the window / alphabet sends the whole batch to the exact
+// path instead.
 template <bool IS_SEQ, uint32_t NSL>
-__device__ __forceinline__ void so_count(const StatsArgs &a, const SoBatch<NSL> &B, uint32_t lane, uint32_t lc,
-                                         uint32_t *hist, const SoLane &c, StatsAcc &acc) {
+__device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbase, SoBatch<NSL> &B, uint32_t lane,
+                                         uint32_t lc, uint32_t *hist, const SoLane &c, uint32_t my_len,
+                                         uint32_t src4, SoTotals &T, StatsAcc &acc) {
     const uint32_t m = lane & 7u, m4 = m * 4u;
-    const uint8_t *const bend = a.buf + a.len;
-    const bool act = (B.meta >> 31) != 0;
-    const uint32_t len = B.meta & 0x7FFFFFFFu;
-    const uint32_t lenc = len <= lc ? len : (lc & ~3u);
-    const uint32_t nfull4 = lenc & ~3u;                             // columns covered by whole dwords
+    const uint32_t P = B.P;
+    const uint32_t nfull4 = P & 0x1FFu;                            // columns covered by whole dwords
     const int tt = (int)nfull4 - (int)m4;
-    uint32_t any_n = 0, any_inv = 0, ovf = 0;
-    uint32_t slow = 0;  // wave-uniform: steps left to the exact path
+    constexpr uint32_t FILL = IS_SEQ ? 0x41414141u : 0x21212121u;
+    uint32_t any_n = 0, any_inv = 0;
+    uint32_t chk = IS_SEQ ? 0u : 0x80808080u;  // sequence: OR of (dword ^ expected); quality: AND of window flags
+    uint32_t nsteps = 0;                       // wave-uniform
     do {
-#define FQH_SO_STEP(U)                                                                   \
-        if (U < NSL) {                                                                   \
-            const bool full = tt > (int)(32u * U);                                       \
-            if (__ballot(full) == 0) break;                                              \
-            if (!so_fast_step<IS_SEQ, U>(B.w[U < NSL ? U : 0], full, c, any_n)) slow |= 1u << U; \
+#define FQH_SO_PASS1(U)                                                                        \
+        if (U < NSL) {                                                                         \
+            const bool full = tt > (int)(32u * U);                                             \
+            if (__ballot(full) == 0) break;                                                    \
+            nsteps = U + 1;                                                                    \
+            const uint32_t wf = full ? B.w[U < NSL ? U : 0] : FILL;                            \
+            B.w[U < NSL ? U : 0] = wf;                                                         \
+            if (IS_SEQ) {                                                                      \
+                chk |= wf ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, wf & 0x07070707u); \
+            } else {                                                                           \
+                const uint32_t lo7 = wf & 0x7F7F7F7Fu;                                         \
+                chk &= (lo7 + 0x5F5F5F5Fu) & ~(lo7 + 0x1F1F1F1Fu) & ~wf;                       \
+            }                                                                                  \
         }
-        FQH_SO_STEP(0) FQH_SO_STEP(1) FQH_SO_STEP(2) FQH_SO_STEP(3)
-        FQH_SO_STEP(4) FQH_SO_STEP(5) FQH_SO_STEP(6) FQH_SO_STEP(7)
-#undef FQH_SO_STEP
+        FQH_SO_PASS1(0) FQH_SO_PASS1(1) FQH_SO_PASS1(2) FQH_SO_PASS1(3)
+        FQH_SO_PASS1(4) FQH_SO_PASS1(5) FQH_SO_PASS1(6) FQH_SO_PASS1(7)
+#undef FQH_SO_PASS1
     } while (0);
+    uint32_t slow = 0;  // wave-uniform: steps left to the exact path
+    if (__ballot(IS_SEQ ? chk != 0 : chk != 0x80808080u) != 0) {
+        slow = (1u << nsteps) - 1u;
+    } else {
+        do {
+#define FQH_SO_PASS2(U)                                                                        \
+            if (U < NSL) {                                                                     \
+                if (U >= nsteps) break;                                                        \
+                const uint32_t wf = B.w[U < NSL ? U : 0];                                      \
+                const uint32_t inc = tt > (int)(32u * U) ? 1u : 0u;                            \
+                uint32_t pb;                                                                   \
+                if (IS_SEQ) {                                                                  \
+                    const uint32_t bins = wf & 0x07070707u;                                    \
+                    any_n |= __builtin_amdgcn_perm(0x00800000u, 0u, bins);                     \
+                    pb = bins | (0x08080808u * (U >> 1));                                      \
+                } else {                                                                       \
+                    pb = wf - 0x21212121u + 0x40404040u * (U >> 1);                            \
+                }                                                                              \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                  \
+                    lds_add<128u * (U & 1u)>(__builtin_amdgcn_perm(c.A[k], pb, c.sel[k]), inc); \
+            }
+            FQH_SO_PASS2(0) FQH_SO_PASS2(1) FQH_SO_PASS2(2) FQH_SO_PASS2(3)
+            FQH_SO_PASS2(4) FQH_SO_PASS2(5) FQH_SO_PASS2(6) FQH_SO_PASS2(7)
+#undef FQH_SO_PASS2
+        } while (0);
+    }
     // the partial last dword: column nfull4 + m is added by lane m (< 3) of the line's group
+    const uint32_t nbt = (P >> SO_P_NBT) & 3u;
     bool tail_exact = false;
-    if (__ballot(nfull4 < lenc) != 0) {
-        const bool has = nfull4 + m < lenc;
+    if (__ballot(nbt != 0) != 0) {
+        const bool has = m < nbt;
         const uint32_t b = (B.wt >> (8u * (m & 3u))) & 0xFFu;
         uint32_t bin;
         bool ok;
@@ -555,10 +586,16 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const SoBatch<NSL> 
             atomicAdd(hist + so_word<IS_SEQ>(bin, nfull4 + m), 1u);
         }
     }
-    // exact work: refused steps, a refused tail, and everything from column nfull4 on in lines
+    // exact work: a refused batch, a refused tail, and everything from column nfull4 on in lines
     // longer than the LDS rows
-    const bool longs = __ballot(len > lc) != 0;
+    const bool longs = __ballot((P >> SO_P_LONG) & 1u) != 0;
     if (__builtin_amdgcn_readfirstlane((int)(slow | (tail_exact ? 256u : 0u) | (longs ? 512u : 0u))) != 0) {
+        const uint8_t *const bend = a.buf + a.len;
+        const uint8_t *const line = tbase + (P >> SO_P_SREL);
+        // (every lane takes part in the permute: a disabled source lane would read as 0)
+        const uint32_t len_src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)my_len);
+        const uint32_t len = (P >> SO_P_ACT) & 1u ? len_src : 0u;
+        const bool islong = ((P >> SO_P_LONG) & 1u) != 0;
         bool tail = tail_exact || longs;
         for (uint32_t ul = lc >> 5;;) {
             uint32_t pos, le;
@@ -570,37 +607,21 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const SoBatch<NSL> 
             } else if (tail) {
                 tail = false;
                 pos = nfull4;
-                le = (m == 0 && (tail_exact || len > lc)) ? len : 0u;
+                le = (m == 0 && (tail_exact || islong)) ? len : 0u;
             } else {
                 if (!longs) break;
                 pos = m4 + 32 * ul++;
                 if (__ballot(pos < len) == 0) break;
-                le = (len > lc && pos > nfull4) ? len : 0u;
+                le = (islong && pos > nfull4) ? len : 0u;
             }
-            const uint32_t wl = pos < le ? load4_any(B.line + pos, bend) : 0u;
-            so_exact_step<IS_SEQ>(a, wl, pos, le, lc, hist, any_n, any_inv, ovf);
+            const uint32_t wl = pos < le ? load4_any(line + pos, bend) : 0u;
+            so_exact_step<IS_SEQ>(a, wl, pos, le, lc, hist, any_n, any_inv, IS_SEQ ? acc.oseq : acc.oqual);
         }
     }
-    // per-line scalars: the 8 lanes of a line OR their flags through two ballots
-    const unsigned long long bn = __ballot(any_n != 0), bi = __ballot(any_inv != 0);
-    unsigned long long so = ovf;
-    if (__ballot(ovf != 0) != 0) {
-        so += __shfl_xor(so, 1);
-        so += __shfl_xor(so, 2);
-        so += __shfl_xor(so, 4);
-    }
-    if (act && m == 0) {
-        const bool gn = ((bn >> (lane & 56u)) & 0xFFu) != 0, gi = ((bi >> (lane & 56u)) & 0xFFu) != 0;
-        if (IS_SEQ) {
-            ++acc.rec;
-            acc.bases += len;
-            acc.dna += (gn || gi) ? 0 : 1;
-            acc.dnan += gi ? 0 : 1;
-            acc.oseq += so;
-        } else {
-            acc.qual += len;
-            acc.oqual += so;
-        }
+    if (IS_SEQ) {  // lines that are not pure ACGT / ACGTN: the 8 lanes of a line OR their flags
+        const unsigned long long bi = __ballot(any_inv != 0);
+        T.not_dna += so_groups(__ballot(any_n != 0) | bi);
+        T.not_dnan += so_groups(bi);
     }
 }
 
@@ -625,8 +646,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         c.sel[k] = 0x07060004u | (j << 8);
         c.A[k] = ((lane & 7u) + 8u * j) * 4u;
     }
-    const uint8_t *const last4 = a.buf + (a.len >= 4 ? a.len - 4 : 0);  // a record has at least 6 bytes
     StatsAcc acc = {0, 0, 0, 0, 0, 0, 0};
+    SoTotals T = {0, 0};
 
     for (uint64_t tile = (uint64_t)blockIdx.x * SO_WAVES + wv; tile < a.n_tiles && a.len >= 4;
          tile += (uint64_t)gridDim.x * SO_WAVES) {
@@ -655,8 +676,11 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         const uint32_t e_hi = a.line_hi - lbase < cnt ? (uint32_t)(a.line_hi - lbase) : cnt;
         const uint32_t lb3 = (uint32_t)lbase & 3u;
         const uint8_t *const tbase = a.buf + tb;
-        // every unconditional load of a line that starts in this tile stays inside the buffer
+        // every unconditional load of a line that starts in this tile stays inside the buffer; the
+        // (at most two) tiles at the end of the buffer for which that does not hold take the exact
+        // path for everything
         const bool safe = tb + WT_BYTES + 32u * NSL + 8u <= a.len;
+        const uint32_t lce = safe ? lc : 0u;  // LDS rows in use for this tile: none => every column is exact
 
         for (uint32_t kind = 0; kind < 2; ++kind) {        // 0: sequence lines, 1: quality lines
             const uint32_t i0 = ((kind ? 3u : 1u) - lb3) & 3u;
@@ -665,52 +689,62 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) c.A[k] = (c.A[k] & 0xFFu) | (kind ? 0u : SO_QBYTES);  // region
             for (uint32_t sb = 0; sb < nlines; sb += 64) {
-                // one lane per line: start, length, '\r' trim
-                uint32_t my_s = 0, my_meta = 0;
+                // one lane per line: start, length, '\r' trim, per-line totals
+                uint32_t my_P = 0, my_len = 0;
                 {
                     const uint32_t i = i0 + 4u * (sb + lane);
                     if (sb + lane < nlines && i >= e_lo && i < e_hi) {
-                        my_s = (i < SO_LISTW ? wl[i] : tl[i]) & 0x3FFFu;
+                        const uint32_t s_rel = (i < SO_LISTW ? wl[i] : tl[i]) & 0x3FFFu;
                         uint32_t n_rel = i + 1 < cnt ? ((i + 1 < SO_LISTW ? wl[i + 1] : tl[i + 1]) & 0x3FFFu) : nf_rel;
                         n_rel = n_rel < vend_rel ? n_rel : vend_rel;
-                        uint32_t len = n_rel - 1 - my_s;                               // raw line, without its '\n'
-                        if (len && tbase[my_s + len - 1] == '\r') --len;               // trim_winline, src/records.rs:66-73
-                        my_meta = 0x80000000u | len;
+                        uint32_t len = n_rel - 1 - s_rel;                              // raw line, without its '\n'
+                        if (len && tbase[s_rel + len - 1] == '\r') --len;              // trim_winline, src/records.rs:66-73
+                        my_len = len;
+                        my_P = so_pack(s_rel, len, lce);
+                        if (kind == 0) {
+                            ++acc.rec;
+                            acc.bases += len;
+                        } else {
+                            acc.qual += len;
+                        }
                     }
                 }
                 const uint32_t nbat = ((nlines - sb < 64 ? nlines - sb : 64u) + 7) >> 3;
-                SoBatch<NSL> cur, nxt;
                 auto fetch = [&](uint32_t b, SoBatch<NSL> &B) {
-                    const uint32_t src = 8u * b + g8;
-                    B.meta = (uint32_t)__shfl((int)my_meta, (int)src);
-                    B.line = tbase + (uint32_t)__shfl((int)my_s, (int)src);
-                    const uint32_t len = B.meta & 0x7FFFFFFFu;
-                    const uint32_t nf4 = (len <= lc ? len : lc) & ~3u;
-                    const uint8_t *const lp = B.line + m4;
-                    if (safe) {
+                    B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)my_P);
+                    const uint32_t s_rel = B.P >> SO_P_SREL;
+                    const uint32_t o = s_rel + m4, ot = s_rel + (B.P & 0x1FFu);
 #pragma unroll
-                        for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(lp + 32 * u);
-                        B.wt = load4_fast(B.line + nf4);
-                    } else {
-                        // near the end of the buffer: a counted dword lies inside its line, hence
-                        // inside the buffer, so clamping the address only changes dwords nobody counts;
-                        // the tail dword may straddle the end and is shifted back into place
-#pragma unroll
-                        for (uint32_t u = 0; u < NSL; ++u) {
-                            const uint8_t *p = lp + 32 * u;
-                            B.w[u] = load4_fast(p < last4 ? p : last4);
-                        }
-                        const uint8_t *pt = B.line + nf4;
-                        const uint32_t over = pt > last4 ? (uint32_t)(pt - last4) : 0u;
-                        B.wt = over < 4 ? load4_fast(pt - over) >> (8u * over) : 0u;
-                    }
+                    for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(tbase + (o + 32 * u));
+                    B.wt = load4_fast(tbase + ot);
                 };
-                fetch(0, nxt);
-                for (uint32_t b = 0; b < nbat; ++b) {
-                    cur = nxt;
-                    if (b + 1 < nbat) fetch(b + 1, nxt);
-                    if (kind == 0) so_count<true, NSL>(a, cur, lane, lc, hist, c, acc);
-                    else so_count<false, NSL>(a, cur, lane, lc, hist, c, acc);
+                auto count = [&](uint32_t b, SoBatch<NSL> &B) {
+                    if (kind == 0) so_count<true, NSL>(a, tbase, B, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
+                    else so_count<false, NSL>(a, tbase, B, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
+                };
+                SoBatch<NSL> B0, B1;  // ping-pong: the loads of one are in flight while the other is counted
+                if (safe) {
+                    // The fetches are unconditional inside the loop (the index is clamped instead) so
+                    // that the compiler's s_waitcnt vmcnt(N) for one buffer leaves the other one's six
+                    // loads in flight.
+                    const uint32_t bl = nbat - 1;
+                    fetch(0, B0);
+                    for (uint32_t b = 0; b < nbat; b += 2) {
+                        fetch(b + 1 < bl ? b + 1 : bl, B1);
+                        count(b, B0);
+                        if (b + 1 < nbat) {
+                            fetch(b + 2 < bl ? b + 2 : bl, B0);
+                            count(b + 1, B1);
+                        }
+                    }
+                } else {
+                    for (uint32_t b = 0; b < nbat; ++b) {
+                        B0.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)my_P);
+                        B0.wt = 0;
+#pragma unroll
+                        for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = 0;
+                        count(b, B0);
+                    }
                 }
             }
         }
@@ -719,13 +753,22 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     __syncthreads();
     uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * SO_WORDS;
     for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) dst[i] = hist[i];
-    unsigned long long sc[7] = {acc.rec, acc.bases, acc.qual, acc.dna, acc.dnan, acc.oseq, acc.oqual};
+    // per-line totals: rec / bases / qual were summed by the lane that owned the line; the two
+    // "not DNA" counts are wave-uniform
+    unsigned long long sc[7] = {acc.rec, acc.bases, acc.qual, 0, 0, acc.oseq, acc.oqual};
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         unsigned long long v = sc[j];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-        if (lane == 0 && v) atomicAdd(&a.scalars[j], v);
+        sc[j] = v;
+    }
+    if (lane == 0) {
+        sc[3] = sc[0] - T.not_dna;
+        sc[4] = sc[0] - T.not_dnan;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (sc[j]) atomicAdd(&a.scalars[j], sc[j]);
     }
 }
 

@@ -227,6 +227,51 @@ def test_stats_long_reads_and_odd_bytes(fqref, gpu):
         assert np.array_equal(gq, qh) and np.array_equal(gb, bh) and np.array_equal(gs, sc)
 
 
+@pytest.mark.parametrize("shape", ["fixed150", "fixed36", "ragged", "binned", "crlf", "dirty", "len4k"])
+def test_stats_fast_path_shapes(fqref, gpu, shape):
+    """Multi-tile buffers (so that the whole-dword LDS path runs, not only the exact one): fixed and
+    ragged read lengths, binned qualities (four distinct values: the worst case for LDS atomics
+    keyed by bin), CRLF, sprinkled bytes outside the alphabet / quality window, and lengths that
+    are / are not multiples of 4 -- against the oracle for row counts around every kernel variant."""
+    rng = np.random.default_rng({"fixed150": 1, "fixed36": 2, "ragged": 3, "binned": 4, "crlf": 5, "dirty": 6,
+                                 "len4k": 7}[shape])
+    recs = []
+    nrec = 6000 if shape != "fixed36" else 20000
+    for i in range(nrec):
+        if shape == "fixed150":
+            n = 150
+        elif shape == "fixed36":
+            n = 36
+        elif shape == "len4k":
+            n = int(rng.choice([148, 152, 256, 260, 0, 1, 3, 4]))
+        else:
+            n = int(rng.integers(0, 301))
+        seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), n, p=[.24, .25, .25, .25, .01]).tobytes()
+        if shape == "binned":
+            qual = rng.choice(np.frombuffer(b"#,:F", dtype=np.uint8), n).tobytes()
+        else:
+            qual = rng.integers(33, 75, n).astype(np.uint8).tobytes()
+        if shape == "dirty" and i % 7 == 0 and n:
+            b = bytearray(seq)
+            b[int(rng.integers(0, n))] = int(rng.choice(list(b"acgtn*.-")))
+            seq = bytes(b)
+            q = bytearray(qual)
+            q[int(rng.integers(0, n))] = int(rng.choice([32, 97, 126, 200, 13]))
+            qual = bytes(q)
+        e = b"\r\n" if (shape == "crlf" and i % 3 == 0) else b"\n"
+        recs.append(b"@read%d" % i + e + seq + e + b"+" + e + qual + e)
+    data = b"".join(recs)
+    assert len(data) > 20 * 16384
+    lmaxes = {"fixed150": (150, 149, 151, 160, 128, 64), "fixed36": (36, 40, 64), "ragged": (100, 101, 250, 256, 300),
+              "binned": (150, 300), "crlf": (150, 257), "dirty": (64, 150, 300), "len4k": (148, 152, 256, 260)}[shape]
+    for lmax in lmaxes:
+        r, qh, bh, sc = fqref.stats(data, lmax)
+        s, gq, gb, gs = gpu.stats(data, lmax)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == nrec
+        assert np.array_equal(gs, sc), (shape, lmax, gs, sc)
+        assert np.array_equal(gq, qh) and np.array_equal(gb, bh), (shape, lmax)
+
+
 def test_synth_generator_and_medium_parity(fqref, gpu, torch):
     """64 MiB of the synthetic 150 bp workload: generator identical on CPU and GPU; offsets, count
     and histograms bit-exact against the oracle."""

@@ -42,6 +42,9 @@
 #include <vector>
 
 #include "../../include/fastq_hip.h"
+#ifndef FASTQ_NO_ZLIB
+#include <zlib.h>
+#endif
 #include "../csrc/replay.h"
 
 namespace fastq {
@@ -557,10 +560,107 @@ auto thread_reader(size_t bufsize, size_t queuelen, Reader reader, F func) {
     return func(Ref{&tr});
 }
 
-// parse_path (src/lib.rs:167-196), plain (uncompressed) input only: compression sniffing is the
-// niffler crate's job in the reference and is out of scope here.  nullopt / "-" = stdin.
+// `&mut dyn Read`: what parse_path hands to Parser::new (src/lib.rs:170, 186-192).
+class DynReader {
+  public:
+    template <class R>
+    explicit DynReader(R *r) : read_([r](uint8_t *d, size_t n) { return r->read(d, n); }) {}
+    size_t read(uint8_t *dst, size_t n) { return read_(dst, n); }
+  private:
+    std::function<size_t(uint8_t *, size_t)> read_;
+};
+
+// Compression sniffing.  The reference delegates it to the niffler crate (src/lib.rs:173-185, dependency
+// `niffler >= 2.4.0`, unpinned and not vendored => parity unpinned here): niffler reads the first five
+// bytes, fails with FileTooShort when there are fewer, matches the magic numbers below and then replays
+// those bytes in front of the stream.
+enum class Compression { No, Gzip, Bzip2, Lzma, Zstd };
+inline Compression sniff_compression(const uint8_t *b5) {
+    if (b5[0] == 0x1f && b5[1] == 0x8b) return Compression::Gzip;
+    if (b5[0] == 0x42 && b5[1] == 0x5a) return Compression::Bzip2;
+    if (b5[0] == 0xfd && b5[1] == 0x37 && b5[2] == 0x7a && b5[3] == 0x58 && b5[4] == 0x5a) return Compression::Lzma;
+    if (b5[0] == 0x28 && b5[1] == 0xb5 && b5[2] == 0x2f && b5[3] == 0xfd) return Compression::Zstd;
+    return Compression::No;
+}
+
+template <class Reader>
+class PrefixReader {  // io::Cursor(first_bytes).chain(stream)
+  public:
+    PrefixReader(Reader r, const uint8_t *pre, size_t n) : r_(std::move(r)), pre_(pre, pre + n) {}
+    size_t read(uint8_t *dst, size_t n) {
+        if (pos_ < pre_.size()) {
+            size_t k = n < pre_.size() - pos_ ? n : pre_.size() - pos_;
+            memcpy(dst, pre_.data() + pos_, k);
+            pos_ += k;
+            return k;
+        }
+        return r_.read(dst, n);
+    }
+  private:
+    Reader r_;
+    std::vector<uint8_t> pre_;
+    size_t pos_ = 0;
+};
+
+#ifndef FASTQ_NO_ZLIB
+// Multi-member gzip decoder on the host (flate2::read::MultiGzDecoder in niffler); it runs on the
+// thread_reader thread and feeds the pinned ring of the scanner like any other Reader.
+template <class Reader>
+class GzReader {
+  public:
+    explicit GzReader(Reader r) : r_(std::move(r)), in_(1 << 16) {
+        memset(&z_, 0, sizeof z_);
+        if (inflateInit2(&z_, 15 + 16) != Z_OK) throw Error(ErrorKind::Other, "zlib init failed");
+        init_ = true;
+    }
+    GzReader(GzReader &&o) noexcept : r_(std::move(o.r_)), in_(std::move(o.in_)) {
+        // a z_stream holds a pointer to itself (state->strm): re-create instead of copying
+        if (o.started_) std::terminate();
+        memset(&z_, 0, sizeof z_);
+        if (inflateInit2(&z_, 15 + 16) != Z_OK) std::terminate();
+        init_ = true;
+    }
+    GzReader(const GzReader &) = delete;
+    ~GzReader() { if (init_) inflateEnd(&z_); }
+    size_t read(uint8_t *dst, size_t n) {
+        started_ = true;
+        if (n == 0) return 0;
+        z_.next_out = dst;
+        z_.avail_out = (uInt)(n < 0x40000000u ? n : 0x40000000u);
+        while (!done_ && z_.next_out == dst) {  // until some output exists or the last member ended
+            if (z_.avail_in == 0 && !in_eof_) {
+                const size_t got = r_.read(in_.data(), in_.size());
+                if (got == 0) in_eof_ = true;
+                z_.next_in = in_.data();
+                z_.avail_in = (uInt)got;
+            }
+            if (member_end_) {  // between members: more input => next member, none => EOF
+                if (z_.avail_in == 0) { done_ = true; break; }
+                if (inflateReset(&z_) != Z_OK) throw Error(ErrorKind::InvalidData, "corrupt gzip stream");
+                member_end_ = false;
+            }
+            if (z_.avail_in == 0) throw Error(ErrorKind::InvalidData, "unexpected end of gzip stream");
+            const int rc = inflate(&z_, Z_NO_FLUSH);
+            if (rc == Z_STREAM_END) member_end_ = true;
+            else if (rc != Z_OK && rc != Z_BUF_ERROR) throw Error(ErrorKind::InvalidData, "corrupt gzip stream");
+        }
+        return (size_t)(z_.next_out - dst);
+    }
+  private:
+    Reader r_;
+    std::vector<uint8_t> in_;
+    z_stream z_;
+    bool init_ = false, started_ = false, in_eof_ = false, member_end_ = false, done_ = false;
+};
+#endif
+
+// parse_path (src/lib.rs:167-196): open the file (nullopt / "-" = stdin), sniff the compression
+// format, hand the closure a Parser over plain bytes.  Plain input goes straight to the parser;
+// compressed input is decoded on a thread_reader thread with the reference's parameters (4 MiB
+// buffers, queue of 2; src/lib.rs:191).  Gzip is decoded with zlib; bzip2 / xz / zstd are detected
+// but no decoder library is present in this build.
 template <class F>
-auto parse_path(const std::optional<std::string> &path, F func, Options opt = Options()) {
+auto with_plain_reader(const std::optional<std::string> &path, F use) {  // use(DynReader &) sees plain bytes
     FILE *f = stdin;
     bool own = false;
     if (path && *path != "-") {
@@ -568,8 +668,43 @@ auto parse_path(const std::optional<std::string> &path, F func, Options opt = Op
         if (!f) throw Error(ErrorKind::Other, "cannot open " + *path);
         own = true;
     }
-    Parser<FileReader> p(FileReader(f, own), opt);
-    return func(p);
+    FileReader file(f, own);
+    uint8_t first[5];
+    size_t have = 0;
+    while (have < 5) {
+        size_t k = file.read(first + have, 5 - have);
+        if (k == 0) break;
+        have += k;
+    }
+    if (have < 5)
+        throw Error(ErrorKind::InvalidData,
+                    "Niffler failled in compression detection File is too short, less than five bytes");
+    const Compression fmt = sniff_compression(first);
+    PrefixReader<FileReader> chained(std::move(file), first, have);
+    if (fmt == Compression::No) {
+        DynReader dyn(&chained);
+        return use(dyn);
+    }
+#ifndef FASTQ_NO_ZLIB
+    if (fmt == Compression::Gzip) {
+        return thread_reader(1 << 22, 2, GzReader<PrefixReader<FileReader>>(std::move(chained)), [&](auto reader) {
+            DynReader dyn(&reader);
+            return use(dyn);
+        });
+    }
+#endif
+    throw Error(ErrorKind::InvalidData,
+                std::string("Niffler failled in compression detection: no decoder in this build for ") +
+                    (fmt == Compression::Gzip ? "gzip" : fmt == Compression::Bzip2 ? "bzip2"
+                     : fmt == Compression::Lzma ? "xz" : "zstd"));
+}
+
+template <class F>
+auto parse_path(const std::optional<std::string> &path, F func, Options opt = Options()) {
+    return with_plain_reader(path, [&](DynReader &dyn) {
+        Parser<DynReader> p(std::move(dyn), opt);
+        return func(p);
+    });
 }
 
 }  // namespace fastq

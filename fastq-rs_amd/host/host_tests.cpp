@@ -187,7 +187,30 @@ static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) 
     return 0;
 }
 
+// --plain FILE: the reader chain of parse_path without a Parser (no GPU needed): prints the number
+// of plain bytes and their FNV-1a hash, or the error.
+static int plain(const char *file) {
+    try {
+        return fastq::with_plain_reader(std::string(file), [](fastq::DynReader &r) {
+            std::vector<uint8_t> buf(1 << 16);
+            uint64_t n = 0, h = 1469598103934665603ull;
+            for (;;) {
+                size_t k = r.read(buf.data(), 1 + (n * 7919) % buf.size());  // odd request sizes
+                if (!k) break;
+                for (size_t i = 0; i < k; ++i) h = (h ^ buf[i]) * 1099511628211ull;
+                n += k;
+            }
+            printf("plain %llu %016llx\n", (unsigned long long)n, (unsigned long long)h);
+            return 0;
+        });
+    } catch (const fastq::Error &e) {
+        printf("error %s\n", e.what());
+        return 3;
+    }
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 3 && !strcmp(argv[1], "--plain")) return plain(argv[2]);
     if (argc >= 5 && !strcmp(argv[1], "--dump"))
         return dump(argv[2], atoi(argv[3]), strtoull(argv[4], 0, 0), argc > 5 ? strtoull(argv[5], 0, 0) : (1 << 20));
 #define RUN(t) do { t(); printf("ok %s\n", #t); fflush(stdout); } while (0)

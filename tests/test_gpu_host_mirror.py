@@ -98,3 +98,26 @@ def test_fastq_count_cli(gpu_ok, fqref, tmp_path):
     p.write_bytes(d[:-5])
     bad = subprocess.run([exe, str(p)], capture_output=True, text=True)
     assert bad.returncode != 0 and "Possibly truncated input file" in bad.stderr
+
+
+def test_fastq_count_on_gzip_input(gpu_ok, fqref, tmp_path):
+    """parse_path (src/lib.rs:167-196): gzip input is sniffed, decoded on a thread_reader thread and
+    scanned on the GPU; the count equals the oracle's on the plain bytes, single- and multi-threaded."""
+    import gzip
+    rng = np.random.default_rng(4242)
+    data = fuzzgen.valid_file(rng, 20000, maxlen=150)
+    want = fqref.count(data).n_records
+    cut = len(data) // 2
+    (tmp_path / "in.fq").write_bytes(data)
+    (tmp_path / "in.fq.gz").write_bytes(gzip.compress(data[:cut]) + gzip.compress(data[cut:]))
+    for name in ("in.fq", "in.fq.gz"):
+        for extra in ([], ["--threads", "3"]):
+            out = subprocess.run([os.path.join(BIN, "fastq_count"), str(tmp_path / name)] + extra,
+                                 capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stdout + out.stderr
+            assert int(out.stdout.strip()) == want == 20000
+    bad = data[:cut] + b"\n" + data[cut:]
+    (tmp_path / "bad.fq.gz").write_bytes(gzip.compress(bad))
+    out = subprocess.run([os.path.join(BIN, "fastq_count"), str(tmp_path / "bad.fq.gz")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 101 and fqref.strerror(fqref.count(bad).status) in out.stderr

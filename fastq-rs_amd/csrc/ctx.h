@@ -8,7 +8,8 @@
 #include "replay.h"
 
 namespace fqh {
-void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint8_t *, uint64_t, DevOut *, int, bool);
+void set_dbg_flags(uint32_t);
+void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint16_t *, uint64_t, DevOut *, int, bool);
 void launch_emit_fast(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize_fast(hipStream_t, const ScanArgs &, DevOut *);
 void launch_prefix(hipStream_t, const uint32_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
@@ -40,7 +41,7 @@ struct fqh_ctx {
     size_t list_elems = 0;
     uint32_t list_cap = LIST_CAP_DEFAULT;
     uint32_t *tile_count = nullptr, *tile_prefix = nullptr;
-    uint8_t *tile_hyp = nullptr;
+    uint16_t *fast_rs = nullptr;  // fast path: per tile two 128-byte lines (record starts | edges, count, alignment)
     uint64_t *block_prefix = nullptr;
     size_t tiles_cap = 0;
     DevOut *d_out = nullptr;      // [0] the scan's, [1] scratch for index-only emits

@@ -95,7 +95,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->list);
     (void)hipFree(ctx->tile_count);
     (void)hipFree(ctx->tile_prefix);
-    (void)hipFree(ctx->tile_hyp);
+    (void)hipFree(ctx->fast_rs);
     (void)hipFree(ctx->block_prefix);
     (void)hipFree(ctx->d_out);
     (void)hipFree(ctx->d_misc);
@@ -138,23 +138,23 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles) {
     if (n_tiles > ctx->tiles_cap) {
         (void)hipFree(ctx->tile_count);
         (void)hipFree(ctx->tile_prefix);
-        (void)hipFree(ctx->tile_hyp);
+        (void)hipFree(ctx->fast_rs);
         (void)hipFree(ctx->block_prefix);
         ctx->tile_count = ctx->tile_prefix = nullptr;
-        ctx->tile_hyp = nullptr;
+        ctx->fast_rs = nullptr;
         ctx->block_prefix = nullptr;
         ctx->tiles_cap = 0;
         const size_t nb = (n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_count, n_tiles * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_prefix, n_tiles * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->tile_hyp, n_tiles));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, n_tiles * 128 * sizeof(uint16_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
         ctx->tiles_cap = n_tiles;
     }
     return FQH_OK;
 }
 
-// fast == true: the speculative path (k_index_t<.,2> + k_emit_fast + k_finalize_fast)
+// fast == true: the speculative path (k_index_fast + k_emit_fast + k_finalize_fast)
 static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     ScanArgs &a = ctx->args;
     hipStream_t s = ctx->stream;
@@ -163,14 +163,14 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     a.list = ctx->list;
     a.list_cap = ctx->list_cap;
     a.tile_count = ctx->tile_count;
-    a.tile_hyp = ctx->tile_hyp;
+    a.fast_rs = ctx->fast_rs;
     a.tile_prefix = ctx->tile_prefix;
     a.block_prefix = ctx->block_prefix;
     ctx->used_spec = fast;
     HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
     if (!reuse_index) {
-        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->tile_hyp, a.n_tiles,
+        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs, a.n_tiles,
                      &ctx->d_out[0], ctx->n_cu, fast);
         ctx->index_full = !fast;
     }
@@ -386,7 +386,7 @@ static fqh_status ensure_full_index(fqh_ctx *ctx) {
         fqh_status st = ensure_workspace(ctx, a.n_tiles);
         if (st != FQH_OK) return st;
         HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
-        launch_index(ctx->stream, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->tile_hyp,
+        launch_index(ctx->stream, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs,
                      a.n_tiles, &ctx->d_out[1], ctx->n_cu, false);
         launch_prefix(ctx->stream, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
         DevOut tmp;
@@ -483,6 +483,13 @@ extern "C" int fqh_debug_last_scan_fast(fqh_ctx *ctx) { return ctx && ctx->used_
 extern "C" void fqh_debug_set_spec(fqh_ctx *ctx, int on) { if (ctx) ctx->spec_enabled = on != 0; }
 // tuning hook, not part of the public header: selects the k_index code variant for A/B runs
 extern "C" void fqh_debug_set_index_variant(int v) { fqh::g_index_variant = v; }
+extern "C" void fqh_debug_set_flags(unsigned f) { fqh::set_dbg_flags(f); }
+// copies the fast path's per-tile record (128 u16) of tile t to the host (tests / tools only)
+extern "C" int fqh_debug_fast_record(fqh_ctx *ctx, uint64_t t, uint16_t *out128) {
+    if (!ctx || !ctx->fast_rs || t >= ctx->tiles_cap) return -1;
+    (void)hipStreamSynchronize(ctx->stream);
+    return (int)hipMemcpy(out128, ctx->fast_rs + t * 128, 256, hipMemcpyDeviceToHost);
+}
 
 fqh_status fqh_invalidate(fqh_ctx *ctx) {
     if (!ctx) return FQH_E_ARG;

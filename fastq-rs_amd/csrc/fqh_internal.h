@@ -41,7 +41,7 @@ struct ScanArgs {
     const uint16_t *list;
     uint32_t list_cap;
     const uint32_t *tile_count;
-    const uint8_t *tile_hyp;       // fast path only: index (0..3) of the tile's first record-start entry
+    const uint16_t *fast_rs;       // fast path only: [tile][128]: 64 record-start offsets, then 8 edge entries, count, alignment
     const uint32_t *tile_prefix;   // exclusive prefix inside its SCAN_CHUNK block
     const uint64_t *block_prefix;  // exclusive prefix of block sums; [n_blocks] = total
     uint64_t n_tiles;

@@ -629,20 +629,12 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 // vmcnt counter with loads, and scattered 2-byte stores between the prefetch loads and their
 // s_waitcnt would put store acknowledgements on the critical path of the next 4 KiB group.
 constexpr uint32_t LSTAGE_ENTRIES = 512;
-// LSTAGE == 2, the FAST PATH: the tile's list is staged in LDS and NOT written out.
-// The wavefront checks every 4-line group that lies completely inside the tile under each of the
-// four possible alignments ('@' on line i, '+' on line i+2, equal raw lengths of lines i+1 and
-// i+3); if exactly one alignment is consistent it writes only what k_emit_fast needs: the offsets
-// of that alignment's record starts and the tile's first and last four entries (for the records that
-// straddle tiles) — a quarter of the bytes.  Nothing is assumed: the alignment is verified against the
-// true line index after the prefix scan, and any tile that cannot be proven valid makes the library
-// fall back to the exact path, which also produces the precise error.
+__device__ uint32_t g_dbg_flags = 0;  // timing experiments only (tools/exp_*.py): 1 no count store, 2 no meta store, 4 no record-start store
 template <int PF, int LSTAGE>
 __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf, uint64_t len,
                                                  uint16_t *__restrict__ list, uint32_t list_cap,
                                                  uint32_t *__restrict__ tile_count,
-                                                 uint8_t *__restrict__ tile_hyp, uint64_t n_tiles,
-                                                 DevOut *__restrict__ out) {
+                                                 uint64_t n_tiles, DevOut *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + (LSTAGE ? LSTAGE_ENTRIES * 2 + 16 : 0)];
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *const lds = lds_all[threadIdx.x >> 6];
@@ -705,9 +697,7 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                     }
                 }
                 const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
-                if (LSTAGE == 2 && (run != nstaged || run + tot > LSTAGE_ENTRIES)) {
-                    // fast path: a tile with more than 512 line starts is left to the exact path
-                } else if (LSTAGE && run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
+                if (LSTAGE && run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
                     uint16_t *dst = lst + run + pre;
                     while (ls_lo) {
                         const uint32_t q = __ffs(ls_lo) - 1;
@@ -750,44 +740,8 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                 const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
                 if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
                 const uint4 v = load16(buf, off, len);
-                if (LSTAGE == 2) index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, LSTAGE_ENTRIES);
-                else index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
+                index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
             }
-            if (LSTAGE == 2) nstaged = run <= LSTAGE_ENTRIES ? run : 0;
-        }
-        if (LSTAGE == 2) {
-            uint32_t hyp = 7;
-            if (nstaged == run && run >= 8) {  // uniform
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                uint32_t bad = 0, have = 0;  // bit r: some / some failing complete group starting at i == r (mod 4)
-                for (uint32_t i = lane; i + 4 < run; i += 64) {
-                    const uint32_t e0 = lst[i], e1 = lst[i + 1], e2 = lst[i + 2], e3 = lst[i + 3], e4 = lst[i + 4];
-                    const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
-                                    ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
-                    have |= 1u << (i & 3u);
-                    bad |= ok ? 0u : 1u << (i & 3u);
-                }
-                uint32_t cons = 0;
-#pragma unroll
-                for (uint32_t r = 0; r < 4; ++r)
-                    if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
-                if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
-            }
-            if (hyp < 4) {
-                // [0..3] first four entries, [4..7] last four, [8..] offsets of the record starts
-                if (lane < 4) tl[lane] = lst[lane];
-                else if (lane < 8) tl[lane] = lst[run - 8 + lane];
-                for (uint32_t j = lane; hyp + 4 * j < run; j += 64) tl[8 + j] = lst[hyp + 4 * j] & 0x3FFFu;
-            } else {
-                ++n_over;  // counted into spec_fail below
-            }
-            if (lane == 0) {
-                tile_count[tile] = run;
-                tile_hyp[tile] = (uint8_t)hyp;
-            }
-            __builtin_amdgcn_wave_barrier();
-            continue;
         }
         if (LSTAGE && nstaged) {  // flush the staged list: 4 entries (8 bytes) per lane and store
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -804,100 +758,294 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
         if (lane == 0) tile_count[tile] = run;
         if (run > list_cap) ++n_over;
     }
-    if (lane == 0 && n_over) atomicAdd(LSTAGE == 2 ? &out->spec_fail : &out->overflow, (unsigned long long)n_over);
+    if (lane == 0 && n_over) atomicAdd(&out->overflow, (unsigned long long)n_over);
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_index_fast: the fast path's index kernel — k_index_t<1, 2> restructured around
+// the one thing that keeps it off the read ceiling: on gfx950 stores share vmcnt with loads, and the
+// compiler's wait in front of a group's LDS write is vmcnt(0).  A wavefront that stores its tile's
+// results and then loads the next tile sits out the store acknowledgement and the load latency once
+// per tile.  Here
+//   * the loads of the NEXT tile's first 4 KiB group (and the byte before that tile) are issued
+//     during the last group of the current tile,
+//   * the tile's results (two stores, each a whole 128-byte line, plus the dense entry count for
+//     the prefix scan) are kept in registers and issued
+//     in the NEXT tile's first group, right after that group's prefetch: the next vmcnt(0) is a
+//     whole group (~5 us of work per wave) away, by which time loads and stores have both landed.
+// Whole tiles only; the (at most one) partial tile at the end of the buffer is taken by wave 0 of
+// block 0 through the generic piece loop afterwards.
+__global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ buf, uint64_t len,
+                                                    uint16_t *__restrict__ list, uint32_t list_cap,
+                                                    uint32_t *__restrict__ tile_count, uint16_t *__restrict__ fast_rs,
+                                                    uint64_t n_tiles, DevOut *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + LSTAGE_ENTRIES * 2 + 16];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *const lds = lds_all[threadIdx.x >> 6];
+    uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + 4096);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t n_full = len >> WT_SHIFT;  // whole tiles
+    uint32_t n_over = 0;
+    const uint32_t dbg = g_dbg_flags;
+    const uint32_t wslot = lane ^ ((lane >> 4) & 3u);        // write: chunk 64 j + lane -> slot 64 j + wslot
+    const uint32_t s4 = ((lane >> 2) & 3u) << 4;              // read:  byte Q of the lane at 64 lane + (Q ^ s4)
+    uint8_t *const wptr = lds + wslot * 16;
+    const uint8_t *const rptr = lds + lane * 64;
+    const uint32_t lo = lane * 16;
+
+    // evaluate the four alignments over the staged list; rv / mv = this lane's slot of the tile's two lines:
+    // [0..63] offsets of the first 64 record starts (unused slots 0), [64..71] the tile's first four
+    // and last four entries, [72..73] the entry count, [74] the alignment (7: none)
+    auto finish_tile = [&](uint64_t tile, uint32_t run, uint32_t nstaged, uint32_t &rv, uint32_t &mv) {
+        uint32_t hyp = 7;
+        if (nstaged == run && run >= 8) {  // uniform
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t bad = 0, have = 0;  // bit r: some / some failing complete group starting at i == r (mod 4)
+            for (uint32_t i = lane; i + 4 < run; i += 64) {
+                const uint32_t e0 = lst[i], e1 = lst[i + 1], e2 = lst[i + 2], e3 = lst[i + 3], e4 = lst[i + 4];
+                const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
+                                ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
+                have |= 1u << (i & 3u);
+                bad |= ok ? 0u : 1u << (i & 3u);
+            }
+            uint32_t cons = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r)
+                if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
+            if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
+        }
+        rv = 0;
+        mv = 0;
+        if (hyp < 4) {
+            rv = hyp + 4 * lane < run ? (uint32_t)(lst[hyp + 4 * lane] & 0x3FFFu) : 0u;
+            mv = lane < 4 ? lst[lane] : lane < 8 ? lst[run - 8 + lane] : 0u;
+            if (hyp + 256 < run) {  // more than 64 record starts: the rest spills into the tile's list area (rare)
+                uint16_t *__restrict__ tl = list + tile * list_cap;
+                for (uint32_t j = 64 + lane; hyp + 4 * j < run; j += 64) tl[8 + j] = lst[hyp + 4 * j] & 0x3FFFu;
+            }
+        } else {
+            ++n_over;  // counted into spec_fail below
+        }
+        mv = lane == 8 ? (run & 0xFFFFu) : lane == 9 ? (run >> 16) : lane == 10 ? hyp : mv;
+    };
+    auto store_tile = [&](uint64_t tile, uint32_t run, uint32_t rv, uint32_t mv) {
+        uint16_t *const fl = fast_rs + tile * 128;
+        if (!(dbg & 4u)) fl[lane] = (uint16_t)rv;
+        if (!(dbg & 2u)) fl[64 + lane] = (uint16_t)mv;
+        if (lane == 0 && !(dbg & 1u)) tile_count[tile] = run;  // dense copy for the prefix scan
+    };
+
+    uint64_t tile = wave0;
+    if (tile < n_full) {
+        const uint8_t *p = buf + (tile << WT_SHIFT) + lo;
+        uint32_t pb = tile ? buf[(tile << WT_SHIFT) - 1] : 0u;  // the byte before the tile
+        uint4 n0 = load16_nt(p), n1 = load16_nt(p + PIECE_BYTES);
+        uint4 n2 = load16_nt(p + 2 * PIECE_BYTES), n3 = load16_nt(p + 3 * PIECE_BYTES);
+        bool pending = false;          // the previous tile's two lines are still in registers
+        uint64_t ptile = 0;
+        uint32_t prv = 0, pmv = 0, prun = 0;
+        for (; tile < n_full; tile += nwaves) {
+            const uint64_t nxt = tile + nwaves < n_full ? tile + nwaves : tile;  // clamped: the prefetch is unconditional
+            uint32_t run = 0, nstaged = 0;
+            uint32_t prev = (tile && pb == '\n') ? 1u : 0u;
+#pragma unroll 1
+            for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
+                __builtin_amdgcn_wave_barrier();
+                *reinterpret_cast<uint4 *>(wptr) = n0;
+                *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
+                *reinterpret_cast<uint4 *>(wptr + 2048) = n2;
+                *reinterpret_cast<uint4 *>(wptr + 3072) = n3;
+                {  // next group of this tile, or the first group of the wave's next tile
+                    const bool last = g + 1 == WT_PIECES / 4;
+                    p = last ? buf + (nxt << WT_SHIFT) + lo : p + 4 * PIECE_BYTES;
+                    if (last) pb = buf[(nxt << WT_SHIFT) - (nxt ? 1 : 0)];
+                    n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
+                    n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
+                }
+                if (g == 0 && pending) store_tile(ptile, prun, prv, pmv);  // a whole group before the next wait
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + (0u ^ s4));
+                const uint4 d1 = *reinterpret_cast<const uint4 *>(rptr + (16u ^ s4));
+                const uint4 d2 = *reinterpret_cast<const uint4 *>(rptr + (32u ^ s4));
+                const uint4 d3 = *reinterpret_cast<const uint4 *>(rptr + (48u ^ s4));
+                const uint32_t m_lo = eqmask16<1>(d0, 0x0A0A0A0Au) | (eqmask16<1>(d1, 0x0A0A0A0Au) << 16);
+                const uint32_t m_hi = eqmask16<1>(d2, 0x0A0A0A0Au) | (eqmask16<1>(d3, 0x0A0A0A0Au) << 16);
+                // line starts: the byte after a newline
+                uint32_t ls_lo = (m_lo << 1) | wave_shr1(m_hi >> 31, prev);
+                uint32_t ls_hi = __builtin_amdgcn_alignbit(m_hi, m_lo, 31);
+                prev = ((uint32_t)__builtin_amdgcn_readlane((int)m_hi, 63)) >> 31;
+                const uint32_t c = __popc(ls_lo) + __popc(ls_hi);
+                const unsigned long long b1 = __ballot(c >= 1), b2 = __ballot(c >= 2), b3 = __ballot(c >= 3);
+                uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
+                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
+                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, pre));
+                uint32_t tot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2) + (uint32_t)__popcll(b3);
+                if (__ballot(c >= 4)) {
+                    for (uint32_t k = 4;; ++k) {
+                        const unsigned long long b = __ballot(c >= k);
+                        if (!b) break;
+                        pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
+                        tot += (uint32_t)__popcll(b);
+                    }
+                }
+                const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
+                if (run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
+                    uint16_t *dst = lst + run + pre;
+                    while (ls_lo) {
+                        const uint32_t q = __ffs(ls_lo) - 1;
+                        ls_lo &= ls_lo - 1;
+                        const uint32_t b = rptr[q ^ s4];
+                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    }
+                    while (ls_hi) {
+                        const uint32_t q = __ffs(ls_hi) + 31;
+                        ls_hi &= ls_hi - 1;
+                        const uint32_t b = rptr[q ^ s4];
+                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    }
+                    nstaged = run + tot;
+                }  // else: more than 512 line starts in a tile: left to the exact path
+                run += tot;
+            }
+            finish_tile(tile, run, nstaged, prv, pmv);
+            prun = run;
+            ptile = tile;
+            pending = true;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (pending) store_tile(ptile, prun, prv, pmv);
+    }
+    // the partial tile at the end of the buffer
+    if (wave0 == 0 && n_full < n_tiles) {
+        const uint64_t t = n_full, tbase = t << WT_SHIFT;
+        uint32_t run = 0;
+        uint32_t prev = (t && buf[tbase - 1] == '\n') ? 1u : 0u;
+#pragma unroll 1
+        for (uint32_t j = 0; j < WT_PIECES; ++j) {
+            const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
+            if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
+            const uint4 v = load16(buf, off, len);
+            index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, LSTAGE_ENTRIES);
+        }
+        uint32_t rv, mv;
+        finish_tile(t, run, run <= LSTAGE_ENTRIES ? run : 0u, rv, mv);
+        store_tile(t, run, rv, mv);
+    }
+    if (lane == 0 && n_over) atomicAdd(&out->spec_fail, (unsigned long long)n_over);
+}
+
 // k_emit_fast: the fast path's emit.  Per tile: verify the tile's alignment against the true line
 // index, store the record starts, and validate the one record that straddles into the tile from
 // the previous one (its five line starts are in the two tiles' edge entries).  Any doubt sets
-// spec_fail; error keys are never produced here.
+// spec_fail; error keys are never produced here.  The per-tile scalar work is done once per LANE, not
+// once per wave: a wavefront takes 64 consecutive tiles.  Phase A, lane = tile: line index of the tile's
+// first entry, alignment check, position of its record starts in the output, and the validation of
+// the record that straddles into it (five line starts out of the two tiles' 16-byte edge blocks).
+// Phase B, one iteration per tile: readlane the three scalars, one 2-byte load and one 8-byte
+// store per lane (the loads run four tiles ahead).  ~25 instructions per tile instead of ~110.
 __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t ngroups = (a.n_tiles + 63) >> 6;
     const unsigned long long r0 = a.nl_count >> 2;
     const uint32_t bufsize32 = a.bufsize > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)a.bufsize;
     unsigned long long first_long = NOKEY;
     uint32_t maxlen32 = 0, fail = 0;
-    struct Pre { uint32_t cnt, tp, cprev, hyp; unsigned long long bp; uint32_t e0, e1, edge, pedge; };
-    auto fetch = [&](uint64_t t, Pre &p) {
-        if (t < a.n_tiles) {
-            p.cnt = a.tile_count[t];
-            p.tp = a.tile_prefix[t];
-            p.bp = a.block_prefix[t >> SCAN_SHIFT];
-            p.hyp = a.tile_hyp[t];
-            p.cprev = t ? a.tile_count[t - 1] : 0u;
-            const uint16_t *tl = a.list + t * a.list_cap;
-            p.e0 = tl[8 + lane];           // record starts (list_cap >= 512: always in bounds)
-            p.e1 = tl[8 + 64 + lane];
-            p.edge = lane < 8 ? tl[lane] : 0u;
-            p.pedge = (t && lane < 4) ? (uint32_t)a.list[(t - 1) * a.list_cap + 4 + lane] : 0u;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += nwaves) {
+        const uint64_t t0 = g << 6;
+        // ---- phase A: lane = tile t0 + lane
+        const uint64_t T = t0 + lane;
+        const bool live = T < a.n_tiles;
+        uint32_t cnt = 0, tp = 0, hyp = 7, cprev = 0;
+        uint4 e = make_uint4(0, 0, 0, 0);
+        if (live) {
+            cnt = a.tile_count[T];
+            tp = a.tile_prefix[T];
+            const uint16_t *meta = a.fast_rs + T * 128 + 64;
+            e = *reinterpret_cast<const uint4 *>(meta);                     // entries 0..3 first, 4..7 last four
+            hyp = meta[10];
         }
-    };
-    // four tiles of loads in flight per wavefront: the per-tile work is tiny, memory latency is not
-    Pre q0, q1, q2, q3;
-    uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    fetch(t, q0);
-    fetch(t + nwaves, q1);
-    fetch(t + 2 * nwaves, q2);
-    fetch(t + 3 * nwaves, q3);
-    for (; t < a.n_tiles; t += nwaves) {
-        const Pre cur = q0;
-        q0 = q1; q1 = q2; q2 = q3;
-        fetch(t + 4 * nwaves, q3);
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.cnt);
-        if (n == 0) continue;
-        const unsigned long long lbase = a.nl_count + 1 + uniform64(cur.bp) +
-                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.tp);
-        const uint32_t hyp = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.hyp);
-        const uint32_t r = (4u - ((uint32_t)lbase & 3u)) & 3u;  // entry index of the first record start
-        if (hyp != r) { fail = 1; continue; }
-        const uint32_t nrs = (n - r + 3) >> 2;
+        const unsigned long long bp = a.block_prefix[t0 >> SCAN_SHIFT];    // 64 | 2^SCAN_SHIFT: one block
+        uint32_t c0 = 0, pz0 = 0, pw0 = 0;                                // tile t0 - 1, for lane 0
+        if (t0) {
+            c0 = a.tile_count[t0 - 1];
+            const uint2 pe0 = *reinterpret_cast<const uint2 *>(a.fast_rs + (t0 - 1) * 128 + 64 + 4);
+            pz0 = pe0.x;
+            pw0 = pe0.y;
+        }
+        cprev = wave_shr1(cnt, c0);
+        const uint32_t pz = wave_shr1(e.z, pz0), pw = wave_shr1(e.w, pw0);  // previous tile's last four entries
+        const unsigned long long lbase = a.nl_count + 1 + bp + tp;
+        const uint32_t r = (4u - ((uint32_t)lbase & 3u)) & 3u;             // entry index of the first record start
+        const bool has = cnt != 0;
+        bool bad = has && hyp != r;
+        const uint32_t nrs = has && cnt > r ? (cnt - r + 3) >> 2 : 0u;
         const unsigned long long rbase = ((lbase + r) >> 2) - r0;
-        const unsigned long long vbase = a.base_offset + (t << WT_SHIFT);
-        const bool cap_ok = rbase + nrs <= a.cap;
-        uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rbase : nullptr;
-        const uint16_t *__restrict__ tl = a.list + t * a.list_cap + 8;
-        uint32_t carry = 0;  // offset of record start mb - 1 (last lane of the previous group of 64)
-        for (uint32_t mb = 0; mb < nrs; mb += 64) {
-            const uint32_t m = mb + lane;
-            const uint32_t o = mb == 0 ? cur.e0 : mb == 64 ? cur.e1 : (m < nrs ? (uint32_t)tl[m] : 0u);
-            const uint32_t oprev = wave_shr1(o, carry);
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)o, 63);
-            if (m < nrs) {
-                if (rs && (cap_ok || rbase + m < a.cap)) rs[m] = vbase + o;
-                if (m) {  // record m-1 of the tile lies inside it: its length
-                    const uint32_t reclen = o - oprev;
-                    maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
-                    if (bufsize32 && reclen + 15 >= bufsize32) {
-                        const unsigned long long rec = r0 + rbase + m - 1;
-                        if (rec < first_long) first_long = rec;
-                    }
+        if (has && T) {  // the record that ends at entry r started in the previous tile (tile 0: k_finalize_fast)
+            bad = bad || cprev < 4 || cnt < 4;
+            // halfwords r .. r+4 of [previous tile's last four | this tile's first four]
+            const unsigned long long A = ((unsigned long long)pw << 32) | pz, B = ((unsigned long long)e.y << 32) | e.x;
+            const uint32_t sh = 16u * r;
+            const unsigned long long lo = r ? (A >> sh) | (B << (64u - sh)) : A;
+            const uint32_t ev0 = (uint32_t)lo & 0xFFFFu, ev1 = (uint32_t)(lo >> 16) & 0xFFFFu;
+            const uint32_t ev2 = (uint32_t)(lo >> 32) & 0xFFFFu, ev3 = (uint32_t)(lo >> 48);
+            const uint32_t ev4 = (uint32_t)(B >> sh) & 0xFFFFu;
+            // entries with index r + k < 4 belong to the previous tile: offset - 16 KiB
+            const int o0 = (int)(ev0 & 0x3FFFu) - (int)WT_BYTES;  // k = 0: always the previous tile
+            const int o1 = (int)(ev1 & 0x3FFFu) - (r + 1 < 4 ? (int)WT_BYTES : 0);
+            const int o2 = (int)(ev2 & 0x3FFFu) - (r + 2 < 4 ? (int)WT_BYTES : 0);
+            const int o3 = (int)(ev3 & 0x3FFFu) - (r + 3 < 4 ? (int)WT_BYTES : 0);
+            const int o4 = (int)(ev4 & 0x3FFFu);                  // k = 4: always this tile
+            const bool ok = (ev0 & 0x4000u) && (ev2 & 0x8000u) && (o2 - o1) == (o4 - o3);
+            bad = bad || !ok;
+            if (!bad) {
+                const uint32_t reclen = (uint32_t)(o4 - o0);
+                maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+                if (bufsize32 && reclen + 15 >= bufsize32) {
+                    const unsigned long long rec = r0 + rbase - 1;
+                    if (rec < first_long) first_long = rec;
                 }
             }
         }
-        // the record that ends at entry r started in the previous tile (tile 0: k_finalize_fast)
-        if (t) {
-            const uint32_t cprev = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.cprev);
-            if (cprev < 4 || n < 4) { fail = 1; continue; }
-            // entries r-4 .. r: negative indices are the previous tile's last four (offset - 16 KiB)
-            uint32_t ev[5];
-            int ov[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int j = (int)r - 4 + k;
-                const uint32_t e = j >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)cur.edge, j)
-                                          : (uint32_t)__builtin_amdgcn_readlane((int)cur.pedge, 4 + j);
-                ev[k] = e;
-                ov[k] = (int)(e & 0x3FFFu) - (j >= 0 ? 0 : (int)WT_BYTES);
-            }
-            const bool ok = (ev[0] & 0x4000u) && (ev[2] & 0x8000u) && (ov[2] - ov[1]) == (ov[4] - ov[3]);
-            if (!ok) { fail = 1; continue; }
-            const uint32_t reclen = (uint32_t)(ov[4] - ov[0]);
-            maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
-            if (bufsize32 && reclen + 15 >= bufsize32) {
-                const unsigned long long rec = r0 + rbase - 1;
-                if (rec < first_long) first_long = rec;
+        fail |= bad ? 1u : 0u;
+        const uint32_t n_emit = bad ? 0u : nrs;   // a failed tile stores nothing (the result is discarded anyway)
+        // ---- phase B: one iteration per tile, loads four tiles ahead
+        const uint32_t ntl = (uint32_t)(a.n_tiles - t0 < 64 ? a.n_tiles - t0 : 64);
+        const uint16_t *const rs0 = a.fast_rs + t0 * 128 + lane;
+        auto ld = [&](uint32_t i) -> uint32_t { return rs0[(i < ntl ? i : ntl - 1) * 128u]; };
+        uint32_t q0 = ld(0), q1 = ld(1), q2 = ld(2), q3 = ld(3);
+        for (uint32_t i = 0; i < ntl; ++i) {
+            const uint32_t o = q0;
+            q0 = q1; q1 = q2; q2 = q3;
+            q3 = ld(i + 4);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_emit, (int)i);
+            if (n == 0) continue;
+            const unsigned long long rb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(rbase >> 32), (int)i) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rbase, (int)i);
+            const unsigned long long vbase = a.base_offset + ((t0 + i) << WT_SHIFT);
+            const bool cap_ok = rb + n <= a.cap;
+            uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rb : nullptr;
+            const uint16_t *__restrict__ tl = a.list + (t0 + i) * a.list_cap + 8;
+            uint32_t carry = 0;  // offset of record start mb - 1 (last lane of the previous group of 64)
+            for (uint32_t mb = 0; mb < n; mb += 64) {
+                const uint32_t m = mb + lane;
+                const uint32_t oo = mb == 0 ? o : (m < n ? (uint32_t)tl[m] : 0u);
+                const uint32_t oprev = wave_shr1(oo, carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)oo, 63);
+                if (m < n) {
+                    if (rs && (cap_ok || rb + m < a.cap)) rs[m] = vbase + oo;
+                    if (m) {  // record m-1 of the tile lies inside it: its length
+                        const uint32_t reclen = oo - oprev;
+                        maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+                        if (bufsize32 && reclen + 15 >= bufsize32) {
+                            const unsigned long long rec = r0 + rb + m - 1;
+                            if (rec < first_long) first_long = rec;
+                        }
+                    }
+                }
             }
         }
     }
@@ -939,7 +1087,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         for (int k = 0; k < 5; ++k) {
             const int j = (int)rr - 4 + k;
             if (j >= 0) {
-                const uint32_t e = a.list[j];
+                const uint32_t e = a.fast_rs[64 + j];
                 S[k] = (long long)(e & 0x3FFFu);
                 cls[k] = ((e & 0x4000u) ? 1u : 0u) | ((e & 0x8000u) ? 2u : 0u);
             } else {
@@ -969,7 +1117,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         if (a.rec_start && a.cap > 0) a.rec_start[0] = a.base_offset - a.back[a.nl_count & 3];
 
         // ---- chunk end: the last four entries (with their class bits)
-        const uint16_t *el = a.list + tl_last * a.list_cap + 4;
+        const uint16_t *el = a.fast_rs + tl_last * 128 + 64 + 4;
         uint32_t le[4];
         long long ls[4];
         for (int k = 0; k < 4; ++k) {  // k = 0: most recent
@@ -1024,23 +1172,37 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
 }
 
+void set_dbg_flags(uint32_t f) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_flags), &f, sizeof f); }
 int g_index_variant = -1;  // tuning hook (bench.py --variants); -1 = FQH_INDEX_VARIANT or default
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
-                  uint32_t *tile_count, uint8_t *tile_hyp, uint64_t n_tiles, DevOut *out, int n_cu, bool fast) {
+                  uint32_t *tile_count, uint16_t *fast_rs, uint64_t n_tiles, DevOut *out, int n_cu, bool fast) {
     if (!n_tiles) return;
     static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 5;
     static const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;
-    typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint8_t *, uint64_t, DevOut *);
+    typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
     // 4: no prefetch, 5: production exact (register prefetch of the next 4 KiB group), 6: list staged
-    // in LDS, 7: fast path (record starts + tile edges only)
-    static const kern_t kerns[8] = {k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>,
-                                    k_index_t<0, 0>, k_index_t<1, 0>, k_index_t<1, 1>, k_index_t<1, 2>};
-    static int occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // in LDS; the fast path has its own kernel (k_index_fast)
+    static const kern_t kerns[7] = {k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>,
+                                    k_index_t<0, 0>, k_index_t<1, 0>, k_index_t<1, 1>};
+    static int occ[7] = {0, 0, 0, 0, 0, 0, 0};
     int v = g_index_variant >= 0 ? g_index_variant : variant;
     const int bpc_dbg = v / 100;  // tuning: variant + 100 * blocks-per-CU
     v %= 100;
     if (v < 0 || v > 6) v = 5;
-    if (fast) v = 7;
+    if (fast) {
+        static int occf = 0;
+        if (!occf) {
+            int o = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast, 256, 0) != hipSuccess || o < 1) o = 4;
+            occf = o > 8 ? 8 : o;
+        }
+        uint64_t blocks = (n_tiles + 3) / 4;
+        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occf);
+        if (blocks > maxb) blocks = maxb;
+        hipLaunchKernelGGL(k_index_fast, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap, tile_count,
+                           fast_rs, n_tiles, out);
+        return;
+    }
     if (!occ[v]) {
         // persistent grid = exactly the blocks that are resident at once: a static round-robin of
         // tiles over a grid with one non-resident block per CU would run that block as a tail
@@ -1052,18 +1214,14 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occ[v]);
     if (blocks > maxb) blocks = maxb;
     hipLaunchKernelGGL(kerns[v], dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
-                       tile_count, tile_hyp, n_tiles, out);
+                       tile_count, n_tiles, out);
 }
 void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     if (a.n_tiles) {
-        static int occ = 0;
-        if (!occ) {
-            int o = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_emit_fast, 256, 0) != hipSuccess || o < 1) o = 4;
-            occ = o > 8 ? 8 : o;
-        }
-        uint64_t blocks = (a.n_tiles + 3) / 4;
-        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ;
+        const uint64_t ngroups = (a.n_tiles + 63) >> 6;  // 64 tiles per wavefront and round
+        uint64_t blocks = (ngroups + 3) / 4;
+        static const int bpc = getenv("FQH_EMIT_BPC") ? atoi(getenv("FQH_EMIT_BPC")) : 8;
+        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc > 0 ? bpc : 8);
         if (blocks > maxb) blocks = maxb;
         hipLaunchKernelGGL(k_emit_fast, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
     }

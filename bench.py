@@ -205,7 +205,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tj = json.load(f)["k_index_t"]
+            tj = json.load(f)["k_index_fast"]
         if tj["workload_bytes"] == nbytes:
             traffic = tj["bytes_per_launch"]
     except Exception:
@@ -229,7 +229,7 @@ def main():
                    "sharding": "byte-range, cuts at multiples of %d" % shard if world > 1 else "none"},
         "records_per_s": round(total_records / (dt / args.steps), 1),
         "hbm_roofline_frac_whole_step": round(gbs / world / HBM_PEAK_GBS, 4),
-        "roofline": {"bound": "hbm", "kernel": "k_index_t", "achieved": round(achieved, 1),
+        "roofline": {"bound": "hbm", "kernel": "k_index_fast", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "kernel_ms": round(k_ms, 4),
                      "algorithmic_bytes_per_launch": nbytes},

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfastq_hip.so")
 
-__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
+__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
            "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "BUFSIZE", "NSCALARS", "EXPORTS"]
 
@@ -18,8 +18,8 @@ NSCALARS = 8
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
-    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_last_timing",
-    "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_acquire", "fqh_stream_submit",
+    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead", "fqh_last_timing",
+    "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
 ]
@@ -56,6 +56,7 @@ class Chunk(C.Structure):
 
 
 STREAM_INDEX = 1
+STREAM_STATS = 2
 
 
 class FqhError(RuntimeError):
@@ -107,6 +108,8 @@ def lib():
                                 C.POINTER(Summary), C.POINTER(Carry)]
         L.fqh_stats_launch.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
         L.fqh_stats_finish.argtypes = [vp, C.POINTER(Summary), C.POINTER(Carry)]
+        L.fqh_stats_launch_lead.argtypes = [vp, vp, u64, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
+        L.fqh_stream_set_stats.argtypes = [vp, u32, vp, vp, vp]
         L.fqh_last_timing.argtypes = [vp, C.POINTER(Timing)]
         L.fqh_debug_last_scan_fast.argtypes = [vp]
         L.fqh_debug_set_spec.argtypes = [vp, i32]
@@ -228,6 +231,12 @@ class Ctx:
                                            C.byref(carry) if carry is not None else None, lmax,
                                            d_qual, d_base, d_scalars))
 
+    def stats_launch_lead(self, d_buf, length, lead_len, lmax, d_qual, d_base, d_scalars, is_final=True, carry=None):
+        """d_buf[-lead_len:] is valid device memory holding the start of the record in progress."""
+        self._chk(self._L.fqh_stats_launch_lead(self._h, d_buf, length, lead_len, 1 if is_final else 0,
+                                                C.byref(carry) if carry is not None else None, lmax,
+                                                d_qual, d_base, d_scalars))
+
     def stats_finish(self):
         s, c = Summary(), Carry()
         self._chk(self._L.fqh_stats_finish(self._h, C.byref(s), C.byref(c)))
@@ -269,6 +278,9 @@ class Stream:
         if self._h:
             self._L.fqh_stream_destroy(self._h)
             self._h = None
+
+    def set_stats(self, lmax, d_qual, d_base, d_scalars):
+        self.ctx._chk(self._L.fqh_stream_set_stats(self._h, lmax, d_qual, d_base, d_scalars))
 
     def acquire(self):
         """-> (host address, capacity) or None when the ring is full."""

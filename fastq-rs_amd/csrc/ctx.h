@@ -21,6 +21,7 @@ size_t stats_lines_scratch_bytes(uint32_t, int);
 hipError_t launch_stats_lines(hipStream_t, StatsArgs, int);
 size_t stats_oct_scratch_bytes(uint32_t, int);
 hipError_t launch_stats_oct(hipStream_t, StatsArgs, int);
+void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
 void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
 extern int g_index_variant;
@@ -90,5 +91,8 @@ fqh_status fqh_internal_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t
                                     const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap, bool reuse_index);
 fqh_status fqh_internal_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
 fqh_status fqh_internal_emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap);
+fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                                     uint32_t lmax, uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars,
+                                     uint64_t lead_len, uint64_t n_limit);
 // error visibility of the failing record of the last finished scan (BufferReplay::step's `need`)
 uint64_t fqh_internal_last_need(const fqh_ctx *ctx);

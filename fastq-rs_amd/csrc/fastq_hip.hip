@@ -534,9 +534,14 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
     return FQH_OK;
 }
 
-fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
-                            const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
-                            uint64_t *d_base_hist, uint64_t *d_scalars) {
+}  // extern "C"
+
+// lead_len: bytes in front of d_buf that are valid device memory and hold the beginning of the
+// record in progress at the chunk start; n_limit: count at most this many records of the chunk.
+fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                                     const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
+                                     uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t lead_len,
+                                     uint64_t n_limit) {
     if (!ctx) return FQH_E_ARG;
     if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
@@ -551,9 +556,12 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
     st = ensure_full_index(ctx);  // the histogram kernel walks complete line lists
     if (st != FQH_OK) return st;
     const fqh_timing scan_t = ctx->timing;
-    const uint64_t n = ctx->last_summary.n_records;
-    // the record in progress at the chunk start began in an earlier chunk: its bytes are not here
-    const uint64_t skip = (n && ctx->carry_in.back[ctx->carry_in.nl_count & 3] > 0) ? 1 : 0;
+    const uint64_t n = std::min<uint64_t>(ctx->last_summary.n_records, n_limit);
+    // the record in progress at the chunk start began in an earlier chunk: the line lists do not
+    // cover it; it is counted separately (k_stats_head) when the caller's buffer holds its beginning
+    const uint64_t back0 = ctx->carry_in.back[ctx->carry_in.nl_count & 3];
+    const uint64_t skip = (n && back0 > 0) ? 1 : 0;
+    const bool head = skip && lead_len >= back0;
     hipStream_t s = ctx->stream;
     static const int stats_variant = getenv("FQH_STATS_VARIANT") ? atoi(getenv("FQH_STATS_VARIANT")) : 2;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
@@ -605,11 +613,42 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
         sa.scalars = (unsigned long long *)d_scalars;
         HIPCHK(ctx, stats_variant == 1 ? launch_stats_lines(s, sa, ctx->n_cu) : launch_stats_oct(s, sa, ctx->n_cu));
     }
+    if (head) {
+        StatsArgs sa = {};
+        sa.buf = d_buf;
+        sa.len = len;
+        sa.nl_count = ctx->carry_in.nl_count;
+        sa.list = ctx->list;
+        sa.list_cap = ctx->list_cap;
+        sa.tile_count = ctx->tile_count;
+        sa.n_tiles = ctx->args.n_tiles;
+        sa.lmax = lmax;
+        sa.qual_hist = (unsigned long long *)d_qual_hist;
+        sa.base_hist = (unsigned long long *)d_base_hist;
+        sa.scalars = (unsigned long long *)d_scalars;
+        launch_stats_head(s, sa, ctx->carry_in.back);
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], s));
     HIPCHK(ctx, hipGetLastError());
     ctx->timing = scan_t;
     ctx->stats_pending = true;
     return FQH_OK;
+}
+
+extern "C" {
+
+fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                            const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
+                            uint64_t *d_base_hist, uint64_t *d_scalars) {
+    return fqh_internal_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars, 0,
+                                     UINT64_MAX);
+}
+
+fqh_status fqh_stats_launch_lead(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t lead_len, int is_final,
+                                 const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
+                                 uint64_t *d_base_hist, uint64_t *d_scalars) {
+    return fqh_internal_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars,
+                                     lead_len, UINT64_MAX);
 }
 
 fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {

@@ -824,6 +824,86 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_stats_head — the record in progress at the chunk start, for callers whose buffer also holds its
+// beginning in front of the chunk (fqh_stats_launch_lead; the streaming ring).  One wavefront.  The
+// record's line starts before the chunk come from the carry (distances back[]), those inside from
+// the full line lists; it ends at the line start with global index 4 (r0 + 1), or at the end of the
+// chunk.  Counting is the plain per-byte statement on the caller's u64 arrays.
+__global__ __launch_bounds__(64) void k_stats_head(StatsArgs a, unsigned long long b0, unsigned long long b1,
+                                                   unsigned long long b2, unsigned long long b3) {
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long back[4] = {b0, b1, b2, b3};
+    const unsigned long long r0 = a.nl_count >> 2;
+    auto entry = [&](unsigned long long j, long long &off) -> bool {  // j-th line start of the chunk
+        unsigned long long cum = 0;
+        for (uint64_t t = 0; t < a.n_tiles; ++t) {
+            uint32_t c = a.tile_count[t];
+            c = c < a.list_cap ? c : a.list_cap;
+            if (j < cum + c) {
+                off = (long long)((t << WT_SHIFT) + (a.list[t * a.list_cap + (uint32_t)(j - cum)] & 0x3FFFu));
+                return true;
+            }
+            cum += c;
+        }
+        return false;
+    };
+    long long p[5];
+    bool ok = true;
+    for (int i = 0; i < 5; ++i) {
+        const unsigned long long g = 4 * r0 + i;  // global line index
+        if (g <= a.nl_count) {
+            p[i] = -(long long)back[a.nl_count - g];
+        } else if (!entry(g - a.nl_count - 1, p[i])) {
+            if (i == 4) p[i] = (long long)a.len;  // the record's last '\n' is the last byte of the chunk
+            else ok = false;
+        }
+    }
+    if (!ok) return;
+    const uint8_t *const base = a.buf;
+    unsigned long long n_bases = 0, n_qual = 0, oseq = 0, oqual = 0;
+    uint32_t any_n = 0, any_inv = 0;
+    for (int kind = 0; kind < 2; ++kind) {
+        const long long s = kind ? p[3] : p[1];
+        long long len = (kind ? p[4] : p[2]) - 1 - s;            // raw line, without its '\n'
+        if (len > 0 && base[s + len - 1] == '\r') --len;         // trim_winline, src/records.rs:66-73
+        if (len < 0) len = 0;
+        if (kind) n_qual = (unsigned long long)len; else n_bases = (unsigned long long)len;
+        for (long long col = lane; col < len; col += 64) {
+            const uint32_t b = base[s + col];
+            if (kind == 0) {
+                const uint32_t c = base_class(b);
+                any_inv |= c == 5 ? 1u : 0u;
+                any_n |= c == 4 ? 1u : 0u;
+                if (col < (long long)a.lmax) atomicAdd(&a.base_hist[(uint64_t)col * 8 + c], 1ull);
+                else ++oseq;
+            } else {
+                if (col < (long long)a.lmax) atomicAdd(&a.qual_hist[(uint64_t)col * 256 + b], 1ull);
+                else ++oqual;
+            }
+        }
+    }
+    const bool gi = __ballot(any_inv != 0) != 0, gn = __ballot(any_n != 0) != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        oseq += __shfl_xor(oseq, d);
+        oqual += __shfl_xor(oqual, d);
+    }
+    if (lane == 0) {
+        atomicAdd(&a.scalars[0], 1ull);
+        if (n_bases) atomicAdd(&a.scalars[1], n_bases);
+        if (n_qual) atomicAdd(&a.scalars[2], n_qual);
+        if (!gi && !gn) atomicAdd(&a.scalars[3], 1ull);
+        if (!gi) atomicAdd(&a.scalars[4], 1ull);
+        if (oseq) atomicAdd(&a.scalars[5], oseq);
+        if (oqual) atomicAdd(&a.scalars[6], oqual);
+    }
+}
+void launch_stats_head(hipStream_t s, const StatsArgs &a, const uint64_t back[4]) {
+    hipLaunchKernelGGL(k_stats_head, dim3(1), dim3(64), 0, s, a, (unsigned long long)back[0],
+                       (unsigned long long)back[1], (unsigned long long)back[2], (unsigned long long)back[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic 150 bp FASTQ: byte b of record i is a pure function of (seed, i, b); the
 // tests regenerate any sub-range on the CPU from the same map.
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {

@@ -16,7 +16,7 @@ struct fqh_stream {
     hipStream_t copy_stream = nullptr;
     struct Slot {
         uint8_t *h = nullptr;   // pinned: [reserve][slot_bytes]
-        uint8_t *d = nullptr;   // device: [slot_bytes + 16]
+        uint8_t *d_base = nullptr, *d = nullptr;  // device: [reserve][slot_bytes + 16], d = d_base + reserve
         uint64_t *d_rec = nullptr, *h_rec = nullptr;
         uint64_t rec_cap = 0;
         fqh_idx_record *d_idx = nullptr, *h_idx = nullptr;
@@ -32,6 +32,9 @@ struct fqh_stream {
     uint64_t records_done = 0;
     bool ended = false;
     fqh::BufferReplay replay;
+    // FQH_STREAM_STATS
+    uint32_t lmax = 0;
+    uint64_t *d_qual_hist = nullptr, *d_base_hist = nullptr, *d_scalars = nullptr;
 };
 
 static fqh_status grow_rec(fqh_stream *st, fqh_stream::Slot &s, uint64_t need) {
@@ -66,7 +69,7 @@ void fqh_stream_destroy(fqh_stream *st) {
     (void)hipStreamSynchronize(st->ctx->stream);
     for (auto &s : st->slots) {
         if (s.h) (void)hipHostFree(s.h);
-        (void)hipFree(s.d);
+        (void)hipFree(s.d_base);
         (void)hipFree(s.d_rec);
         if (s.h_rec) (void)hipHostFree(s.h_rec);
         (void)hipFree(s.d_idx);
@@ -92,15 +95,16 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
     st->reserve = 2 * (uint64_t)FQH_BUFSIZE;
     st->slots.resize(n_slots);
     st->replay.reset(ctx->bufsize);
-    if (flags & FQH_STREAM_INDEX) ctx->spec_enabled = false;  // every chunk needs complete line lists
+    if (flags & (FQH_STREAM_INDEX | FQH_STREAM_STATS)) ctx->spec_enabled = false;  // every chunk needs complete line lists
     fqh_status rc = FQH_OK;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = FQH_E_DEVICE; break; }
         if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) { rc = FQH_E_DEVICE; break; }
         for (auto &s : st->slots) {
             if (hipHostMalloc((void **)&s.h, st->reserve + st->slot_bytes, hipHostMallocDefault) != hipSuccess ||
-                hipMalloc((void **)&s.d, st->slot_bytes + 16) != hipSuccess ||
+                hipMalloc((void **)&s.d_base, st->reserve + st->slot_bytes + 16) != hipSuccess ||
                 hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+            s.d = s.d_base + st->reserve;  // reserve is a multiple of 16
             if (grow_rec(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
             if ((flags & FQH_STREAM_INDEX) && grow_idx(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
         }
@@ -111,6 +115,16 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
         return rc;
     }
     *out = st;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_set_stats(fqh_stream *st, uint32_t lmax, uint64_t *d_qual_hist, uint64_t *d_base_hist,
+                                uint64_t *d_scalars) {
+    if (!st || !(st->flags & FQH_STREAM_STATS) || !lmax || !d_qual_hist || !d_base_hist || !d_scalars) return FQH_E_ARG;
+    st->lmax = lmax;
+    st->d_qual_hist = d_qual_hist;
+    st->d_base_hist = d_base_hist;
+    st->d_scalars = d_scalars;
     return FQH_OK;
 }
 
@@ -205,6 +219,15 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         c.n_records = which >= st->records_done ? which - st->records_done : 0;
         c.err_offset = s.h_rec[c.n_records];
     }
+    // histograms of the records this chunk delivers (the one in progress at its start included: its
+    // beginning sits in front of the slot's device data)
+    if ((st->flags & FQH_STREAM_STATS) && st->lmax && c.n_records) {
+        rc = fqh_internal_stats_launch(ctx, s.d, s.n_new, s.is_final, &st->carry, st->lmax, st->d_qual_hist,
+                                       st->d_base_hist, st->d_scalars, s.lead, c.n_records);
+        if (rc != FQH_OK) return rc;
+        rc = fqh_stats_finish(ctx, nullptr, nullptr);
+        if (rc != FQH_OK) return rc;
+    }
     // the partial trailing record goes in front of the next slot's data
     const uint64_t tail = known_end - s.h_rec[n];
     if (c.parse_status == FQH_OK && !s.is_final) {
@@ -215,6 +238,10 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         } else {
             fqh_stream::Slot &nx = st->slots[(st->col + 1) % st->n_slots];
             if (tail) memcpy(nx.h + st->reserve - tail, s.h + st->reserve + s.n_new - tail, tail);
+            if (tail && (st->flags & FQH_STREAM_STATS)) {  // device twin of the same move (may reach into s's own lead)
+                HIPCHK(ctx, hipMemcpyAsync(nx.d - tail, s.d + s.n_new - tail, tail, hipMemcpyDeviceToDevice, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
             nx.lead = tail;
         }
     }

@@ -148,6 +148,15 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
                             const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                             uint64_t *d_base_hist, uint64_t *d_scalars);
 fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
+/* As fqh_stats_launch, for a chunk whose buffer also holds the beginning of the record in progress
+ * at the chunk start: d_buf[-lead_len .. -1] is valid device memory and ends with the bytes of that
+ * record that precede the chunk (in->back[in->nl_count & 3] of them; the streaming ring and a
+ * Buffer-style compaction, src/buffer.rs:51-72, both keep them there).  The record is then counted
+ * with the chunk it ends in, so the calls over consecutive chunks of a file add up to exactly the
+ * whole-file histograms.  Without enough lead the record is left out, as in fqh_stats_launch. */
+fqh_status fqh_stats_launch_lead(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t lead_len,
+                                 int is_final, const fqh_carry *in, uint32_t lmax,
+                                 uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars);
 
 /* ---- Streaming ingest: the GPU counterpart of Buffer + thread_reader --------------------------
  * src/buffer.rs keeps one 68 KiB window and memmoves the partial trailing record to its front;
@@ -177,9 +186,15 @@ typedef struct {
                               input of a host-side replay of the reference's Buffer                   */
 } fqh_chunk;
 #define FQH_STREAM_INDEX 1u /* also build + download the IdxRecord-style index per chunk */
+#define FQH_STREAM_STATS 2u /* also add every delivered record to the histograms of fqh_stream_set_stats */
 fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots, uint32_t flags,
                              fqh_stream **out);
 void fqh_stream_destroy(fqh_stream *st);
+/* FQH_STREAM_STATS: device arrays as for fqh_stats (ADDED to).  Every record the stream delivers is
+ * counted exactly once, with the chunk it ends in; the device slots keep the partial trailing record in
+ * front of the next chunk for that. */
+fqh_status fqh_stream_set_stats(fqh_stream *st, uint32_t lmax, uint64_t *d_qual_hist, uint64_t *d_base_hist,
+                                uint64_t *d_scalars);
 /* Where to put the next input bytes (pinned host memory, *cap bytes).  FQH_E_CAPACITY if every slot
  * is submitted or held by the caller. */
 fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap);

@@ -126,3 +126,121 @@ def test_stream_fuzzing_bufsize(fqref, env):
         res = fqref.count(data, bufsize=64)
         status, recs, _ = stream_all(pkg, data, 4096, bufsize=64)
         assert (status, len(recs)) == (res.status, res.n_records), data
+
+
+def stream_stats(torch, pkg, data, slot_bytes, lmax, n_slots=3, read_sizes=None, seed=0):
+    """Feeds `data` through a FQH_STREAM_STATS stream; returns (status, n_records, qual, base, scalars)."""
+    dev = torch.device("cuda:0")
+    ctx = pkg.Ctx(0)
+    st = pkg.Stream(ctx, slot_bytes, n_slots, pkg.STREAM_STATS)
+    qh = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+    bh = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+    sc = torch.zeros(8, dtype=torch.int64, device=dev)
+    st.set_stats(lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    pos, total = 0, len(data)
+    status, nrec = pkg.OK, 0
+    submitted = collected = 0
+    done_reading = False
+    rng = np.random.default_rng(seed)
+    while True:
+        while not done_reading:
+            a = st.acquire()
+            if a is None:
+                break
+            addr, cap = a
+            n = min(cap, total - pos)
+            if read_sizes:
+                n = min(n, int(rng.integers(1, read_sizes + 1)))
+            C.memmove(addr, data[pos: pos + n], n)
+            pos += n
+            done_reading = pos >= total
+            st.submit(n, done_reading)
+            submitted += 1
+        if collected == submitted:
+            break
+        c = st.collect()
+        collected += 1
+        nrec += c.n_records
+        st.release()
+        if c.parse_status != pkg.OK:
+            status = c.parse_status
+            break
+        if c.is_final:
+            break
+    torch.cuda.synchronize()
+    out = (status, nrec, qh.cpu().numpy().astype(np.uint64).reshape(lmax, 256),
+           bh.cpu().numpy().astype(np.uint64).reshape(lmax, 8), sc.cpu().numpy().astype(np.uint64))
+    st.close()
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_streamed_stats_equal_whole_file_oracle(fqref, env, seed):
+    """FQH_STREAM_STATS: histograms accumulated chunk by chunk == the oracle's on the whole file, for
+    slots far smaller than the file (every slot boundary cuts a record; some records span several
+    slots), ragged reads, CRLF and files that end in an error (records before it still count)."""
+    torch, pkg = env
+    rng = np.random.default_rng(7000 + seed)
+    if seed == 0:
+        data, slot, reads = fuzzgen.valid_file(rng, 3000, maxlen=150), 4096, None
+    elif seed == 1:
+        data, slot, reads = fuzzgen.valid_file(rng, 2000, maxlen=300, crlf=True), 8192, 3000
+    elif seed == 2:   # long records against small slots: a record spans several chunks
+        data, slot, reads = fuzzgen.valid_file(rng, 60, seqlen=9000), 4096, None
+    elif seed == 3:
+        data, slot, reads = fuzzgen.mutate(rng, fuzzgen.valid_file(rng, 2500, maxlen=150), 1), 16384, 5000
+    else:
+        data, slot, reads = fuzzgen.valid_file(rng, 4000, maxlen=150)[:-9], 65536, None
+    for lmax in (150, 64):
+        r, qh, bh, sc = fqref.stats(data, lmax)
+        status, nrec, gq, gb, gs = stream_stats(torch, pkg, data, slot, lmax, read_sizes=reads, seed=seed)
+        assert (status, nrec) == (r.status, r.n_records), (seed, lmax)
+        assert np.array_equal(gs, sc), (seed, lmax, gs, sc)
+        assert np.array_equal(gq, qh) and np.array_equal(gb, bh), (seed, lmax)
+
+
+def test_stats_lead_chunks_add_up(fqref, env):
+    """fqh_stats_launch_lead on hand-made chunks of one device buffer (the bytes in front of a chunk
+    are simply the rest of the file): the chunked calls add up to the whole-file oracle; without the
+    lead every cut loses exactly the record it goes through."""
+    torch, pkg = env
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(99)
+    data = fuzzgen.valid_file(rng, 5000, maxlen=200)
+    n = len(data)
+    d = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    d[:n].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()))
+    cuts = [0] + sorted(int(x) // 16 * 16 for x in rng.integers(1, n, 7)) + [n]   # 16-byte aligned chunk starts
+    lmax = 200
+    r, qh, bh, sc = fqref.stats(data, lmax)
+    for use_lead in (True, False):
+        ctx = pkg.Ctx(0)
+        gq = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+        gb = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+        gs = torch.zeros(8, dtype=torch.int64, device=dev)
+        carry, total, lost = None, 0, 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if a == b:
+                continue
+            if use_lead:
+                ctx.stats_launch_lead(d.data_ptr() + a, b - a, a, lmax, gq.data_ptr(), gb.data_ptr(), gs.data_ptr(),
+                                      is_final=(b == n), carry=carry)
+            else:
+                ctx.stats_launch(d.data_ptr() + a, b - a, lmax, gq.data_ptr(), gb.data_ptr(), gs.data_ptr(),
+                                 is_final=(b == n), carry=carry)
+            s, c = ctx.stats_finish()
+            assert s.parse_status == pkg.OK
+            total += s.n_records
+            if carry is not None and carry.back[carry.nl_count & 3] > 0 and s.n_records:
+                lost += 1
+            carry = c
+        assert total == r.n_records
+        got = gs.cpu().numpy().astype(np.uint64)
+        if use_lead:
+            assert np.array_equal(got, sc)
+            assert np.array_equal(gq.cpu().numpy().astype(np.uint64).reshape(lmax, 256), qh)
+            assert np.array_equal(gb.cpu().numpy().astype(np.uint64).reshape(lmax, 8), bh)
+        else:
+            assert got[0] == sc[0] - lost and lost > 0
+        ctx.close()

@@ -945,7 +945,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // first entry, alignment check, position of its record starts in the output, and the validation of
 // the record that straddles into it (five line starts out of the two tiles' 16-byte edge blocks).
 // Phase B, one iteration per tile: readlane the three scalars, one 2-byte load and one 8-byte
-// store per lane (the loads run four tiles ahead).  ~25 instructions per tile instead of ~110.
+// store per lane, in rounds of 16 loads then 16 stores.  ~25 instructions per tile instead of ~110.
+template <uint32_t EMIT_ROUND>
 __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -1012,37 +1013,44 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
         }
         fail |= bad ? 1u : 0u;
         const uint32_t n_emit = bad ? 0u : nrs;   // a failed tile stores nothing (the result is discarded anyway)
-        // ---- phase B: one iteration per tile, loads four tiles ahead
+        // ---- phase B: rounds of 16 tiles: 16 loads, then 16 stores.  Stores share vmcnt with loads on
+        // gfx950, so a load that is consumed a few stores after it was issued waits for those stores'
+        // acknowledgements; in rounds, the only wait is the one in front of a round's first store and
+        // the previous round's stores have had a whole load latency to land.
         const uint32_t ntl = (uint32_t)(a.n_tiles - t0 < 64 ? a.n_tiles - t0 : 64);
         const uint16_t *const rs0 = a.fast_rs + t0 * 128 + lane;
-        auto ld = [&](uint32_t i) -> uint32_t { return rs0[(i < ntl ? i : ntl - 1) * 128u]; };
-        uint32_t q0 = ld(0), q1 = ld(1), q2 = ld(2), q3 = ld(3);
-        for (uint32_t i = 0; i < ntl; ++i) {
-            const uint32_t o = q0;
-            q0 = q1; q1 = q2; q2 = q3;
-            q3 = ld(i + 4);
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_emit, (int)i);
-            if (n == 0) continue;
-            const unsigned long long rb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(rbase >> 32), (int)i) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rbase, (int)i);
-            const unsigned long long vbase = a.base_offset + ((t0 + i) << WT_SHIFT);
-            const bool cap_ok = rb + n <= a.cap;
-            uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rb : nullptr;
-            const uint16_t *__restrict__ tl = a.list + (t0 + i) * a.list_cap + 8;
-            uint32_t carry = 0;  // offset of record start mb - 1 (last lane of the previous group of 64)
-            for (uint32_t mb = 0; mb < n; mb += 64) {
-                const uint32_t m = mb + lane;
-                const uint32_t oo = mb == 0 ? o : (m < n ? (uint32_t)tl[m] : 0u);
-                const uint32_t oprev = wave_shr1(oo, carry);
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)oo, 63);
-                if (m < n) {
-                    if (rs && (cap_ok || rb + m < a.cap)) rs[m] = vbase + oo;
-                    if (m) {  // record m-1 of the tile lies inside it: its length
-                        const uint32_t reclen = oo - oprev;
-                        maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
-                        if (bufsize32 && reclen + 15 >= bufsize32) {
-                            const unsigned long long rec = r0 + rb + m - 1;
-                            if (rec < first_long) first_long = rec;
+        for (uint32_t ib = 0; ib < ntl; ib += EMIT_ROUND) {
+            uint32_t q[EMIT_ROUND];
+#pragma unroll
+            for (uint32_t j = 0; j < EMIT_ROUND; ++j) q[j] = rs0[(ib + j) * 128u];  // the array has 64 tiles of slack
+#pragma unroll
+            for (uint32_t j = 0; j < EMIT_ROUND; ++j) {
+                const uint32_t i = ib + j;
+                if (i >= ntl) break;
+                const uint32_t o = q[j];
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_emit, (int)i);
+                if (n == 0) continue;
+                const unsigned long long rb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(rbase >> 32), (int)i) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rbase, (int)i);
+                const unsigned long long vbase = a.base_offset + ((t0 + i) << WT_SHIFT);
+                const bool cap_ok = rb + n <= a.cap;
+                uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rb : nullptr;
+                const uint16_t *__restrict__ tl = a.list + (t0 + i) * a.list_cap + 8;
+                uint32_t carry = 0;  // offset of record start mb - 1 (last lane of the previous group of 64)
+                for (uint32_t mb = 0; mb < n; mb += 64) {
+                    const uint32_t m = mb + lane;
+                    const uint32_t oo = mb == 0 ? o : (m < n ? (uint32_t)tl[m] : 0u);
+                    const uint32_t oprev = wave_shr1(oo, carry);
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)oo, 63);
+                    if (m < n) {
+                        if (rs && (cap_ok || rb + m < a.cap)) rs[m] = vbase + oo;
+                        if (m) {  // record m-1 of the tile lies inside it: its length
+                            const uint32_t reclen = oo - oprev;
+                            maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+                            if (bufsize32 && reclen + 15 >= bufsize32) {
+                                const unsigned long long rec = r0 + rb + m - 1;
+                                if (rec < first_long) first_long = rec;
+                            }
                         }
                     }
                 }
@@ -1220,10 +1228,14 @@ void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     if (a.n_tiles) {
         const uint64_t ngroups = (a.n_tiles + 63) >> 6;  // 64 tiles per wavefront and round
         uint64_t blocks = (ngroups + 3) / 4;
-        static const int bpc = getenv("FQH_EMIT_BPC") ? atoi(getenv("FQH_EMIT_BPC")) : 8;
-        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc > 0 ? bpc : 8);
+        static const int bpc = getenv("FQH_EMIT_BPC") ? atoi(getenv("FQH_EMIT_BPC")) : 4;
+        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc > 0 ? bpc : 4);
         if (blocks > maxb) blocks = maxb;
-        hipLaunchKernelGGL(k_emit_fast, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        static const int rnd = getenv("FQH_EMIT_ROUND") ? atoi(getenv("FQH_EMIT_ROUND")) : 16;
+        if (rnd == 4) hipLaunchKernelGGL(k_emit_fast<4>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        else if (rnd == 8) hipLaunchKernelGGL(k_emit_fast<8>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        else if (rnd == 32) hipLaunchKernelGGL(k_emit_fast<32>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        else hipLaunchKernelGGL(k_emit_fast<16>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
     }
 }
 void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {

@@ -147,8 +147,8 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles) {
         const size_t nb = (n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_count, n_tiles * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_prefix, n_tiles * sizeof(uint32_t)));
-        // + 64 tiles: k_emit_fast loads whole rounds of tiles without clamping
-        HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, (n_tiles + 64) * 128 * sizeof(uint16_t)));
+        // first lines (+ 64 tiles: k_emit_fast loads whole rounds of tiles without clamping), then the second lines
+        HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, (2 * n_tiles + 64) * 64 * sizeof(uint16_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
         ctx->tiles_cap = n_tiles;
     }
@@ -489,7 +489,7 @@ extern "C" void fqh_debug_set_flags(unsigned f) { fqh::set_dbg_flags(f); }
 extern "C" int fqh_debug_fast_record(fqh_ctx *ctx, uint64_t t, uint16_t *out128) {
     if (!ctx || !ctx->fast_rs || t >= ctx->tiles_cap) return -1;
     (void)hipStreamSynchronize(ctx->stream);
-    return (int)hipMemcpy(out128, ctx->fast_rs + t * 128, 256, hipMemcpyDeviceToHost);
+    return (int)hipMemcpy(out128, ctx->fast_rs + t * 64, 128, hipMemcpyDeviceToHost);
 }
 
 fqh_status fqh_invalidate(fqh_ctx *ctx) {

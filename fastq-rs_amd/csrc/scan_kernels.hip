@@ -629,6 +629,12 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 // vmcnt counter with loads, and scattered 2-byte stores between the prefetch loads and their
 // s_waitcnt would put store acknowledgements on the critical path of the next 4 KiB group.
 constexpr uint32_t LSTAGE_ENTRIES = 512;
+// fast path: one 128-byte line of u16 per tile: [0..FR_N) offsets of the tile's first record starts
+// (unused slots 0), [FR_EDGE..+8) its first four and last four entries, [FR_CNT..+2) the entry count,
+// [FR_HYP] the alignment (7: none).  Record starts FR_N .. FR_N + 63 of a tile (reads shorter than ~140 bp)
+// go to a second whole line, fast_rs + FR2_OFF(n_tiles) + tile * 64; anything beyond into list[tile][8 + j].
+constexpr uint32_t FR_N = 52, FR_EDGE = 52, FR_CNT = 60, FR_HYP = 62, FR_STRIDE = 64, FR2_N = 64;
+__host__ __device__ __forceinline__ uint64_t fr2_off(uint64_t n_tiles) { return (n_tiles + 64) * FR_STRIDE; }
 __device__ uint32_t g_dbg_flags = 0;  // timing experiments only (tools/exp_*.py): 1 no count store, 2 no meta store, 4 no record-start store
 template <int PF, int LSTAGE>
 __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf, uint64_t len,
@@ -794,10 +800,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
     const uint8_t *const rptr = lds + lane * 64;
     const uint32_t lo = lane * 16;
 
-    // evaluate the four alignments over the staged list; rv / mv = this lane's slot of the tile's two lines:
-    // [0..63] offsets of the first 64 record starts (unused slots 0), [64..71] the tile's first four
-    // and last four entries, [72..73] the entry count, [74] the alignment (7: none)
-    auto finish_tile = [&](uint64_t tile, uint32_t run, uint32_t nstaged, uint32_t &rv, uint32_t &mv) {
+    // evaluate the four alignments over the staged list; rv = this lane's slot of the tile's line
+    auto finish_tile = [&](uint64_t tile, uint32_t run, uint32_t nstaged, uint32_t &rv) {
         uint32_t hyp = 7;
         if (nstaged == run && run >= 8) {  // uniform
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -817,24 +821,27 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
             if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
         }
         rv = 0;
-        mv = 0;
         if (hyp < 4) {
-            rv = hyp + 4 * lane < run ? (uint32_t)(lst[hyp + 4 * lane] & 0x3FFFu) : 0u;
-            mv = lane < 4 ? lst[lane] : lane < 8 ? lst[run - 8 + lane] : 0u;
-            if (hyp + 256 < run) {  // more than 64 record starts: the rest spills into the tile's list area (rare)
-                uint16_t *__restrict__ tl = list + tile * list_cap;
-                for (uint32_t j = 64 + lane; hyp + 4 * j < run; j += 64) tl[8 + j] = lst[hyp + 4 * j] & 0x3FFFu;
+            if (lane < FR_N) rv = hyp + 4 * lane < run ? (uint32_t)(lst[hyp + 4 * lane] & 0x3FFFu) : 0u;
+            else if (lane < FR_EDGE + 4) rv = lst[lane - FR_EDGE];
+            else if (lane < FR_EDGE + 8) rv = lst[run - 8 + (lane - FR_EDGE)];
+            if (hyp + 4 * FR_N < run) {  // more record starts than the line holds: a second whole line ...
+                const uint32_t j2 = FR_N + lane;
+                fast_rs[fr2_off(n_tiles) + tile * FR2_N + lane] =
+                    hyp + 4 * j2 < run ? (uint16_t)(lst[hyp + 4 * j2] & 0x3FFFu) : (uint16_t)0;
+                if (hyp + 4 * (FR_N + FR2_N) < run) {  // ... and the list area for the rest (reads shorter than ~25 bp)
+                    uint16_t *__restrict__ tl = list + tile * list_cap;
+                    for (uint32_t j = FR_N + FR2_N + lane; hyp + 4 * j < run; j += 64) tl[8 + j] = lst[hyp + 4 * j] & 0x3FFFu;
+                }
             }
         } else {
             ++n_over;  // counted into spec_fail below
         }
-        mv = lane == 8 ? (run & 0xFFFFu) : lane == 9 ? (run >> 16) : lane == 10 ? hyp : mv;
+        rv = lane == FR_CNT ? (run & 0xFFFFu) : lane == FR_CNT + 1 ? (run >> 16) : lane == FR_HYP ? hyp : rv;
     };
-    auto store_tile = [&](uint64_t tile, uint32_t run, uint32_t rv, uint32_t mv) {
-        uint16_t *const fl = fast_rs + tile * 128;
-        if (!(dbg & 4u)) fl[lane] = (uint16_t)rv;
-        if (!(dbg & 2u)) fl[64 + lane] = (uint16_t)mv;
-        if (lane == 0 && !(dbg & 1u)) tile_count[tile] = run;  // dense copy for the prefix scan
+    auto store_tile = [&](uint64_t tile, uint32_t run, uint32_t rv) {
+        if (!(dbg & 4u)) fast_rs[tile * FR_STRIDE + lane] = (uint16_t)rv;        // one whole 128-byte line
+        if (lane == 0 && !(dbg & 1u)) tile_count[tile] = run;                    // dense copy for the prefix scan
     };
 
     uint64_t tile = wave0;
@@ -845,7 +852,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         uint4 n2 = load16_nt(p + 2 * PIECE_BYTES), n3 = load16_nt(p + 3 * PIECE_BYTES);
         bool pending = false;          // the previous tile's two lines are still in registers
         uint64_t ptile = 0;
-        uint32_t prv = 0, pmv = 0, prun = 0;
+        uint32_t prv = 0, prun = 0;
         for (; tile < n_full; tile += nwaves) {
             const uint64_t nxt = tile + nwaves < n_full ? tile + nwaves : tile;  // clamped: the prefetch is unconditional
             uint32_t run = 0, nstaged = 0;
@@ -864,7 +871,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                     n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
                     n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
                 }
-                if (g == 0 && pending) store_tile(ptile, prun, prv, pmv);  // a whole group before the next wait
+                if (g == 0 && pending) store_tile(ptile, prun, prv);  // a whole group before the next wait
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + (0u ^ s4));
@@ -910,13 +917,13 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                 }  // else: more than 512 line starts in a tile: left to the exact path
                 run += tot;
             }
-            finish_tile(tile, run, nstaged, prv, pmv);
+            finish_tile(tile, run, nstaged, prv);
             prun = run;
             ptile = tile;
             pending = true;
             __builtin_amdgcn_wave_barrier();
         }
-        if (pending) store_tile(ptile, prun, prv, pmv);
+        if (pending) store_tile(ptile, prun, prv);
     }
     // the partial tile at the end of the buffer
     if (wave0 == 0 && n_full < n_tiles) {
@@ -930,9 +937,9 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
             const uint4 v = load16(buf, off, len);
             index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, LSTAGE_ENTRIES);
         }
-        uint32_t rv, mv;
-        finish_tile(t, run, run <= LSTAGE_ENTRIES ? run : 0u, rv, mv);
-        store_tile(t, run, rv, mv);
+        uint32_t rv;
+        finish_tile(t, run, run <= LSTAGE_ENTRIES ? run : 0u, rv);
+        store_tile(t, run, rv);
     }
     if (lane == 0 && n_over) atomicAdd(&out->spec_fail, (unsigned long long)n_over);
 }
@@ -948,6 +955,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // store per lane, in rounds of 16 loads then 16 stores.  ~25 instructions per tile instead of ~110.
 template <uint32_t EMIT_ROUND>
 __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
+    __shared__ uint16_t stage_all[4][EMIT_ROUND * 64];
+    uint16_t *const stage = stage_all[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const uint64_t ngroups = (a.n_tiles + 63) >> 6;
@@ -965,15 +974,16 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
         if (live) {
             cnt = a.tile_count[T];
             tp = a.tile_prefix[T];
-            const uint16_t *meta = a.fast_rs + T * 128 + 64;
-            e = *reinterpret_cast<const uint4 *>(meta);                     // entries 0..3 first, 4..7 last four
-            hyp = meta[10];
+            const uint16_t *meta = a.fast_rs + T * FR_STRIDE + FR_EDGE;        // 8-byte aligned
+            const uint2 ea = *reinterpret_cast<const uint2 *>(meta), eb = *reinterpret_cast<const uint2 *>(meta + 4);
+            e = make_uint4(ea.x, ea.y, eb.x, eb.y);                           // entries 0..3 first, 4..7 last four
+            hyp = meta[FR_HYP - FR_EDGE];
         }
         const unsigned long long bp = a.block_prefix[t0 >> SCAN_SHIFT];    // 64 | 2^SCAN_SHIFT: one block
         uint32_t c0 = 0, pz0 = 0, pw0 = 0;                                // tile t0 - 1, for lane 0
         if (t0) {
             c0 = a.tile_count[t0 - 1];
-            const uint2 pe0 = *reinterpret_cast<const uint2 *>(a.fast_rs + (t0 - 1) * 128 + 64 + 4);
+            const uint2 pe0 = *reinterpret_cast<const uint2 *>(a.fast_rs + (t0 - 1) * FR_STRIDE + FR_EDGE + 4);
             pz0 = pe0.x;
             pw0 = pe0.y;
         }
@@ -1018,16 +1028,23 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
         // acknowledgements; in rounds, the only wait is the one in front of a round's first store and
         // the previous round's stores have had a whole load latency to land.
         const uint32_t ntl = (uint32_t)(a.n_tiles - t0 < 64 ? a.n_tiles - t0 : 64);
-        const uint16_t *const rs0 = a.fast_rs + t0 * 128 + lane;
+        const uint16_t *const rs0 = a.fast_rs + t0 * FR_STRIDE + lane;
         for (uint32_t ib = 0; ib < ntl; ib += EMIT_ROUND) {
             uint32_t q[EMIT_ROUND];
 #pragma unroll
-            for (uint32_t j = 0; j < EMIT_ROUND; ++j) q[j] = rs0[(ib + j) * 128u];  // the array has 64 tiles of slack
+            for (uint32_t j = 0; j < EMIT_ROUND; ++j) q[j] = rs0[(ib + j) * FR_STRIDE];  // the array has 64 tiles of slack
+            // through LDS, so that the store loop below is ONE body indexed by j (unrolled, its two
+            // paths times 16 need 180+ VGPRs and halve the occupancy)
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
+            for (uint32_t j = 0; j < EMIT_ROUND; ++j) stage[j * 64 + lane] = (uint16_t)q[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
             for (uint32_t j = 0; j < EMIT_ROUND; ++j) {
                 const uint32_t i = ib + j;
                 if (i >= ntl) break;
-                const uint32_t o = q[j];
+                const uint32_t o = stage[j * 64 + lane];
                 const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_emit, (int)i);
                 if (n == 0) continue;
                 const unsigned long long rb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(rbase >> 32), (int)i) << 32) |
@@ -1036,10 +1053,28 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
                 const bool cap_ok = rb + n <= a.cap;
                 uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rb : nullptr;
                 const uint16_t *__restrict__ tl = a.list + (t0 + i) * a.list_cap + 8;
+                if (n <= FR_N) {  // the common case: everything is in the tile's line
+                    const uint32_t oprev = wave_shr1(o, 0u);
+                    if (lane < n) {
+                        if (rs && (cap_ok || rb + lane < a.cap)) rs[lane] = vbase + o;
+                        if (lane) {  // record lane-1 of the tile lies inside it: its length
+                            const uint32_t reclen = o - oprev;
+                            maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+                            if (bufsize32 && reclen + 15 >= bufsize32) {
+                                const unsigned long long rec = r0 + rb + lane - 1;
+                                if (rec < first_long) first_long = rec;
+                            }
+                        }
+                    }
+                    continue;
+                }
                 uint32_t carry = 0;  // offset of record start mb - 1 (last lane of the previous group of 64)
                 for (uint32_t mb = 0; mb < n; mb += 64) {
                     const uint32_t m = mb + lane;
-                    const uint32_t oo = mb == 0 ? o : (m < n ? (uint32_t)tl[m] : 0u);
+                    const uint32_t oo = m < FR_N ? o
+                                        : m >= n ? 0u
+                                        : m < FR_N + FR2_N ? (uint32_t)a.fast_rs[fr2_off(a.n_tiles) + (t0 + i) * FR2_N + (m - FR_N)]
+                                                           : (uint32_t)tl[m];
                     const uint32_t oprev = wave_shr1(oo, carry);
                     carry = (uint32_t)__builtin_amdgcn_readlane((int)oo, 63);
                     if (m < n) {
@@ -1095,7 +1130,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         for (int k = 0; k < 5; ++k) {
             const int j = (int)rr - 4 + k;
             if (j >= 0) {
-                const uint32_t e = a.fast_rs[64 + j];
+                const uint32_t e = a.fast_rs[FR_EDGE + j];
                 S[k] = (long long)(e & 0x3FFFu);
                 cls[k] = ((e & 0x4000u) ? 1u : 0u) | ((e & 0x8000u) ? 2u : 0u);
             } else {
@@ -1125,7 +1160,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         if (a.rec_start && a.cap > 0) a.rec_start[0] = a.base_offset - a.back[a.nl_count & 3];
 
         // ---- chunk end: the last four entries (with their class bits)
-        const uint16_t *el = a.fast_rs + tl_last * 128 + 64 + 4;
+        const uint16_t *el = a.fast_rs + tl_last * FR_STRIDE + FR_EDGE + 4;
         uint32_t le[4];
         long long ls[4];
         for (int k = 0; k < 4; ++k) {  // k = 0: most recent

@@ -69,6 +69,7 @@ struct StatsArgs {
     uint32_t lmax, lc;           // lc = columns kept in LDS
     uint32_t *scratch;           // [gridDim.x][lc * 128] per-block partial histograms
     unsigned long long *qual_hist, *base_hist, *scalars;
+    uint32_t dbg;                // timing experiments only (FQH_STATS_DBG): 1 no LDS atomics, 2 no data loads, 4 no counting
 };
 
 // Device-resident accumulators and the finalize kernel's results (one D2H copy per scan).

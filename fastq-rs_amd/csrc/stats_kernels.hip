@@ -517,7 +517,7 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
     const int tt = (int)nfull4 - (int)m4;
     constexpr uint32_t FILL = IS_SEQ ? 0x41414141u : 0x21212121u;
     uint32_t any_n = 0, any_inv = 0;
-    uint32_t chk = IS_SEQ ? 0u : 0x80808080u;  // sequence: OR of (dword ^ expected); quality: AND of window flags
+    uint32_t chk = 0;  // sequence: OR of (dword ^ expected); quality: OR of the bins' bits 6-7
     uint32_t nsteps = 0;                       // wave-uniform
     do {
 #define FQH_SO_PASS1(U)                                                                        \
@@ -530,8 +530,9 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
             if (IS_SEQ) {                                                                      \
                 chk |= wf ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, wf & 0x07070707u); \
             } else {                                                                           \
-                const uint32_t lo7 = wf & 0x7F7F7F7Fu;                                         \
-                chk &= (lo7 + 0x5F5F5F5Fu) & ~(lo7 + 0x1F1F1F1Fu) & ~wf;                       \
+                /* byte - 33 < 64 for all four bytes: a byte below '!' borrows, but its own    */ \
+                /* difference is then >= 0xDF, one above '`' gives >= 0x40: bits 6-7 tell     */ \
+                chk |= (wf - 0x21212121u) & 0xC0C0C0C0u;                                       \
             }                                                                                  \
         }
         FQH_SO_PASS1(0) FQH_SO_PASS1(1) FQH_SO_PASS1(2) FQH_SO_PASS1(3)
@@ -539,7 +540,7 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
 #undef FQH_SO_PASS1
     } while (0);
     uint32_t slow = 0;  // wave-uniform: steps left to the exact path
-    if (__ballot(IS_SEQ ? chk != 0 : chk != 0x80808080u) != 0) {
+    if (__ballot(chk != 0) != 0) {
         slow = (1u << nsteps) - 1u;
     } else {
         do {
@@ -556,6 +557,7 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
                 } else {                                                                       \
                     pb = wf - 0x21212121u + 0x40404040u * (U >> 1);                            \
                 }                                                                              \
+                if (!(a.dbg & 1u))                                                             \
                 _Pragma("unroll") for (int k = 0; k < 4; ++k)                                  \
                     lds_add<128u * (U & 1u)>(__builtin_amdgcn_perm(c.A[k], pb, c.sel[k]), inc); \
             }
@@ -649,23 +651,56 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     StatsAcc acc = {0, 0, 0, 0, 0, 0, 0};
     SoTotals T = {0, 0};
 
-    for (uint64_t tile = (uint64_t)blockIdx.x * SO_WAVES + wv; tile < a.n_tiles && a.len >= 4;
-         tile += (uint64_t)gridDim.x * SO_WAVES) {
-        uint32_t cnt = a.tile_count[tile];
+    // What a wave needs to know about a tile before it can start on it, loaded one tile ahead (the
+    // per-tile chain count -> prefix -> list -> '\r' bytes -> first dwords is otherwise paid in full,
+    // 256 times per wave: 2.5 of the kernel's 6 ms).
+    struct TilePre {
+        uint32_t cnt, tp, cnt1, first1;
+        unsigned long long bp;
+        uint2 l0, l1;  // list entries 4 lane .. 4 lane + 3 and 256 + 4 lane .. + 3
+    };
+    auto prefetch = [&](uint64_t t, TilePre &P) {
+        const uint64_t tc = t < a.n_tiles ? t : a.n_tiles - 1;  // clamped: the loads are unconditional
+        P.cnt = a.tile_count[tc];
+        P.tp = a.tile_prefix[tc];
+        P.bp = a.block_prefix[tc >> SCAN_SHIFT];
+        const uint16_t *__restrict__ tl = a.list + tc * a.list_cap;
+        P.l0 = *reinterpret_cast<const uint2 *>(tl + lane * 4);
+        P.l1 = *reinterpret_cast<const uint2 *>(tl + 256 + lane * 4);  // list_cap >= 512
+        const uint64_t t1 = tc + 1 < a.n_tiles ? tc + 1 : tc;
+        P.cnt1 = a.tile_count[t1];
+        P.first1 = a.list[t1 * a.list_cap];
+    };
+    const uint64_t tstride = (uint64_t)gridDim.x * SO_WAVES;
+    uint64_t tile = (uint64_t)blockIdx.x * SO_WAVES + wv;
+    TilePre nextP;
+    if (tile < a.n_tiles && a.len >= 4) prefetch(tile, nextP);
+    for (; tile < a.n_tiles && a.len >= 4; tile += tstride) {
+        const TilePre cur = nextP;
+        prefetch(tile + tstride, nextP);
+        uint32_t cnt = cur.cnt;
         cnt = cnt < a.list_cap ? cnt : a.list_cap;
         if (cnt == 0) continue;
-        const unsigned long long lbase = a.nl_count + 1 + a.block_prefix[tile >> SCAN_SHIFT] + a.tile_prefix[tile];
+        const unsigned long long lbase = a.nl_count + 1 + cur.bp + cur.tp;
         if (lbase >= a.line_hi || lbase + cnt <= a.line_lo) continue;
         const uint16_t *__restrict__ tl = a.list + tile * a.list_cap;
         const uint64_t tb = tile << WT_SHIFT;
-        // stage the list (4 entries = 8 bytes per lane and round)
-        const uint32_t nst = cnt < SO_LISTW ? cnt : SO_LISTW;
-        for (uint32_t e = lane * 4; e < nst; e += 256)
-            *reinterpret_cast<uint2 *>(wl + e) = *reinterpret_cast<const uint2 *>(tl + e);
+        // stage the list
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<uint2 *>(wl + lane * 4) = cur.l0;
+        *reinterpret_cast<uint2 *>(wl + 256 + lane * 4) = cur.l1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // start of the first line after this tile (ends the tile's last line), tile-relative
         uint64_t next_first = a.valid_end;
-        for (uint64_t t2 = tile + 1; t2 < a.n_tiles; ++t2) {
-            if (a.tile_count[t2]) { next_first = (t2 << WT_SHIFT) + (a.list[t2 * a.list_cap] & 0x3FFFu); break; }
+        if (tile + 1 < a.n_tiles) {
+            if (cur.cnt1) {
+                next_first = ((tile + 1) << WT_SHIFT) + (cur.first1 & 0x3FFFu);
+            } else {
+                for (uint64_t t2 = tile + 2; t2 < a.n_tiles; ++t2) {
+                    if (a.tile_count[t2]) { next_first = (t2 << WT_SHIFT) + (a.list[t2 * a.list_cap] & 0x3FFFu); break; }
+                }
+            }
         }
         const uint64_t vend = a.valid_end > tb ? a.valid_end - tb : 0;
         const uint32_t vend_rel = vend < 0x7FFFFFFFull ? (uint32_t)vend : 0x7FFFFFFFu;
@@ -682,22 +717,84 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         const bool safe = tb + WT_BYTES + 32u * NSL + 8u <= a.len;
         const uint32_t lce = safe ? lc : 0u;  // LDS rows in use for this tile: none => every column is exact
 
-        for (uint32_t kind = 0; kind < 2; ++kind) {        // 0: sequence lines, 1: quality lines
+        // one lane per line: start and raw length of line `sbl` of `kind`; false: no line that counts
+        auto line_of = [&](uint32_t kind, uint32_t sbl, uint32_t &s_rel, uint32_t &len) -> bool {
             const uint32_t i0 = ((kind ? 3u : 1u) - lb3) & 3u;
-            if (i0 >= cnt) continue;
-            const uint32_t nlines = (cnt - i0 + 3) >> 2;
+            const uint32_t i = i0 + 4u * sbl;
+            if (i >= cnt || i < e_lo || i >= e_hi) return false;
+            s_rel = (i < SO_LISTW ? wl[i] : tl[i]) & 0x3FFFu;
+            uint32_t n_rel = i + 1 < cnt ? ((i + 1 < SO_LISTW ? wl[i + 1] : tl[i + 1]) & 0x3FFFu) : nf_rel;
+            n_rel = n_rel < vend_rel ? n_rel : vend_rel;
+            len = n_rel - 1 - s_rel;  // raw line, without its '\n'
+            return true;
+        };
+        auto set_region = [&](uint32_t kind) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) c.A[k] = (c.A[k] & 0xFFu) | (kind ? 0u : SO_QBYTES);  // region
+            for (uint32_t k = 0; k < 4; ++k) c.A[k] = (c.A[k] & 0xFFu) | (kind ? 0u : SO_QBYTES);
+        };
+        const uint32_t i0s = (1u - lb3) & 3u, i0q = (3u - lb3) & 3u;
+        const uint32_t nls = i0s < cnt ? (cnt - i0s + 3) >> 2 : 0u, nlq = i0q < cnt ? (cnt - i0q + 3) >> 2 : 0u;
+
+        if (safe && nls <= 64 && nlq <= 64 && !(a.dbg & 8u)) {
+            // ---- the usual tile: at most 64 lines of each kind.  Both kinds' lines are worked out at
+            // once (their '\r' bytes are in flight together), then all batches run as one sequence so that
+            // the first quality batch is fetched while the last sequence batch is counted.
+            uint32_t s_s = 0, l_s = 0, s_q = 0, l_q = 0;
+            const bool has_s = line_of(0, lane, s_s, l_s), has_q = line_of(1, lane, s_q, l_q);
+            const uint32_t cr_s = (has_s && l_s) ? tbase[s_s + l_s - 1] : 0u;
+            const uint32_t cr_q = (has_q && l_q) ? tbase[s_q + l_q - 1] : 0u;
+            if (cr_s == '\r') --l_s;                                                   // trim_winline, src/records.rs:66-73
+            if (cr_q == '\r') --l_q;
+            const uint32_t P_s = has_s ? so_pack(s_s, l_s, lce) : 0u, P_q = has_q ? so_pack(s_q, l_q, lce) : 0u;
+            if (has_s) { ++acc.rec; acc.bases += l_s; }
+            if (has_q) acc.qual += l_q;
+            const uint32_t nbs = (nls + 7) >> 3, nbq = (nlq + 7) >> 3, nbt = nbs + nbq;
+            auto fetch = [&](uint32_t f, SoBatch<NSL> &B) {
+                const bool isq = f >= nbs;
+                const uint32_t b = isq ? f - nbs : f;
+                B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)(isq ? P_q : P_s));
+                const uint32_t s_rel = B.P >> SO_P_SREL;
+                const uint32_t o = s_rel + m4, ot = s_rel + (B.P & 0x1FFu);
+#pragma unroll
+                for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(tbase + (o + 32 * u));
+                B.wt = load4_fast(tbase + ot);
+            };
+            auto count = [&](uint32_t f, SoBatch<NSL> &B) {
+                if (a.dbg & 4u) { acc.oseq += B.w[0] == 0x12345u; return; }
+                if (f == nbs) set_region(1);
+                if (f < nbs) so_count<true, NSL>(a, tbase, B, lane, lce, hist, c, l_s, 32u * f + 4u * g8, T, acc);
+                else so_count<false, NSL>(a, tbase, B, lane, lce, hist, c, l_q, 32u * (f - nbs) + 4u * g8, T, acc);
+            };
+            if (nbt) {
+                set_region(0);
+                SoBatch<NSL> B0, B1;  // ping-pong: the loads of one are in flight while the other is counted
+                // The fetches are unconditional inside the loop (the index is clamped instead) so that
+                // the compiler's s_waitcnt vmcnt(N) for one buffer leaves the other one's loads in flight.
+                const uint32_t fl = nbt - 1;
+                fetch(0, B0);
+                for (uint32_t f = 0; f < nbt; f += 2) {
+                    fetch(f + 1 < fl ? f + 1 : fl, B1);
+                    count(f, B0);
+                    if (f + 1 < nbt) {
+                        fetch(f + 2 < fl ? f + 2 : fl, B0);
+                        count(f + 1, B1);
+                    }
+                }
+            }
+            continue;
+        }
+
+        // ---- any other tile (more than 64 lines of a kind, or too close to the end of the buffer for
+        // unconditional loads): one kind after the other, 64 lines at a time
+        for (uint32_t kind = 0; kind < 2; ++kind) {        // 0: sequence lines, 1: quality lines
+            const uint32_t nlines = kind ? nlq : nls;
+            if (!nlines) continue;
+            set_region(kind);
             for (uint32_t sb = 0; sb < nlines; sb += 64) {
-                // one lane per line: start, length, '\r' trim, per-line totals
                 uint32_t my_P = 0, my_len = 0;
                 {
-                    const uint32_t i = i0 + 4u * (sb + lane);
-                    if (sb + lane < nlines && i >= e_lo && i < e_hi) {
-                        const uint32_t s_rel = (i < SO_LISTW ? wl[i] : tl[i]) & 0x3FFFu;
-                        uint32_t n_rel = i + 1 < cnt ? ((i + 1 < SO_LISTW ? wl[i + 1] : tl[i + 1]) & 0x3FFFu) : nf_rel;
-                        n_rel = n_rel < vend_rel ? n_rel : vend_rel;
-                        uint32_t len = n_rel - 1 - s_rel;                              // raw line, without its '\n'
+                    uint32_t s_rel = 0, len = 0;
+                    if (sb + lane < nlines && line_of(kind, sb + lane, s_rel, len)) {
                         if (len && tbase[s_rel + len - 1] == '\r') --len;              // trim_winline, src/records.rs:66-73
                         my_len = len;
                         my_P = so_pack(s_rel, len, lce);
@@ -710,41 +807,22 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                     }
                 }
                 const uint32_t nbat = ((nlines - sb < 64 ? nlines - sb : 64u) + 7) >> 3;
-                auto fetch = [&](uint32_t b, SoBatch<NSL> &B) {
-                    B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)my_P);
-                    const uint32_t s_rel = B.P >> SO_P_SREL;
-                    const uint32_t o = s_rel + m4, ot = s_rel + (B.P & 0x1FFu);
+                SoBatch<NSL> B0;
+                for (uint32_t b = 0; b < nbat; ++b) {
+                    B0.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)my_P);
+                    const uint32_t s_rel = B0.P >> SO_P_SREL;
+                    const uint32_t o = s_rel + m4, ot = s_rel + (B0.P & 0x1FFu);
+                    if (safe) {
 #pragma unroll
-                    for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(tbase + (o + 32 * u));
-                    B.wt = load4_fast(tbase + ot);
-                };
-                auto count = [&](uint32_t b, SoBatch<NSL> &B) {
-                    if (kind == 0) so_count<true, NSL>(a, tbase, B, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
-                    else so_count<false, NSL>(a, tbase, B, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
-                };
-                SoBatch<NSL> B0, B1;  // ping-pong: the loads of one are in flight while the other is counted
-                if (safe) {
-                    // The fetches are unconditional inside the loop (the index is clamped instead) so
-                    // that the compiler's s_waitcnt vmcnt(N) for one buffer leaves the other one's six
-                    // loads in flight.
-                    const uint32_t bl = nbat - 1;
-                    fetch(0, B0);
-                    for (uint32_t b = 0; b < nbat; b += 2) {
-                        fetch(b + 1 < bl ? b + 1 : bl, B1);
-                        count(b, B0);
-                        if (b + 1 < nbat) {
-                            fetch(b + 2 < bl ? b + 2 : bl, B0);
-                            count(b + 1, B1);
-                        }
-                    }
-                } else {
-                    for (uint32_t b = 0; b < nbat; ++b) {
-                        B0.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)my_P);
-                        B0.wt = 0;
+                        for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = load4_fast(tbase + (o + 32 * u));
+                        B0.wt = load4_fast(tbase + ot);
+                    } else {  // lce == 0: every column goes through the exact path, which loads for itself
 #pragma unroll
                         for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = 0;
-                        count(b, B0);
+                        B0.wt = 0;
                     }
+                    if (kind == 0) so_count<true, NSL>(a, tbase, B0, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
+                    else so_count<false, NSL>(a, tbase, B0, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
                 }
             }
         }
@@ -810,6 +888,8 @@ static hipError_t launch_stats_oct_n(hipStream_t s, const StatsArgs &a, uint32_t
 }
 hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
     a.lc = stats_oct_lc(a.lmax);
+    static const uint32_t dbg = getenv("FQH_STATS_DBG") ? (uint32_t)atoi(getenv("FQH_STATS_DBG")) : 0u;
+    a.dbg = dbg;
     const size_t lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * SO_LISTW * sizeof(uint16_t);
     const uint32_t blocks = stats_lines_blocks(n_cu);
     const uint32_t nsl = (a.lc + 31) / 32;  // steps that hold LDS rows

@@ -89,8 +89,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: small exchanges go through preallocated pinned host staging (no per-step allocations)
     gather_in = torch.zeros(7, dtype=torch.int64, device=dev)
-    gather_out = [torch.zeros(7, dtype=torch.int64, device=dev) for _ in range(world)] if world > 1 else None
+    gather_all = torch.zeros(world * 7, dtype=torch.int64, device=dev) if world > 1 else None
+    h_in = torch.zeros(7, dtype=torch.int64).pin_memory() if world > 1 else None
+    h_all = torch.zeros(world * 7, dtype=torch.int64).pin_memory() if world > 1 else None
+    h_counts = torch.zeros(2, dtype=torch.int64).pin_memory() if world > 1 else None
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
     index_ms = []
 
@@ -102,17 +106,22 @@ def main():
         # 1) shard-local byte scan (phase-free), 2) carry exchange, 3) emit with the true carry
         nn, ns, back0 = ctx.shard_prescan(buf.data_ptr(), nbytes)
         index_ms.append(ctx.timing().index_ms)
-        gather_in.copy_(torch.tensor([nbytes, nn, ns] + back0, dtype=torch.int64), non_blocking=False)
-        dist.all_gather(gather_out, gather_in)
-        rows = torch.stack(gather_out).cpu().numpy()
+        h_in[0], h_in[1], h_in[2] = nbytes, nn, ns
+        h_in[3], h_in[4], h_in[5], h_in[6] = back0
+        gather_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(gather_all, gather_in)
+        h_all.copy_(gather_all, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        rows = h_all.numpy().reshape(world, 7)
         carry = None
         for r in range(rank):
             carry = pkg.carry_combine(carry, int(rows[r][0]), int(rows[r][1]), int(rows[r][2]),
                                       [int(x) for x in rows[r][3:7]])
         ctx.rescan_launch(is_last, carry, rec_start.data_ptr(), cap)
         s, c, st = ctx.scan_finish()
-        counts[0] = s.n_records
-        counts[1] = 1 if s.parse_status != pkg.OK else 0
+        h_counts[0] = s.n_records
+        h_counts[1] = 1 if s.parse_status != pkg.OK else 0
+        counts.copy_(h_counts, non_blocking=True)
         dist.all_reduce(counts)
         return s
 

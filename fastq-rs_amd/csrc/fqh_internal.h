@@ -67,6 +67,7 @@ struct StatsArgs {
     const uint64_t *block_prefix;
     uint64_t n_tiles;
     uint32_t lmax, lc;           // lc = columns kept in LDS
+    uint32_t lx, listw;          // k_stats_oct: extra plain LDS rows lc .. lc + lx (long reads); staged list entries per wave
     uint32_t *scratch;           // [gridDim.x][lc * 128] per-block partial histograms
     unsigned long long *qual_hist, *base_hist, *scalars;
     uint32_t dbg;                // timing experiments only (FQH_STATS_DBG): 1 no LDS atomics, 2 no data loads, 4 no counting

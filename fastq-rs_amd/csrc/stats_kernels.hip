@@ -407,7 +407,9 @@ constexpr uint32_t SO_LC_MAX = 256;           // rows kept in LDS
 constexpr uint32_t SO_QBYTES = 4 * 64 * 256;  // quality region: 4 row blocks x 64 bins x 64 slots x 4 B
 constexpr uint32_t SO_SBYTES = 4 * 8 * 256;   // sequence region
 constexpr uint32_t SO_WORDS = (SO_QBYTES + SO_SBYTES) / 4;
-constexpr uint32_t SO_LISTW = 512;            // list entries staged in LDS per wave (u16 each)
+constexpr uint32_t SO_LISTW = 512;            // list entries staged in LDS per wave (u16 each); 256 when extra rows need the room
+constexpr uint32_t SO_LX_MAX = 256;           // extra rows (columns 256 .. 511) in a plain [row][72] layout, exact path only
+constexpr uint32_t SO_LDS_MAX = 160 * 1024;
 
 __device__ __forceinline__ uint32_t so_slot(uint32_t r) {  // r = row % 64
     return ((r >> 2) & 7u) | ((r & 3u) << 3) | (r & 32u);
@@ -450,7 +452,14 @@ __device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v) {
     asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF));
 }
 
-// The exact per-byte statement: columns pos .. of a line of `len` columns held in w.
+// Columns a.lc .. a.lc + a.lx - 1 (reads longer than the 256 bank-scheduled rows) have plain LDS rows of
+// 72 words (64 quality bins, 8 sequence bins) behind the staged lists; only the exact path touches them.
+__device__ __forceinline__ uint32_t *so_extra(const StatsArgs &a, uint32_t *hist) {
+    return hist + SO_WORDS + (SO_WAVES * a.listw) / 2;
+}
+
+// The exact per-byte statement: columns pos .. of a line of `len` columns held in w.  (lc is the tile's
+// view of the bank-scheduled rows: 0 in tiles that take the exact path for everything.)
 template <bool IS_SEQ>
 __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, uint32_t pos, uint32_t len, uint32_t lc,
                                               uint32_t *hist, uint32_t &any_n, uint32_t &any_inv,
@@ -466,10 +475,12 @@ __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, ui
             any_inv |= valid ? 0u : 1u;
             any_n |= b == 'N' ? 1u : 0u;
             if (col < lc) atomicAdd(hist + so_word<true>(bin, col), 1u);
+            else if (col - a.lc < a.lx) atomicAdd(so_extra(a, hist) + (col - a.lc) * 72u + 64u + bin, 1u);
             else if (col < a.lmax) atomicAdd(&a.base_hist[(uint64_t)col * 8 + bin_to_class(bin)], 1ull);
             else ++ovf;
         } else {
             if (col < lc && b - 33u < 64u) atomicAdd(hist + so_word<false>(b - 33u, col), 1u);
+            else if (col - a.lc < a.lx && b - 33u < 64u) atomicAdd(so_extra(a, hist) + (col - a.lc) * 72u + (b - 33u), 1u);
             else if (col < a.lmax) atomicAdd(&a.qual_hist[(uint64_t)col * 256 + b], 1ull);
             else ++ovf;
         }
@@ -631,13 +642,15 @@ template <uint32_t NSL>
 __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // quality + sequence regions, then the staged lists
     const uint32_t lc = a.lc;
+    const uint32_t listw = a.listw;  // 512, or 256 when the extra rows need the room
     for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < a.lx * 72u; i += SO_THREADS) so_extra(a, hist)[i] = 0;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t m4 = (lane & 7u) * 4u, g8 = lane >> 3;
-    uint16_t *const wl = reinterpret_cast<uint16_t *>(hist + SO_WORDS) + wv * SO_LISTW;  // this wave's staged list
+    uint16_t *const wl = reinterpret_cast<uint16_t *>(hist + SO_WORDS) + wv * listw;  // this wave's staged list
     // The address registers assume the histogram starts at LDS address 0 (it is the kernel's only
     // LDS object); a shared-memory pointer is its LDS address in the low 32 bits.
     if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         // stage the list
         __builtin_amdgcn_wave_barrier();
         *reinterpret_cast<uint2 *>(wl + lane * 4) = cur.l0;
-        *reinterpret_cast<uint2 *>(wl + 256 + lane * 4) = cur.l1;
+        if (listw > 256) *reinterpret_cast<uint2 *>(wl + 256 + lane * 4) = cur.l1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // start of the first line after this tile (ends the tile's last line), tile-relative
@@ -722,8 +735,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             const uint32_t i0 = ((kind ? 3u : 1u) - lb3) & 3u;
             const uint32_t i = i0 + 4u * sbl;
             if (i >= cnt || i < e_lo || i >= e_hi) return false;
-            s_rel = (i < SO_LISTW ? wl[i] : tl[i]) & 0x3FFFu;
-            uint32_t n_rel = i + 1 < cnt ? ((i + 1 < SO_LISTW ? wl[i + 1] : tl[i + 1]) & 0x3FFFu) : nf_rel;
+            s_rel = (i < listw ? wl[i] : tl[i]) & 0x3FFFu;
+            uint32_t n_rel = i + 1 < cnt ? ((i + 1 < listw ? wl[i + 1] : tl[i + 1]) & 0x3FFFu) : nf_rel;
             n_rel = n_rel < vend_rel ? n_rel : vend_rel;
             len = n_rel - 1 - s_rel;  // raw line, without its '\n'
             return true;
@@ -829,8 +842,9 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the inline ds_add of lds_add
     __syncthreads();
-    uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * SO_WORDS;
+    uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * (SO_WORDS + a.lx * 72u);
     for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) dst[i] = hist[i];
+    for (uint32_t i = threadIdx.x; i < a.lx * 72u; i += SO_THREADS) dst[SO_WORDS + i] = so_extra(a, hist)[i];
     // per-line totals: rec / bases / qual were summed by the lane that owned the line; the two
     // "not DNA" counts are wave-uniform
     unsigned long long sc[7] = {acc.rec, acc.bases, acc.qual, 0, 0, acc.oseq, acc.oqual};
@@ -852,36 +866,51 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
 
 // Sum the per-block partial histograms into the caller's u64 arrays (coalesced reads).
 __global__ __launch_bounds__(256) void k_stats_reduce_oct(const uint32_t *__restrict__ scratch, uint32_t n_blocks,
-                                                          uint32_t lc, unsigned long long *__restrict__ qual_hist,
+                                                          uint32_t lc, uint32_t lx,
+                                                          unsigned long long *__restrict__ qual_hist,
                                                           unsigned long long *__restrict__ base_hist) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= SO_WORDS) return;
-    const bool isq = id < SO_QBYTES / 4;
-    const uint32_t r = isq ? id : id - SO_QBYTES / 4;
-    const uint32_t rb = isq ? r >> 12 : r >> 9, bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
-    const uint32_t row = rb * 64 + so_row6(r & 63u);
-    if (row >= lc) return;
+    const uint32_t words = SO_WORDS + lx * 72u;
+    if (id >= words) return;
+    bool isq;
+    uint32_t bin, row;
+    if (id < SO_WORDS) {  // bank-scheduled rows
+        isq = id < SO_QBYTES / 4;
+        const uint32_t r = isq ? id : id - SO_QBYTES / 4;
+        const uint32_t rb = isq ? r >> 12 : r >> 9;
+        bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
+        row = rb * 64 + so_row6(r & 63u);
+        if (row >= lc) return;
+    } else {              // plain rows lc .. lc + lx - 1: 64 quality bins, 8 sequence bins
+        const uint32_t r = id - SO_WORDS;
+        row = lc + r / 72u;
+        isq = r % 72u < 64u;
+        bin = isq ? r % 72u : r % 72u - 64u;
+    }
     const uint32_t b0 = blockIdx.y * RED_GROUP;
     const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
     unsigned long long s = 0;
-    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * SO_WORDS + id];
+    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * words + id];
     if (!s) return;
     if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
     else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
 }
 
 uint32_t stats_oct_lc(uint32_t lmax) { return lmax < SO_LC_MAX ? lmax : SO_LC_MAX; }
-size_t stats_oct_scratch_bytes(uint32_t, int n_cu) {
-    return (size_t)stats_lines_blocks(n_cu) * SO_WORDS * sizeof(uint32_t);
+static uint32_t stats_oct_lx(uint32_t lmax) {
+    return lmax > SO_LC_MAX ? (lmax - SO_LC_MAX < SO_LX_MAX ? lmax - SO_LC_MAX : SO_LX_MAX) : 0u;
+}
+size_t stats_oct_scratch_bytes(uint32_t lmax, int n_cu) {
+    return (size_t)stats_lines_blocks(n_cu) * (SO_WORDS + stats_oct_lx(lmax) * 72u) * sizeof(uint32_t);
 }
 template <uint32_t NSL>
 static hipError_t launch_stats_oct_n(hipStream_t s, const StatsArgs &a, uint32_t blocks, size_t lds) {
-    static bool set = false;
-    if (!set) {
+    static size_t set = 0;
+    if (lds > set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_oct<NSL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        set = true;
+        set = lds;
     }
     hipLaunchKernelGGL(k_stats_oct<NSL>, dim3(blocks), dim3(SO_THREADS), lds, s, a);
     return hipSuccess;
@@ -890,7 +919,14 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
     a.lc = stats_oct_lc(a.lmax);
     static const uint32_t dbg = getenv("FQH_STATS_DBG") ? (uint32_t)atoi(getenv("FQH_STATS_DBG")) : 0u;
     a.dbg = dbg;
-    const size_t lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * SO_LISTW * sizeof(uint16_t);
+    a.lx = stats_oct_lx(a.lmax);
+    a.listw = a.lx ? 256u : SO_LISTW;
+    size_t lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * a.listw * sizeof(uint16_t) +
+                 (size_t)a.lx * 72 * sizeof(uint32_t);
+    if (lds > SO_LDS_MAX) {  // cannot happen with the constants above; keep the kernel launchable anyway
+        a.lx = 0;
+        lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * a.listw * sizeof(uint16_t);
+    }
     const uint32_t blocks = stats_lines_blocks(n_cu);
     const uint32_t nsl = (a.lc + 31) / 32;  // steps that hold LDS rows
     hipError_t e = nsl <= 2   ? launch_stats_oct_n<2>(s, a, blocks, lds)
@@ -898,8 +934,8 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
                    : nsl <= 5 ? launch_stats_oct_n<5>(s, a, blocks, lds)
                               : launch_stats_oct_n<8>(s, a, blocks, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stats_reduce_oct, dim3((SO_WORDS + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP),
-                       dim3(256), 0, s, a.scratch, blocks, a.lc, a.qual_hist, a.base_hist);
+    hipLaunchKernelGGL(k_stats_reduce_oct, dim3((SO_WORDS + a.lx * 72u + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP),
+                       dim3(256), 0, s, a.scratch, blocks, a.lc, a.lx, a.qual_hist, a.base_hist);
     return hipGetLastError();
 }
 

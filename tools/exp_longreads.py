@@ -28,4 +28,13 @@ for _ in range(3):
     t = ctx.timing().stats_ms
     best = t if best is None else min(best, t)
 assert int(sc[0]) == reps * nrec and int(qh.sum()) == reps * nrec * L and int(bh.sum()) == reps * nrec * L
-print("read length %d: %.2f GiB in %.3f ms = %.0f GB/s" % (L, n / 2**30, best, n / 1e6 / best))
+print("read length %d: histograms %.2f GiB in %.3f ms = %.0f GB/s" % (L, n / 2**30, best, n / 1e6 / best))
+ctx2 = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+rs = torch.empty(reps * nrec + 16, dtype=torch.int64, device=dev)
+ts = []
+for _ in range(6):
+    s, c, st = ctx2.scan(buf.data_ptr(), n, True, None, rs.data_ptr(), reps * nrec + 16)
+    t = ctx2.timing(); ts.append((t.total_ms, t.index_ms, t.emit_ms))
+assert s.n_records == reps * nrec and s.parse_status == 0
+print("read length %d: scan total %.3f ms (index %.3f emit %.3f) = %.0f GB/s, fast path: %s" % (
+    L, min(x[0] for x in ts), min(x[1] for x in ts), min(x[2] for x in ts), n / 1e6 / min(x[0] for x in ts), ctx2.last_scan_fast()))

@@ -67,7 +67,9 @@ struct fqh_ctx {
     bool whole_file = false;
     bool skip_emit = false;  // shard prescan: only the byte scan, the prefix and the chunk-end summary
     // fast path: prove validity with a quarter of the list traffic; any doubt -> exact rerun
-    bool spec_enabled = true;   // switched off for good once an input needed the exact path
+    bool spec_enabled = true;   // false: exact path only (callers that need full line lists, FQH_SPEC=0)
+    uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...
+    uint32_t spec_backoff = 0;  // ... 1, 2, 4 .. 64 of them, doubling with every failure in a row
     bool index_full = true;     // the tile index in the workspace holds complete line lists
     bool used_spec = false;     // the scan in flight runs the fast path
     fqh_summary last_summary = {};

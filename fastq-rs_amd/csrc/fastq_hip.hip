@@ -326,7 +326,11 @@ static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     a.idx_cap = 0;
     // fast path: when the caller does not need full line lists and no earlier input needed the exact
     // path; a rescan on a retained index uses whichever kind of index is there
-    const bool fast = reuse_index ? !ctx->index_full : (ctx->spec_enabled && ctx->list_cap >= LIST_CAP_DEFAULT);
+    bool fast = reuse_index ? !ctx->index_full : (ctx->spec_enabled && ctx->list_cap >= LIST_CAP_DEFAULT);
+    if (fast && !reuse_index && ctx->spec_skip) {  // backing off after a failed attempt
+        --ctx->spec_skip;
+        fast = false;
+    }
     fqh_status st = enqueue_scan(ctx, reuse_index, fast);
     if (st != FQH_OK) return st;
     ctx->pending = true;
@@ -341,12 +345,16 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->used_spec && ctx->h_out->spec_fail) {
         // the fast path could not prove the input valid (a real error, lines longer than a few KiB,
-        // or a degenerate layout): run the exact path, and stay on it for later scans of this context
-        ctx->spec_enabled = false;
+        // or a degenerate layout): run the exact path, and keep later scans of this context on it for a
+        // while (1, 2, 4 .. 64 scans: one bad file should not cost the fast path for good, a stream of
+        // inputs the fast path cannot handle should not pay for an attempt every time)
+        ctx->spec_backoff = ctx->spec_backoff ? (ctx->spec_backoff < 64 ? ctx->spec_backoff * 2 : 64) : 1;
+        ctx->spec_skip = ctx->spec_backoff;
         fqh_status st = enqueue_scan(ctx, false, false);
         if (st != FQH_OK) return st;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    else if (ctx->used_spec) ctx->spec_backoff = 0;
     // (ctx->used_spec now tells whether the result in h_out came from the fast path)
     if (ctx->h_out->overflow) {
         // a tile has more line starts than list_cap (lines shorter than 32 bytes on average): rerun
@@ -481,7 +489,11 @@ fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, ui
 
 // test hooks, not part of the public header
 extern "C" int fqh_debug_last_scan_fast(fqh_ctx *ctx) { return ctx && ctx->used_spec ? 1 : 0; }
-extern "C" void fqh_debug_set_spec(fqh_ctx *ctx, int on) { if (ctx) ctx->spec_enabled = on != 0; }
+extern "C" void fqh_debug_set_spec(fqh_ctx *ctx, int on) {
+    if (!ctx) return;
+    ctx->spec_enabled = on != 0;
+    ctx->spec_skip = ctx->spec_backoff = 0;
+}
 // tuning hook, not part of the public header: selects the k_index code variant for A/B runs
 extern "C" void fqh_debug_set_index_variant(int v) { fqh::g_index_variant = v; }
 extern "C" void fqh_debug_set_flags(unsigned f) { fqh::set_dbg_flags(f); }
@@ -548,9 +560,13 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
     fqh_status st;
     if (!same_scan(ctx, d_buf, len, is_final, in)) {
+        // the histogram kernel needs complete line lists: scan on the exact path right away instead of
+        // taking the fast path and indexing a second time
+        const bool spec = ctx->spec_enabled;
+        ctx->spec_enabled = false;
         st = do_scan_launch(ctx, d_buf, len, is_final, in, nullptr, 0);
-        if (st != FQH_OK) return st;
-        st = do_scan_finish(ctx, nullptr, nullptr);
+        if (st == FQH_OK) st = do_scan_finish(ctx, nullptr, nullptr);
+        ctx->spec_enabled = spec;
         if (st != FQH_OK) return st;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -431,3 +431,32 @@ def test_fast_path_is_taken_and_falls_back_exactly(fqref, torch, pkg):
             assert s.err_record == res.n_records
     assert taken >= 10 and fell >= 10, (taken, fell)
     ctx.close()
+
+
+def test_fast_path_backoff_after_failure(fqref, torch, pkg):
+    """A file the fast path cannot prove valid sends the context to the exact path for 1, 2, 4 ... later
+    scans (not for good): results are oracle-exact on every call either way."""
+    rng = np.random.default_rng(31)
+    dev = torch.device("cuda:0")
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    good = fuzzgen.valid_file(rng, 3000, seqlen=150)
+    bad = fuzzgen.mutate(rng, good, 1)
+    while fqref.count(bad).status == fqref.OK:
+        bad = fuzzgen.mutate(rng, good, 1)
+
+    def run(data):
+        d = torch.empty(len(data) + 16, dtype=torch.uint8, device=dev)
+        d[: len(data)].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()))
+        s, c, st = ctx.scan(d.data_ptr(), len(data), True, None, None, 0)
+        r = fqref.count(data)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records)
+        return ctx.last_scan_fast()
+
+    assert run(good) is True
+    assert run(bad) is False                              # fails -> 1 scan of back-off
+    assert [run(good) for _ in range(3)] == [False, True, True]
+    assert run(bad) is False                              # back-off starts again at 1 after a success
+    assert run(bad) is False                              # (this one is the back-off scan itself)
+    assert run(bad) is False                              # second failure in a row -> 2 scans
+    assert [run(good) for _ in range(4)] == [False, False, True, True]
+    ctx.close()

@@ -36,6 +36,10 @@ def main():
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=4096)
     ap.add_argument("--variants", default="", help="tuning: comma list of k_index variants to A/B (interleaved rounds)")
+    ap.add_argument("--shard-stats", action="store_true",
+                    help="N > 1 only, after the timed steps: per-position histograms over the shards (every rank "
+                         "gets the tail of the previous rank's shard in front of its own, one all_reduce of the "
+                         "histograms) and a check of the global totals; one extra JSON line, not part of the metric")
     ap.add_argument("--stream-gib", type=float, default=0.0,
                     help="configs[3]: stream this many GiB from pinned host memory through fqh_stream_* "
                          "(a record-aligned pinned region is replayed) and report the PCIe-inclusive rate")
@@ -78,7 +82,9 @@ def main():
     nbytes = hi - lo
 
     ctx = pkg.Ctx(dev.index, stream=torch.cuda.current_stream().cuda_stream)
-    buf = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+    LEAD = 2 * pkg.BUFSIZE  # room in front of the shard for the tail of the previous rank's shard (--shard-stats)
+    store = torch.empty(LEAD + nbytes + 16, dtype=torch.uint8, device=dev)
+    buf = store[LEAD:]
     ctx.synth_fill(buf.data_ptr(), lo, nbytes)
     cap = nbytes // 300 + 16
     rec_start = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -291,6 +297,41 @@ def main():
             out["cpu_baseline"]["stats_gbs"] = round(hs / 1e9 / d1, 3)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if world > 1 and args.shard_stats:
+        # histograms over byte-range shards.  The record that straddles a cut is counted by the
+        # rank it ENDS in, which needs its beginning: the last LEAD bytes of every shard are all-gathered
+        # (world x 136 KiB) and rank r puts rank r-1's in front of its buffer; then one all_reduce of
+        # [scalars, quality histogram, base histogram].
+        tails = torch.empty(world * LEAD, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(tails, buf[nbytes - LEAD: nbytes].contiguous())
+        if rank:
+            store[:LEAD].copy_(tails[(rank - 1) * LEAD: rank * LEAD])
+        rows = h_all.numpy().reshape(world, 7)
+        carry = None
+        for r in range(rank):
+            carry = pkg.carry_combine(carry, int(rows[r][0]), int(rows[r][1]), int(rows[r][2]),
+                                      [int(x) for x in rows[r][3:7]])
+        LMAX = 150
+        hist = torch.zeros(8 + LMAX * 256 + LMAX * 8, dtype=torch.int64, device=dev)
+        sc, qh, bh = hist[:8], hist[8: 8 + LMAX * 256], hist[8 + LMAX * 256:]
+        barrier()
+        t1 = time.perf_counter()
+        ctx.stats_launch_lead(buf.data_ptr(), nbytes, LEAD if rank else 0, LMAX, qh.data_ptr(), bh.data_ptr(),
+                              sc.data_ptr(), is_final=is_last, carry=carry)
+        s2, _ = ctx.stats_finish()
+        dist.all_reduce(hist)
+        barrier()
+        dts = time.perf_counter() - t1
+        assert s2.parse_status == pkg.OK
+        tot = hist.cpu().numpy()
+        assert int(tot[0]) == total_records, (int(tot[0]), total_records)
+        assert int(tot[1]) == int(tot[2]) == total_records * 150
+        assert int(tot[8: 8 + LMAX * 256].sum()) == total_records * 150 == int(tot[8 + LMAX * 256:].sum())
+        if rank == 0:
+            print(json.dumps({"mode": "shard-stats", "n_gpus": world, "records_total": int(tot[0]),
+                              "seconds_incl_full_index_and_allreduce": round(dts, 4),
+                              "check": "sum over ranks: records, bases, quality and base histogram totals match the "
+                                       "generator's; every cut-straddling record counted exactly once"}), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

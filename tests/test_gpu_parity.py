@@ -392,6 +392,49 @@ def test_sharded_two_stage_protocol(fqref, torch, pkg, seed):
     assert starts[: res.n_records] == [int(x) for x in idx[:, 0]]
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_sharded_histograms_with_tail_exchange(fqref, torch, pkg, seed):
+    """bench.py --shard-stats on one GPU: byte-range shards cut anywhere; every shard gets the tail of the
+    previous one in front of its buffer (what the all_gather of tails delivers), is scanned with the
+    combined carry and histogrammed with fqh_stats_launch_lead; the sum over the shards (the all_reduce)
+    equals the oracle's histograms of the whole file, scalars included."""
+    rng = np.random.default_rng(170 + seed)
+    data = fuzzgen.valid_file(rng, 2500, maxlen=200, crlf=(seed == 2))
+    lmax = 200
+    r, qh, bh, sc = fqref.stats(data, lmax)
+    nsh = 4
+    lead = 2 * pkg.BUFSIZE
+    cuts = [0] + sorted(int(x) for x in rng.integers(1, len(data), nsh - 1)) + [len(data)]
+    dev = torch.device("cuda:0")
+    gq = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+    gb = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+    gs = torch.zeros(8, dtype=torch.int64, device=dev)
+    carry, total = None, 0
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        n = b - a
+        store = torch.zeros(lead + max(n, 16) + 16, dtype=torch.uint8, device=dev)
+        have = min(a, lead)  # what the previous shards can deliver (short shards: less than a full tail)
+        chunk = np.frombuffer(data[a - have: b], dtype=np.uint8).copy()
+        store[lead - have: lead + n].copy_(torch.from_numpy(chunk))
+        c = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream, bufsize=0)
+        d_ptr = store.data_ptr() + lead
+        nn, ns, back0 = c.shard_prescan(d_ptr, n)
+        c.rescan_launch(i == nsh - 1, carry, None, 0)
+        s, cout, st = c.scan_finish()
+        assert s.parse_status == pkg.OK
+        c.stats_launch_lead(d_ptr, n, have, lmax, gq.data_ptr(), gb.data_ptr(), gs.data_ptr(),
+                            is_final=(i == nsh - 1), carry=carry)
+        s2, _ = c.stats_finish()
+        assert s2.n_records == s.n_records
+        total += s.n_records
+        carry = pkg.carry_combine(carry, n, nn, ns, back0)
+        c.close()
+    assert total == r.n_records
+    assert np.array_equal(gs.cpu().numpy().astype(np.uint64), sc)
+    assert np.array_equal(gq.cpu().numpy().astype(np.uint64).reshape(lmax, 256), qh)
+    assert np.array_equal(gb.cpu().numpy().astype(np.uint64).reshape(lmax, 8), bh)
+
+
 def test_fast_path_is_taken_and_falls_back_exactly(fqref, torch, pkg):
     """The fast path (record starts + tile edges only) must (a) really run on valid
     multi-tile input and (b) hand every input it cannot prove valid to the exact path: same status,

@@ -18,7 +18,7 @@ NSCALARS = 8
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
-    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead", "fqh_last_timing",
+    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
@@ -111,6 +111,9 @@ def lib():
         L.fqh_stats_launch_lead.argtypes = [vp, vp, u64, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
         L.fqh_stream_set_stats.argtypes = [vp, u32, vp, vp, vp]
         L.fqh_last_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.fqh_record_flags.argtypes = [vp, vp, u64, u64, vp, u64, vp]
+        L.fqh_gather_records.argtypes = [vp, vp, u64, u64, vp, u64, vp, C.c_uint8, C.c_uint8, vp, u64,
+                                         C.POINTER(u64), C.POINTER(u64)]
         L.fqh_debug_last_scan_fast.argtypes = [vp]
         L.fqh_debug_set_spec.argtypes = [vp, i32]
         L.fqh_stream_create.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
@@ -225,6 +228,18 @@ class Ctx:
                                     C.byref(carry) if carry is not None else None, lmax,
                                     d_qual, d_base, d_scalars, C.byref(s), C.byref(c)))
         return s, c
+
+    def record_flags(self, d_buf, length, d_index, n, d_flags, base_offset=0):
+        self._chk(self._L.fqh_record_flags(self._h, d_buf, length, base_offset, d_index, n, d_flags))
+
+    def gather_records(self, d_buf, length, d_index, n, d_flags, mask, want, d_out, out_cap, base_offset=0):
+        """-> (status, n_selected, out_bytes); status is OK or E_CAPACITY."""
+        ns, nb = C.c_uint64(), C.c_uint64()
+        st = self._L.fqh_gather_records(self._h, d_buf, length, base_offset, d_index, n, d_flags, mask, want,
+                                        d_out, out_cap, C.byref(ns), C.byref(nb))
+        if st not in (OK, E_CAPACITY):
+            self._chk(st)
+        return st, ns.value, nb.value
 
     def stats_launch(self, d_buf, length, lmax, d_qual, d_base, d_scalars, is_final=True, carry=None):
         self._chk(self._L.fqh_stats_launch(self._h, d_buf, length, 1 if is_final else 0,

@@ -22,6 +22,10 @@ hipError_t launch_stats_lines(hipStream_t, StatsArgs, int);
 size_t stats_oct_scratch_bytes(uint32_t, int);
 hipError_t launch_stats_oct(hipStream_t, StatsArgs, int);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
+void launch_record_flags(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_idx_record *, uint64_t, uint8_t *);
+uint64_t gather_blocks(uint64_t n);
+void launch_gather(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_idx_record *, uint64_t, const uint8_t *, uint32_t,
+                   uint32_t, unsigned long long *, unsigned long long *, unsigned long long *, uint8_t *, uint64_t);
 void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
 void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
 extern int g_index_variant;
@@ -42,6 +46,8 @@ struct fqh_ctx {
     size_t list_elems = 0;
     uint32_t list_cap = LIST_CAP_DEFAULT;
     uint32_t *tile_count = nullptr, *tile_prefix = nullptr;
+    unsigned long long *gather_ws = nullptr;  // fqh_gather_records: block byte sums, block record sums, totals
+    uint64_t gather_ws_blocks = 0;
     uint16_t *fast_rs = nullptr;  // fast path: per tile two 128-byte lines (record starts | edges, count, alignment)
     uint64_t *block_prefix = nullptr;
     size_t tiles_cap = 0;

@@ -102,6 +102,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->idx);
     (void)hipFree(ctx->tmp_rec);
     (void)hipFree(ctx->stats_scratch);
+    (void)hipFree(ctx->gather_ws);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->h_init) (void)hipHostFree(ctx->h_init);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -689,6 +690,45 @@ fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_fi
     fqh_status st = fqh_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars);
     if (st != FQH_OK) return st;
     return fqh_stats_finish(ctx, out, carry_out);
+}
+
+fqh_status fqh_record_flags(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t base_offset,
+                            const fqh_idx_record *d_index, uint64_t n, uint8_t *d_flags) {
+    if (!ctx || (n && (!d_buf || !d_index || !d_flags))) return FQH_E_ARG;
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is pending");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_record_flags(ctx->stream, d_buf, len, base_offset, d_index, n, d_flags);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FQH_OK;
+}
+
+fqh_status fqh_gather_records(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t base_offset,
+                              const fqh_idx_record *d_index, uint64_t n, const uint8_t *d_flags, uint8_t mask,
+                              uint8_t want, uint8_t *d_out, uint64_t out_cap, uint64_t *n_selected,
+                              uint64_t *out_bytes) {
+    if (!ctx || !n_selected || !out_bytes || (n && (!d_buf || !d_index || !d_flags))) return FQH_E_ARG;
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is pending");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t nb = gather_blocks(n);
+    if (nb + 1 > ctx->gather_ws_blocks) {
+        (void)hipFree(ctx->gather_ws);
+        ctx->gather_ws = nullptr;
+        ctx->gather_ws_blocks = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->gather_ws, (2 * (nb + 1) + 2) * sizeof(unsigned long long)));
+        ctx->gather_ws_blocks = nb + 1;
+    }
+    unsigned long long *bb = ctx->gather_ws, *br = bb + ctx->gather_ws_blocks, *tot = br + ctx->gather_ws_blocks;
+    launch_gather(ctx->stream, d_buf, len, base_offset, d_index, n, d_flags, mask, want, bb, br, tot, d_out,
+                  d_out ? out_cap : 0);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, tot, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_bytes = h[0];
+    *n_selected = h[1];
+    if (d_out && h[0] > out_cap) return fail(ctx, FQH_E_CAPACITY, "d_out capacity < bytes of the selected records");
+    return FQH_OK;
 }
 
 fqh_status fqh_last_timing(fqh_ctx *ctx, fqh_timing *out) {

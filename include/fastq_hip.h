@@ -15,7 +15,8 @@
  *   RecordSetIter::next             src/lib.rs:364-425            fqh_scan (record offsets) +
  *                                                                 fqh_index_records
  *   loop over Record::seq()/qual()  src/records.rs:75-90 (a8)     fqh_stats
- *   validate_dna / validate_dnan    src/records.rs:19-33          fqh_stats (scalars 3,4)
+ *   validate_dna / validate_dnan    src/records.rs:19-33          fqh_stats (scalars 3,4), fqh_record_flags
+ *   Record::write (filter loops)    src/records.rs:93-96          fqh_gather_records
  *   Buffer                          src/buffer.rs:1-112           fqh_stream_* (pinned ring)
  *   thread_reader                   src/thread_reader.rs:182-200  fqh_stream_* (copy stream)
  *   parallel_each gather            src/lib.rs:553-559            fqh_reduce_* (RCCL/torch)
@@ -157,6 +158,23 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
 fqh_status fqh_stats_launch_lead(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t lead_len,
                                  int is_final, const fqh_carry *in, uint32_t lmax,
                                  uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars);
+
+/* ---- Filter and rewrite: scan -> select -> gather -> write ----------------------
+ * Per-record alphabet flags of the sequence lines: bit 0 = Record::validate_dna (all of ACGT), bit 1 =
+ * Record::validate_dnan (all of ACGTN), src/records.rs:19-33, over seq() (one trailing '\r' trimmed).
+ * d_index[0..n): the IdxRecord-style index of fqh_index_records for this buffer; base_offset: file
+ * offset of d_buf[0] (the scan's carry-in base_offset; 0 for a whole file). */
+fqh_status fqh_record_flags(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t base_offset,
+                            const fqh_idx_record *d_index, uint64_t n, uint8_t *d_flags);
+/* Copies the raw bytes of every record with (d_flags[i] & mask) == want, in order and back to back,
+ * to d_out: what a filter loop over Record::write (RefRecord::write copies the record's bytes,
+ * src/records.rs:93-96) writes on the CPU.  *n_selected and *out_bytes always receive the totals;
+ * d_out may be NULL to size the output; FQH_E_CAPACITY if out_bytes > out_cap (records that do not
+ * fit completely are not written). */
+fqh_status fqh_gather_records(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t base_offset,
+                              const fqh_idx_record *d_index, uint64_t n, const uint8_t *d_flags,
+                              uint8_t mask, uint8_t want, uint8_t *d_out, uint64_t out_cap,
+                              uint64_t *n_selected, uint64_t *out_bytes);
 
 /* ---- Streaming ingest: the GPU counterpart of Buffer + thread_reader --------------------------
  * src/buffer.rs keeps one 68 KiB window and memmoves the partial trailing record to its front;

@@ -41,11 +41,22 @@ extern "C" {
     pub fn fqh_stream_submit(st: *mut fqh_stream, nbytes: u64, is_final: c_int) -> c_int;
     pub fn fqh_stream_collect(st: *mut fqh_stream, out: *mut fqh_chunk) -> c_int;
     pub fn fqh_stream_release(st: *mut fqh_stream) -> c_int;
+    // histograms per delivered record (FQH_STREAM_STATS) and the device-side filter (flags + gather);
+    // not needed by Parser itself, bound for consumers that want them
+    pub fn fqh_stream_set_stats(st: *mut fqh_stream, lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64,
+                                d_scalars: *mut u64) -> c_int;
+    pub fn fqh_record_flags(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, base_offset: u64,
+                            d_index: *const fqh_idx_record, n: u64, d_flags: *mut u8) -> c_int;
+    pub fn fqh_gather_records(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, base_offset: u64,
+                              d_index: *const fqh_idx_record, n: u64, d_flags: *const u8, mask: u8, want: u8,
+                              d_out: *mut u8, out_cap: u64, n_selected: *mut u64, out_bytes: *mut u64) -> c_int;
 }
 
 const FQH_OK: c_int = 0;
 const FQH_E_CAPACITY: c_int = 9;
 const FQH_STREAM_INDEX: u32 = 1;
+#[allow(dead_code)]
+const FQH_STREAM_STATS: u32 = 2;
 
 /// What `Parser` holds instead of `buffer::Buffer`.
 pub struct GpuScanner<R: Read> {

@@ -12,7 +12,7 @@ void set_dbg_flags(uint32_t);
 void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint16_t *, uint64_t, DevOut *, int, bool);
 void launch_emit_fast(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize_fast(hipStream_t, const ScanArgs &, DevOut *);
-void launch_prefix(hipStream_t, const uint32_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
+void launch_prefix(hipStream_t, uint32_t *, const uint16_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
 void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
 void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_record *, uint64_t,

@@ -178,7 +178,8 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     if (!reuse_index)
-        launch_prefix(s, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
+        launch_prefix(s, ctx->tile_count, fast ? ctx->fast_rs : nullptr, ctx->tile_prefix, ctx->block_prefix, a.n_tiles,
+                      a.n_blocks);
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     if (fast) {
         if (!ctx->skip_emit) launch_emit_fast(s, a, &ctx->d_out[0], ctx->n_cu);
@@ -398,7 +399,7 @@ static fqh_status ensure_full_index(fqh_ctx *ctx) {
         HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
         launch_index(ctx->stream, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs,
                      a.n_tiles, &ctx->d_out[1], ctx->n_cu, false);
-        launch_prefix(ctx->stream, ctx->tile_count, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
+        launch_prefix(ctx->stream, ctx->tile_count, nullptr, ctx->tile_prefix, ctx->block_prefix, a.n_tiles, a.n_blocks);
         DevOut tmp;
         HIPCHK(ctx, hipMemcpyAsync(&tmp, &ctx->d_out[1], sizeof(DevOut), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

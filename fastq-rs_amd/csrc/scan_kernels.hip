@@ -125,7 +125,11 @@ __device__ __forceinline__ void index_piece(const uint4 v, const uint64_t off, c
 
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of tile_count: per-block local prefix + block sums, then the block sums.
-__global__ __launch_bounds__(256) void k_prefix_local(const uint32_t *__restrict__ tile_count,
+// The counts are read at cnt[t * stride]: stride 1 = the dense tile_count array; stride 32 = the count
+// slot of the fast path's per-tile line (k_index_fast then issues one whole-line store per tile and
+// nothing else), copied to dense_out for later readers.
+__global__ __launch_bounds__(256) void k_prefix_local(const uint32_t *__restrict__ cnt, uint32_t stride,
+                                                      uint32_t *__restrict__ dense_out,
                                                       uint32_t *__restrict__ tile_prefix,
                                                       uint64_t *__restrict__ block_sum,
                                                       uint64_t n_tiles) {
@@ -136,8 +140,13 @@ __global__ __launch_bounds__(256) void k_prefix_local(const uint32_t *__restrict
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        c[i] = (t0 + i < n_tiles) ? tile_count[t0 + i] : 0u;
+        c[i] = (t0 + i < n_tiles) ? cnt[(t0 + i) * stride] : 0u;
         s += c[i];
+    }
+    if (dense_out) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (t0 + i < n_tiles) dense_out[t0 + i] = c[i];
     }
     // inclusive wave scan of s
     uint32_t inc = s;
@@ -841,7 +850,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
     };
     auto store_tile = [&](uint64_t tile, uint32_t run, uint32_t rv) {
         if (!(dbg & 4u)) fast_rs[tile * FR_STRIDE + lane] = (uint16_t)rv;        // one whole 128-byte line
-        if (lane == 0 && !(dbg & 1u)) tile_count[tile] = run;                    // dense copy for the prefix scan
+        if (lane == 0 && !(dbg & 1u) && tile_count) tile_count[tile] = run;      // dense copy (A/B: the prefix scan can read the line)
     };
 
     uint64_t tile = wave0;
@@ -1215,6 +1224,10 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
 }
 
+bool fast_count_in_line() {  // A/B switch (default on): the fast path keeps its entry count in the tile's line only
+    const char *e = getenv("FQH_FAST_COUNT_IN_LINE");
+    return !e || atoi(e) != 0;
+}
 void set_dbg_flags(uint32_t f) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_flags), &f, sizeof f); }
 int g_index_variant = -1;  // tuning hook (bench.py --variants); -1 = FQH_INDEX_VARIANT or default
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
@@ -1242,8 +1255,8 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
         uint64_t blocks = (n_tiles + 3) / 4;
         const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occf);
         if (blocks > maxb) blocks = maxb;
-        hipLaunchKernelGGL(k_index_fast, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap, tile_count,
-                           fast_rs, n_tiles, out);
+        hipLaunchKernelGGL(k_index_fast, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
+                           fast_count_in_line() ? (uint32_t *)nullptr : tile_count, fast_rs, n_tiles, out);
         return;
     }
     if (!occ[v]) {
@@ -1276,11 +1289,16 @@ void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
 void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {
     hipLaunchKernelGGL(k_finalize_fast, dim3(1), dim3(64), 0, s, a, out);
 }
-void launch_prefix(hipStream_t s, const uint32_t *tile_count, uint32_t *tile_prefix,
+void launch_prefix(hipStream_t s, uint32_t *tile_count, const uint16_t *fast_rs, uint32_t *tile_prefix,
                    uint64_t *block_prefix, uint64_t n_tiles, uint64_t n_blocks) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_prefix_local, dim3((uint32_t)n_blocks), dim3(256), 0, s, tile_count,
-                       tile_prefix, block_prefix, n_tiles);
+    if (fast_rs && fast_count_in_line())
+        hipLaunchKernelGGL(k_prefix_local, dim3((uint32_t)n_blocks), dim3(256), 0, s,
+                           reinterpret_cast<const uint32_t *>(fast_rs + FR_CNT), FR_STRIDE / 2, tile_count, tile_prefix,
+                           block_prefix, n_tiles);
+    else
+        hipLaunchKernelGGL(k_prefix_local, dim3((uint32_t)n_blocks), dim3(256), 0, s, (const uint32_t *)tile_count, 1u,
+                           (uint32_t *)nullptr, tile_prefix, block_prefix, n_tiles);
     hipLaunchKernelGGL(k_prefix_top, dim3(1), dim3(1024), 0, s, block_prefix, n_blocks);
 }
 void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {

@@ -790,6 +790,7 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
 //     whole group (~5 us of work per wave) away, by which time loads and stores have both landed.
 // Whole tiles only; the (at most one) partial tile at the end of the buffer is taken by wave 0 of
 // block 0 through the generic piece loop afterwards.
+template <bool NT>
 __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ buf, uint64_t len,
                                                     uint16_t *__restrict__ list, uint32_t list_cap,
                                                     uint32_t *__restrict__ tile_count, uint16_t *__restrict__ fast_rs,
@@ -836,8 +837,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
             else if (lane < FR_EDGE + 8) rv = lst[run - 8 + (lane - FR_EDGE)];
             if (hyp + 4 * FR_N < run) {  // more record starts than the line holds: a second whole line ...
                 const uint32_t j2 = FR_N + lane;
-                fast_rs[fr2_off(n_tiles) + tile * FR2_N + lane] =
-                    hyp + 4 * j2 < run ? (uint16_t)(lst[hyp + 4 * j2] & 0x3FFFu) : (uint16_t)0;
+                __builtin_nontemporal_store(hyp + 4 * j2 < run ? (uint16_t)(lst[hyp + 4 * j2] & 0x3FFFu) : (uint16_t)0,
+                                            fast_rs + fr2_off(n_tiles) + tile * FR2_N + lane);
                 if (hyp + 4 * (FR_N + FR2_N) < run) {  // ... and the list area for the rest (reads shorter than ~25 bp)
                     uint16_t *__restrict__ tl = list + tile * list_cap;
                     for (uint32_t j = FR_N + FR2_N + lane; hyp + 4 * j < run; j += 64) tl[8 + j] = lst[hyp + 4 * j] & 0x3FFFu;
@@ -849,7 +850,13 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         rv = lane == FR_CNT ? (run & 0xFFFFu) : lane == FR_CNT + 1 ? (run >> 16) : lane == FR_HYP ? hyp : rv;
     };
     auto store_tile = [&](uint64_t tile, uint32_t run, uint32_t rv) {
-        if (!(dbg & 4u)) fast_rs[tile * FR_STRIDE + lane] = (uint16_t)rv;        // one whole 128-byte line
+        // one whole 128-byte line, non-temporal: written once, read once by k_emit_fast.  On the boxes where
+        // a plain store costs the kernel 0.45 ms, this one costs 0.2.  (No plain/nt switch here: the
+        // optimizer merges two stores to one address and drops the hint.)
+        if (!(dbg & 4u)) {
+            if (NT) __builtin_nontemporal_store((uint16_t)rv, fast_rs + tile * FR_STRIDE + lane);
+            else fast_rs[tile * FR_STRIDE + lane] = (uint16_t)rv;  // A/B only (FQH_NT_STORES=0)
+        }
         if (lane == 0 && !(dbg & 1u) && tile_count) tile_count[tile] = run;      // dense copy (A/B: the prefix scan can read the line)
     };
 
@@ -962,7 +969,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // the record that straddles into it (five line starts out of the two tiles' 16-byte edge blocks).
 // Phase B, one iteration per tile: readlane the three scalars, one 2-byte load and one 8-byte
 // store per lane, in rounds of 16 loads then 16 stores.  ~25 instructions per tile instead of ~110.
-template <uint32_t EMIT_ROUND>
+template <uint32_t EMIT_ROUND, bool NT>
 __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
     __shared__ uint16_t stage_all[4][EMIT_ROUND * 64];
     uint16_t *const stage = stage_all[threadIdx.x >> 6];
@@ -1065,7 +1072,10 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
                 if (n <= FR_N) {  // the common case: everything is in the tile's line
                     const uint32_t oprev = wave_shr1(o, 0u);
                     if (lane < n) {
-                        if (rs && (cap_ok || rb + lane < a.cap)) rs[lane] = vbase + o;
+                        if (rs && (cap_ok || rb + lane < a.cap)) {
+                            if (NT) __builtin_nontemporal_store((uint64_t)(vbase + o), rs + lane);  // written once, not read here
+                            else rs[lane] = vbase + o;
+                        }
                         if (lane) {  // record lane-1 of the tile lies inside it: its length
                             const uint32_t reclen = o - oprev;
                             maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
@@ -1087,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
                     const uint32_t oprev = wave_shr1(oo, carry);
                     carry = (uint32_t)__builtin_amdgcn_readlane((int)oo, 63);
                     if (m < n) {
-                        if (rs && (cap_ok || rb + m < a.cap)) rs[m] = vbase + oo;
+                        if (rs && (cap_ok || rb + m < a.cap)) __builtin_nontemporal_store((uint64_t)(vbase + oo), rs + m);
                         if (m) {  // record m-1 of the tile lies inside it: its length
                             const uint32_t reclen = oo - oprev;
                             maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
@@ -1224,6 +1234,10 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
 }
 
+int nt_stores() {  // A/B switch: bit 0 non-temporal stores in k_index_fast, bit 1 in k_emit_fast (default: both)
+    const char *e = getenv("FQH_NT_STORES");
+    return e ? atoi(e) : 3;
+}
 bool fast_count_in_line() {  // A/B switch (default on): the fast path keeps its entry count in the tile's line only
     const char *e = getenv("FQH_FAST_COUNT_IN_LINE");
     return !e || atoi(e) != 0;
@@ -1249,14 +1263,18 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
         static int occf = 0;
         if (!occf) {
             int o = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast, 256, 0) != hipSuccess || o < 1) o = 4;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast<true>, 256, 0) != hipSuccess || o < 1) o = 4;
             occf = o > 8 ? 8 : o;
         }
         uint64_t blocks = (n_tiles + 3) / 4;
         const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occf);
         if (blocks > maxb) blocks = maxb;
-        hipLaunchKernelGGL(k_index_fast, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
-                           fast_count_in_line() ? (uint32_t *)nullptr : tile_count, fast_rs, n_tiles, out);
+        if (nt_stores() & 1)
+            hipLaunchKernelGGL(k_index_fast<true>, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
+                               fast_count_in_line() ? (uint32_t *)nullptr : tile_count, fast_rs, n_tiles, out);
+        else
+            hipLaunchKernelGGL(k_index_fast<false>, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
+                               fast_count_in_line() ? (uint32_t *)nullptr : tile_count, fast_rs, n_tiles, out);
         return;
     }
     if (!occ[v]) {
@@ -1279,11 +1297,8 @@ void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
         static const int bpc = getenv("FQH_EMIT_BPC") ? atoi(getenv("FQH_EMIT_BPC")) : 4;
         const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc > 0 ? bpc : 4);
         if (blocks > maxb) blocks = maxb;
-        static const int rnd = getenv("FQH_EMIT_ROUND") ? atoi(getenv("FQH_EMIT_ROUND")) : 16;
-        if (rnd == 4) hipLaunchKernelGGL(k_emit_fast<4>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
-        else if (rnd == 8) hipLaunchKernelGGL(k_emit_fast<8>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
-        else if (rnd == 32) hipLaunchKernelGGL(k_emit_fast<32>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
-        else hipLaunchKernelGGL(k_emit_fast<16>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        if (nt_stores() & 2) hipLaunchKernelGGL((k_emit_fast<16, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        else hipLaunchKernelGGL((k_emit_fast<16, false>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
     }
 }
 void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {

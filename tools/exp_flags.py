@@ -15,12 +15,12 @@ ctx.synth_fill(buf.data_ptr(), 0, nbytes)
 rs = torch.empty(nrec + 16, dtype=torch.int64, device=dev)
 ctx.scan(buf.data_ptr(), nbytes, True, None, rs.data_ptr(), nrec + 16)
 for rnd in range(3):
-    for f in (0, 1, 2, 4, 3, 7, 0):
+    for f in [int(x) for x in os.environ.get("FQH_EXP_FLAGS", "0,4,8,16,32,0").split(",")]:
         L.fqh_debug_set_flags(ctypes.c_uint(f))
-        ts = []
+        ts = []; te = []
         for _ in range(5):  # the skipped stores' targets still hold the previous (identical) results
             ctx.scan(buf.data_ptr(), nbytes, True, None, rs.data_ptr(), nrec + 16)
             assert ctx.last_scan_fast()
-            ts.append(ctx.timing().index_ms)
-        print("flags %d: index min %.3f med %.3f" % (f, min(ts), sorted(ts)[2]), flush=True)
+            tt = ctx.timing(); ts.append(tt.index_ms); te.append(tt.emit_ms)
+        print("flags %d: index min %.3f med %.3f | emit min %.3f med %.3f" % (f, min(ts), sorted(ts)[2], min(te), sorted(te)[2]), flush=True)
 L.fqh_debug_set_flags(ctypes.c_uint(0))

@@ -53,7 +53,7 @@ struct ScanArgs {
     uint64_t idx_cap;
 };
 
-// Arguments of the line-parallel histogram kernel (stats_kernels.hip: k_stats_lines).
+// Arguments of the line-parallel histogram kernels (stats_kernels.hip: k_stats_oct, k_stats_lines).
 struct StatsArgs {
     const uint8_t *buf;
     uint64_t len;

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_index_fast: the fast path's index kernel — k_index_t<1, 2> restructured around
+// k_index_fast: the fast path's index kernel — the byte scan of k_index_t, restructured around
 // the one thing that keeps it off the read ceiling: on gfx950 stores share vmcnt with loads, and the
 // compiler's wait in front of a group's LDS write is vmcnt(0).  A wavefront that stores its tile's
 // results and then loads the next tile sits out the store acknowledgement and the load latency once

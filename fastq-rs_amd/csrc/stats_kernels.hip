@@ -102,7 +102,8 @@ void launch_stats_records(hipStream_t s, const uint8_t *buf, uint64_t base_offse
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_stats_lines — the production histogram kernel.
+// k_stats_lines — the second histogram kernel (one line per lane); superseded by k_stats_oct below and kept
+// as FQH_STATS_VARIANT=1, an independent statement of the same result for cross-checks.
 //
 // Unit of parallelism = one LINE per lane.  The scan's tile index already lists every line start,
 // and the tile prefix gives each line its global index, hence its role (index % 4 == 1: sequence,

@@ -1,5 +1,5 @@
 // tools/ldsatom.hip — cost model of ds_add_u32 (LDS atomics without return) on gfx950, the
-// primitive behind k_stats_lines.  One 1024-thread block per CU; every wave issues ITER x 16
+// primitive behind the histogram kernels (k_stats_lines, k_stats_oct).  One 1024-thread block per CU; every wave issues ITER x 16
 // atomics whose address pattern is selected by `pat`.  Prints LDS-array cycles per wave-instruction
 // per CU (wall time x clock / instructions issued on that CU).
 //   pat 0: lane l -> word l                    (conflict-free, 64 distinct banks/addresses)

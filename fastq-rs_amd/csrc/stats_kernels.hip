@@ -503,6 +503,10 @@ struct SoBatch {                 // one batch in flight: 8 lines, this lane's dw
     uint32_t w[NSL];
 };
 
+struct SoAcc {                   // per-lane totals (the lane that owns a line adds it)
+    uint32_t rec;
+    unsigned long long bases, qual, oseq, oqual;
+};
 // Wave-uniform per-wave totals that need no vector registers.
 struct SoTotals {
     uint32_t not_dna;            // sequence lines with an 'N' or a byte outside the alphabet
@@ -522,7 +526,7 @@ __device__ __forceinline__ uint32_t so_groups(unsigned long long lanes) {  // 8-
 template <bool IS_SEQ, uint32_t NSL>
 __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbase, SoBatch<NSL> &B, uint32_t lane,
                                          uint32_t lc, uint32_t *hist, const SoLane &c, uint32_t my_len,
-                                         uint32_t src4, SoTotals &T, StatsAcc &acc) {
+                                         uint32_t src4, SoTotals &T, SoAcc &acc) {
     const uint32_t m = lane & 7u, m4 = m * 4u;
     const uint32_t P = B.P;
     const uint32_t nfull4 = P & 0x1FFu;                            // columns covered by whole dwords
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         c.sel[k] = 0x07060004u | (j << 8);
         c.A[k] = ((lane & 7u) + 8u * j) * 4u;
     }
-    StatsAcc acc = {0, 0, 0, 0, 0, 0, 0};
+    SoAcc acc = {0, 0, 0, 0, 0};
     SoTotals T = {0, 0};
 
     // What a wave needs to know about a tile before it can start on it, loaded one tile ahead (the

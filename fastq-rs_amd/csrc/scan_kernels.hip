@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ o
             const int j = (int)(i0 + 4 * m);
             const uint32_t o = st[j] & 0x1FFFFu, o1 = st[j - 1] & 0x1FFFFu, o2 = st[j - 2] & 0x1FFFFu;
             const uint32_t o3 = st[j - 3] & 0x1FFFFu, o4 = st[j - 4] & 0x1FFFFu;
-            if (rs && (cap_ok || rbase + m < a.cap)) rs[m] = vbase + o;
+            if (rs && (cap_ok || rbase + m < a.cap)) __builtin_nontemporal_store((uint64_t)(vbase + o), rs + m);  // written once, not read here
             mism |= ((o - o1) != (o2 - o3)) ? 1u : 0u;  // src/records.rs:233-238
             const uint32_t reclen = o - o4;
             maxlen32 = reclen > maxlen32 ? reclen : maxlen32;

@@ -642,6 +642,9 @@ constexpr uint32_t LSTAGE_ENTRIES = 512;
 // (unused slots 0), [FR_EDGE..+8) its first four and last four entries, [FR_CNT..+2) the entry count,
 // [FR_HYP] the alignment (7: none).  Record starts FR_N .. FR_N + 63 of a tile (reads shorter than ~140 bp)
 // go to a second whole line, fast_rs + FR2_OFF(n_tiles) + tile * 64; anything beyond into list[tile][8 + j].
+// Line starts per tile the fast path can stage (reads down to ~25 bp); 6 blocks per CU fit with this, which
+// measures the same as the 7 that 512 entries allow (tools/exp_ab_env.py FQH_INDEX_BPC 0 6).
+constexpr uint32_t FAST_ENTRIES = 1024;
 constexpr uint32_t FR_N = 52, FR_EDGE = 52, FR_CNT = 60, FR_HYP = 62, FR_STRIDE = 64, FR2_N = 64;
 __host__ __device__ __forceinline__ uint64_t fr2_off(uint64_t n_tiles) { return (n_tiles + 64) * FR_STRIDE; }
 __device__ uint32_t g_dbg_flags = 0;  // timing experiments only (tools/exp_*.py): 1 no count store, 2 no meta store, 4 no record-start store
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                                                     uint16_t *__restrict__ list, uint32_t list_cap,
                                                     uint32_t *__restrict__ tile_count, uint16_t *__restrict__ fast_rs,
                                                     uint64_t n_tiles, DevOut *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + LSTAGE_ENTRIES * 2 + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + FAST_ENTRIES * 2 + 16];
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *const lds = lds_all[threadIdx.x >> 6];
     uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + 4096);
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                     }
                 }
                 const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
-                if (run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
+                if (run == nstaged && run + tot <= FAST_ENTRIES) {  // uniform: stage in LDS
                     uint16_t *dst = lst + run + pre;
                     while (ls_lo) {
                         const uint32_t q = __ffs(ls_lo) - 1;
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                         *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
                     }
                     nstaged = run + tot;
-                }  // else: more than 512 line starts in a tile: left to the exact path
+                }  // else: more than FAST_ENTRIES line starts in a tile: left to the exact path
                 run += tot;
             }
             finish_tile(tile, run, nstaged, prv);
@@ -951,10 +954,10 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
             const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
             if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
             const uint4 v = load16(buf, off, len);
-            index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, LSTAGE_ENTRIES);
+            index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, FAST_ENTRIES);
         }
         uint32_t rv;
-        finish_tile(t, run, run <= LSTAGE_ENTRIES ? run : 0u, rv);
+        finish_tile(t, run, run <= FAST_ENTRIES ? run : 0u, rv);
         store_tile(t, run, rv);
     }
     if (lane == 0 && n_over) atomicAdd(&out->spec_fail, (unsigned long long)n_over);
@@ -1248,7 +1251,7 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
                   uint32_t *tile_count, uint16_t *fast_rs, uint64_t n_tiles, DevOut *out, int n_cu, bool fast) {
     if (!n_tiles) return;
     static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 5;
-    static const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;
+    const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;  // tuning: blocks per CU
     typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
     // 4: no prefetch, 5: production exact (register prefetch of the next 4 KiB group), 6: list staged
     // in LDS; the fast path has its own kernel (k_index_fast)

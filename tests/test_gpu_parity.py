@@ -505,18 +505,20 @@ def test_fast_path_backoff_after_failure(fqref, torch, pkg):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["ragged", "short", "tiny", "mixed_crlf"])
+@pytest.mark.parametrize("shape", ["ragged", "short", "tiny", "micro", "mixed_crlf"])
 def test_quarter_gib_ragged_reads_offsets_and_histograms(fqref, torch, pkg, shape):
     """256 MiB of reads with ragged lengths (a ~3 MiB random block repeated; its size is not a multiple of
     the 16 KiB tile, so every repetition meets the tile grid differently): 16 384 tiles through the fast
     path (second lines for short reads included), offsets and histograms bit-exact against the oracle."""
-    rng = np.random.default_rng({"ragged": 11, "short": 12, "tiny": 14, "mixed_crlf": 13}[shape])
+    rng = np.random.default_rng({"ragged": 11, "short": 12, "tiny": 14, "micro": 15, "mixed_crlf": 13}[shape])
     if shape == "ragged":
         block = fuzzgen.valid_file(rng, 12000, maxlen=250)
     elif shape == "short":   # ~105 records per tile: the second line of the fast path's tile record
         block = fuzzgen.valid_file(rng, 25000, maxlen=140)
-    elif shape == "tiny":    # more than 512 line starts per tile: the fast path declines, the exact path answers
+    elif shape == "tiny":    # ~870 line starts per tile: record starts beyond the two lines spill into the list area
         block = fuzzgen.valid_file(rng, 40000, maxlen=60)
+    elif shape == "micro":   # more than 1024 line starts per tile: the fast path declines, the exact path answers
+        block = fuzzgen.valid_file(rng, 80000, maxlen=20)
     else:
         block = b"".join(fuzzgen.valid_file(rng, 50, maxlen=200, crlf=bool(i & 1)) for i in range(200))
     reps = (256 << 20) // len(block)
@@ -531,7 +533,7 @@ def test_quarter_gib_ragged_reads_offsets_and_histograms(fqref, torch, pkg, shap
     rs = torch.zeros(res.n_records + 1, dtype=torch.int64, device=dev)
     s, c, st = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), res.n_records + 1)
     assert (s.parse_status, s.n_records) == (res.status, res.n_records)
-    assert ctx.last_scan_fast() == (shape != "tiny")
+    assert ctx.last_scan_fast() == (shape != "micro")
     assert np.array_equal(rs.cpu().numpy().astype(np.uint64)[:-1], off)
     lmax = 250
     r, qh, bh, sc = fqref.stats(host, lmax)

@@ -77,6 +77,7 @@ struct fqh_ctx {
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...
     uint32_t spec_backoff = 0;  // ... 1, 2, 4 .. 64 of them, doubling with every failure in a row
     bool index_full = true;     // the tile index in the workspace holds complete line lists
+    bool dout_clean = false;    // d_out[0]'s accumulators were reset by the last finalize kernel (no init copy needed)
     bool used_spec = false;     // the scan in flight runs the fast path
     fqh_summary last_summary = {};
     fqh_carry last_carry_out = {};

@@ -169,7 +169,9 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     a.tile_prefix = ctx->tile_prefix;
     a.block_prefix = ctx->block_prefix;
     ctx->used_spec = fast;
-    HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
+    a.mirror = ctx->h_out;  // the finalize kernel publishes its results there and resets the accumulators
+    if (!ctx->dout_clean) HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
+    ctx->dout_clean = false;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
     if (!reuse_index) {
         launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs, a.n_tiles,
@@ -190,7 +192,6 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_out, &ctx->d_out[0], sizeof(DevOut), hipMemcpyDeviceToHost, s));
     return FQH_OK;
 }
 
@@ -250,6 +251,7 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
                 fqh_status fst = ensure_full_index(ctx);
                 if (fst != FQH_OK) return fst;
                 ScanArgs b = ctx->args;
+                b.mirror = nullptr;  // a side launch on d_out[1]: the main results in h_out stay
                 b.rec_start = ctx->tmp_rec;
                 b.cap = n + 1;
                 b.idx = nullptr;
@@ -345,6 +347,7 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     ctx->pending = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dout_clean = true;  // the finalize kernel has run
     if (ctx->used_spec && ctx->h_out->spec_fail) {
         // the fast path could not prove the input valid (a real error, lines longer than a few KiB,
         // or a degenerate layout): run the exact path, and keep later scans of this context on it for a
@@ -355,6 +358,7 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
         fqh_status st = enqueue_scan(ctx, false, false);
         if (st != FQH_OK) return st;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->dout_clean = true;
     }
     else if (ctx->used_spec) ctx->spec_backoff = 0;
     // (ctx->used_spec now tells whether the result in h_out came from the fast path)
@@ -367,6 +371,7 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
             fqh_status st = enqueue_scan(ctx, false, false);
             if (st != FQH_OK) return st;
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->dout_clean = true;
         }
     }
     float ms = 0;
@@ -420,6 +425,7 @@ static fqh_status emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t cap) {
     fqh_status fst = ensure_full_index(ctx);
     if (fst != FQH_OK) return fst;
     ScanArgs b = ctx->args;
+    b.mirror = nullptr;  // a side launch on d_out[1]: the main results in h_out stay
     b.rec_start = nullptr;
     b.cap = 0;
     b.idx = dst;

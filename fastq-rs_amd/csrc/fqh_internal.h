@@ -51,6 +51,7 @@ struct ScanArgs {
     uint64_t cap;
     fqh_idx_record *idx;
     uint64_t idx_cap;
+    struct DevOut *mirror;         // pinned host copy of the results, written by the finalize kernel (nullable)
 };
 
 // Arguments of the line-parallel histogram kernels (stats_kernels.hip: k_stats_oct, k_stats_lines).

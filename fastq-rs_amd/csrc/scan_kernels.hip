@@ -549,6 +549,19 @@ __device__ long long start_of_line(const ScanArgs &a, unsigned long long L, unsi
 
 // k_finalize: one thread.  EOF rule of src/lib.rs:264-294, virtual entries at both chunk ends,
 // carry-out, summary.
+// Last act of a finalize kernel: hand the results to the host (pinned memory, visible when the kernel has
+// completed: no separate device-to-host copy) and leave the accumulators clean for the next scan (no
+// host-to-device copy in front of it).
+__device__ __forceinline__ void publish_and_reset(const ScanArgs &a, DevOut *out) {
+    if (!a.mirror) return;
+    *a.mirror = *out;
+    out->min_key = NOKEY;
+    out->first_long = NOKEY;
+    out->max_len = 0;
+    out->overflow = 0;
+    out->spec_fail = 0;
+}
+
 __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
@@ -621,6 +634,7 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
     out->err_start = err_start;
     out->err_need = need;
     out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
+    publish_and_reset(a, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1235,6 +1249,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     out->err_start = recent[T & 3];
     out->err_need = 0;
     out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
+    publish_and_reset(a, out);
 }
 
 int nt_stores() {  // A/B switch: bit 0 non-temporal stores in k_index_fast, bit 1 in k_emit_fast (default: both)

@@ -407,10 +407,11 @@ constexpr uint32_t SO_WAVES = SO_THREADS / 64;
 constexpr uint32_t SO_LC_MAX = 256;           // rows kept in LDS
 constexpr uint32_t SO_QBYTES = 4 * 64 * 256;  // quality region: 4 row blocks x 64 bins x 64 slots x 4 B
 constexpr uint32_t SO_SBYTES = 4 * 8 * 256;   // sequence region
-constexpr uint32_t SO_WORDS = (SO_QBYTES + SO_SBYTES) / 4;
+constexpr uint32_t SO_WORDS = (SO_QBYTES + SO_SBYTES) / 4;  // the sequence region comes first: [0, SO_SBYTES)
 constexpr uint32_t SO_LISTW = 512;            // list entries staged in LDS per wave (u16 each); 256 when extra rows need the room
 constexpr uint32_t SO_LX_MAX = 256;           // extra rows (columns 256 .. 511) in a plain [row][72] layout, exact path only
 constexpr uint32_t SO_LDS_MAX = 160 * 1024;
+constexpr uint32_t SO_ADDR_SPAN = 65536 + SO_SBYTES + 128 + 3 * 16384;  // see launch_stats_oct
 
 __device__ __forceinline__ uint32_t so_slot(uint32_t r) {  // r = row % 64
     return ((r >> 2) & 7u) | ((r & 3u) << 3) | (r & 32u);
@@ -422,7 +423,7 @@ __device__ __forceinline__ uint32_t so_row6(uint32_t slot) {
 template <bool IS_SEQ>
 __device__ __forceinline__ uint32_t so_word(uint32_t bin, uint32_t row) {
     const uint32_t rb = row >> 6, slot = so_slot(row & 63u);
-    return IS_SEQ ? SO_QBYTES / 4 + ((rb << 9) | (bin << 6) | slot) : ((rb << 12) | (bin << 6) | slot);
+    return IS_SEQ ? ((rb << 9) | (bin << 6) | slot) : SO_SBYTES / 4 + ((rb << 12) | (bin << 6) | slot);
 }
 __device__ __forceinline__ uint32_t load4_any(const uint8_t *__restrict__ p, const uint8_t *__restrict__ end) {
     uint32_t v = 0;
@@ -440,10 +441,9 @@ __device__ __forceinline__ uint32_t load4_fast(const uint8_t *__restrict__ p) {
 }
 
 struct SoLane {          // per-lane constants of the bank schedule
-    uint32_t sel[4];     // v_perm selector of the k-th atomic: bytes 0, 2, 3 of the address register,
-                         // byte 1 = byte k ^ (g & 3) of the bins
-    uint32_t A[4];       // address registers: LDS byte address of slot m + 8 (k ^ g) in the region of
-                         // the kind being counted, byte 1 (the bin) zero
+    uint32_t sel[4];     // v_perm selector of the k-th atomic: byte 0 = byte k of `slots`, byte 1 = byte
+                         // j = k ^ (g & 3) of the bins, bytes 2-3 zero
+    uint32_t slots;      // byte k: 4 * (m + 8 j), the slot's byte offset in a bin's 256 bytes
 };
 
 // ds_add_u32 with the u & 1 half of the slot (128 bytes) as the instruction's immediate offset.
@@ -463,8 +463,7 @@ __device__ __forceinline__ uint32_t *so_extra(const StatsArgs &a, uint32_t *hist
 // view of the bank-scheduled rows: 0 in tiles that take the exact path for everything.)
 template <bool IS_SEQ>
 __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, uint32_t pos, uint32_t len, uint32_t lc,
-                                              uint32_t *hist, uint32_t &any_n, uint32_t &any_inv,
-                                              unsigned long long &ovf) {
+                                              uint32_t *hist, uint32_t &any_n, uint32_t &any_inv) {
     const int rem = (int)len - (int)pos;
     const uint32_t nb = rem >= 4 ? 4u : (uint32_t)(rem > 0 ? rem : 0);
     for (uint32_t j = 0; j < nb; ++j) {
@@ -478,12 +477,12 @@ __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, ui
             if (col < lc) atomicAdd(hist + so_word<true>(bin, col), 1u);
             else if (col - a.lc < a.lx) atomicAdd(so_extra(a, hist) + (col - a.lc) * 72u + 64u + bin, 1u);
             else if (col < a.lmax) atomicAdd(&a.base_hist[(uint64_t)col * 8 + bin_to_class(bin)], 1ull);
-            else ++ovf;
+            else atomicAdd(&a.scalars[IS_SEQ ? 5 : 6], 1ull);  // a column beyond the caller's lmax
         } else {
             if (col < lc && b - 33u < 64u) atomicAdd(hist + so_word<false>(b - 33u, col), 1u);
             else if (col - a.lc < a.lx && b - 33u < 64u) atomicAdd(so_extra(a, hist) + (col - a.lc) * 72u + (b - 33u), 1u);
             else if (col < a.lmax) atomicAdd(&a.qual_hist[(uint64_t)col * 256 + b], 1ull);
-            else ++ovf;
+            else atomicAdd(&a.scalars[IS_SEQ ? 5 : 6], 1ull);  // a column beyond the caller's lmax
         }
     }
 }
@@ -505,7 +504,7 @@ struct SoBatch {                 // one batch in flight: 8 lines, this lane's dw
 
 struct SoAcc {                   // per-lane totals (the lane that owns a line adds it)
     uint32_t rec;
-    unsigned long long bases, qual, oseq, oqual;
+    unsigned long long bases, qual;
 };
 // Wave-uniform per-wave totals that need no vector registers.
 struct SoTotals {
@@ -519,95 +518,116 @@ __device__ __forceinline__ uint32_t so_groups(unsigned long long lanes) {  // 8-
     return (uint32_t)__builtin_popcountll(lanes & 0x0101010101010101ull);
 }
 
-// Count one batch (its loads were issued one batch earlier).  Pass 1 checks every whole dword the
-// batch counts (lanes without one get a filler), pass 2 adds them: one v_perm_b32 and one ds_add
-// per byte, no divergence.  A byte outside the window / alphabet sends the whole batch to the exact
-// path instead.
-template <bool IS_SEQ, uint32_t NSL>
-__device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbase, SoBatch<NSL> &B, uint32_t lane,
-                                         uint32_t lc, uint32_t *hist, const SoLane &c, uint32_t my_len,
+// What a lane derives from the shape of its line (whole dwords, partial tail, longer than the LDS rows)
+// and its place in the group; kept across batches and worked out again only when a line of another
+// shape turns up (reads of one length: once per tile kind).
+template <uint32_t NSL>
+struct SoShape {
+    uint32_t key;             // low 16 bits of the P it was derived from
+    uint32_t full[NSL];       // ~0 where this lane has a whole dword of its line at step u
+    uint32_t tmask;           // ~0 in the lanes (m < nbt) that add one column of the partial last dword
+    uint32_t tsel;            // v_perm selector: that column's byte over three filler bytes
+    uint32_t taddr_q, taddr_s;  // its LDS byte address (bin byte zero) in the quality / sequence region
+    uint32_t any;             // wave-uniform: 1 some line has a partial last dword, 2 some line is longer than the rows
+};
+template <uint32_t NSL>
+__device__ __forceinline__ void so_shape(SoShape<NSL> &S, uint32_t P, uint32_t m) {
+    S.key = P & 0xFFFFu;
+    const uint32_t nfull4 = P & 0x1FFu;
+    const int tt = (int)nfull4 - (int)(4u * m);
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) S.full[u] = tt > (int)(32u * u) ? 0xFFFFFFFFu : 0u;
+    const uint32_t nbt = (P >> SO_P_NBT) & 3u;
+    const bool has = m < nbt;
+    const uint32_t row = nfull4 + m, rb = row >> 6, slot4 = so_slot(row & 63u) << 2;
+    S.tmask = has ? 0xFFFFFFFFu : 0u;
+    S.tsel = has ? (0x04040400u | m) : 0x04040404u;
+    S.taddr_q = has ? (SO_SBYTES + ((rb << 14) | slot4)) : SO_SBYTES;
+    S.taddr_s = has ? ((rb << 11) | slot4) : 0u;
+    S.any = (__ballot(nbt != 0) != 0 ? 1u : 0u) | (__ballot((P >> SO_P_LONG) & 1u) != 0 ? 2u : 0u);
+}
+// ds_sub_u32 of a lane mask (~0 counts one, 0 counts nothing) with the row block and the u & 1 half of
+// the slot as the instruction's immediate offset.
+template <uint32_t OFF>
+__device__ __forceinline__ void lds_sub(uint32_t byte_addr, uint32_t v) {
+    asm volatile("ds_sub_u32 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF));
+}
+
+// Count one batch (its loads were issued one batch earlier), straight-line: pass 1 checks every byte
+// the batch counts (whole dwords under the lane's masks, the partial tail over filler bytes), pass 2
+// adds them -- one v_perm_b32 and one ds_sub per byte; lanes without a whole dword subtract 0 at
+// whatever address their bytes give (the kernel's LDS allocation covers every address a byte can
+// form).  A byte outside the window / alphabet sends the whole batch to the exact path instead.
+template <bool IS_SEQ, uint32_t NSL, bool DBG>
+__device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbase, SoBatch<NSL> &B, SoShape<NSL> &S,
+                                         uint32_t lane, uint32_t lc, uint32_t *hist, const SoLane &c, uint32_t my_len,
                                          uint32_t src4, SoTotals &T, SoAcc &acc) {
     const uint32_t m = lane & 7u, m4 = m * 4u;
     const uint32_t P = B.P;
+    if (__ballot((P & 0xFFFFu) != S.key) != 0) so_shape<NSL>(S, P, m);
     const uint32_t nfull4 = P & 0x1FFu;                            // columns covered by whole dwords
-    const int tt = (int)nfull4 - (int)m4;
     constexpr uint32_t FILL = IS_SEQ ? 0x41414141u : 0x21212121u;
-    uint32_t any_n = 0, any_inv = 0;
-    uint32_t chk = 0;  // sequence: OR of (dword ^ expected); quality: OR of the bins' bits 6-7
-    uint32_t nsteps = 0;                       // wave-uniform
-    do {
-#define FQH_SO_PASS1(U)                                                                        \
-        if (U < NSL) {                                                                         \
-            const bool full = tt > (int)(32u * U);                                             \
-            if (__ballot(full) == 0) break;                                                    \
-            nsteps = U + 1;                                                                    \
-            const uint32_t wf = full ? B.w[U < NSL ? U : 0] : FILL;                            \
-            B.w[U < NSL ? U : 0] = wf;                                                         \
-            if (IS_SEQ) {                                                                      \
-                chk |= wf ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, wf & 0x07070707u); \
-            } else {                                                                           \
-                /* byte - 33 < 64 for all four bytes: a byte below '!' borrows, but its own    */ \
-                /* difference is then >= 0xDF, one above '`' gives >= 0x40: bits 6-7 tell     */ \
-                chk |= (wf - 0x21212121u) & 0xC0C0C0C0u;                                       \
-            }                                                                                  \
-        }
-        FQH_SO_PASS1(0) FQH_SO_PASS1(1) FQH_SO_PASS1(2) FQH_SO_PASS1(3)
-        FQH_SO_PASS1(4) FQH_SO_PASS1(5) FQH_SO_PASS1(6) FQH_SO_PASS1(7)
+    constexpr uint32_t RB = IS_SEQ ? 2048u : 16384u;               // address step of a row block
+    constexpr uint32_t REGION = IS_SEQ ? 0u : SO_SBYTES;           // the region's base goes into the immediate offset too
+    const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.any);
+    const bool tails = (any & 1u) != 0, longs = (any & 2u) != 0;
+    uint32_t chk = 0;  // sequence: OR of (dword ^ expected); quality: OR of (byte - 33), bits 6-7 tell
+    uint32_t orw = 0;  // sequence: OR of the counted bytes; bit 3 is set in 'N' only
+    uint32_t wt = 0;
+#define FQH_SO_PASS1(U)                                                                            \
+    if (U < NSL) {                                                                                 \
+        const uint32_t w = B.w[U < NSL ? U : 0], f = S.full[U < NSL ? U : 0];                      \
+        if (IS_SEQ) {                                                                              \
+            const uint32_t bins = w & 0x07070707u;                                                 \
+            chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;                \
+            orw |= w & f;                                                                          \
+            B.w[U < NSL ? U : 0] = bins;                                                           \
+        } else {                                                                                   \
+            /* byte - 33 < 64 for all four bytes: a byte below '!' borrows, but its own         */ \
+            /* difference is then >= 0xDF, one above '`' gives >= 0x40: bits 6-7 tell           */ \
+            const uint32_t t = w - 0x21212121u;                                                    \
+            chk |= t & f;                                                                          \
+            B.w[U < NSL ? U : 0] = t;                                                              \
+        }                                                                                          \
+    }
+    FQH_SO_PASS1(0) FQH_SO_PASS1(1) FQH_SO_PASS1(2) FQH_SO_PASS1(3)
+    FQH_SO_PASS1(4) FQH_SO_PASS1(5) FQH_SO_PASS1(6) FQH_SO_PASS1(7)
 #undef FQH_SO_PASS1
-    } while (0);
-    uint32_t slow = 0;  // wave-uniform: steps left to the exact path
-    if (__ballot(chk != 0) != 0) {
-        slow = (1u << nsteps) - 1u;
-    } else {
-        do {
-#define FQH_SO_PASS2(U)                                                                        \
-            if (U < NSL) {                                                                     \
-                if (U >= nsteps) break;                                                        \
-                const uint32_t wf = B.w[U < NSL ? U : 0];                                      \
-                const uint32_t inc = tt > (int)(32u * U) ? 1u : 0u;                            \
-                uint32_t pb;                                                                   \
-                if (IS_SEQ) {                                                                  \
-                    const uint32_t bins = wf & 0x07070707u;                                    \
-                    any_n |= __builtin_amdgcn_perm(0x00800000u, 0u, bins);                     \
-                    pb = bins | (0x08080808u * (U >> 1));                                      \
-                } else {                                                                       \
-                    pb = wf - 0x21212121u + 0x40404040u * (U >> 1);                            \
-                }                                                                              \
-                if (!(a.dbg & 1u))                                                             \
-                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                  \
-                    lds_add<128u * (U & 1u)>(__builtin_amdgcn_perm(c.A[k], pb, c.sel[k]), inc); \
-            }
-            FQH_SO_PASS2(0) FQH_SO_PASS2(1) FQH_SO_PASS2(2) FQH_SO_PASS2(3)
-            FQH_SO_PASS2(4) FQH_SO_PASS2(5) FQH_SO_PASS2(6) FQH_SO_PASS2(7)
-#undef FQH_SO_PASS2
-        } while (0);
-    }
-    // the partial last dword: column nfull4 + m is added by lane m (< 3) of the line's group
-    const uint32_t nbt = (P >> SO_P_NBT) & 3u;
-    bool tail_exact = false;
-    if (__ballot(nbt != 0) != 0) {
-        const bool has = m < nbt;
-        const uint32_t b = (B.wt >> (8u * (m & 3u))) & 0xFFu;
-        uint32_t bin;
-        bool ok;
+    if (tails) {  // column nfull4 + m is added by lane m (< 3) of the line's group
+        wt = __builtin_amdgcn_perm(FILL, B.wt, S.tsel);
         if (IS_SEQ) {
-            bin = b & 7u;
-            ok = (b | 0xFFFFFF00u) == __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bin);
+            const uint32_t bins = wt & 0x07070707u;
+            chk |= wt ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins);
+            orw |= wt;
+            wt = bins;
         } else {
-            bin = b - 33u;
-            ok = bin < 64u;
-        }
-        if (__ballot(has && !ok) != 0) {
-            tail_exact = true;
-        } else if (has) {
-            if (IS_SEQ) any_n |= b == 'N' ? 1u : 0u;
-            atomicAdd(hist + so_word<IS_SEQ>(bin, nfull4 + m), 1u);
+            wt -= 0x21212121u;
+            chk |= wt;
         }
     }
-    // exact work: a refused batch, a refused tail, and everything from column nfull4 on in lines
-    // longer than the LDS rows
-    const bool longs = __ballot((P >> SO_P_LONG) & 1u) != 0;
-    if (__builtin_amdgcn_readfirstlane((int)(slow | (tail_exact ? 256u : 0u) | (longs ? 512u : 0u))) != 0) {
+    uint32_t slow = 0;        // wave-uniform: steps left to the exact path
+    bool tail_exact = false;
+    if (__ballot(IS_SEQ ? chk != 0 : (chk & 0xC0C0C0C0u) != 0) != 0) {
+        slow = (1u << NSL) - 1u;
+        tail_exact = tails;
+    } else if (!DBG || !(a.dbg & 1u)) {
+#define FQH_SO_PASS2(U)                                                                            \
+        if (U < NSL) {                                                                             \
+            const uint32_t pb = B.w[U < NSL ? U : 0], f = S.full[U < NSL ? U : 0];                 \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                          \
+                lds_sub<REGION + 128u * (U & 1u) + RB * (U >> 1)>(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]), f); \
+        }
+        FQH_SO_PASS2(0) FQH_SO_PASS2(1) FQH_SO_PASS2(2) FQH_SO_PASS2(3)
+        FQH_SO_PASS2(4) FQH_SO_PASS2(5) FQH_SO_PASS2(6) FQH_SO_PASS2(7)
+#undef FQH_SO_PASS2
+        // (the bin of the tail column is byte 0 of wt; the other bytes are filler)
+        if (tails) lds_sub<0>((IS_SEQ ? S.taddr_s : S.taddr_q) + ((IS_SEQ ? wt & 0xFFu : wt) << 8), S.tmask);
+    }
+    uint32_t any_n = IS_SEQ ? orw & 0x08080808u : 0u, any_inv = 0;
+    // exact work: a refused batch (every step and the tails), and everything from column nfull4 on in
+    // lines longer than the LDS rows
+    if (__builtin_amdgcn_readfirstlane((int)(slow | (longs ? 512u : 0u))) != 0) {
+        any_n = 0;
         const uint8_t *const bend = a.buf + a.len;
         const uint8_t *const line = tbase + (P >> SO_P_SREL);
         // (every lane takes part in the permute: a disabled source lane would read as 0)
@@ -615,6 +635,7 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
         const uint32_t len = (P >> SO_P_ACT) & 1u ? len_src : 0u;
         const bool islong = ((P >> SO_P_LONG) & 1u) != 0;
         bool tail = tail_exact || longs;
+        if (!slow) any_n = IS_SEQ ? orw & 0x08080808u : 0u;   // the counted part stands
         for (uint32_t ul = lc >> 5;;) {
             uint32_t pos, le;
             if (slow) {
@@ -633,19 +654,21 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
                 le = (islong && pos > nfull4) ? len : 0u;
             }
             const uint32_t wl = pos < le ? load4_any(line + pos, bend) : 0u;
-            so_exact_step<IS_SEQ>(a, wl, pos, le, lc, hist, any_n, any_inv, IS_SEQ ? acc.oseq : acc.oqual);
+            so_exact_step<IS_SEQ>(a, wl, pos, le, lc, hist, any_n, any_inv);
         }
     }
     if (IS_SEQ) {  // lines that are not pure ACGT / ACGTN: the 8 lanes of a line OR their flags
-        const unsigned long long bi = __ballot(any_inv != 0);
-        T.not_dna += so_groups(__ballot(any_n != 0) | bi);
-        T.not_dnan += so_groups(bi);
+        const unsigned long long bi = __ballot(any_inv != 0), bn = __ballot(any_n != 0) | bi;
+        if (bn) {
+            T.not_dna += so_groups(bn);
+            T.not_dnan += so_groups(bi);
+        }
     }
 }
 
-template <uint32_t NSL>
+template <uint32_t NSL, bool DBG>
 __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // quality + sequence regions, then the staged lists
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // sequence + quality regions, the staged lists, the extra rows
     const uint32_t lc = a.lc;
     const uint32_t listw = a.listw;  // 512, or 256 when the extra rows need the room
     for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) hist[i] = 0;
@@ -653,41 +676,46 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // a scalar: so is the tile
     const uint32_t m4 = (lane & 7u) * 4u, g8 = lane >> 3;
     uint16_t *const wl = reinterpret_cast<uint16_t *>(hist + SO_WORDS) + wv * listw;  // this wave's staged list
     // The address registers assume the histogram starts at LDS address 0 (it is the kernel's only
     // LDS object); a shared-memory pointer is its LDS address in the low 32 bits.
     if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();
     SoLane c;
+    c.slots = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t j = k ^ (g8 & 3u);
-        c.sel[k] = 0x07060004u | (j << 8);
-        c.A[k] = ((lane & 7u) + 8u * j) * 4u;
+        c.sel[k] = 0x0C0C0004u + k + (j << 8);
+        c.slots |= (((lane & 7u) + 8u * j) * 4u) << (8u * k);
     }
-    SoAcc acc = {0, 0, 0, 0, 0};
+    SoAcc acc = {0, 0, 0};
     SoTotals T = {0, 0};
+    SoShape<NSL> S = {};
+    S.key = 0xFFFFFFFFu;  // no P has this key: the first batch works the shape out
 
     // What a wave needs to know about a tile before it can start on it, loaded one tile ahead (the
     // per-tile chain count -> prefix -> list -> '\r' bytes -> first dwords is otherwise paid in full,
     // 256 times per wave: 2.5 of the kernel's 6 ms).
     struct TilePre {
-        uint32_t cnt, tp, cnt1, first1;
-        unsigned long long bp;
-        uint2 l0, l1;  // list entries 4 lane .. 4 lane + 3 and 256 + 4 lane .. + 3
+        uint32_t meta;  // lane 0: the tile's count, 1: its prefix, 2: the next tile's count, 3: that tile's first
+                        // entry, 4-5: the block prefix -- six words, one load, one register
+        uint2 l0, l1;   // list entries 4 lane .. 4 lane + 3 and 256 + 4 lane .. + 3
     };
     auto prefetch = [&](uint64_t t, TilePre &P) {
         const uint64_t tc = t < a.n_tiles ? t : a.n_tiles - 1;  // clamped: the loads are unconditional
-        P.cnt = a.tile_count[tc];
-        P.tp = a.tile_prefix[tc];
-        P.bp = a.block_prefix[tc >> SCAN_SHIFT];
         const uint16_t *__restrict__ tl = a.list + tc * a.list_cap;
         P.l0 = *reinterpret_cast<const uint2 *>(tl + lane * 4);
         P.l1 = *reinterpret_cast<const uint2 *>(tl + 256 + lane * 4);  // list_cap >= 512
         const uint64_t t1 = tc + 1 < a.n_tiles ? tc + 1 : tc;
-        P.cnt1 = a.tile_count[t1];
-        P.first1 = a.list[t1 * a.list_cap];
+        const uint32_t *mp = a.tile_count + tc;
+        if (lane == 1) mp = a.tile_prefix + tc;
+        if (lane == 2) mp = a.tile_count + t1;
+        if (lane == 3) mp = reinterpret_cast<const uint32_t *>(a.list + t1 * a.list_cap);  // (list_cap is even)
+        if (lane == 4 || lane == 5)
+            mp = reinterpret_cast<const uint32_t *>(a.block_prefix + (tc >> SCAN_SHIFT)) + (lane - 4);
+        P.meta = *mp;
     };
     const uint64_t tstride = (uint64_t)gridDim.x * SO_WAVES;
     uint64_t tile = (uint64_t)blockIdx.x * SO_WAVES + wv;
@@ -696,10 +724,17 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     for (; tile < a.n_tiles && a.len >= 4; tile += tstride) {
         const TilePre cur = nextP;
         prefetch(tile + tstride, nextP);
-        uint32_t cnt = cur.cnt;
+        // (six lanes hold the tile's six words: as scalars, the tile's bookkeeping runs on the scalar unit)
+        uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 0);
         cnt = cnt < a.list_cap ? cnt : a.list_cap;
         if (cnt == 0) continue;
-        const unsigned long long lbase = a.nl_count + 1 + cur.bp + cur.tp;
+        const uint32_t cur_tp = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 1);
+        const uint32_t cur_cnt1 = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 2);
+        const uint32_t cur_first1 = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 3);
+        const unsigned long long cur_bp =
+            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 4) |
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 5) << 32);
+        const unsigned long long lbase = a.nl_count + 1 + cur_bp + cur_tp;
         if (lbase >= a.line_hi || lbase + cnt <= a.line_lo) continue;
         const uint16_t *__restrict__ tl = a.list + tile * a.list_cap;
         const uint64_t tb = tile << WT_SHIFT;
@@ -712,8 +747,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         // start of the first line after this tile (ends the tile's last line), tile-relative
         uint64_t next_first = a.valid_end;
         if (tile + 1 < a.n_tiles) {
-            if (cur.cnt1) {
-                next_first = ((tile + 1) << WT_SHIFT) + (cur.first1 & 0x3FFFu);
+            if (cur_cnt1) {
+                next_first = ((tile + 1) << WT_SHIFT) + (cur_first1 & 0x3FFFu);
             } else {
                 for (uint64_t t2 = tile + 2; t2 < a.n_tiles; ++t2) {
                     if (a.tile_count[t2]) { next_first = (t2 << WT_SHIFT) + (a.list[t2 * a.list_cap] & 0x3FFFu); break; }
@@ -746,14 +781,10 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             len = n_rel - 1 - s_rel;  // raw line, without its '\n'
             return true;
         };
-        auto set_region = [&](uint32_t kind) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) c.A[k] = (c.A[k] & 0xFFu) | (kind ? 0u : SO_QBYTES);
-        };
         const uint32_t i0s = (1u - lb3) & 3u, i0q = (3u - lb3) & 3u;
         const uint32_t nls = i0s < cnt ? (cnt - i0s + 3) >> 2 : 0u, nlq = i0q < cnt ? (cnt - i0q + 3) >> 2 : 0u;
 
-        if (safe && nls <= 64 && nlq <= 64 && !(a.dbg & 8u)) {
+        if (safe && nls <= 64 && nlq <= 64 && !(DBG && (a.dbg & 8u))) {
             // ---- the usual tile: at most 64 lines of each kind.  Both kinds' lines are worked out at
             // once (their '\r' bytes are in flight together), then all batches run as one sequence so that
             // the first quality batch is fetched while the last sequence batch is counted.
@@ -778,16 +809,14 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                 B.wt = load4_fast(tbase + ot);
             };
             auto count = [&](uint32_t f, SoBatch<NSL> &B) {
-                if (a.dbg & 4u) { acc.oseq += B.w[0] == 0x12345u; return; }
-                if (f == nbs) set_region(1);
-                if (f < nbs) so_count<true, NSL>(a, tbase, B, lane, lce, hist, c, l_s, 32u * f + 4u * g8, T, acc);
-                else so_count<false, NSL>(a, tbase, B, lane, lce, hist, c, l_q, 32u * (f - nbs) + 4u * g8, T, acc);
+                if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
+                if (f < nbs) so_count<true, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_s, 32u * f + 4u * g8, T, acc);
+                else so_count<false, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_q, 32u * (f - nbs) + 4u * g8, T, acc);
             };
+            // The fetches are unconditional inside the loops (the index is clamped instead) so that the
+            // compiler's s_waitcnt for the batch it needs leaves the next one's loads in flight.
             if (nbt) {
-                set_region(0);
                 SoBatch<NSL> B0, B1;  // ping-pong: the loads of one are in flight while the other is counted
-                // The fetches are unconditional inside the loop (the index is clamped instead) so that
-                // the compiler's s_waitcnt vmcnt(N) for one buffer leaves the other one's loads in flight.
                 const uint32_t fl = nbt - 1;
                 fetch(0, B0);
                 for (uint32_t f = 0; f < nbt; f += 2) {
@@ -807,7 +836,6 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         for (uint32_t kind = 0; kind < 2; ++kind) {        // 0: sequence lines, 1: quality lines
             const uint32_t nlines = kind ? nlq : nls;
             if (!nlines) continue;
-            set_region(kind);
             for (uint32_t sb = 0; sb < nlines; sb += 64) {
                 uint32_t my_P = 0, my_len = 0;
                 {
@@ -839,8 +867,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                         for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = 0;
                         B0.wt = 0;
                     }
-                    if (kind == 0) so_count<true, NSL>(a, tbase, B0, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
-                    else so_count<false, NSL>(a, tbase, B0, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
+                    if (kind == 0) so_count<true, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
+                    else so_count<false, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
                 }
             }
         }
@@ -852,9 +880,9 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     for (uint32_t i = threadIdx.x; i < a.lx * 72u; i += SO_THREADS) dst[SO_WORDS + i] = so_extra(a, hist)[i];
     // per-line totals: rec / bases / qual were summed by the lane that owned the line; the two
     // "not DNA" counts are wave-uniform
-    unsigned long long sc[7] = {acc.rec, acc.bases, acc.qual, 0, 0, acc.oseq, acc.oqual};
+    unsigned long long sc[5] = {acc.rec, acc.bases, acc.qual, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < 3; ++j) {
         unsigned long long v = sc[j];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -864,7 +892,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         sc[3] = sc[0] - T.not_dna;
         sc[4] = sc[0] - T.not_dnan;
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < 5; ++j)
             if (sc[j]) atomicAdd(&a.scalars[j], sc[j]);
     }
 }
@@ -880,8 +908,8 @@ __global__ __launch_bounds__(256) void k_stats_reduce_oct(const uint32_t *__rest
     bool isq;
     uint32_t bin, row;
     if (id < SO_WORDS) {  // bank-scheduled rows
-        isq = id < SO_QBYTES / 4;
-        const uint32_t r = isq ? id : id - SO_QBYTES / 4;
+        isq = id >= SO_SBYTES / 4;
+        const uint32_t r = isq ? id - SO_SBYTES / 4 : id;
         const uint32_t rb = isq ? r >> 12 : r >> 9;
         bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
         row = rb * 64 + so_row6(r & 63u);
@@ -908,16 +936,20 @@ static uint32_t stats_oct_lx(uint32_t lmax) {
 size_t stats_oct_scratch_bytes(uint32_t lmax, int n_cu) {
     return (size_t)stats_lines_blocks(n_cu) * (SO_WORDS + stats_oct_lx(lmax) * 72u) * sizeof(uint32_t);
 }
-template <uint32_t NSL>
+template <uint32_t NSL, bool DBG>
 static hipError_t launch_stats_oct_n(hipStream_t s, const StatsArgs &a, uint32_t blocks, size_t lds) {
+    // Lanes without a whole dword subtract 0 at the address their bytes happen to form: any bin byte
+    // (< 64 KiB) plus the largest row-block offset.  The allocation covers all of them.
+    if (lds < SO_ADDR_SPAN) lds = SO_ADDR_SPAN;
+    if (lds > SO_LDS_MAX) return hipErrorInvalidValue;
     static size_t set = 0;
     if (lds > set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_oct<NSL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_oct<NSL, DBG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         set = lds;
     }
-    hipLaunchKernelGGL(k_stats_oct<NSL>, dim3(blocks), dim3(SO_THREADS), lds, s, a);
+    hipLaunchKernelGGL((k_stats_oct<NSL, DBG>), dim3(blocks), dim3(SO_THREADS), lds, s, a);
     return hipSuccess;
 }
 hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
@@ -934,10 +966,11 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
     }
     const uint32_t blocks = stats_lines_blocks(n_cu);
     const uint32_t nsl = (a.lc + 31) / 32;  // steps that hold LDS rows
-    hipError_t e = nsl <= 2   ? launch_stats_oct_n<2>(s, a, blocks, lds)
-                   : nsl <= 4 ? launch_stats_oct_n<4>(s, a, blocks, lds)
-                   : nsl <= 5 ? launch_stats_oct_n<5>(s, a, blocks, lds)
-                              : launch_stats_oct_n<8>(s, a, blocks, lds);
+    hipError_t e = dbg        ? launch_stats_oct_n<5, true>(s, a, blocks, lds)   // timing experiments: 150-bp shape only
+                   : nsl <= 2 ? launch_stats_oct_n<2, false>(s, a, blocks, lds)
+                   : nsl <= 4 ? launch_stats_oct_n<4, false>(s, a, blocks, lds)
+                   : nsl <= 5 ? launch_stats_oct_n<5, false>(s, a, blocks, lds)
+                              : launch_stats_oct_n<8, false>(s, a, blocks, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stats_reduce_oct, dim3((SO_WORDS + a.lx * 72u + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP),
                        dim3(256), 0, s, a.scratch, blocks, a.lc, a.lx, a.qual_hist, a.base_hist);

@@ -71,7 +71,10 @@ struct StatsArgs {
     uint32_t lx, listw;          // k_stats_oct: extra plain LDS rows lc .. lc + lx (long reads); staged list entries per wave
     uint32_t *scratch;           // [gridDim.x][lc * 128] per-block partial histograms
     unsigned long long *qual_hist, *base_hist, *scalars;
-    uint32_t dbg;                // timing experiments only (FQH_STATS_DBG): 1 no LDS atomics, 2 no data loads, 4 no counting
+    uint32_t dbg;                // timing experiments only (FQH_STATS_DBG, k_stats_oct<5, true>): 1 no LDS atomics, 4 no counting,
+                                 // 8 generic tile path, 16 no '\\r' probes, 64 sequence lines only, 128 / 256 one / no load per batch,
+                                 // 512 no batches, 1024 only walk the tiles, 8192 report section cycles, 16384 every load twice,
+                                 // 32768 all groups read one line, 65536 half the waves idle
 };
 
 // Device-resident accumulators and the finalize kernel's results (one D2H copy per scan).

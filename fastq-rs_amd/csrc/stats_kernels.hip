@@ -692,6 +692,9 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     }
     SoAcc acc = {0, 0, 0};
     SoTotals T = {0, 0};
+    // DBG (FQH_STATS_DBG & 8192): cycles this wave spent waiting for a tile's words, staging its list, working out
+    // its lines, and in its batches (added to qual_hist[0..3] at the end; tools/exp_statsdbg.py prints them)
+    unsigned long long dbgt[4] = {0, 0, 0, 0};
     SoShape<NSL> S = {};
     S.key = 0xFFFFFFFFu;  // no P has this key: the first batch works the shape out
 
@@ -721,8 +724,11 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     uint64_t tile = (uint64_t)blockIdx.x * SO_WAVES + wv;
     TilePre nextP;
     if (tile < a.n_tiles && a.len >= 4) prefetch(tile, nextP);
+    if (DBG && (a.dbg & 65536u) && wv >= 8) tile = a.n_tiles;  // half the waves idle: does the other half get faster?
     for (; tile < a.n_tiles && a.len >= 4; tile += tstride) {
         const TilePre cur = nextP;
+        unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        if (DBG) tk0 = __builtin_readcyclecounter();
         prefetch(tile + tstride, nextP);
         // (six lanes hold the tile's six words: as scalars, the tile's bookkeeping runs on the scalar unit)
         uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 0);
@@ -736,6 +742,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 5) << 32);
         const unsigned long long lbase = a.nl_count + 1 + cur_bp + cur_tp;
         if (lbase >= a.line_hi || lbase + cnt <= a.line_lo) continue;
+        if (DBG && (a.dbg & 1024u)) { acc.rec += cnt; continue; }  // only the walk over the tiles' words
+        if (DBG) { tk1 = __builtin_readcyclecounter(); dbgt[0] += tk1 - tk0; }
         const uint16_t *__restrict__ tl = a.list + tile * a.list_cap;
         const uint64_t tb = tile << WT_SHIFT;
         // stage the list
@@ -744,6 +752,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         if (listw > 256) *reinterpret_cast<uint2 *>(wl + 256 + lane * 4) = cur.l1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (DBG) { tk2 = __builtin_readcyclecounter(); dbgt[1] += tk2 - tk1; }
         // start of the first line after this tile (ends the tile's last line), tile-relative
         uint64_t next_first = a.valid_end;
         if (tile + 1 < a.n_tiles) {
@@ -790,23 +799,39 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             // the first quality batch is fetched while the last sequence batch is counted.
             uint32_t s_s = 0, l_s = 0, s_q = 0, l_q = 0;
             const bool has_s = line_of(0, lane, s_s, l_s), has_q = line_of(1, lane, s_q, l_q);
-            const uint32_t cr_s = (has_s && l_s) ? tbase[s_s + l_s - 1] : 0u;
-            const uint32_t cr_q = (has_q && l_q) ? tbase[s_q + l_q - 1] : 0u;
+            const bool probe = !(DBG && (a.dbg & 16u));
+            const uint32_t cr_s = (probe && has_s && l_s) ? tbase[s_s + l_s - 1] : 0u;
+            const uint32_t cr_q = (probe && has_q && l_q) ? tbase[s_q + l_q - 1] : 0u;
             if (cr_s == '\r') --l_s;                                                   // trim_winline, src/records.rs:66-73
             if (cr_q == '\r') --l_q;
             const uint32_t P_s = has_s ? so_pack(s_s, l_s, lce) : 0u, P_q = has_q ? so_pack(s_q, l_q, lce) : 0u;
             if (has_s) { ++acc.rec; acc.bases += l_s; }
             if (has_q) acc.qual += l_q;
-            const uint32_t nbs = (nls + 7) >> 3, nbq = (nlq + 7) >> 3, nbt = nbs + nbq;
+            if (DBG) { tk3 = __builtin_readcyclecounter(); dbgt[2] += tk3 - tk2; }
+            const uint32_t nbs = (nls + 7) >> 3, nbq = (DBG && (a.dbg & 64u)) ? 0u : (nlq + 7) >> 3;  // 64: sequence lines only
+            const uint32_t nbt = (DBG && (a.dbg & 512u)) ? 0u : nbs + nbq;                              // 512: no batches
             auto fetch = [&](uint32_t f, SoBatch<NSL> &B) {
                 const bool isq = f >= nbs;
                 const uint32_t b = isq ? f - nbs : f;
                 B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)(isq ? P_q : P_s));
+                if (DBG && (a.dbg & 32768u))  // every group reads the first group's line: an eighth of the cache lines
+                    B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b), (int)(isq ? P_q : P_s));
                 const uint32_t s_rel = B.P >> SO_P_SREL;
                 const uint32_t o = s_rel + m4, ot = s_rel + (B.P & 0x1FFu);
+                if (DBG && (a.dbg & 384u)) {  // 128: only the first step's load, 256: none
+#pragma unroll
+                    for (uint32_t u = 0; u < NSL; ++u) B.w[u] = o;
+                    B.wt = o;
+                    if (a.dbg & 128u) B.w[0] = load4_fast(tbase + o);
+                    return;
+                }
 #pragma unroll
                 for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(tbase + (o + 32 * u));
                 B.wt = load4_fast(tbase + ot);
+                if (DBG && (a.dbg & 16384u)) {  // the same loads once more, one byte on: what does a load that hits cost?
+#pragma unroll
+                    for (uint32_t u = 0; u < NSL; ++u) B.w[u] ^= load4_fast(tbase + (o + 32 * u + 1));
+                }
             };
             auto count = [&](uint32_t f, SoBatch<NSL> &B) {
                 if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
@@ -828,6 +853,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                     }
                 }
             }
+            if (DBG) dbgt[3] += __builtin_readcyclecounter() - tk3;
             continue;
         }
 
@@ -878,6 +904,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * (SO_WORDS + a.lx * 72u);
     for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) dst[i] = hist[i];
     for (uint32_t i = threadIdx.x; i < a.lx * 72u; i += SO_THREADS) dst[SO_WORDS + i] = so_extra(a, hist)[i];
+    if (DBG && (a.dbg & 8192u) && lane == 0)
+        for (int j = 0; j < 4; ++j) atomicAdd(&a.qual_hist[j], dbgt[j]);
     // per-line totals: rec / bases / qual were summed by the lane that owned the line; the two
     // "not DNA" counts are wave-uniform
     unsigned long long sc[5] = {acc.rec, acc.bases, acc.qual, 0, 0};

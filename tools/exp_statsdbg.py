@@ -1,5 +1,5 @@
 """tools/exp_statsdbg.py [GiB] — histogram kernel time on the bench's synthetic 150 bp data; with
-FQH_STATS_DBG set (1 no LDS atomics, 4 no counting, 8 generic tile path) the results are wrong by design
+FQH_STATS_DBG set (bits: see StatsArgs::dbg in csrc/fqh_internal.h) the results are wrong by design
 and are not checked: this is the time decomposition of DESIGN.md §5."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,3 +22,5 @@ for _ in range(6):
     ts.append(ctx.timing().stats_ms)
 print("FQH_STATS_DBG=%s: %.2f GiB  stats kernel %.3f ms (min of 6; all: %s)  %.0f GB/s  qual entries %d" % (
     os.environ.get("FQH_STATS_DBG", "0"), n / 2**30, min(ts), " ".join("%.3f" % t for t in ts), n / 1e6 / min(ts), int(qh.sum())))
+if int(os.environ.get("FQH_STATS_DBG", "0")) & 8192:  # cycles per wave and launch in the kernel's sections (4096 waves)
+    print("  cycles per wave: words %.0f  staging %.0f  lines %.0f  batches %.0f" % tuple(int(x) / 4096.0 for x in qh[:4]))

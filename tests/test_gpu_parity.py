@@ -545,3 +545,56 @@ def test_quarter_gib_ragged_reads_offsets_and_histograms(fqref, torch, pkg, shap
     assert np.array_equal(gq.cpu().numpy().astype(np.uint64).reshape(lmax, 256), qh)
     assert np.array_equal(gb.cpu().numpy().astype(np.uint64).reshape(lmax, 8), bh)
     ctx.close()
+
+
+def test_full_size_16gib_properties(fqref, gpu, torch):
+    """BASELINE.json's full size (configs[1] and [2]: 16 GiB of the synthetic 150 bp workload, HBM-resident)
+    through properties that need no 16 GiB oracle run: every record offset (the generator's records
+    are 330 bytes), the count, the whole-file histograms as the sum of the histograms of 32 record-
+    aligned parts (linearity), their totals, and one part bit-exact against the oracle."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20 * 2**30:
+        pytest.skip("needs 20 GiB of device memory")
+    nrec = (16 * 2**30) // 330
+    n = nrec * 330
+    d = torch.empty(n, dtype=torch.uint8, device=gpu.dev)
+    gpu.ctx.synth_fill(d.data_ptr(), 0, n)
+    gpu.ctx.set_bufsize(gpu.pkg.BUFSIZE)
+    rs = torch.empty(nrec + 8, dtype=torch.int64, device=gpu.dev)
+    s, c, st = gpu.ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), nrec + 8)
+    assert st == gpu.pkg.OK and s.parse_status == gpu.pkg.OK and s.n_records == nrec and s.bytes_consumed == n
+    want = torch.arange(nrec + 1, dtype=torch.int64, device=gpu.dev) * 330
+    assert bool(torch.equal(rs[: nrec + 1], want))
+    del want, rs
+
+    def hist(ptr, length):
+        qh = torch.zeros(150 * 256, dtype=torch.int64, device=gpu.dev)
+        bh = torch.zeros(150 * 8, dtype=torch.int64, device=gpu.dev)
+        sc = torch.zeros(8, dtype=torch.int64, device=gpu.dev)
+        s2, _ = gpu.ctx.stats(ptr, length, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+        assert s2.parse_status == gpu.pkg.OK
+        return qh, bh, sc
+
+    qh, bh, sc = hist(d.data_ptr(), n)
+    assert int(sc[0]) == nrec and int(sc[1]) == nrec * 150 and int(sc[2]) == nrec * 150
+    assert int(qh.sum()) == nrec * 150 and int(bh.sum()) == nrec * 150
+    assert bool((qh.view(150, 256).sum(1) == nrec).all()) and bool((bh.view(150, 8).sum(1) == nrec).all())
+    parts = 32
+    per = ((nrec + parts - 1) // parts + 7) // 8 * 8  # 8 records = 2640 bytes: the parts stay 16-byte aligned (fqh_stats)
+    tq, tb, ts = torch.zeros_like(qh), torch.zeros_like(bh), torch.zeros_like(sc)
+    for p in range(parts):
+        r0, r1 = p * per, min(nrec, (p + 1) * per)
+        q2, b2, s2 = hist(d.data_ptr() + r0 * 330, (r1 - r0) * 330)
+        tq += q2
+        tb += b2
+        ts += s2
+        if p == 17:  # one part against the oracle (the generator is a pure function of the byte offset)
+            m = 64 * 2**20 // 330 * 330
+            host = d[r0 * 330: r0 * 330 + m].cpu().numpy()
+            assert np.array_equal(host, fqref.synth(r0 * 330, m))
+            q3, b3, s3 = hist(d.data_ptr() + r0 * 330, m)
+            r, oq, ob, osc = fqref.stats(host, 150)
+            assert np.array_equal(q3.cpu().numpy().astype(np.uint64).reshape(150, 256), oq)
+            assert np.array_equal(b3.cpu().numpy().astype(np.uint64).reshape(150, 8), ob)
+            assert np.array_equal(s3.cpu().numpy().astype(np.uint64), osc)
+    assert bool(torch.equal(tq, qh)) and bool(torch.equal(tb, bh)) and bool(torch.equal(ts, sc))

@@ -295,6 +295,18 @@ def main():
             fqref.stats(host[:hs], 150)
             d1 = time.perf_counter() - t1
             out["cpu_baseline"]["stats_gbs"] = round(hs / 1e9 / d1, 3)
+            # the histogram loop the way parallel_each would run it: record-aligned pieces on worker threads
+            # (ctypes releases the GIL), SURVEY.md 8(d) cfg 0
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(32, (os.cpu_count() or 1)))
+            per = (sample // RECLEN + nthr - 1) // nthr * RECLEN
+            pieces = [host[i:i + per] for i in range(0, sample, per)]
+            with ThreadPoolExecutor(nthr) as ex:
+                t1 = time.perf_counter()
+                list(ex.map(lambda h: fqref.stats(h, 150), pieces))
+                d1 = time.perf_counter() - t1
+            out["cpu_baseline"]["stats_parallel_gbs"] = round(sample / 1e9 / d1, 3)
+            out["cpu_baseline"]["stats_parallel_threads"] = nthr
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 and args.shard_stats:

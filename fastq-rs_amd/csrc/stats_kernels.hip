@@ -809,11 +809,16 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             if (has_q) acc.qual += l_q;
             if (DBG) { tk3 = __builtin_readcyclecounter(); dbgt[2] += tk3 - tk2; }
             const uint32_t nbs = (nls + 7) >> 3, nbq = (DBG && (a.dbg & 64u)) ? 0u : (nlq + 7) >> 3;  // 64: sequence lines only
-            const uint32_t nbt = (DBG && (a.dbg & 512u)) ? 0u : nbs + nbq;                              // 512: no batches
+            // Batch f = 2 k + kind: the k-th eight sequence lines, then the k-th eight quality lines -- the lines of (nearly) the
+            // same records, a few hundred bytes apart, so the second batch's loads find the first one's cache lines.  A kind
+            // that has run out of lines gets an empty batch (P = 0 counts nothing).
+            const uint32_t nbm = nbs > nbq ? nbs : nbq;
+            const uint32_t nbt = (DBG && (a.dbg & 512u)) ? 0u : 2u * nbm;                               // 512: no batches
             auto fetch = [&](uint32_t f, SoBatch<NSL> &B) {
-                const bool isq = f >= nbs;
-                const uint32_t b = isq ? f - nbs : f;
+                const bool isq = (f & 1u) != 0;
+                const uint32_t b = f >> 1;
                 B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)(isq ? P_q : P_s));
+                if (b >= (isq ? nbq : nbs)) B.P = 0;
                 if (DBG && (a.dbg & 32768u))  // every group reads the first group's line: an eighth of the cache lines
                     B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b), (int)(isq ? P_q : P_s));
                 const uint32_t s_rel = B.P >> SO_P_SREL;
@@ -833,24 +838,25 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                     for (uint32_t u = 0; u < NSL; ++u) B.w[u] ^= load4_fast(tbase + (o + 32 * u + 1));
                 }
             };
-            auto count = [&](uint32_t f, SoBatch<NSL> &B) {
+            auto count_s = [&](uint32_t f, SoBatch<NSL> &B) {  // f even
                 if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
-                if (f < nbs) so_count<true, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_s, 32u * f + 4u * g8, T, acc);
-                else so_count<false, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_q, 32u * (f - nbs) + 4u * g8, T, acc);
+                so_count<true, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_s, 32u * (f >> 1) + 4u * g8, T, acc);
+            };
+            auto count_q = [&](uint32_t f, SoBatch<NSL> &B) {  // f odd
+                if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
+                so_count<false, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_q, 32u * (f >> 1) + 4u * g8, T, acc);
             };
             // The fetches are unconditional inside the loops (the index is clamped instead) so that the
             // compiler's s_waitcnt for the batch it needs leaves the next one's loads in flight.
             if (nbt) {
                 SoBatch<NSL> B0, B1;  // ping-pong: the loads of one are in flight while the other is counted
-                const uint32_t fl = nbt - 1;
+                const uint32_t fl = nbt - 1;  // (nbt is even: B0 holds the sequence batches, B1 the quality batches)
                 fetch(0, B0);
                 for (uint32_t f = 0; f < nbt; f += 2) {
-                    fetch(f + 1 < fl ? f + 1 : fl, B1);
-                    count(f, B0);
-                    if (f + 1 < nbt) {
-                        fetch(f + 2 < fl ? f + 2 : fl, B0);
-                        count(f + 1, B1);
-                    }
+                    fetch(f + 1, B1);
+                    count_s(f, B0);
+                    fetch(f + 2 < fl ? f + 2 : fl, B0);  // (past the end: the last batch once more, not counted)
+                    count_q(f + 1, B1);
                 }
             }
             if (DBG) dbgt[3] += __builtin_readcyclecounter() - tk3;

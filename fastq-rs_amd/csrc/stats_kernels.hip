@@ -548,9 +548,12 @@ __device__ __forceinline__ void so_shape(SoShape<NSL> &S, uint32_t P, uint32_t m
 }
 // ds_sub_u32 of a lane mask (~0 counts one, 0 counts nothing) with the row block and the u & 1 half of
 // the slot as the instruction's immediate offset.
+// (A builtin atomic on an LDS address, not inline asm: the compiler then counts these in its s_waitcnt lgkmcnt(N)
+// and a wave that waits for a ds_bpermute issued before them does not wait for them as well.)
+typedef __attribute__((address_space(3))) uint32_t so_lds_u32;
 template <uint32_t OFF>
 __device__ __forceinline__ void lds_sub(uint32_t byte_addr, uint32_t v) {
-    asm volatile("ds_sub_u32 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF));
+    (void)__hip_atomic_fetch_sub((so_lds_u32 *)(byte_addr + OFF), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // Count one batch (its loads were issued one batch earlier), straight-line: pass 1 checks every byte
@@ -814,13 +817,20 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             // that has run out of lines gets an empty batch (P = 0 counts nothing).
             const uint32_t nbm = nbs > nbq ? nbs : nbq;
             const uint32_t nbt = (DBG && (a.dbg & 512u)) ? 0u : 2u * nbm;                               // 512: no batches
-            auto fetch = [&](uint32_t f, SoBatch<NSL> &B) {
+            // The line words of a batch are looked up a batch early, before the atomics of the batch being counted:
+            // the ds_bpermute then does not queue behind them, and the loads go out as soon as their turn comes.
+            auto lookup = [&](uint32_t f) -> uint32_t {
                 const bool isq = (f & 1u) != 0;
                 const uint32_t b = f >> 1;
-                B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)(isq ? P_q : P_s));
-                if (b >= (isq ? nbq : nbs)) B.P = 0;
+                uint32_t P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)(isq ? P_q : P_s));
                 if (DBG && (a.dbg & 32768u))  // every group reads the first group's line: an eighth of the cache lines
-                    B.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b), (int)(isq ? P_q : P_s));
+                    P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b), (int)(isq ? P_q : P_s));
+                if (b >= (isq ? nbq : nbs)) P = 0;
+                __builtin_amdgcn_sched_barrier(0);  // (keep it where it is: ahead of the count's atomics)
+                return P;
+            };
+            auto fetch = [&](uint32_t P, SoBatch<NSL> &B) {
+                B.P = P;
                 const uint32_t s_rel = B.P >> SO_P_SREL;
                 const uint32_t o = s_rel + m4, ot = s_rel + (B.P & 0x1FFu);
                 if (DBG && (a.dbg & 384u)) {  // 128: only the first step's load, 256: none
@@ -851,11 +861,14 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             if (nbt) {
                 SoBatch<NSL> B0, B1;  // ping-pong: the loads of one are in flight while the other is counted
                 const uint32_t fl = nbt - 1;  // (nbt is even: B0 holds the sequence batches, B1 the quality batches)
-                fetch(0, B0);
+                uint32_t pa = lookup(0), pb = lookup(1);  // the words of the next even / odd batch
+                fetch(pa, B0);
                 for (uint32_t f = 0; f < nbt; f += 2) {
-                    fetch(f + 1, B1);
+                    fetch(pb, B1);
+                    pa = lookup(f + 2 < fl ? f + 2 : fl);  // (past the end: the last batch once more, not counted)
                     count_s(f, B0);
-                    fetch(f + 2 < fl ? f + 2 : fl, B0);  // (past the end: the last batch once more, not counted)
+                    fetch(pa, B0);
+                    pb = lookup(f + 3 < fl ? f + 3 : fl);
                     count_q(f + 1, B1);
                 }
             }

@@ -498,8 +498,9 @@ __device__ __forceinline__ uint32_t so_pack(uint32_t s_rel, uint32_t len, uint32
 template <uint32_t NSL>
 struct SoBatch {                 // one batch in flight: 8 lines, this lane's dword of each step
     uint32_t P;                  // so_pack() of this lane's line (0: no line in this slot)
-    uint32_t wt;                 // the dword at the line's column nfull4: its partial tail
-    uint32_t w[NSL];
+    uint32_t w[NSL];             // (no load for the line's partial last dword: it is one of these, and the lane that
+                                 // holds it counts its one to three bytes under byte masks -- a sixth load per batch
+                                 // cost the L1 as much as any of the five)
 };
 
 struct SoAcc {                   // per-lane totals (the lane that owns a line adds it)
@@ -525,10 +526,11 @@ template <uint32_t NSL>
 struct SoShape {
     uint32_t key;             // low 16 bits of the P it was derived from
     uint32_t full[NSL];       // ~0 where this lane has a whole dword of its line at step u
-    uint32_t tmask;           // ~0 in the lanes (m < nbt) that add one column of the partial last dword
-    uint32_t tsel;            // v_perm selector: that column's byte over three filler bytes
-    uint32_t taddr_q, taddr_s;  // its LDS byte address (bin byte zero) in the quality / sequence region
-    uint32_t any;             // wave-uniform: 1 some line has a partial last dword, 2 some line is longer than the rows
+    uint32_t tu;              // the step that holds the line's partial last dword (column nfull4) ...
+    uint32_t tb;              // ... this lane's byte mask in that step (0xFF per byte it counts) ...
+    uint32_t tf[4];           // ... and the value of its k-th atomic there (~0: the byte k ^ (g & 3) counts)
+    uint32_t any;             // wave-uniform: 1 some line has a partial last dword, 2 some line is longer than the rows,
+                              // bit 8 + u: some line's partial last dword is in step u
 };
 template <uint32_t NSL>
 __device__ __forceinline__ void so_shape(SoShape<NSL> &S, uint32_t P, uint32_t m) {
@@ -538,13 +540,17 @@ __device__ __forceinline__ void so_shape(SoShape<NSL> &S, uint32_t P, uint32_t m
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) S.full[u] = tt > (int)(32u * u) ? 0xFFFFFFFFu : 0u;
     const uint32_t nbt = (P >> SO_P_NBT) & 3u;
-    const bool has = m < nbt;
-    const uint32_t row = nfull4 + m, rb = row >> 6, slot4 = so_slot(row & 63u) << 2;
-    S.tmask = has ? 0xFFFFFFFFu : 0u;
-    S.tsel = has ? (0x04040400u | m) : 0x04040404u;
-    S.taddr_q = has ? (SO_SBYTES + ((rb << 14) | slot4)) : SO_SBYTES;
-    S.taddr_s = has ? ((rb << 11) | slot4) : 0u;
-    S.any = (__ballot(nbt != 0) != 0 ? 1u : 0u) | (__ballot((P >> SO_P_LONG) & 1u) != 0 ? 2u : 0u);
+    // In step tu lane mt = nfull4 / 4 % 8 holds columns nfull4 .. nfull4 + 3, of which nbt belong to the line;
+    // the lanes below it hold whole dwords, the lanes above it nothing.
+    const uint32_t tu = nfull4 >> 5, mt = (nfull4 >> 2) & 7u, g3 = (__lane_id() >> 3) & 3u;
+    S.tu = nbt ? tu : 0xFFu;
+    S.tb = m < mt ? 0xFFFFFFFFu : m == mt ? (1u << (8u * nbt)) - 1u : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) S.tf[k] = (m < mt || (m == mt && (k ^ g3) < nbt)) ? 0xFFFFFFFFu : 0u;
+    uint32_t any = (__ballot(nbt != 0) != 0 ? 1u : 0u) | (__ballot((P >> SO_P_LONG) & 1u) != 0 ? 2u : 0u);
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) any |= __ballot(nbt != 0 && tu == u) != 0 ? 256u << u : 0u;
+    S.any = any;
 }
 // ds_sub_u32 of a lane mask (~0 counts one, 0 counts nothing) with the row block and the u & 1 half of
 // the slot as the instruction's immediate offset.
@@ -569,17 +575,17 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
     const uint32_t P = B.P;
     if (__ballot((P & 0xFFFFu) != S.key) != 0) so_shape<NSL>(S, P, m);
     const uint32_t nfull4 = P & 0x1FFu;                            // columns covered by whole dwords
-    constexpr uint32_t FILL = IS_SEQ ? 0x41414141u : 0x21212121u;
     constexpr uint32_t RB = IS_SEQ ? 2048u : 16384u;               // address step of a row block
     constexpr uint32_t REGION = IS_SEQ ? 0u : SO_SBYTES;           // the region's base goes into the immediate offset too
     const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.any);
     const bool tails = (any & 1u) != 0, longs = (any & 2u) != 0;
     uint32_t chk = 0;  // sequence: OR of (dword ^ expected); quality: OR of (byte - 33), bits 6-7 tell
     uint32_t orw = 0;  // sequence: OR of the counted bytes; bit 3 is set in 'N' only
-    uint32_t wt = 0;
 #define FQH_SO_PASS1(U)                                                                            \
     if (U < NSL) {                                                                                 \
-        const uint32_t w = B.w[U < NSL ? U : 0], f = S.full[U < NSL ? U : 0];                      \
+        const uint32_t w = B.w[U < NSL ? U : 0];                                                   \
+        uint32_t f = S.full[U < NSL ? U : 0];                                                      \
+        if (any & (256u << U)) f = S.tu == U ? S.tb : f;   /* a step with partial last dwords */  \
         if (IS_SEQ) {                                                                              \
             const uint32_t bins = w & 0x07070707u;                                                 \
             chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;                \
@@ -596,18 +602,6 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
     FQH_SO_PASS1(0) FQH_SO_PASS1(1) FQH_SO_PASS1(2) FQH_SO_PASS1(3)
     FQH_SO_PASS1(4) FQH_SO_PASS1(5) FQH_SO_PASS1(6) FQH_SO_PASS1(7)
 #undef FQH_SO_PASS1
-    if (tails) {  // column nfull4 + m is added by lane m (< 3) of the line's group
-        wt = __builtin_amdgcn_perm(FILL, B.wt, S.tsel);
-        if (IS_SEQ) {
-            const uint32_t bins = wt & 0x07070707u;
-            chk |= wt ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins);
-            orw |= wt;
-            wt = bins;
-        } else {
-            wt -= 0x21212121u;
-            chk |= wt;
-        }
-    }
     uint32_t slow = 0;        // wave-uniform: steps left to the exact path
     bool tail_exact = false;
     if (__ballot(IS_SEQ ? chk != 0 : (chk & 0xC0C0C0C0u) != 0) != 0) {
@@ -617,14 +611,14 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
 #define FQH_SO_PASS2(U)                                                                            \
         if (U < NSL) {                                                                             \
             const uint32_t pb = B.w[U < NSL ? U : 0], f = S.full[U < NSL ? U : 0];                 \
+            const bool tstep = (any & (256u << U)) != 0;  /* wave-uniform */                       \
             _Pragma("unroll") for (int k = 0; k < 4; ++k)                                          \
-                lds_sub<REGION + 128u * (U & 1u) + RB * (U >> 1)>(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]), f); \
+                lds_sub<REGION + 128u * (U & 1u) + RB * (U >> 1)>(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]), \
+                                                                  tstep && S.tu == U ? S.tf[k] : f); \
         }
         FQH_SO_PASS2(0) FQH_SO_PASS2(1) FQH_SO_PASS2(2) FQH_SO_PASS2(3)
         FQH_SO_PASS2(4) FQH_SO_PASS2(5) FQH_SO_PASS2(6) FQH_SO_PASS2(7)
 #undef FQH_SO_PASS2
-        // (the bin of the tail column is byte 0 of wt; the other bytes are filler)
-        if (tails) lds_sub<0>((IS_SEQ ? S.taddr_s : S.taddr_q) + ((IS_SEQ ? wt & 0xFFu : wt) << 8), S.tmask);
     }
     uint32_t any_n = IS_SEQ ? orw & 0x08080808u : 0u, any_inv = 0;
     // exact work: a refused batch (every step and the tails), and everything from column nfull4 on in
@@ -831,18 +825,15 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             };
             auto fetch = [&](uint32_t P, SoBatch<NSL> &B) {
                 B.P = P;
-                const uint32_t s_rel = B.P >> SO_P_SREL;
-                const uint32_t o = s_rel + m4, ot = s_rel + (B.P & 0x1FFu);
+                const uint32_t o = (B.P >> SO_P_SREL) + m4;
                 if (DBG && (a.dbg & 384u)) {  // 128: only the first step's load, 256: none
 #pragma unroll
                     for (uint32_t u = 0; u < NSL; ++u) B.w[u] = o;
-                    B.wt = o;
                     if (a.dbg & 128u) B.w[0] = load4_fast(tbase + o);
                     return;
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(tbase + (o + 32 * u));
-                B.wt = load4_fast(tbase + ot);
                 if (DBG && (a.dbg & 16384u)) {  // the same loads once more, one byte on: what does a load that hits cost?
 #pragma unroll
                     for (uint32_t u = 0; u < NSL; ++u) B.w[u] ^= load4_fast(tbase + (o + 32 * u + 1));
@@ -901,16 +892,13 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                 SoBatch<NSL> B0;
                 for (uint32_t b = 0; b < nbat; ++b) {
                     B0.P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)my_P);
-                    const uint32_t s_rel = B0.P >> SO_P_SREL;
-                    const uint32_t o = s_rel + m4, ot = s_rel + (B0.P & 0x1FFu);
+                    const uint32_t o = (B0.P >> SO_P_SREL) + m4;
                     if (safe) {
 #pragma unroll
                         for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = load4_fast(tbase + (o + 32 * u));
-                        B0.wt = load4_fast(tbase + ot);
                     } else {  // lce == 0: every column goes through the exact path, which loads for itself
 #pragma unroll
                         for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = 0;
-                        B0.wt = 0;
                     }
                     if (kind == 0) so_count<true, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
                     else so_count<false, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);

@@ -570,7 +570,7 @@ __device__ __forceinline__ void lds_sub(uint32_t byte_addr, uint32_t v) {
 template <bool IS_SEQ, uint32_t NSL, bool DBG>
 __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbase, SoBatch<NSL> &B, SoShape<NSL> &S,
                                          uint32_t lane, uint32_t lc, uint32_t *hist, const SoLane &c, uint32_t my_len,
-                                         uint32_t src4, SoTotals &T, SoAcc &acc) {
+                                         uint32_t src4, SoTotals &T, SoAcc &acc, bool trimmed, bool &cr_seen) {
     const uint32_t m = lane & 7u, m4 = m * 4u;
     const uint32_t P = B.P;
     if (__ballot((P & 0xFFFFu) != S.key) != 0) so_shape<NSL>(S, P, m);
@@ -629,7 +629,20 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
         const uint8_t *const line = tbase + (P >> SO_P_SREL);
         // (every lane takes part in the permute: a disabled source lane would read as 0)
         const uint32_t len_src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src4, (int)my_len);
-        const uint32_t len = (P >> SO_P_ACT) & 1u ? len_src : 0u;
+        uint32_t len = (P >> SO_P_ACT) & 1u ? len_src : 0u;
+        if (!trimmed) {  // (wave-uniform) the tile's lengths were taken without looking for a '\r' at the line's end: a
+            // line that has one fails pass 1 (neither alphabet holds '\r') and is trimmed here; the wave looks
+            // before it packs from its next tile on (trim_winline, src/records.rs:66-73)
+            const bool cr = len != 0 && line[len - 1] == '\r';
+            if (cr) {
+                --len;
+                if (m == 0) {
+                    if (IS_SEQ) acc.bases -= 1;
+                    else acc.qual -= 1;
+                }
+            }
+            if (__ballot(cr) != 0) cr_seen = true;
+        }
         const bool islong = ((P >> SO_P_LONG) & 1u) != 0;
         bool tail = tail_exact || longs;
         if (!slow) any_n = IS_SEQ ? orw & 0x08080808u : 0u;   // the counted part stands
@@ -639,7 +652,7 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
                 const uint32_t u = (uint32_t)__builtin_ctz(slow);
                 slow &= slow - 1;
                 pos = m4 + 32 * u;
-                le = nfull4;
+                le = nfull4 < len ? nfull4 : len;
             } else if (tail) {
                 tail = false;
                 pos = nfull4;
@@ -689,6 +702,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     }
     SoAcc acc = {0, 0, 0};
     SoTotals T = {0, 0};
+    bool cr_seen = false;  // wave-uniform: a line of this wave's tiles ended in "\r\n" -- look for it from the next tile on
     // DBG (FQH_STATS_DBG & 8192): cycles this wave spent waiting for a tile's words, staging its list, working out
     // its lines, and in its batches (added to qual_hist[0..3] at the end; tools/exp_statsdbg.py prints them)
     unsigned long long dbgt[4] = {0, 0, 0, 0};
@@ -796,7 +810,9 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             // the first quality batch is fetched while the last sequence batch is counted.
             uint32_t s_s = 0, l_s = 0, s_q = 0, l_q = 0;
             const bool has_s = line_of(0, lane, s_s, l_s), has_q = line_of(1, lane, s_q, l_q);
-            const bool probe = !(DBG && (a.dbg & 16u));
+            // The byte before each line's '\n' is only looked at (two scattered loads per tile, and their latency before the
+            // first batch can be packed) once the wave has met a "\r\n"; until then so_count's exact path does the trimming.
+            const bool probe = cr_seen && !(DBG && (a.dbg & 16u));
             const uint32_t cr_s = (probe && has_s && l_s) ? tbase[s_s + l_s - 1] : 0u;
             const uint32_t cr_q = (probe && has_q && l_q) ? tbase[s_q + l_q - 1] : 0u;
             if (cr_s == '\r') --l_s;                                                   // trim_winline, src/records.rs:66-73
@@ -841,11 +857,11 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             };
             auto count_s = [&](uint32_t f, SoBatch<NSL> &B) {  // f even
                 if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
-                so_count<true, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_s, 32u * (f >> 1) + 4u * g8, T, acc);
+                so_count<true, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_s, 32u * (f >> 1) + 4u * g8, T, acc, probe, cr_seen);
             };
             auto count_q = [&](uint32_t f, SoBatch<NSL> &B) {  // f odd
                 if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
-                so_count<false, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_q, 32u * (f >> 1) + 4u * g8, T, acc);
+                so_count<false, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_q, 32u * (f >> 1) + 4u * g8, T, acc, probe, cr_seen);
             };
             // The fetches are unconditional inside the loops (the index is clamped instead) so that the
             // compiler's s_waitcnt for the batch it needs leaves the next one's loads in flight.
@@ -900,8 +916,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
 #pragma unroll
                         for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = 0;
                     }
-                    if (kind == 0) so_count<true, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
-                    else so_count<false, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc);
+                    if (kind == 0) so_count<true, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc, true, cr_seen);
+                    else so_count<false, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc, true, cr_seen);
                 }
             }
         }

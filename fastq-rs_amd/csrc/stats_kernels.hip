@@ -393,15 +393,17 @@ hipError_t launch_stats_lines(hipStream_t s, StatsArgs a, int n_cu) {
 //   * at the k-th atomic of a step, lane (line slot g, dword m) adds the byte j = k ^ (g & 3) of
 //     its dword: row = 32 u + 4 m + j, slot = m + 8 j + 32 (u & 1), bank = m + 8 j — the 32 lanes
 //     of a group (4 line slots x 8 dwords) are on 32 distinct banks whatever the bins are;
-//   * the bin sits in byte 1 of the address, so one v_perm_b32 (bytes 0, 2, 3 of the lane's address
-//     register, byte 1 from the bins) is the whole address computation.
+//   * the bin sits in byte 1 of the address, so one v_perm_b32 (byte 0 from the lane's register of slot
+//     offsets, byte 1 from the bins, bytes 2-3 zero; row block and region in the ds immediate offset) is the
+//     whole address computation.
 // A wave stages its tile's line-start list in LDS.  64 lines at a time, one lane per line works out
-// where the line starts, how long it is and whether it ends in '\r'; batches then pick that up with
-// ds_bpermute.  The loads of batch b+1 (every step of the line at once, unconditional, plus the
-// dword that holds the line's partial tail) are in flight while batch b is counted.  Whole dwords
-// of in-window bytes cost 1 VALU + 1 DS per byte; a line's last 1-3 columns are added by lanes 0-2
-// of its group; bytes outside the window / alphabet and columns beyond the LDS rows take the exact
-// per-byte path.  Quality bins: byte - 33 (0..63); sequence bins: byte & 7.
+// where the line starts and how long it is (whether it ends in '\r' only once the wave has met a CRLF);
+// batches then pick that up with ds_bpermute, a batch early.  Batches alternate between the sequence and
+// the quality lines of the same records.  The five loads of batch b+1 (every step of the line at once,
+// unconditional) are in flight while batch b is counted.  Whole dwords of in-window bytes cost 1 VALU +
+// 1 DS per byte; a line's last 1-3 columns are counted by the lane that holds that dword, under byte
+// masks; bytes outside the window / alphabet and columns beyond the LDS rows take the exact per-byte
+// path.  Quality bins: byte - 33 (0..63); sequence bins: byte & 7.
 constexpr uint32_t SO_THREADS = 1024;
 constexpr uint32_t SO_WAVES = SO_THREADS / 64;
 constexpr uint32_t SO_LC_MAX = 256;           // rows kept in LDS

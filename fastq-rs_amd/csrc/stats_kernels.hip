@@ -529,10 +529,10 @@ struct SoShape {
     uint32_t key;             // low 16 bits of the P it was derived from
     uint32_t full[NSL];       // ~0 where this lane has a whole dword of its line at step u
     uint32_t tu;              // the step that holds the line's partial last dword (column nfull4) ...
-    uint32_t tb;              // ... this lane's byte mask in that step (0xFF per byte it counts) ...
-    uint32_t tf[4];           // ... and the value of its k-th atomic there (~0: the byte k ^ (g & 3) counts)
+    uint32_t tb;              // ... the byte mask of the lane that holds it (0xFF per byte of the line; 0 in the other lanes) ...
+    uint32_t tf[4];           // ... and the value of that lane's k-th atomic there (~0: the byte k ^ (g & 3) counts)
     uint32_t any;             // wave-uniform: 1 some line has a partial last dword, 2 some line is longer than the rows,
-                              // bit 8 + u: some line's partial last dword is in step u
+                              // bits 8-15: the step of the partial last dwords if it is the same for all of them, else 0xFF
 };
 template <uint32_t NSL>
 __device__ __forceinline__ void so_shape(SoShape<NSL> &S, uint32_t P, uint32_t m) {
@@ -545,14 +545,17 @@ __device__ __forceinline__ void so_shape(SoShape<NSL> &S, uint32_t P, uint32_t m
     // In step tu lane mt = nfull4 / 4 % 8 holds columns nfull4 .. nfull4 + 3, of which nbt belong to the line;
     // the lanes below it hold whole dwords, the lanes above it nothing.
     const uint32_t tu = nfull4 >> 5, mt = (nfull4 >> 2) & 7u, g3 = (__lane_id() >> 3) & 3u;
-    S.tu = nbt ? tu : 0xFFu;
-    S.tb = m < mt ? 0xFFFFFFFFu : m == mt ? (1u << (8u * nbt)) - 1u : 0u;
+    S.tu = nbt ? tu : 7u;  // (7: no partial dword here; the masks below are 0 then)
+    S.tb = (nbt && m == mt) ? (1u << (8u * nbt)) - 1u : 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) S.tf[k] = (m < mt || (m == mt && (k ^ g3) < nbt)) ? 0xFFFFFFFFu : 0u;
-    uint32_t any = (__ballot(nbt != 0) != 0 ? 1u : 0u) | (__ballot((P >> SO_P_LONG) & 1u) != 0 ? 2u : 0u);
-#pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) any |= __ballot(nbt != 0 && tu == u) != 0 ? 256u << u : 0u;
-    S.any = any;
+    for (uint32_t k = 0; k < 4; ++k) S.tf[k] = (m == mt && (k ^ g3) < nbt) ? 0xFFFFFFFFu : 0u;
+    const unsigned long long tl = __ballot(nbt != 0);
+    uint32_t tus = 0xFFu;
+    if (tl) {
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tu, (int)(__ffsll((long long)tl) - 1));
+        if (__ballot(nbt != 0 && tu != t0) == 0) tus = t0;
+    }
+    S.any = (tl ? 1u : 0u) | (__ballot((P >> SO_P_LONG) & 1u) != 0 ? 2u : 0u) | (tus << 8);
 }
 // ds_sub_u32 of a lane mask (~0 counts one, 0 counts nothing) with the row block and the u & 1 half of
 // the slot as the instruction's immediate offset.
@@ -583,11 +586,32 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
     const bool tails = (any & 1u) != 0, longs = (any & 2u) != 0;
     uint32_t chk = 0;  // sequence: OR of (dword ^ expected); quality: OR of (byte - 33), bits 6-7 tell
     uint32_t orw = 0;  // sequence: OR of the counted bytes; bit 3 is set in 'N' only
+    // The partial last dwords: the raw dword of step tu (one scalar pick when every line has it in the same step),
+    // checked under the byte mask of the one lane that holds it, counted by that lane after pass 2.
+    uint32_t pt = 0;
+    const uint32_t tus = (any >> 8) & 0xFFu;
+    if (tails) {
+        uint32_t x = B.w[0];
+        if (tus < NSL) {
+#pragma unroll
+            for (uint32_t u = 1; u < NSL; ++u)
+                if (tus == u) x = B.w[u];
+        } else {
+#pragma unroll
+            for (uint32_t u = 1; u < NSL; ++u) x = S.tu == u ? B.w[u] : x;
+        }
+        if (IS_SEQ) {
+            pt = x & 0x07070707u;
+            chk |= (x ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pt)) & S.tb;
+            orw |= x & S.tb;
+        } else {
+            pt = x - 0x21212121u;
+            chk |= pt & S.tb;
+        }
+    }
 #define FQH_SO_PASS1(U)                                                                            \
     if (U < NSL) {                                                                                 \
-        const uint32_t w = B.w[U < NSL ? U : 0];                                                   \
-        uint32_t f = S.full[U < NSL ? U : 0];                                                      \
-        if (any & (256u << U)) f = S.tu == U ? S.tb : f;   /* a step with partial last dwords */  \
+        const uint32_t w = B.w[U < NSL ? U : 0], f = S.full[U < NSL ? U : 0];                      \
         if (IS_SEQ) {                                                                              \
             const uint32_t bins = w & 0x07070707u;                                                 \
             chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;                \
@@ -613,14 +637,18 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
 #define FQH_SO_PASS2(U)                                                                            \
         if (U < NSL) {                                                                             \
             const uint32_t pb = B.w[U < NSL ? U : 0], f = S.full[U < NSL ? U : 0];                 \
-            const bool tstep = (any & (256u << U)) != 0;  /* wave-uniform */                       \
             _Pragma("unroll") for (int k = 0; k < 4; ++k)                                          \
-                lds_sub<REGION + 128u * (U & 1u) + RB * (U >> 1)>(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]), \
-                                                                  tstep && S.tu == U ? S.tf[k] : f); \
+                lds_sub<REGION + 128u * (U & 1u) + RB * (U >> 1)>(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]), f); \
         }
         FQH_SO_PASS2(0) FQH_SO_PASS2(1) FQH_SO_PASS2(2) FQH_SO_PASS2(3)
         FQH_SO_PASS2(4) FQH_SO_PASS2(5) FQH_SO_PASS2(6) FQH_SO_PASS2(7)
 #undef FQH_SO_PASS2
+        if (tails) {  // (the row block and slot half of step tu go into the address, not the immediate offset)
+            const uint32_t tu = tus < NSL ? tus : S.tu;
+            const uint32_t off = REGION + ((tu & 1u) << 7) + (tu >> 1) * RB;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_sub<0>(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off, S.tf[k]);
+        }
     }
     uint32_t any_n = IS_SEQ ? orw & 0x08080808u : 0u, any_inv = 0;
     // exact work: a refused batch (every step and the tails), and everything from column nfull4 on in

@@ -18,7 +18,8 @@ NSCALARS = 8
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
-    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead", "fqh_last_timing",
+    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
+    "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
@@ -109,6 +110,10 @@ def lib():
         L.fqh_stats_launch.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
         L.fqh_stats_finish.argtypes = [vp, C.POINTER(Summary), C.POINTER(Carry)]
         L.fqh_stats_launch_lead.argtypes = [vp, vp, u64, u64, i32, C.POINTER(Carry), u32, vp, vp, vp]
+        L.fqh_scan_stats.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), vp, u64, u32, vp, vp, vp,
+                                     C.POINTER(Summary), C.POINTER(Carry)]
+        L.fqh_scan_stats_launch.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), vp, u64, u32, vp, vp, vp]
+        L.fqh_scan_stats_finish.argtypes = [vp, C.POINTER(Summary), C.POINTER(Carry)]
         L.fqh_stream_set_stats.argtypes = [vp, u32, vp, vp, vp]
         L.fqh_last_timing.argtypes = [vp, C.POINTER(Timing)]
         L.fqh_record_flags.argtypes = [vp, vp, u64, u64, vp, u64, vp]
@@ -251,6 +256,22 @@ class Ctx:
         self._chk(self._L.fqh_stats_launch_lead(self._h, d_buf, length, lead_len, 1 if is_final else 0,
                                                 C.byref(carry) if carry is not None else None, lmax,
                                                 d_qual, d_base, d_scalars))
+
+    def scan_stats(self, d_buf, length, lmax, d_qual, d_base, d_scalars, is_final=True, carry=None,
+                   d_rec_start=None, cap=0):
+        """Offsets + histograms in one call (one read of the input for a whole file) -> (summary, carry, status)."""
+        s, c = Summary(), Carry()
+        st = self._L.fqh_scan_stats(self._h, d_buf, length, 1 if is_final else 0,
+                                    C.byref(carry) if carry is not None else None, d_rec_start, cap, lmax,
+                                    d_qual, d_base, d_scalars, C.byref(s), C.byref(c))
+        self._chk(st, allow=(E_CAPACITY,))
+        return s, c, st
+
+    def scan_stats_launch(self, d_buf, length, lmax, d_qual, d_base, d_scalars, is_final=True, carry=None,
+                          d_rec_start=None, cap=0):
+        self._chk(self._L.fqh_scan_stats_launch(self._h, d_buf, length, 1 if is_final else 0,
+                                                C.byref(carry) if carry is not None else None, d_rec_start, cap,
+                                                lmax, d_qual, d_base, d_scalars))
 
     def stats_finish(self):
         s, c = Summary(), Carry()

@@ -8,19 +8,20 @@
 #include "replay.h"
 
 namespace fqh {
-void set_dbg_flags(uint32_t);
 void launch_index(hipStream_t, const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint16_t *, uint64_t, DevOut *, int, bool);
 void launch_emit_fast(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize_fast(hipStream_t, const ScanArgs &, DevOut *);
 void launch_prefix(hipStream_t, uint32_t *, const uint16_t *, uint32_t *, uint64_t *, uint64_t, uint64_t);
 void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
-void launch_stats_records(hipStream_t, const uint8_t *, uint64_t, const fqh_idx_record *, uint64_t,
-                          uint32_t, uint64_t *, uint64_t *, uint64_t *, int);
-size_t stats_lines_scratch_bytes(uint32_t, int);
-hipError_t launch_stats_lines(hipStream_t, StatsArgs, int);
 size_t stats_oct_scratch_bytes(uint32_t, int);
 hipError_t launch_stats_oct(hipStream_t, StatsArgs, int);
+bool scan_stats_supports(uint32_t lmax);
+uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu);
+size_t scan_stats_scratch_bytes(int n_cu);
+hipError_t launch_scan_stats(hipStream_t, StatsArgs, FusedArgs, int);
+void launch_stats_commit(hipStream_t, const DevOut *, const StatsArgs &, uint32_t, unsigned long long *, unsigned long long *,
+                         unsigned long long *);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_record_flags(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_idx_record *, uint64_t, uint8_t *);
 uint64_t gather_blocks(uint64_t n);
@@ -28,7 +29,6 @@ void launch_gather(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_i
                    uint32_t, unsigned long long *, unsigned long long *, unsigned long long *, uint8_t *, uint64_t);
 void launch_synth(hipStream_t, uint8_t *, uint64_t, uint64_t, uint64_t);
 void launch_read_ceiling(hipStream_t, const uint8_t *, uint64_t, uint64_t *, int);
-extern int g_index_variant;
 }  // namespace fqh
 
 using namespace fqh;
@@ -83,6 +83,14 @@ struct fqh_ctx {
     fqh_carry last_carry_out = {};
     // stats in flight
     bool stats_pending = false;
+    // single-pass scan + histograms (k_scan_stats): the request of the launch in flight, and the side arrays the
+    // kernel's 64-bit counters go to until k_stats_commit adds them to the caller's
+    bool fused = false;           // the scan being enqueued / in flight counts as well
+    uint32_t f_lmax = 0;
+    uint64_t *f_qual = nullptr, *f_base = nullptr, *f_scalars = nullptr;
+    unsigned long long *side = nullptr;   // [lmax * 256 | lmax * 8 | FQH_NSCALARS]
+    size_t side_elems = 0;
+    bool fused_enabled = true;    // FQH_FUSED=0: histograms always as a second pass over a full index
 };
 
 #define HIPCHK(ctx, call)                                                                      \

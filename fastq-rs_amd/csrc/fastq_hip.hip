@@ -81,7 +81,8 @@ fqh_status fqh_create(int device, fqh_ctx **out) {
         fqh_destroy(ctx);
         return st;
     }
-    if (const char *e = getenv("FQH_SPEC")) ctx->spec_enabled = atoi(e) != 0;  // tuning hook: 0 = exact path only
+    if (const char *e = getenv("FQH_SPEC")) ctx->spec_enabled = atoi(e) != 0;    // knob: 0 = exact path only
+    if (const char *e = getenv("FQH_FUSED")) ctx->fused_enabled = atoi(e) != 0;  // knob: 0 = histograms as a second pass
     *out = ctx;
     return FQH_OK;
 }
@@ -103,6 +104,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->tmp_rec);
     (void)hipFree(ctx->stats_scratch);
     (void)hipFree(ctx->gather_ws);
+    (void)hipFree(ctx->side);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->h_init) (void)hipHostFree(ctx->h_init);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -173,7 +175,46 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     if (!ctx->dout_clean) HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
     ctx->dout_clean = false;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
-    if (!reuse_index) {
+    StatsArgs fsa = {};
+    const bool fused = fast && ctx->fused && !reuse_index;
+    if (fused) {
+        // the single-pass kernel: byte scan of the fast path + histograms (fused_kernels.hip).  Its partial
+        // histograms and 64-bit counters go to scratch; k_stats_commit (below) adds them to the caller's arrays
+        // if the finalize kernel keeps the fast path's result.
+        const size_t need = scan_stats_scratch_bytes(ctx->n_cu);
+        if (need > ctx->stats_scratch_bytes) {
+            (void)hipFree(ctx->stats_scratch);
+            ctx->stats_scratch = nullptr;
+            ctx->stats_scratch_bytes = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->stats_scratch, need));
+            ctx->stats_scratch_bytes = need;
+        }
+        const size_t side = (size_t)ctx->f_lmax * 264 + FQH_NSCALARS;
+        if (side > ctx->side_elems) {
+            (void)hipFree(ctx->side);
+            ctx->side = nullptr;
+            ctx->side_elems = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->side, side * sizeof(unsigned long long)));
+            ctx->side_elems = side;
+        }
+        HIPCHK(ctx, hipMemsetAsync(ctx->side, 0, side * sizeof(unsigned long long), s));
+        fsa.buf = a.buf;
+        fsa.len = a.len;
+        fsa.lmax = ctx->f_lmax;
+        fsa.scratch = ctx->stats_scratch;
+        fsa.qual_hist = ctx->side;
+        fsa.base_hist = ctx->side + (size_t)ctx->f_lmax * 256;
+        fsa.scalars = ctx->side + (size_t)ctx->f_lmax * 264;
+        HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));  // (after the memset: index_ms is the kernel alone)
+        FusedArgs z = {};
+        z.list = ctx->list;
+        z.list_cap = ctx->list_cap;
+        z.fast_rs = ctx->fast_rs;
+        z.n_tiles = a.n_tiles;
+        z.out = &ctx->d_out[0];
+        if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fsa, z, ctx->n_cu));
+        ctx->index_full = false;
+    } else if (!reuse_index) {
         launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs, a.n_tiles,
                      &ctx->d_out[0], ctx->n_cu, fast);
         ctx->index_full = !fast;
@@ -186,6 +227,9 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     if (fast) {
         if (!ctx->skip_emit) launch_emit_fast(s, a, &ctx->d_out[0], ctx->n_cu);
         launch_finalize_fast(s, a, &ctx->d_out[0]);  // a prescan still needs the newline count and the carry
+        if (fused && a.n_tiles)
+            launch_stats_commit(s, &ctx->d_out[0], fsa, scan_stats_blocks(a.n_tiles, ctx->n_cu), (unsigned long long *)ctx->f_qual,
+                                (unsigned long long *)ctx->f_base, (unsigned long long *)ctx->f_scalars);
     } else {
         if (!ctx->skip_emit) launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
         launch_finalize(s, a, &ctx->d_out[0]);
@@ -502,9 +546,6 @@ extern "C" void fqh_debug_set_spec(fqh_ctx *ctx, int on) {
     ctx->spec_enabled = on != 0;
     ctx->spec_skip = ctx->spec_backoff = 0;
 }
-// tuning hook, not part of the public header: selects the k_index code variant for A/B runs
-extern "C" void fqh_debug_set_index_variant(int v) { fqh::g_index_variant = v; }
-extern "C" void fqh_debug_set_flags(unsigned f) { fqh::set_dbg_flags(f); }
 // copies the fast path's per-tile record (128 u16) of tile t to the host (tests / tools only)
 extern "C" int fqh_debug_fast_record(fqh_ctx *ctx, uint64_t t, uint16_t *out128) {
     if (!ctx || !ctx->fast_rs || t >= ctx->tiles_cap) return -1;
@@ -557,6 +598,40 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 
 }  // extern "C"
 
+// The single-pass route (k_scan_stats) counts every sequence / quality line of the buffer: it applies when all
+// records of the buffer count — a whole file from its first byte (no carry, no lead bytes, no record limit) — the
+// histogram fits the kernel's LDS rows, and the context is not backing off from the fast path.  Anything else
+// takes the two-pass route (exact index + k_stats_oct), which knows about chunk edges and error limits.
+static bool fused_eligible(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                           uint32_t lmax, uint64_t lead_len, uint64_t n_limit) {
+    if (!ctx->fused_enabled || !ctx->spec_enabled || ctx->spec_skip || ctx->list_cap != LIST_CAP_DEFAULT) return false;
+    if (!is_final || lead_len || n_limit != UINT64_MAX || !scan_stats_supports(lmax) || !len) return false;
+    if (in && !carry_is_zero(*in)) return false;
+    if (same_scan(ctx, d_buf, len, is_final, in) && ctx->index_full) return false;  // a full index is there: second pass only
+    return true;
+}
+static fqh_status fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                               uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
+                               uint64_t *d_base_hist, uint64_t *d_scalars) {
+    ctx->fused = true;
+    ctx->f_lmax = lmax;
+    ctx->f_qual = d_qual_hist;
+    ctx->f_base = d_base_hist;
+    ctx->f_scalars = d_scalars;
+    fqh_status st = do_scan_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap);
+    if (st != FQH_OK) ctx->fused = false;
+    return st;
+}
+// Finish of a single-pass launch: the scan's finish (which reruns the exact path if the fast path's proof failed);
+// *two_pass = the histograms were NOT committed and have to be counted over the exact index.
+static fqh_status fused_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out, bool *two_pass) {
+    fqh_status st = do_scan_finish(ctx, out, carry_out);
+    ctx->fused = false;
+    *two_pass = !ctx->used_spec;
+    if (ctx->used_spec) ctx->timing.stats_ms = ctx->timing.index_ms;  // the one kernel that read the input
+    return st;
+}
+
 // lead_len: bytes in front of d_buf that are valid device memory and hold the beginning of the
 // record in progress at the chunk start; n_limit: count at most this many records of the chunk.
 fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
@@ -567,6 +642,15 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
     fqh_status st;
+    if (fused_eligible(ctx, d_buf, len, is_final, in, lmax, lead_len, n_limit)) {
+        // one read of the input: scan + histograms in k_scan_stats (src/lib.rs:226-237 hands each record to the
+        // closure that reads seq()/qual(): one pass).  fqh_stats_finish falls back to the two-pass route if
+        // the fast path's proof fails.
+        st = fused_launch(ctx, d_buf, len, is_final, in, nullptr, 0, lmax, d_qual_hist, d_base_hist, d_scalars);
+        if (st != FQH_OK) return st;
+        ctx->stats_pending = true;
+        return FQH_OK;
+    }
     if (!same_scan(ctx, d_buf, len, is_final, in)) {
         // the histogram kernel needs complete line lists: scan on the exact path right away instead of
         // taking the fast path and indexing a second time
@@ -588,28 +672,10 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     const uint64_t skip = (n && back0 > 0) ? 1 : 0;
     const bool head = skip && lead_len >= back0;
     hipStream_t s = ctx->stream;
-    static const int stats_variant = getenv("FQH_STATS_VARIANT") ? atoi(getenv("FQH_STATS_VARIANT")) : 2;
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
-    if (n > skip && stats_variant == 0) {
-        // first implementation (one lane per record over an index of records): kept as a second,
-        // independent statement of the histogram for cross-checks
-        if (ctx->idx_cap < n) {
-            (void)hipFree(ctx->idx);
-            ctx->idx = nullptr;
-            ctx->idx_cap = 0;
-            HIPCHK(ctx, hipMalloc((void **)&ctx->idx, n * sizeof(fqh_idx_record)));
-            ctx->idx_cap = n;
-        }
-        st = emit_index(ctx, ctx->idx, n);
-        if (st != FQH_OK) return st;
-    }
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
-    if (n > skip && stats_variant == 0) {
-        launch_stats_records(s, d_buf, ctx->carry_in.base_offset, ctx->idx + skip, n - skip, lmax,
-                             d_qual_hist, d_base_hist, d_scalars, ctx->n_cu);
-    } else if (n > skip) {
-        const size_t need = stats_variant == 1 ? stats_lines_scratch_bytes(lmax, ctx->n_cu)
-                                                 : stats_oct_scratch_bytes(lmax, ctx->n_cu);
+    if (n > skip) {
+        const size_t need = stats_oct_scratch_bytes(lmax, ctx->n_cu);
         if (need > ctx->stats_scratch_bytes) {
             (void)hipFree(ctx->stats_scratch);
             ctx->stats_scratch = nullptr;
@@ -636,7 +702,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         sa.qual_hist = (unsigned long long *)d_qual_hist;
         sa.base_hist = (unsigned long long *)d_base_hist;
         sa.scalars = (unsigned long long *)d_scalars;
-        HIPCHK(ctx, stats_variant == 1 ? launch_stats_lines(s, sa, ctx->n_cu) : launch_stats_oct(s, sa, ctx->n_cu));
+        HIPCHK(ctx, launch_stats_oct(s, sa, ctx->n_cu));
     }
     if (head) {
         StatsArgs sa = {};
@@ -681,6 +747,22 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
     if (!ctx->stats_pending) return fail(ctx, FQH_E_ARG, "no stats pending");
     ctx->stats_pending = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->fused) {
+        const uint8_t *buf = ctx->args.buf;
+        const uint64_t len = ctx->args.len;
+        const int is_final = ctx->args.is_final;
+        const fqh_carry cin = ctx->carry_in;
+        const uint32_t lmax = ctx->f_lmax;
+        uint64_t *qh = ctx->f_qual, *bh = ctx->f_base, *sc = ctx->f_scalars;
+        bool two_pass = false;
+        fqh_status st = fused_finish(ctx, out, carry_out, &two_pass);
+        if (st != FQH_OK && st != FQH_E_CAPACITY) return st;
+        if (!two_pass) return FQH_OK;
+        // the exact path has rerun the scan (same buffer, full index): count over it
+        st = fqh_internal_stats_launch(ctx, buf, len, is_final, &cin, lmax, qh, bh, sc, 0, UINT64_MAX);
+        if (st != FQH_OK) return st;
+        ctx->stats_pending = false;
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->timing.emit_ms = ms;
@@ -689,6 +771,40 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
     if (out) *out = ctx->last_summary;
     if (carry_out) *carry_out = ctx->last_carry_out;
     return FQH_OK;
+}
+
+fqh_status fqh_scan_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                                 uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
+                                 uint64_t *d_base_hist, uint64_t *d_scalars) {
+    if (!ctx) return FQH_E_ARG;
+    if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
+    ctx->last_valid = false;  // never a reuse of an earlier scan: the offsets are wanted as well
+    if (fused_eligible(ctx, d_buf, len, is_final, in, lmax, 0, UINT64_MAX)) {
+        fqh_status st = fused_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap, lmax, d_qual_hist, d_base_hist, d_scalars);
+        if (st != FQH_OK) return st;
+        ctx->stats_pending = true;
+        return FQH_OK;
+    }
+    // two passes: the exact scan (offsets + full index), then the histogram kernel over that index
+    const bool spec = ctx->spec_enabled;
+    ctx->spec_enabled = false;
+    fqh_status st = do_scan_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap);
+    if (st == FQH_OK) st = do_scan_finish(ctx, nullptr, nullptr);
+    ctx->spec_enabled = spec;
+    if (st != FQH_OK) return st;  // (FQH_E_CAPACITY included: the summary of fqh_scan_stats_finish is not available then)
+    return fqh_internal_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars, 0, UINT64_MAX);
+}
+fqh_status fqh_scan_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
+    return fqh_stats_finish(ctx, out, carry_out);
+}
+fqh_status fqh_scan_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                          uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
+                          uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out, fqh_carry *carry_out) {
+    fqh_status st = fqh_scan_stats_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap, lmax, d_qual_hist, d_base_hist,
+                                          d_scalars);
+    if (st != FQH_OK) return st;
+    return fqh_stats_finish(ctx, out, carry_out);
 }
 
 fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,

@@ -96,6 +96,18 @@ struct DevOut {
     long long err_start;            // chunk-relative start of the failing record
     unsigned long long err_need;    // bytes of the failing record needed to see its error (0: n/a)
     unsigned long long tail_len;
+    unsigned long long stats_commit; // written by k_finalize_fast: 1 = the fast path's result stands (k_stats_commit may add
+                                     // what k_scan_stats counted to the caller's histograms), 0 = it is discarded
+};
+
+// What k_scan_stats (fused_kernels.hip) needs besides StatsArgs: the fast path's outputs of the byte scan.
+struct FusedArgs {
+    uint16_t *list;       // list area: record starts beyond a tile's two lines (reads shorter than ~25 bp)
+    uint32_t list_cap;
+    uint16_t *fast_rs;    // per tile one 128-byte line (+ a second one), as k_index_fast writes them
+    uint64_t n_tiles;
+    DevOut *out;          // spec_fail
+    uint32_t wave_base;   // set by the launcher: bytes of histogram in front of the wavefronts' LDS areas
 };
 
 }  // namespace fqh

@@ -12,116 +12,10 @@
 
 #include <cstdlib>
 
-#include "fqh_internal.h"
+#include "scan_dev.h"
 
 namespace fqh {
 
-// ---------------------------------------------------------------------------------------------
-// byte-scan helpers
-// 0x80 in every byte of x that equals the (7-bit) pattern byte — exact, no false positives, three
-// VALU ops: ((x & 0x7F..) ^ pat) in one v_bitop3; + 0x7F.. carries into bit 7 iff the low 7 bits
-// differ; bit 7 of x itself must be clear as well: ~(a | x) & 0x80.. in one v_bitop3.
-__device__ __forceinline__ uint32_t eq_flags(uint32_t x, uint32_t pat4) {
-    const uint32_t a = ((x & 0x7F7F7F7Fu) ^ pat4) + 0x7F7F7F7Fu;
-    return ~(a | x) & 0x80808080u;
-}
-// positional 16-bit mask: bit q set iff byte q of the 16-byte chunk equals the pattern byte.
-// MASKV 0: shift/or nibble gather.  MASKV 1: v_dot4_u32_u8 gathers the four 0x80 flags of a dword
-// in ONE instruction (byte weights 1,2,4,8 give nibble << 7; the next dword's weights 16..128 add
-// its nibble four bits higher).
-__device__ __forceinline__ uint32_t nib(uint32_t m) {
-    m >>= 7;
-    m |= m >> 7;
-    m |= m >> 14;
-    return m & 0xFu;
-}
-template <int MASKV>
-__device__ __forceinline__ uint32_t eqmask16(const uint4 &v, uint32_t pat4) {
-    if (MASKV == 0) {
-        return nib(eq_flags(v.x, pat4)) | (nib(eq_flags(v.y, pat4)) << 4) |
-               (nib(eq_flags(v.z, pat4)) << 8) | (nib(eq_flags(v.w, pat4)) << 12);
-    } else {
-        const uint32_t lo = __builtin_amdgcn_udot4(eq_flags(v.y, pat4), 0x80402010u,
-                            __builtin_amdgcn_udot4(eq_flags(v.x, pat4), 0x08040201u, 0u, false), false);
-        const uint32_t hi = __builtin_amdgcn_udot4(eq_flags(v.w, pat4), 0x80402010u,
-                            __builtin_amdgcn_udot4(eq_flags(v.z, pat4), 0x08040201u, 0u, false), false);
-        return (lo >> 7) | (hi << 1);
-    }
-}
-// byte q (0..15) of a 16-byte chunk held in registers: pick the 8-byte half with two selects, then
-// v_perm_b32 pulls the byte out (selector 0x0C = constant zero).  Written this way so the compiler
-// does not turn it into an indexed vector extract through LDS.
-__device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t q) {
-    const uint32_t lo = q < 8 ? v.x : v.z;
-    const uint32_t hi = q < 8 ? v.y : v.w;
-    return __builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (q & 7u));
-}
-// 16 bytes at buf+off; bytes at or beyond len read as 0
-// The input is read exactly once: non-temporal loads keep it from displacing useful lines and are
-// worth ~12 % of HBM read rate on MI355X (tools/readbw.hip: 5.8 -> 6.5 TB/s).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 load16_nt(const uint8_t *p) {
-    const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(r.x, r.y, r.z, r.w);
-}
-__device__ __forceinline__ uint4 load16(const uint8_t *__restrict__ buf, uint64_t off, uint64_t len) {
-    if (off + 16 <= len) return load16_nt(buf + off);
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // no indexed array: it would be promoted to LDS
-    if (off < len) {
-        const uint32_t n = (uint32_t)(len - off);
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t b = (uint32_t)buf[off + i] << ((i & 3u) * 8u);
-            if (i < 4) w0 |= b; else if (i < 8) w1 |= b; else if (i < 12) w2 |= b; else w3 |= b;
-        }
-    }
-    return make_uint4(w0, w1, w2, w3);
-}
-// ---------------------------------------------------------------------------------------------
-// helpers of the index kernel (k_index_t below)
-// lane-1's value (lane 0 gets `first`): DPP wave_shr:1, no LDS crossbar round trip
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t first) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xF, 0xF, false);
-}
-
-// One 1 KiB piece: 16 bytes per lane, already in registers.  FULL: every byte of the piece exists.
-template <bool FULL, int MASKV>
-__device__ __forceinline__ void index_piece(const uint4 v, const uint64_t off, const uint64_t len,
-                                            const uint32_t pbase, const uint32_t lane,
-                                            uint32_t &prev, uint32_t &run,
-                                            uint16_t *__restrict__ tl, const uint32_t list_cap) {
-    const uint32_t M = eqmask16<MASKV>(v, 0x0A0A0A0Au);
-    uint32_t LS = ((M << 1) | wave_shr1(M >> 15, prev)) & 0xFFFFu;
-    if (!FULL && off + 16 > len) {  // a line start must be an existing byte
-        const uint32_t nvalid = off < len ? (uint32_t)(len - off) : 0u;
-        LS &= (1u << nvalid) - 1u;
-    }
-    prev = ((uint32_t)__builtin_amdgcn_readlane((int)M, 63)) >> 15;
-    // exclusive prefix of popc(LS) over the wave: two ballot levels cover FASTQ ("\n+\n" puts two
-    // line starts in one 16-byte chunk); deeper levels only for pathological input
-    const uint32_t c = __popc(LS);
-    const unsigned long long b1 = __ballot(c >= 1), b2 = __ballot(c >= 2);
-    uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
-    pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
-    uint32_t tot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
-    if (__ballot(c >= 3)) {
-        for (uint32_t k = 3;; ++k) {
-            const unsigned long long b = __ballot(c >= k);
-            if (!b) break;
-            pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
-            tot += (uint32_t)__popcll(b);
-        }
-    }
-    if (run + tot <= list_cap) {  // uniform: no per-entry bound check
-        uint16_t *__restrict__ dst = tl + run + pre;
-        while (LS) {
-            const uint32_t q = __ffs(LS) - 1;
-            LS &= LS - 1;
-            const uint32_t b = byte_of(v, q);
-            *dst++ = (uint16_t)((pbase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
-        }
-    }
-    run += tot;
-}
 
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of tile_count: per-block local prefix + block sums, then the block sums.
@@ -647,30 +541,13 @@ __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
 // LDS image: logical 16-byte chunk c of the group lives in slot c ^ ((c >> 4) & 3) — conflict-free
 // for the lane-strided ds_write_b128 and for the lane-contiguous ds_read_b128 (MI355X LDS services
 // b128 reads in 16-lane groups over a 16-slot bank row).
-// LSTAGE: the tile's list entries are collected in LDS and written to HBM once per tile with
-// 8-byte coalesced stores, so the emit loops issue no global stores: on gfx950 stores share the
-// vmcnt counter with loads, and scattered 2-byte stores between the prefetch loads and their
-// s_waitcnt would put store acknowledgements on the critical path of the next 4 KiB group.
-constexpr uint32_t LSTAGE_ENTRIES = 512;
-// fast path: one 128-byte line of u16 per tile: [0..FR_N) offsets of the tile's first record starts
-// (unused slots 0), [FR_EDGE..+8) its first four and last four entries, [FR_CNT..+2) the entry count,
-// [FR_HYP] the alignment (7: none).  Record starts FR_N .. FR_N + 63 of a tile (reads shorter than ~140 bp)
-// go to a second whole line, fast_rs + FR2_OFF(n_tiles) + tile * 64; anything beyond into list[tile][8 + j].
-// Line starts per tile the fast path can stage (reads down to ~25 bp); 6 blocks per CU fit with this, which
-// measures the same as the 7 that 512 entries allow (tools/exp_ab_env.py FQH_INDEX_BPC 0 6).
-constexpr uint32_t FAST_ENTRIES = 1024;
-constexpr uint32_t FR_N = 52, FR_EDGE = 52, FR_CNT = 60, FR_HYP = 62, FR_STRIDE = 64, FR2_N = 64;
-__host__ __device__ __forceinline__ uint64_t fr2_off(uint64_t n_tiles) { return (n_tiles + 64) * FR_STRIDE; }
-__device__ uint32_t g_dbg_flags = 0;  // timing experiments only (tools/exp_*.py): 1 no count store, 2 no meta store, 4 no record-start store
-template <int PF, int LSTAGE>
 __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf, uint64_t len,
                                                  uint16_t *__restrict__ list, uint32_t list_cap,
                                                  uint32_t *__restrict__ tile_count,
                                                  uint64_t n_tiles, DevOut *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + (LSTAGE ? LSTAGE_ENTRIES * 2 + 16 : 0)];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096];
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *const lds = lds_all[threadIdx.x >> 6];
-    uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + 4096);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     uint32_t n_over = 0;
     // per-lane constants of the LDS image
@@ -682,7 +559,6 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
         const uint64_t tbase = tile << WT_SHIFT;
         uint16_t *__restrict__ tl = list + tile * list_cap;
         uint32_t run = 0;
-        uint32_t nstaged = 0;  // entries [0, nstaged) of this tile live in LDS until the tile ends
         uint32_t prev = 0;
         if (tile > 0) prev = (buf[tbase - 1] == '\n') ? 1u : 0u;
         const uint32_t lo = lane * 16;
@@ -697,7 +573,7 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                 *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
                 *reinterpret_cast<uint4 *>(wptr + 2048) = n2;
                 *reinterpret_cast<uint4 *>(wptr + 3072) = n3;
-                if (PF && g + 1 < WT_PIECES / 4) {
+                if (g + 1 < WT_PIECES / 4) {  // the next group's loads are in flight while this one is processed
                     p += 4 * PIECE_BYTES;
                     n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
                     n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
@@ -729,22 +605,7 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                     }
                 }
                 const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
-                if (LSTAGE && run == nstaged && run + tot <= LSTAGE_ENTRIES) {  // uniform: stage in LDS
-                    uint16_t *dst = lst + run + pre;
-                    while (ls_lo) {
-                        const uint32_t q = __ffs(ls_lo) - 1;
-                        ls_lo &= ls_lo - 1;
-                        const uint32_t b = rptr[q ^ s4];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
-                    }
-                    while (ls_hi) {
-                        const uint32_t q = __ffs(ls_hi) + 31;
-                        ls_hi &= ls_hi - 1;
-                        const uint32_t b = rptr[q ^ s4];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
-                    }
-                    nstaged = run + tot;
-                } else if (run + tot <= list_cap) {  // uniform
+                if (run + tot <= list_cap) {  // uniform
                     uint16_t *__restrict__ dst = tl + run + pre;
                     while (ls_lo) {
                         const uint32_t q = __ffs(ls_lo) - 1;
@@ -760,11 +621,6 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                     }
                 }
                 run += tot;
-                if (!PF && g + 1 < WT_PIECES / 4) {
-                    p += 4 * PIECE_BYTES;
-                    n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
-                    n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
-                }
             }
         } else {
 #pragma unroll 1
@@ -774,18 +630,6 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
                 const uint4 v = load16(buf, off, len);
                 index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, tl, list_cap);
             }
-        }
-        if (LSTAGE && nstaged) {  // flush the staged list: 4 entries (8 bytes) per lane and store
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane * 4; i < nstaged; i += 256) {
-                if (i + 4 <= nstaged) {
-                    *reinterpret_cast<uint2 *>(tl + i) = *reinterpret_cast<const uint2 *>(lst + i);
-                } else {  // never write past the staged part: later entries may already be in HBM
-                    for (uint32_t k = i; k < nstaged; ++k) tl[k] = lst[k];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) tile_count[tile] = run;
         if (run > list_cap) ++n_over;
@@ -807,10 +651,9 @@ __global__ __launch_bounds__(256) void k_index_t(const uint8_t *__restrict__ buf
 //     whole group (~5 us of work per wave) away, by which time loads and stores have both landed.
 // Whole tiles only; the (at most one) partial tile at the end of the buffer is taken by wave 0 of
 // block 0 through the generic piece loop afterwards.
-template <bool NT>
 __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ buf, uint64_t len,
                                                     uint16_t *__restrict__ list, uint32_t list_cap,
-                                                    uint32_t *__restrict__ tile_count, uint16_t *__restrict__ fast_rs,
+                                                    uint16_t *__restrict__ fast_rs,
                                                     uint64_t n_tiles, DevOut *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][4096 + FAST_ENTRIES * 2 + 16];
     const uint32_t lane = threadIdx.x & 63u;
@@ -820,7 +663,6 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t n_full = len >> WT_SHIFT;  // whole tiles
     uint32_t n_over = 0;
-    const uint32_t dbg = g_dbg_flags;
     const uint32_t wslot = lane ^ ((lane >> 4) & 3u);        // write: chunk 64 j + lane -> slot 64 j + wslot
     const uint32_t s4 = ((lane >> 2) & 3u) << 4;              // read:  byte Q of the lane at 64 lane + (Q ^ s4)
     uint8_t *const wptr = lds + wslot * 16;
@@ -870,11 +712,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         // one whole 128-byte line, non-temporal: written once, read once by k_emit_fast.  On the boxes where
         // a plain store costs the kernel 0.45 ms, this one costs 0.2.  (No plain/nt switch here: the
         // optimizer merges two stores to one address and drops the hint.)
-        if (!(dbg & 4u)) {
-            if (NT) __builtin_nontemporal_store((uint16_t)rv, fast_rs + tile * FR_STRIDE + lane);
-            else fast_rs[tile * FR_STRIDE + lane] = (uint16_t)rv;  // A/B only (FQH_NT_STORES=0)
-        }
-        if (lane == 0 && !(dbg & 1u) && tile_count) tile_count[tile] = run;      // dense copy (A/B: the prefix scan can read the line)
+        __builtin_nontemporal_store((uint16_t)rv, fast_rs + tile * FR_STRIDE + lane);
+        (void)run;
     };
 
     uint64_t tile = wave0;
@@ -986,7 +825,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // the record that straddles into it (five line starts out of the two tiles' 16-byte edge blocks).
 // Phase B, one iteration per tile: readlane the three scalars, one 2-byte load and one 8-byte
 // store per lane, in rounds of 16 loads then 16 stores.  ~25 instructions per tile instead of ~110.
-template <uint32_t EMIT_ROUND, bool NT>
+template <uint32_t EMIT_ROUND>
 __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
     __shared__ uint16_t stage_all[4][EMIT_ROUND * 64];
     uint16_t *const stage = stage_all[threadIdx.x >> 6];
@@ -1090,8 +929,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
                     const uint32_t oprev = wave_shr1(o, 0u);
                     if (lane < n) {
                         if (rs && (cap_ok || rb + lane < a.cap)) {
-                            if (NT) __builtin_nontemporal_store((uint64_t)(vbase + o), rs + lane);  // written once, not read here
-                            else rs[lane] = vbase + o;
+                            __builtin_nontemporal_store((uint64_t)(vbase + o), rs + lane);  // written once, not read here
                         }
                         if (lane) {  // record lane-1 of the tile lies inside it: its length
                             const uint32_t reclen = o - oprev;
@@ -1236,6 +1074,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         if (a.is_final && ((T & 3) != 0 || col > 0)) fail = true;  // truncated: the exact path reports it
     }
     out->spec_fail = fail ? 1 : 0;
+    out->stats_commit = fail ? 0 : 1;
     out->min_key = NOKEY;
     out->first_long = first_long;
     out->max_len = max_len;
@@ -1252,71 +1091,36 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     publish_and_reset(a, out);
 }
 
-int nt_stores() {  // A/B switch: bit 0 non-temporal stores in k_index_fast, bit 1 in k_emit_fast (default: both)
-    const char *e = getenv("FQH_NT_STORES");
-    return e ? atoi(e) : 3;
-}
-bool fast_count_in_line() {  // A/B switch (default on): the fast path keeps its entry count in the tile's line only
-    const char *e = getenv("FQH_FAST_COUNT_IN_LINE");
-    return !e || atoi(e) != 0;
-}
-void set_dbg_flags(uint32_t f) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_flags), &f, sizeof f); }
-int g_index_variant = -1;  // tuning hook (bench.py --variants); -1 = FQH_INDEX_VARIANT or default
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,
                   uint32_t *tile_count, uint16_t *fast_rs, uint64_t n_tiles, DevOut *out, int n_cu, bool fast) {
     if (!n_tiles) return;
-    static const int variant = getenv("FQH_INDEX_VARIANT") ? atoi(getenv("FQH_INDEX_VARIANT")) : 5;
-    const int bpc_env = getenv("FQH_INDEX_BPC") ? atoi(getenv("FQH_INDEX_BPC")) : 0;  // tuning: blocks per CU
-    typedef void (*kern_t)(const uint8_t *, uint64_t, uint16_t *, uint32_t, uint32_t *, uint64_t, DevOut *);
-    // 4: no prefetch, 5: production exact (register prefetch of the next 4 KiB group), 6: list staged
-    // in LDS; the fast path has its own kernel (k_index_fast)
-    static const kern_t kerns[7] = {k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>, k_index_t<1, 0>,
-                                    k_index_t<0, 0>, k_index_t<1, 0>, k_index_t<1, 1>};
-    static int occ[7] = {0, 0, 0, 0, 0, 0, 0};
-    int v = g_index_variant >= 0 ? g_index_variant : variant;
-    const int bpc_dbg = v / 100;  // tuning: variant + 100 * blocks-per-CU
-    v %= 100;
-    if (v < 0 || v > 6) v = 5;
-    if (fast) {
-        static int occf = 0;
-        if (!occf) {
-            int o = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast<true>, 256, 0) != hipSuccess || o < 1) o = 4;
-            occf = o > 8 ? 8 : o;
-        }
-        uint64_t blocks = (n_tiles + 3) / 4;
-        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occf);
-        if (blocks > maxb) blocks = maxb;
-        if (nt_stores() & 1)
-            hipLaunchKernelGGL(k_index_fast<true>, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
-                               fast_count_in_line() ? (uint32_t *)nullptr : tile_count, fast_rs, n_tiles, out);
-        else
-            hipLaunchKernelGGL(k_index_fast<false>, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
-                               fast_count_in_line() ? (uint32_t *)nullptr : tile_count, fast_rs, n_tiles, out);
-        return;
-    }
-    if (!occ[v]) {
-        // persistent grid = exactly the blocks that are resident at once: a static round-robin of
-        // tiles over a grid with one non-resident block per CU would run that block as a tail
+    // persistent grid = exactly the blocks that are resident at once: a static round-robin of tiles over
+    // a grid with one non-resident block per CU would run that block as a tail
+    static int occ[2] = {0, 0};
+    if (!occ[fast]) {
         int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kerns[v], 256, 0) != hipSuccess || o < 1) o = 4;
-        occ[v] = o > 8 ? 8 : o;
+        const hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_t, 256, 0);
+        if (e != hipSuccess || o < 1) o = 4;
+        occ[fast] = o > 8 ? 8 : o;
     }
     uint64_t blocks = (n_tiles + 3) / 4;
-    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc_dbg > 0 ? bpc_dbg : bpc_env > 0 ? bpc_env : occ[v]);
+    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ[fast];
     if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(kerns[v], dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
-                       tile_count, n_tiles, out);
+    if (fast)  // (the entry count travels in the tile's line: the prefix scan leaves the dense copy)
+        hipLaunchKernelGGL(k_index_fast, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
+                           fast_rs, n_tiles, out);
+    else
+        hipLaunchKernelGGL(k_index_t, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap, tile_count,
+                           n_tiles, out);
 }
 void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     if (a.n_tiles) {
         const uint64_t ngroups = (a.n_tiles + 63) >> 6;  // 64 tiles per wavefront and round
         uint64_t blocks = (ngroups + 3) / 4;
-        static const int bpc = getenv("FQH_EMIT_BPC") ? atoi(getenv("FQH_EMIT_BPC")) : 4;
-        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * (bpc > 0 ? bpc : 4);
+        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * 4;
         if (blocks > maxb) blocks = maxb;
-        if (nt_stores() & 2) hipLaunchKernelGGL((k_emit_fast<16, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
-        else hipLaunchKernelGGL((k_emit_fast<16, false>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        hipLaunchKernelGGL((k_emit_fast<16>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
     }
 }
 void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {
@@ -1325,7 +1129,7 @@ void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {
 void launch_prefix(hipStream_t s, uint32_t *tile_count, const uint16_t *fast_rs, uint32_t *tile_prefix,
                    uint64_t *block_prefix, uint64_t n_tiles, uint64_t n_blocks) {
     if (!n_tiles) return;
-    if (fast_rs && fast_count_in_line())
+    if (fast_rs)
         hipLaunchKernelGGL(k_prefix_local, dim3((uint32_t)n_blocks), dim3(256), 0, s,
                            reinterpret_cast<const uint32_t *>(fast_rs + FR_CNT), FR_STRIDE / 2, tile_count, tile_prefix,
                            block_prefix, n_tiles);

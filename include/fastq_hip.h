@@ -14,7 +14,7 @@
  *   RecordRefIter::advance / each   src/lib.rs:221-304            fqh_scan + fqh_summary
  *   RecordSetIter::next             src/lib.rs:364-425            fqh_scan (record offsets) +
  *                                                                 fqh_index_records
- *   loop over Record::seq()/qual()  src/records.rs:75-90 (a8)     fqh_stats
+ *   loop over Record::seq()/qual()  src/records.rs:75-90 (a8)     fqh_stats, fqh_scan_stats (one read)
  *   validate_dna / validate_dnan    src/records.rs:19-33          fqh_stats (scalars 3,4), fqh_record_flags
  *   Record::write (filter loops)    src/records.rs:93-96          fqh_gather_records
  *   Buffer                          src/buffer.rs:1-112           fqh_stream_* (pinned ring)
@@ -149,6 +149,21 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
                             const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                             uint64_t *d_base_hist, uint64_t *d_scalars);
 fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
+/* Record scan AND statistics of one buffer in a single call — for a whole file (is_final, no carry, lmax <= 256) in a
+ * single READ of the input: one kernel scans, validates and counts (k_scan_stats), the way the reference's
+ * Parser::each hands each record to the closure that reads seq()/qual() (src/lib.rs:226-237).  Outputs as
+ * fqh_scan (d_rec_start may be NULL) plus fqh_stats.  fqh_stats on its own takes the same single-pass route.
+ * Other shapes of call (chunks with a carry, non-final chunks, lmax > 256) and inputs the fast path cannot
+ * prove valid (any parse error, reads longer than ~500 bp) run the exact scan followed by the histogram kernel;
+ * results are identical either way. */
+fqh_status fqh_scan_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                          uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
+                          uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out,
+                          fqh_carry *carry_out);
+fqh_status fqh_scan_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
+                                 const fqh_carry *in, uint64_t *d_rec_start, uint64_t cap, uint32_t lmax,
+                                 uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars);
+fqh_status fqh_scan_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
 /* As fqh_stats_launch, for a chunk whose buffer also holds the beginning of the record in progress
  * at the chunk start: d_buf[-lead_len .. -1] is valid device memory and ends with the bytes of that
  * record that precede the chunk (in->back[in->nl_count & 3] of them; the streaming ring and a

@@ -19,8 +19,8 @@ hipError_t launch_stats_oct(hipStream_t, StatsArgs, int);
 bool scan_stats_supports(uint32_t lmax);
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu);
 size_t scan_stats_scratch_bytes(int n_cu);
-hipError_t launch_scan_stats(hipStream_t, StatsArgs, FusedArgs, int);
-void launch_stats_commit(hipStream_t, const DevOut *, const StatsArgs &, uint32_t, unsigned long long *, unsigned long long *,
+hipError_t launch_scan_stats(hipStream_t, FusedArgs, int);
+void launch_stats_commit(hipStream_t, const DevOut *, const FusedArgs &, uint32_t, unsigned long long *, unsigned long long *,
                          unsigned long long *);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_record_flags(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_idx_record *, uint64_t, uint8_t *);
@@ -88,8 +88,7 @@ struct fqh_ctx {
     bool fused = false;           // the scan being enqueued / in flight counts as well
     uint32_t f_lmax = 0;
     uint64_t *f_qual = nullptr, *f_base = nullptr, *f_scalars = nullptr;
-    unsigned long long *side = nullptr;   // [lmax * 256 | lmax * 8 | FQH_NSCALARS]
-    size_t side_elems = 0;
+    unsigned long long *side = nullptr;   // FQH_NSCALARS totals of the launch in flight
     bool fused_enabled = true;    // FQH_FUSED=0: histograms always as a second pass over a full index
 };
 

@@ -175,12 +175,12 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     if (!ctx->dout_clean) HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[0], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, s));
     ctx->dout_clean = false;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
-    StatsArgs fsa = {};
+    FusedArgs fz = {};
     const bool fused = fast && ctx->fused && !reuse_index;
     if (fused) {
         // the single-pass kernel: byte scan of the fast path + histograms (fused_kernels.hip).  Its partial
-        // histograms and 64-bit counters go to scratch; k_stats_commit (below) adds them to the caller's arrays
-        // if the finalize kernel keeps the fast path's result.
+        // histograms and totals go to scratch; k_stats_commit (below) adds them to the caller's arrays if the
+        // finalize kernel keeps the fast path's result.
         const size_t need = scan_stats_scratch_bytes(ctx->n_cu);
         if (need > ctx->stats_scratch_bytes) {
             (void)hipFree(ctx->stats_scratch);
@@ -189,30 +189,20 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
             HIPCHK(ctx, hipMalloc((void **)&ctx->stats_scratch, need));
             ctx->stats_scratch_bytes = need;
         }
-        const size_t side = (size_t)ctx->f_lmax * 264 + FQH_NSCALARS;
-        if (side > ctx->side_elems) {
-            (void)hipFree(ctx->side);
-            ctx->side = nullptr;
-            ctx->side_elems = 0;
-            HIPCHK(ctx, hipMalloc((void **)&ctx->side, side * sizeof(unsigned long long)));
-            ctx->side_elems = side;
-        }
-        HIPCHK(ctx, hipMemsetAsync(ctx->side, 0, side * sizeof(unsigned long long), s));
-        fsa.buf = a.buf;
-        fsa.len = a.len;
-        fsa.lmax = ctx->f_lmax;
-        fsa.scratch = ctx->stats_scratch;
-        fsa.qual_hist = ctx->side;
-        fsa.base_hist = ctx->side + (size_t)ctx->f_lmax * 256;
-        fsa.scalars = ctx->side + (size_t)ctx->f_lmax * 264;
+        if (!ctx->side) HIPCHK(ctx, hipMalloc((void **)&ctx->side, FQH_NSCALARS * sizeof(unsigned long long)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->side, 0, FQH_NSCALARS * sizeof(unsigned long long), s));
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));  // (after the memset: index_ms is the kernel alone)
-        FusedArgs z = {};
-        z.list = ctx->list;
-        z.list_cap = ctx->list_cap;
-        z.fast_rs = ctx->fast_rs;
-        z.n_tiles = a.n_tiles;
-        z.out = &ctx->d_out[0];
-        if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fsa, z, ctx->n_cu));
+        fz.buf = a.buf;
+        fz.len = a.len;
+        fz.n_tiles = a.n_tiles;
+        fz.list = ctx->list;
+        fz.list_cap = ctx->list_cap;
+        fz.fast_rs = ctx->fast_rs;
+        fz.out = &ctx->d_out[0];
+        fz.lmax = ctx->f_lmax;
+        fz.scratch = ctx->stats_scratch;
+        fz.scalars = ctx->side;
+        if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fz, ctx->n_cu));
         ctx->index_full = false;
     } else if (!reuse_index) {
         launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs, a.n_tiles,
@@ -228,7 +218,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         if (!ctx->skip_emit) launch_emit_fast(s, a, &ctx->d_out[0], ctx->n_cu);
         launch_finalize_fast(s, a, &ctx->d_out[0]);  // a prescan still needs the newline count and the carry
         if (fused && a.n_tiles)
-            launch_stats_commit(s, &ctx->d_out[0], fsa, scan_stats_blocks(a.n_tiles, ctx->n_cu), (unsigned long long *)ctx->f_qual,
+            launch_stats_commit(s, &ctx->d_out[0], fz, scan_stats_blocks(a.n_tiles, ctx->n_cu), (unsigned long long *)ctx->f_qual,
                                 (unsigned long long *)ctx->f_base, (unsigned long long *)ctx->f_scalars);
     } else {
         if (!ctx->skip_emit) launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);

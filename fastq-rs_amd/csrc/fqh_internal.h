@@ -100,14 +100,21 @@ struct DevOut {
                                      // what k_scan_stats counted to the caller's histograms), 0 = it is discarded
 };
 
-// What k_scan_stats (fused_kernels.hip) needs besides StatsArgs: the fast path's outputs of the byte scan.
+// Arguments of k_scan_stats (fused_kernels.hip): the input, the fast path's outputs of the byte scan, and where the
+// counts go.
 struct FusedArgs {
+    const uint8_t *buf;
+    uint64_t len;
+    uint64_t n_tiles;
     uint16_t *list;       // list area: record starts beyond a tile's two lines (reads shorter than ~25 bp)
     uint32_t list_cap;
     uint16_t *fast_rs;    // per tile one 128-byte line (+ a second one), as k_index_fast writes them
-    uint64_t n_tiles;
     DevOut *out;          // spec_fail
+    uint32_t lmax, lc;    // the caller's lmax; lc = rows of the LDS histogram in use (set by the launcher)
+    uint32_t *scratch;    // [gridDim.x][SO_WORDS] per-block partial histograms
+    unsigned long long *scalars;  // FQH_NSCALARS totals (a zeroed side array: k_stats_commit adds them to the caller's)
     uint32_t wave_base;   // set by the launcher: bytes of histogram in front of the wavefronts' LDS areas
+    uint32_t dbg;         // knock-out flags for timing experiments (FQH_FZ_DBG; results are wrong by design)
 };
 
 }  // namespace fqh

@@ -2,56 +2,203 @@
 // (DESIGN.md §5b).  The reference touches every record once: Parser::each hands it to the closure that
 // reads seq()/qual() (src/lib.rs:226-237, src/records.rs:83-90).  Here the byte scan of the fast path
 // (k_index_fast, scan_kernels.hip) and the eight-lanes-per-line count of k_stats_oct (stats_dev.h) run in
-// the same wavefront on the same LDS image of the data:
+// the same wavefront on the same LDS image of the data.
 //
-//   * one 1024-thread block per CU owns the CU's LDS: the bank-scheduled histogram (stats_dev.h) and,
-//     behind it, 5 KiB per wavefront: [512 B tail of the previous group | 4 KiB group | 128 B tile line |
-//     4 + 188 line-start entries];
-//   * a wavefront takes 16 KiB tiles round-robin, 4 KiB groups at a time, exactly like k_index_fast:
-//     16-byte non-temporal loads a group ahead, LDS transposition, SWAR newline masks, ballot prefix;
-//   * the group's line starts are staged in LDS; 5-entry windows ('@' on line i, '+' on line i+2, equal
-//     raw lengths of lines i+1 and i+3) are checked under the four possible alignments.  The tile's FIRST
-//     group must single out one alignment: that is the phase the tile's lines are counted under, and at
-//     the tile's end it must still be the only consistent one.  k_emit_fast later checks it against the
-//     true global line index; any doubt sets spec_fail and nothing of this pass is used;
-//   * every line that ENDS in the group (its successor's start is one of the group's entries) is counted
-//     from LDS: one lane per line works out start / length, batches of eight lines are read back with
-//     aligned ds_read_b32 (the tail keeps the 512 bytes in front of the group, so a line that straddles
-//     two groups is contiguous) and shifted into place with v_alignbyte and two DPP moves; then the
-//     straight-line pass 1 / pass 2 of so_count: one v_perm_b32 + one ds_sub_u32 per byte;
-//   * the tile's last line ends in another wavefront's tile: it is counted byte-wise from global memory
-//     (one line per tile), as is nothing else in well-formed input;
-//   * per-block partial histograms, per-lane totals and the exact path's 64-bit counters go to scratch;
-//     k_stats_commit adds them to the caller's arrays only if the scan's finalize kernel found no reason
-//     to doubt the fast path.
+// What bounds it is the vector ALU (a wave64 VALU operation occupies its SIMD for four cycles: 4.8e9 of them
+// per 16 GiB made the first version take 11 ms), then the LDS atomic unit; HBM comes third.  Hence:
+//   * one block per CU owns the CU's LDS: the bank-scheduled histogram (stats_dev.h) and, behind it, 5.5 KiB per
+//     wavefront: [512 B tail of the previous group | 4 KiB group | 512 B of the bytes after the span | 128 B tile
+//     line | 4 + 188 line-start entries];
+//   * a wavefront takes SPANS of four 16 KiB tiles round-robin and walks them 4 KiB at a time like k_index_fast
+//     (16-byte non-temporal loads a group ahead, SWAR newline masks, ballot prefix).  The LDS image is LINEAR; the
+//     lane-contiguous read-back is conflict-free because lane l reads its four 16-byte chunks in the order
+//     (i + l / 4) % 4 and rotates its 64-bit newline mask back (4 VALU per group);
+//   * the group's line starts are staged in LDS; windows of five entries are checked under the four alignments
+//     exactly as in k_index_fast.  The span's first group must single out one alignment: the phase everything in
+//     the span is counted under; every tile must confirm it, and k_emit_fast checks each tile's against the true
+//     global line index.  Any doubt sets spec_fail and nothing of this pass is used;
+//   * every line that ENDS in a group is counted from LDS (the tail keeps the 512 bytes in front of the group, so
+//     a line that straddles groups or tiles is contiguous): one lane per line works out start and length
+//     (trim_winline: one '\r'), eight lines make a batch, a lane's dword of each step is one ds_read2_b32 with an
+//     immediate offset and one v_alignbyte, then pass 1 / pass 2 of the bank schedule: one v_perm_b32 + one
+//     ds_sub_u32 per byte.  A batch that is not full at the end of a group stays in registers and is filled up by
+//     the next group's lines (batches are 97 % full instead of 77 %);
+//   * the span's last line ends in another wavefront's span: the 512 bytes after the span are read as well and
+//     the line is closed there;
+//   * no exact path in here: a byte outside ACGTN / '!'..'`', a line longer than the histogram's rows or than the
+//     kept tail, more than 188 line starts in 4 KiB — the span is marked bad, spec_fail is set, and the caller
+//     reruns on the exact two-pass route (k_index_t + k_stats_oct), which handles all of it;
+//   * per-block partial histograms and the totals go to scratch; k_stats_commit adds them to the caller's arrays
+//     only if the scan's finalize kernel found no reason to doubt the fast path.
 //
 // Algorithmic bytes: len per launch — the only read of the input for offsets, validation and histograms.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "scan_dev.h"
 #include "stats_dev.h"
 
 namespace fqh {
 
-constexpr uint32_t FZ_THREADS = 1024;
+constexpr uint32_t FZ_THREADS = 768;
 constexpr uint32_t FZ_WAVES = FZ_THREADS / 64;
+constexpr uint32_t FZ_SPAN = 4;                     // tiles a wavefront walks in one go
 constexpr uint32_t FZ_GROUP = 4096;                 // bytes per group: 64 contiguous bytes per lane
 constexpr uint32_t FZ_TAIL = 512;                   // bytes of the previous group kept in front of the group
-constexpr uint32_t FZ_DATA = FZ_TAIL + FZ_GROUP;
+constexpr uint32_t FZ_POST = 512;                   // bytes after the span, for the span's last line
+constexpr uint32_t FZ_DATA = FZ_TAIL + FZ_GROUP + FZ_POST;
 constexpr uint32_t FZ_GLIST = 188;                  // line starts per group that can be staged
-constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 128 + (4 + FZ_GLIST) * 2;  // 5120
+constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 128 + (4 + FZ_GLIST) * 2;  // 5632
 constexpr uint32_t FZ_SLACK = 512;                  // a batch reads up to 32 NSL + 32 bytes past a line's start
-static_assert(FZ_WAVE_BYTES % 64 == 0, "wave areas must keep the 64-byte blocks of the swizzle");
+static_assert(FZ_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesses");
 
-// LDS image of a wave's data: logical address L -> physical L ^ (bits 8-9 of L moved to bits 4-5).  Permutes
-// the four 16-byte chunks of every aligned 64-byte block: conflict-free for the lane-strided ds_write_b128
-// of the loads and for the lane-contiguous ds_read_b128 of the scan, whatever the area's (64-byte aligned) base.
-__device__ __forceinline__ uint32_t fz_swz(uint32_t L) { return L ^ ((L >> 4) & 0x30u); }
+typedef uint32_t fz_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+
+struct FzLane {              // what a lane needs to read and count lines; constant over the kernel
+    uint32_t wbase;          // LDS address of y = 0 of the wave's data area (wave-uniform)
+    uint32_t m, m4, g8;      // lane % 8, 4 * that, lane / 8
+    SoLane c;                // the bank schedule's selectors and slot offsets
+};
+
+// this lane's dword of every step of its line: two aligned dwords (ds_read2_b32, immediate offsets) and one shift
+template <uint32_t NSL>
+__device__ __forceinline__ void fz_fetch(SoBatch<NSL> &B, const FzLane &L, const uint8_t *lds8) {
+    const uint32_t ys = B.P >> SO_P_SREL;
+    const uint32_t la = L.wbase + (ys & ~3u) + L.m4;
+    const uint32_t sh = ys & 3u;
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) {
+        const fz_u32x2 v = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + 32u * u);
+        B.w[u] = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+    }
+}
+
+// Count one batch: so_count (stats_dev.h) without its exact path — anything that one would handle (a byte outside
+// the alphabet / window, a line longer than the rows) sets `bad` and counts nothing.
+template <bool IS_SEQ, uint32_t NSL>
+__device__ __forceinline__ void fz_count(SoBatch<NSL> &B, SoShape<NSL> &S, const FzLane &L, SoTotals &T, bool &bad) {
+    const SoLane &c = L.c;
+    const uint32_t P = B.P;
+    if (__ballot((P & 0xFFFFu) != S.key) != 0) so_shape<NSL>(S, P, L.m);
+    constexpr uint32_t RB = IS_SEQ ? 2048u : 16384u;
+    constexpr uint32_t REGION = IS_SEQ ? 0u : SO_SBYTES;
+    const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.any);
+    const bool tails = (any & 1u) != 0;
+    if (any & 2u) {  // a line longer than the histogram's rows
+        bad = true;
+        return;
+    }
+    uint32_t chk = 0, orw = 0, pt = 0;
+    const uint32_t tus = (any >> 8) & 0xFFu;
+    if (tails) {
+        uint32_t x = B.w[0];
+        if (tus < NSL) {
+#pragma unroll
+            for (uint32_t u = 1; u < NSL; ++u)
+                if (tus == u) x = B.w[u];
+        } else {
+#pragma unroll
+            for (uint32_t u = 1; u < NSL; ++u) x = S.tu == u ? B.w[u] : x;
+        }
+        if (IS_SEQ) {
+            pt = x & 0x07070707u;
+            chk |= (x ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pt)) & S.tb;
+            orw |= x & S.tb;
+        } else {
+            pt = x - 0x21212121u;
+            chk |= pt & S.tb;
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) {
+        const uint32_t w = B.w[u], f = S.full[u];
+        if (IS_SEQ) {
+            const uint32_t bins = w & 0x07070707u;
+            chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;
+            orw |= w & f;
+            B.w[u] = bins;
+        } else {
+            const uint32_t t = w - 0x21212121u;  // byte - 33 < 64 for all four bytes <=> bits 6-7 clear (stats_dev.h)
+            chk |= t & f;
+            B.w[u] = t;
+        }
+    }
+    if (__ballot(IS_SEQ ? chk != 0 : (chk & 0xC0C0C0C0u) != 0) != 0) {
+        bad = true;
+        return;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) {
+        const uint32_t pb = B.w[u], f = S.full[u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ad = __builtin_amdgcn_perm(c.slots, pb, c.sel[k]);
+            switch (u) {  // (the row block and slot half go into the instruction's immediate offset)
+            case 0: lds_sub<REGION>(ad, f); break;
+            case 1: lds_sub<REGION + 128u>(ad, f); break;
+            case 2: lds_sub<REGION + RB>(ad, f); break;
+            case 3: lds_sub<REGION + RB + 128u>(ad, f); break;
+            case 4: lds_sub<REGION + 2 * RB>(ad, f); break;
+            case 5: lds_sub<REGION + 2 * RB + 128u>(ad, f); break;
+            case 6: lds_sub<REGION + 3 * RB>(ad, f); break;
+            default: lds_sub<REGION + 3 * RB + 128u>(ad, f); break;
+            }
+        }
+    }
+    if (tails) {
+        const uint32_t tu = tus < NSL ? tus : S.tu;
+        const uint32_t off = REGION + ((tu & 1u) << 7) + (tu >> 1) * RB;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_sub<0>(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off, S.tf[k]);
+    }
+    if (IS_SEQ) {  // sequence lines with an 'N' (bit 3 is set in 'N' only): the 8 lanes of a line OR their flags
+        const unsigned long long bn = __ballot((orw & 0x08080808u) != 0);
+        if (bn) T.not_dna += so_groups(bn);
+    }
+}
+
+// The lines that ended in this group join the batch in progress.  Pnew: lane i holds the packed word of new line i
+// (i < n).  Position q = nfill + i of the running sequence of lines: batch q / 8, slot q % 8.  Full batches are
+// counted; what is left (fewer than eight lines) stays in PB for the next call; flush counts that as well.
+template <bool IS_SEQ, uint32_t NSL>
+__device__ __forceinline__ void fz_lines(SoBatch<NSL> &PB, uint32_t &nfill, uint32_t Pnew, uint32_t n, bool flush,
+                                         const FzLane &L, const uint8_t *lds8, SoShape<NSL> &S, SoTotals &T, bool &bad,
+                                         bool do_count) {
+    const uint32_t q0 = nfill;
+    const uint32_t total = q0 + n;
+    const uint32_t nb = total >> 3;
+    int lo_i = -(int)q0;
+    for (uint32_t b = 0; b <= nb; ++b, lo_i += 8) {
+        const int i = lo_i + (int)L.g8;
+        const bool isnew = i >= 0 && i < (int)n;
+        uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * i, (int)Pnew);
+        if (!isnew) Pn = 0;
+        if (b == 0) {
+            if (L.g8 >= q0) PB.P = Pn;  // (slots below q0 keep the lines they hold)
+        } else {
+            PB.P = Pn;
+        }
+        if (isnew) fz_fetch<NSL>(PB, L, lds8);
+        if (b < nb && do_count) fz_count<IS_SEQ, NSL>(PB, S, L, T, bad);
+    }
+    nfill = total & 7u;
+    if (flush) {
+        if (nfill && do_count) fz_count<IS_SEQ, NSL>(PB, S, L, T, bad);
+        nfill = 0;
+        PB.P = 0;
+    }
+}
+
+// 16 bytes at buf + off of the partial tile at the end of the buffer; bytes at or beyond len read as 0
+__device__ __attribute__((noinline)) uint4 fz_load16_tail(const uint8_t *__restrict__ buf, uint64_t off, uint64_t len) {
+    return load16(buf, off, len);
+}
 
 template <uint32_t NSL>
-__global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(StatsArgs a, FusedArgs z) {
+__global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    const uint32_t lc = a.lc;
+    const uint32_t lc = z.lc;
     const uint32_t wb0 = z.wave_base;  // bytes of histogram in front of the waves' areas
     for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) hist[i] = 0;
     __syncthreads();
@@ -61,356 +208,356 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(StatsArgs a, FusedArg
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t m4 = (lane & 7u) * 4u, g8 = lane >> 3;
-    const bool is7 = (lane & 7u) == 7u;
-    const uint32_t wbase = wb0 + wv * FZ_WAVE_BYTES;                 // logical address of y = 0
-    uint8_t *const wptr = lds8 + fz_swz(wbase + FZ_TAIL + 16u * lane);  // chunk 64 j + lane of the group: + 1024 j
-    const uint32_t L0 = wbase + FZ_TAIL + 64u * lane;                // this lane's 64 contiguous bytes
-    const uint32_t s4 = ((L0 >> 8) & 3u) << 4;                       // byte Q of the lane at L0 + (Q ^ s4)
-    const uint8_t *const rptr = lds8 + L0;
+    FzLane L;
+    L.wbase = wb0 + wv * FZ_WAVE_BYTES;
+    L.m = lane & 7u;
+    L.m4 = L.m * 4u;
+    L.g8 = lane >> 3;
+    L.c.slots = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t j = k ^ (L.g8 & 3u);
+        L.c.sel[k] = 0x0C0C0004u + k + (j << 8);
+        L.c.slots |= ((L.m + 8u * j) * 4u) << (8u * k);
+    }
+    const uint32_t wbase = L.wbase;
+    uint8_t *const wptr = lds8 + wbase + FZ_TAIL + 16u * lane;      // chunk 64 j + lane of the group: + 1024 j
+    const uint32_t rbase = wbase + FZ_TAIL + 64u * lane;            // this lane's 64 contiguous bytes
+    const uint8_t *const rptr = lds8 + rbase;
+    // conflict-free read-back of the linear image: instruction i reads chunk (i + rot) % 4 of the lane
+    const uint32_t rot = (lane >> 2) & 3u;
+    const uint32_t kro = (4u - rot) & 3u;                           // rotate the 64-bit mask right by 16 kro bits
+    const bool swp = (kro & 2u) != 0;
+    const uint32_t s16 = (kro & 1u) * 16u;
     uint16_t *const tline = reinterpret_cast<uint16_t *>(lds8 + wbase + FZ_DATA);  // the tile's line, 64 u16
     uint16_t *const lst = tline + 64 + 4;  // the group's entries; lst[-4 .. -1]: the last four before the group
 
-    SoLane c;
-    c.slots = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        const uint32_t j = k ^ (g8 & 3u);
-        c.sel[k] = 0x0C0C0004u + k + (j << 8);
-        c.slots |= (((lane & 7u) + 8u * j) * 4u) << (8u * k);
-    }
-    SoAcc acc = {0, 0, 0};
+    uint32_t acc_rec = 0, acc_bases = 0, acc_qual = 0;  // per lane (a wave never reads 4 GiB)
     SoTotals T = {0, 0};
-    bool cr_seen = false;
     SoShape<NSL> S = {};
     S.key = 0xFFFFFFFFu;
 
-    const uint8_t *__restrict__ const buf = a.buf;
-    const uint64_t len = a.len;
-    const uint64_t n_tiles = z.n_tiles;
-    const uint64_t n_full = len >> WT_SHIFT;
-    const uint64_t nwaves = (uint64_t)gridDim.x * FZ_WAVES;
+    const uint8_t *__restrict__ const buf = z.buf;
+    const uint64_t len = z.len;
+    const uint32_t n_tiles = (uint32_t)z.n_tiles;
+    const uint32_t n_full = (uint32_t)(len >> WT_SHIFT);
+    const uint32_t n_spans = (n_tiles + FZ_SPAN - 1) / FZ_SPAN;
+    const uint32_t nw = gridDim.x * FZ_WAVES;
     const uint32_t lo = lane * 16u;
     uint32_t n_over = 0;
 
     // the four 16-byte pieces of this lane for group g of tile t (whole tiles: unconditional loads)
-    auto fetch_group = [&](uint64_t t, uint32_t g, uint4 &n0, uint4 &n1, uint4 &n2, uint4 &n3) {
-        const uint64_t off = (t << WT_SHIFT) + g * FZ_GROUP + lo;
+    auto fetch_group = [&](uint32_t t, uint32_t g, uint4 &n0, uint4 &n1, uint4 &n2, uint4 &n3) {
+        const uint64_t off = ((uint64_t)t << WT_SHIFT) + g * FZ_GROUP + lo;
         if (t < n_full) {
             const uint8_t *p = buf + off;
             n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
             n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
-        } else {  // the partial tile at the end of the buffer: bytes at or beyond len read as 0
-            n0 = load16(buf, off, len); n1 = load16(buf, off + PIECE_BYTES, len);
-            n2 = load16(buf, off + 2 * PIECE_BYTES, len); n3 = load16(buf, off + 3 * PIECE_BYTES, len);
+        } else {  // the partial tile at the end of the buffer
+            n0 = fz_load16_tail(buf, off, len); n1 = fz_load16_tail(buf, off + PIECE_BYTES, len);
+            n2 = fz_load16_tail(buf, off + 2 * PIECE_BYTES, len); n3 = fz_load16_tail(buf, off + 3 * PIECE_BYTES, len);
         }
     };
 
-    uint64_t tile = (uint64_t)blockIdx.x * FZ_WAVES + wv;
-    if (tile < n_tiles) {
+    uint32_t span = blockIdx.x * FZ_WAVES + wv;
+    if (span < n_spans) {
         uint4 n0, n1, n2, n3;
-        fetch_group(tile, 0, n0, n1, n2, n3);
-        uint32_t pb = tile ? buf[(tile << WT_SHIFT) - 1] : 0u;  // the byte before the tile
+        fetch_group(span * FZ_SPAN, 0, n0, n1, n2, n3);
+        uint32_t pb = span ? buf[((uint64_t)(span * FZ_SPAN) << WT_SHIFT) - 1] : 0u;  // the byte before the span
         bool pending = false;  // the previous tile's line is still in a register
-        uint64_t ptile = 0;
-        uint32_t prv = 0;
-        for (; tile < n_tiles; tile += nwaves) {
-            const uint64_t nxt = tile + nwaves < n_tiles ? tile + nwaves : tile;  // clamped: the prefetch is unconditional
-            const uint64_t tb = tile << WT_SHIFT;
-            const bool full = tile < n_full;
-            const uint32_t tile_bytes = full ? WT_BYTES : (uint32_t)(len - tb);
-            uint32_t run = 0;        // entries of the tile before the current group
+        uint32_t ptile = 0, prv = 0;
+        for (; span < n_spans; span += nw) {
+            const uint32_t nspan = span + nw < n_spans ? span + nw : span;  // clamped: the prefetch is unconditional
+            const uint32_t t0 = span * FZ_SPAN;
+            const uint32_t t1 = t0 + FZ_SPAN < n_tiles ? t0 + FZ_SPAN : n_tiles;
+            uint32_t srun = 0;       // entries of the span before the current group
             uint32_t tot = 0;        // entries of the current group
-            uint32_t prev = (tile && pb == '\n') ? 1u : 0u;
-            uint32_t hyp = 7;        // the tile's alignment: entries hyp, hyp + 4, .. start records
-            bool tile_bad = false;
-            uint32_t have = 0, bad = 0;  // bit r: some / some failing window of five entries starting at r (mod 4)
-            __builtin_amdgcn_wave_barrier();
-            tline[lane] = 0;
+            uint32_t prev = (t0 && pb == '\n') ? 1u : 0u;
+            uint32_t hyp = 7;        // the span's alignment: entries hyp, hyp + 4, .. (counted from the span's first) start records
+            bool span_bad = false;
+            SoBatch<NSL> PBs, PBq;   // the batches in progress
+            PBs.P = 0;
+            PBq.P = 0;
+            uint32_t nfill_s = 0, nfill_q = 0;
+            uint2 post = make_uint2(0, 0);
+            uint32_t last_ng = 1, last_bytes = 0;
+            bool last_full = true;
+            for (uint32_t tile = t0; tile < t1; ++tile) {
+                const uint64_t tb = (uint64_t)tile << WT_SHIFT;
+                const bool full = tile < n_full;
+                const uint32_t tile_bytes = full ? WT_BYTES : (uint32_t)(len - tb);
+                const uint32_t ng = full ? WT_BYTES / FZ_GROUP : (tile_bytes + FZ_GROUP - 1) / FZ_GROUP;
+                last_ng = ng;
+                last_bytes = tile_bytes;
+                last_full = full;
+                uint32_t run = 0;            // entries of the tile before the current group
+                uint32_t have = 0, bad = 0;  // bit r: some / some failing window of five entries starting at r (mod 4), tile-relative
+                uint32_t hyp_t = hyp < 4 ? (hyp - srun - tot) & 3u : 7u;  // the same alignment counted from the tile's first entry
+                __builtin_amdgcn_wave_barrier();
+                tline[lane] = 0;
 #pragma unroll 1
-            for (uint32_t g = 0; g < WT_BYTES / FZ_GROUP; ++g) {
-                __builtin_amdgcn_wave_barrier();
-                *reinterpret_cast<uint4 *>(wptr) = n0;
-                *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
-                *reinterpret_cast<uint4 *>(wptr + 2048) = n2;
-                *reinterpret_cast<uint4 *>(wptr + 3072) = n3;
-                {  // next group of this tile, or the first group of the wave's next tile
-                    const bool last = g + 1 == WT_BYTES / FZ_GROUP;
-                    if (last) pb = buf[(nxt << WT_SHIFT) - (nxt ? 1 : 0)];
-                    fetch_group(last ? nxt : tile, last ? 0u : g + 1, n0, n1, n2, n3);
-                }
-                if (g == 0 && pending)  // a whole group before the next wait on vmcnt
-                    __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + ptile * FR_STRIDE + lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + (0u ^ s4));
-                const uint4 d1 = *reinterpret_cast<const uint4 *>(rptr + (16u ^ s4));
-                const uint4 d2 = *reinterpret_cast<const uint4 *>(rptr + (32u ^ s4));
-                const uint4 d3 = *reinterpret_cast<const uint4 *>(rptr + (48u ^ s4));
-                const uint32_t m_lo = eqmask16<1>(d0, 0x0A0A0A0Au) | (eqmask16<1>(d1, 0x0A0A0A0Au) << 16);
-                const uint32_t m_hi = eqmask16<1>(d2, 0x0A0A0A0Au) | (eqmask16<1>(d3, 0x0A0A0A0Au) << 16);
-                // line starts: the byte after a newline
-                uint32_t ls_lo = (m_lo << 1) | wave_shr1(m_hi >> 31, prev);
-                uint32_t ls_hi = __builtin_amdgcn_alignbit(m_hi, m_lo, 31);
-                prev = ((uint32_t)__builtin_amdgcn_readlane((int)m_hi, 63)) >> 31;
-                if (!full) {  // a line start must be an existing byte
-                    const int nv = (int)tile_bytes - (int)(g * FZ_GROUP + lane * 64u);
-                    const uint32_t nvalid = nv < 0 ? 0u : nv > 64 ? 64u : (uint32_t)nv;
-                    const unsigned long long keep = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-                    ls_lo &= (uint32_t)keep;
-                    ls_hi &= (uint32_t)(keep >> 32);
-                }
-                const uint32_t cl = __popc(ls_lo) + __popc(ls_hi);
-                const unsigned long long b1 = __ballot(cl >= 1), b2 = __ballot(cl >= 2), b3 = __ballot(cl >= 3);
-                uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
-                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
-                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, pre));
-                uint32_t gtot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2) + (uint32_t)__popcll(b3);
-                if (__ballot(cl >= 4)) {
-                    for (uint32_t k = 4;; ++k) {
-                        const unsigned long long b = __ballot(cl >= k);
-                        if (!b) break;
-                        pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
-                        gtot += (uint32_t)__popcll(b);
+                for (uint32_t g = 0; g < ng; ++g) {
+                    __builtin_amdgcn_wave_barrier();
+                    *reinterpret_cast<uint4 *>(wptr) = n0;
+                    *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
+                    *reinterpret_cast<uint4 *>(wptr + 2048) = n2;
+                    *reinterpret_cast<uint4 *>(wptr + 3072) = n3;
+                    {  // the next group: of this tile, of the span's next tile, or of the wave's next span
+                        const bool last_g = g + 1 == ng;
+                        const bool last_t = tile + 1 == t1;
+                        if (last_g && last_t) {
+                            pb = buf[((uint64_t)(nspan * FZ_SPAN) << WT_SHIFT) - (nspan ? 1 : 0)];
+                            const uint64_t pe = tb + tile_bytes + 8u * lane;   // the bytes after the span
+                            if (pe + 8 <= len) post = *reinterpret_cast<const uint2 *>(buf + pe);
+                            else post = make_uint2(0, 0);
+                        }
+                        fetch_group(last_g ? (last_t ? nspan * FZ_SPAN : tile + 1) : tile, last_g ? 0u : g + 1, n0, n1, n2, n3);
                     }
-                }
-                run += tot;   // the previous group's entries are behind us now
-                tot = gtot;
-                if (tot > FZ_GLIST) {  // lines shorter than ~22 bytes on average: left to the exact path
-                    tile_bad = true;
-                    tot = 0;           // (the header below stays what it was: nothing more is counted in this tile)
-                    run += gtot;
-                    continue;
-                }
-                const uint32_t ebase = g * FZ_GROUP + lane * 64u;
-                {
-                    uint16_t *dst = lst + pre;
-                    while (ls_lo) {
-                        const uint32_t q = __ffs(ls_lo) - 1;
-                        ls_lo &= ls_lo - 1;
-                        const uint32_t b = rptr[q ^ s4];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    if (g == 0 && pending)  // a whole group before the next wait on vmcnt
+                        __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t m_lo, m_hi;
+                    {
+                        const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u) & 48u));
+                        const uint4 d1 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 16u) & 48u));
+                        const uint4 d2 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 32u) & 48u));
+                        const uint4 d3 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 48u) & 48u));
+                        const uint32_t r_lo = eqmask16<1>(d0, 0x0A0A0A0Au) | (eqmask16<1>(d1, 0x0A0A0A0Au) << 16);
+                        const uint32_t r_hi = eqmask16<1>(d2, 0x0A0A0A0Au) | (eqmask16<1>(d3, 0x0A0A0A0Au) << 16);
+                        const uint32_t a_lo = swp ? r_hi : r_lo, a_hi = swp ? r_lo : r_hi;
+                        m_lo = __builtin_amdgcn_alignbit(a_hi, a_lo, s16);
+                        m_hi = __builtin_amdgcn_alignbit(a_lo, a_hi, s16);
                     }
-                    while (ls_hi) {
-                        const uint32_t q = __ffs(ls_hi) + 31;
-                        ls_hi &= ls_hi - 1;
-                        const uint32_t b = rptr[q ^ s4];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    // line starts: the byte after a newline
+                    uint32_t ls_lo = (m_lo << 1) | wave_shr1(m_hi >> 31, prev);
+                    uint32_t ls_hi = __builtin_amdgcn_alignbit(m_hi, m_lo, 31);
+                    prev = ((uint32_t)__builtin_amdgcn_readlane((int)m_hi, 63)) >> 31;
+                    if (!full) {  // a line start must be an existing byte
+                        const int nv = (int)tile_bytes - (int)(g * FZ_GROUP + lane * 64u);
+                        const uint32_t nvalid = nv < 0 ? 0u : nv > 64 ? 64u : (uint32_t)nv;
+                        const unsigned long long keep = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+                        ls_lo &= (uint32_t)keep;
+                        ls_hi &= (uint32_t)(keep >> 32);
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // ---- windows of five entries that end in this group (src/records.rs:141,155,233 under each alignment)
-                for (uint32_t p = lane; p < tot; p += 64) {
-                    const uint32_t ti = run + p;
-                    if (ti < 4) {
-                        tline[FR_EDGE + ti] = lst[p];  // the tile's first four entries
+                    const uint32_t cl = __popc(ls_lo) + __popc(ls_hi);
+                    const unsigned long long b1 = __ballot(cl >= 1), b2 = __ballot(cl >= 2), b3 = __ballot(cl >= 3);
+                    uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
+                    pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
+                    pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, pre));
+                    uint32_t gtot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2) + (uint32_t)__popcll(b3);
+                    if (__ballot(cl >= 4)) {
+                        for (uint32_t k = 4;; ++k) {
+                            const unsigned long long b = __ballot(cl >= k);
+                            if (!b) break;
+                            pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
+                            gtot += (uint32_t)__popcll(b);
+                        }
+                    }
+                    run += tot;   // the previous group's entries are behind us now
+                    srun += tot;
+                    if (g == 0) run = 0;  // (they belonged to the previous tile)
+                    tot = gtot;
+                    if (tot > FZ_GLIST) {  // lines shorter than ~22 bytes on average: left to the exact path
+                        span_bad = true;
+                        run += gtot;
+                        srun += gtot;
+                        tot = 0;
                         continue;
                     }
-                    const uint32_t e0 = lst[(int)p - 4], e1 = lst[(int)p - 3], e2 = lst[(int)p - 2], e3 = lst[(int)p - 1], e4 = lst[p];
-                    const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
-                                    ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
-                    have |= 1u << (ti & 3u);
-                    bad |= ok ? 0u : 1u << (ti & 3u);
+                    const uint32_t ebase = g * FZ_GROUP + lane * 64u;
+                    {
+                        uint16_t *dst = lst + pre;
+                        while (ls_lo) {
+                            const uint32_t q = __ffs(ls_lo) - 1;
+                            ls_lo &= ls_lo - 1;
+                            const uint32_t b = rptr[q];
+                            *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                        }
+                        while (ls_hi) {
+                            const uint32_t q = __ffs(ls_hi) + 31;
+                            ls_hi &= ls_hi - 1;
+                            const uint32_t b = rptr[q];
+                            *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- windows of five entries that end in this group (src/records.rs:141,155,233 under each alignment)
+                    if (!(z.dbg & 8u))
+                        for (uint32_t p = lane; p < tot; p += 64) {
+                            const uint32_t ti = run + p;
+                            if (ti < 4) {
+                                tline[FR_EDGE + ti] = lst[p];  // the tile's first four entries
+                                continue;
+                            }
+                            const uint32_t e0 = lst[(int)p - 4], e1 = lst[(int)p - 3], e2 = lst[(int)p - 2], e3 = lst[(int)p - 1], e4 = lst[p];
+                            const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
+                                            ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
+                            have |= 1u << (ti & 3u);
+                            bad |= ok ? 0u : 1u << (ti & 3u);
+                        }
+                    if (tile == t0 && g == 0) {  // the span's first group must single out the alignment it is counted under
+                        uint32_t cons = 0;
+#pragma unroll
+                        for (uint32_t r = 0; r < 4; ++r)
+                            if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
+                        if (cons && !(cons & (cons - 1))) hyp = hyp_t = (uint32_t)__ffs(cons) - 1;
+                        else span_bad = true;
+                    }
+                    if (!span_bad && tot && !(z.dbg & 1u)) {
+                        // ---- one lane per line that ends in this group.  Entry p closes the line that entry p - 1 starts.
+                        // Lines, counted from the span's first entry: hyp (mod 4) header, + 1 sequence, + 2 separator, + 3 quality.
+                        const uint32_t pq = (hyp - srun) & 3u;         // these entries start a record and close a quality line
+                        const uint32_t ps = (pq + 2u) & 3u;            // these close a sequence line
+                        const int gofs = (int)FZ_TAIL - (int)(g * FZ_GROUP);  // tile offset -> y (the wave's data area)
+                        uint32_t P_s = 0, P_q = 0;
+                        bool far = false;
+                        {
+                            const uint32_t p = ps + 4u * lane;
+                            if (p < tot && (srun | p) != 0) {
+                                const int n = (int)(lst[p] & 0x3FFFu);
+                                uint32_t l = ((uint32_t)(n - (int)lst[(int)p - 1]) & 0x3FFFu) - 1u;   // raw line, without its '\n'
+                                const int ys = n + gofs - 1 - (int)l;
+                                if (ys < 0) far = true;
+                                else {
+                                    if (l && lds8[wbase + (uint32_t)ys + l - 1] == '\r') --l;  // trim_winline, src/records.rs:66-73
+                                    P_s = so_pack((uint32_t)ys, l, lc);
+                                    ++acc_rec;
+                                    acc_bases += l;
+                                }
+                            }
+                        }
+                        {
+                            const uint32_t p = pq + 4u * lane;
+                            if (p < tot) {
+                                const uint32_t e = lst[p] & 0x3FFFu;
+                                // record start k of the tile: the first FR_N in the tile's line, then a second line, then the list area
+                                if (run + p >= hyp_t) {
+                                    const uint32_t k = (run + p - hyp_t) >> 2;
+                                    if (k < FR_N) tline[k] = (uint16_t)e;
+                                    else if (k < FR_N + FR2_N) z.fast_rs[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + (k - FR_N)] = (uint16_t)e;
+                                    else z.list[(uint64_t)tile * z.list_cap + 8 + k] = (uint16_t)e;
+                                }
+                                if ((srun | p) != 0) {
+                                    uint32_t l = ((e - (uint32_t)lst[(int)p - 1]) & 0x3FFFu) - 1u;
+                                    const int ys = (int)e + gofs - 1 - (int)l;
+                                    if (ys < 0) far = true;
+                                    else {
+                                        if (l && lds8[wbase + (uint32_t)ys + l - 1] == '\r') --l;
+                                        P_q = so_pack((uint32_t)ys, l, lc);
+                                        acc_qual += l;
+                                    }
+                                }
+                            }
+                        }
+                        if (__ballot(far)) span_bad = true;  // a line that began before the kept tail (longer than ~500 bytes)
+                        uint32_t nls = tot > ps ? (tot - ps + 3) >> 2 : 0u, nlq = tot > pq ? (tot - pq + 3) >> 2 : 0u;
+                        uint32_t Ps2 = P_s, Pq2 = P_q;
+                        if (srun == 0) {  // the span's very first entry closes a line that is not this wave's: lane 0 of its kind is empty
+                            if (ps == 0 && nls) { Ps2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * lane + 4u), (int)P_s); --nls; }
+                            if (pq == 0 && nlq) { Pq2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * lane + 4u), (int)P_q); --nlq; }
+                        }
+                        const bool cnt = !(z.dbg & 2u);
+                        fz_lines<true, NSL>(PBs, nfill_s, Ps2, nls, false, L, lds8, S, T, span_bad, cnt);
+                        fz_lines<false, NSL>(PBq, nfill_q, Pq2, nlq, false, L, lds8, S, T, span_bad, cnt);
+                    }
+                    // ---- the next group finds this one's last 512 bytes and last four entries in front of its own
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        const uint2 tv = *reinterpret_cast<const uint2 *>(lds8 + wbase + FZ_GROUP + 8u * lane);
+                        const uint32_t hv = lane < 4 ? (uint32_t)lst[(int)tot - 4 + (int)lane] : 0u;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        *reinterpret_cast<uint2 *>(lds8 + wbase + 8u * lane) = tv;
+                        if (lane < 4) lst[(int)lane - 4] = (uint16_t)hv;
+                    }
                 }
-                if (g == 0) {  // the first group must single out the alignment the tile is counted under
+                const uint32_t trun = run + tot;  // entries of the whole tile
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // ---- the tile must confirm the alignment: still the only consistent one
+                {
                     uint32_t cons = 0;
 #pragma unroll
                     for (uint32_t r = 0; r < 4; ++r)
                         if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
-                    if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
-                    else tile_bad = true;
+                    if (trun < 8 || hyp_t > 3 || cons != (1u << hyp_t)) span_bad = true;
                 }
-                if (hyp < 4 && !tile_bad && tot) {
-                    // ---- one lane per line that ends in this group.  Entry p closes the line that entry p - 1 starts.
-                    // Lines of tile index i: i == hyp (mod 4) header, + 1 sequence, + 2 separator, + 3 quality.
-                    const uint32_t pq = (hyp - run) & 3u;          // these entries start a record and close a quality line
-                    const uint32_t ps = (pq + 2u) & 3u;            // these close a sequence line
-                    const int gofs = (int)FZ_TAIL - (int)(g * FZ_GROUP);  // tile offset -> y (the wave's data area)
-                    const uint8_t *const ybase = buf + tb - gofs;  // global address of y = 0
-                    uint32_t P_s = 0, P_q = 0, l_s = 0, l_q = 0;
-                    bool far = false;
-                    {
-                        const uint32_t p = ps + 4u * lane;
-                        if (p < tot && (run | p) != 0) {
-                            const int s = (int)(lst[(int)p - 1] & 0x3FFFu), n = (int)(lst[p] & 0x3FFFu);
-                            const int ys = s + gofs;
-                            uint32_t l = (uint32_t)(n - 1 - s);
-                            if (ys < 0) far = true;
-                            else {
-                                if (cr_seen && l && lds8[fz_swz(wbase + (uint32_t)ys + l - 1)] == '\r') --l;  // trim_winline, src/records.rs:66-73
-                                l_s = l;
-                                P_s = so_pack((uint32_t)ys, l, lc);
-                                ++acc.rec;
-                                acc.bases += l;
-                            }
-                        }
-                    }
-                    {
-                        const uint32_t p = pq + 4u * lane;
-                        if (p < tot) {
-                            const uint32_t e = lst[p] & 0x3FFFu;
-                            // record start k of the tile: the first FR_N in the tile's line, then a second line, then the list area
-                            const uint32_t k = (run + p - hyp) >> 2;
-                            if (run + p >= hyp) {
-                                if (k < FR_N) tline[k] = (uint16_t)e;
-                                else if (k < FR_N + FR2_N) z.fast_rs[fr2_off(n_tiles) + tile * FR2_N + (k - FR_N)] = (uint16_t)e;
-                                else z.list[tile * z.list_cap + 8 + k] = (uint16_t)e;
-                            }
-                            if ((run | p) != 0) {
-                                const int s = (int)(lst[(int)p - 1] & 0x3FFFu);
-                                const int ys = s + gofs;
-                                uint32_t l = (uint32_t)((int)e - 1 - s);
-                                if (ys < 0) far = true;
-                                else {
-                                    if (cr_seen && l && lds8[fz_swz(wbase + (uint32_t)ys + l - 1)] == '\r') --l;
-                                    l_q = l;
-                                    P_q = so_pack((uint32_t)ys, l, lc);
-                                    acc.qual += l;
-                                }
-                            }
-                        }
-                    }
-                    if (__ballot(far)) tile_bad = true;  // a line that began before the kept tail (longer than ~500 bytes)
-                    const uint32_t nls = tot > ps ? (tot - ps + 3) >> 2 : 0u, nlq = tot > pq ? (tot - pq + 3) >> 2 : 0u;
-                    const uint32_t nbs = (nls + 7) >> 3, nbq = (nlq + 7) >> 3;
-                    const uint32_t nbm = nbs > nbq ? nbs : nbq;
-                    const uint32_t nbt = 2u * nbm;
-                    const bool probe = cr_seen;
-                    auto lookup = [&](uint32_t f) -> uint32_t {
-                        const bool isq = (f & 1u) != 0;
-                        const uint32_t b = f >> 1;
-                        uint32_t P = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(32u * b + 4u * g8), (int)(isq ? P_q : P_s));
-                        if (b >= (isq ? nbq : nbs)) P = 0;
-                        __builtin_amdgcn_sched_barrier(0);  // (keep it ahead of the count's atomics)
-                        return P;
-                    };
-                    // this lane's dword of every step of its line: aligned reads, the lane above supplies the
-                    // bytes that complete it (lane 7 of a line: lane 0's dword of the next step)
-                    auto fetch = [&](uint32_t P, SoBatch<NSL> &B) {
-                        B.P = P;
-                        const uint32_t ys = P >> SO_P_SREL;
-                        const uint32_t L = wbase + (ys & ~3u) + m4;
-                        uint32_t W[NSL + 1];
-#pragma unroll
-                        for (uint32_t u = 0; u <= NSL; ++u)
-                            W[u] = *reinterpret_cast<const uint32_t *>(lds8 + fz_swz(L + 32u * u));
-#pragma unroll
-                        for (uint32_t u = 0; u < NSL; ++u) {
-                            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W[u], 0x101, 0xF, 0xF, false);      // row_shl:1
-                            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)W[u + 1], 0x117, 0xF, 0xF, false);  // row_shr:7
-                            B.w[u] = __builtin_amdgcn_alignbyte(is7 ? nx : up, W[u], ys & 3u);
-                        }
-                    };
-                    if (nbt) {
-                        SoBatch<NSL> B0, B1;  // ping-pong: the reads of one are in flight while the other is counted
-                        const uint32_t fl = nbt - 1;
-                        uint32_t pa = lookup(0), pbq = lookup(1);
-                        fetch(pa, B0);
-                        for (uint32_t f = 0; f < nbt; f += 2) {
-                            fetch(pbq, B1);
-                            pa = lookup(f + 2 < fl ? f + 2 : fl);
-                            so_count<true, NSL, false>(a, ybase, B0, S, lane, lc, hist, c, l_s, 32u * (f >> 1) + 4u * g8, T, acc, probe, cr_seen);
-                            fetch(pa, B0);
-                            pbq = lookup(f + 3 < fl ? f + 3 : fl);
-                            so_count<false, NSL, false>(a, ybase, B1, S, lane, lc, hist, c, l_q, 32u * (f >> 1) + 4u * g8, T, acc, probe, cr_seen);
-                        }
-                    }
-                }
-                // ---- the next group finds this one's last 512 bytes and last four entries in front of its own
-                __builtin_amdgcn_wave_barrier();
+                // ---- the tile's line: record starts (the lanes wrote them), first and last four entries, count, alignment
                 {
-                    const uint2 tv = *reinterpret_cast<const uint2 *>(lds8 + wbase + FZ_GROUP + 8u * lane);
-                    const uint32_t hv = lane < 4 ? (uint32_t)lst[(int)tot - 4 + (int)lane] : 0u;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    *reinterpret_cast<uint2 *>(lds8 + wbase + 8u * lane) = tv;
-                    if (lane < 4) lst[(int)lane - 4] = (uint16_t)hv;
+                    uint32_t rv = tline[lane];
+                    if (lane >= FR_EDGE + 4 && lane < FR_EDGE + 8) rv = lst[(int)lane - (int)(FR_EDGE + 8)];
+                    if (span_bad) ++n_over;
+                    prv = lane == FR_CNT ? (trun & 0xFFFFu) : lane == FR_CNT + 1 ? (trun >> 16) : lane == FR_HYP ? (span_bad ? 7u : hyp_t) : rv;
                 }
+                ptile = tile;
+                pending = true;
+                __builtin_amdgcn_wave_barrier();
             }
-            run += tot;  // entries of the whole tile
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- the tile's alignment must still be the only consistent one
-            {
-                uint32_t cons = 0;
-#pragma unroll
-                for (uint32_t r = 0; r < 4; ++r)
-                    if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
-                if (run < 8 || cons != (1u << hyp)) tile_bad = true;
-            }
-            // ---- the tile's last line ends in another wavefront's tile (or with the tile's, or the buffer's, last
-            // byte): counted here, byte-wise from global memory
-            if (!tile_bad) {
-                const uint32_t kind = (run - 1u - hyp) & 3u;
+            srun += tot;  // entries of the whole span
+            // ---- the span's last line ends in another wavefront's span (or with the buffer): close it with the bytes
+            // after the span, then count what is left in the batches
+            uint32_t Pv = 0;
+            uint32_t kind = 0;
+            if (!span_bad && srun && !(z.dbg & 16u)) {
+                kind = (srun - 1u - hyp) & 3u;
                 if (kind == 1u || kind == 3u) {
-                    const uint32_t e_last = lst[-1] & 0x3FFFu;  // (the header holds the tile's last four entries now)
-                    const uint64_t S0 = tb + e_last;
-                    const uint8_t *const bend = buf + len;
-                    const bool last_nl = full ? prev != 0 : buf[len - 1] == '\n';
-                    uint64_t end = 0;
-                    bool found = false;
+                    const int yend = (int)(FZ_TAIL + last_bytes - (last_ng - 1) * FZ_GROUP);  // y of the first byte after the span
+                    const bool last_nl = last_full ? prev != 0 : buf[len - 1] == '\n';
+                    int yclose = -1;
                     if (last_nl) {
-                        end = tb + tile_bytes - 1;
-                        found = true;
-                    } else {
-                        uint64_t pos = tb + tile_bytes;
-                        for (uint32_t it = 0; it < 64 && pos < len && !found; ++it, pos += 256) {
-                            const uint32_t w = load4_any(buf + pos + 4u * lane, bend);
-                            const uint32_t fl = eq_flags(w, 0x0A0A0A0Au);
-                            const unsigned long long bm = __ballot(fl != 0);
-                            if (bm) {
-                                const uint32_t first = (uint32_t)__ffsll((long long)bm) - 1u;
-                                const uint32_t ff = (uint32_t)__builtin_amdgcn_readlane((int)fl, (int)first);
-                                end = pos + 4u * first + ((uint32_t)__ffs(ff) - 1u) / 8u;
-                                found = true;
-                            }
-                        }
-                        if (!found && pos < len) tile_bad = true;  // a line of more than 16 KiB
+                        yclose = yend;
+                    } else if (last_full) {
+                        __builtin_amdgcn_wave_barrier();
+                        *reinterpret_cast<uint2 *>(lds8 + wbase + FZ_TAIL + FZ_GROUP + 8u * lane) = post;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t f0 = eq_flags(post.x, 0x0A0A0A0Au), f1 = eq_flags(post.y, 0x0A0A0A0Au);
+                        const unsigned long long bm = __ballot((f0 | f1) != 0);
+                        if (bm) {
+                            const uint32_t first = (uint32_t)__ffsll((long long)bm) - 1u;
+                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, (int)first);
+                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane((int)f1, (int)first);
+                            const uint32_t byte = g0 ? ((uint32_t)__ffs(g0) - 1u) / 8u : 4u + ((uint32_t)__ffs(g1) - 1u) / 8u;
+                            yclose = yend + (int)(8u * first + byte) + 1;
+                        } else if (((uint64_t)(t1 - 1) << WT_SHIFT) + last_bytes + FZ_POST <= len) {
+                            span_bad = true;  // a line that goes on for more than 512 bytes after the span
+                        }  // (else: no '\n' before the end of the buffer: not a line the parser delivers)
                     }
-                    if (found) {
-                        uint32_t l = (uint32_t)(end - S0);
-                        if (l && buf[end - 1] == '\r') --l;  // trim_winline, src/records.rs:66-73
-                        uint32_t any_n = 0, any_inv = 0;
-                        for (uint32_t pos = 4u * lane; pos < l; pos += 256) {
-                            const uint32_t w = load4_any(buf + S0 + pos, bend);
-                            if (kind == 1u) so_exact_step<true>(a, w, pos, l, lc, hist, any_n, any_inv);
-                            else so_exact_step<false>(a, w, pos, l, lc, hist, any_n, any_inv);
-                        }
-                        if (kind == 1u) {
-                            const bool gi = __ballot(any_inv != 0) != 0, gn = __ballot(any_n != 0) != 0;
-                            T.not_dna += (gi || gn) ? 1u : 0u;
-                            T.not_dnan += gi ? 1u : 0u;
-                            if (lane == 0) { ++acc.rec; acc.bases += l; }
+                    if (yclose >= 0) {
+                        const int ystart = (int)FZ_TAIL + (int)(lst[-1] & 0x3FFFu) - (int)((last_ng - 1) * FZ_GROUP);
+                        if (ystart < 0) {
+                            span_bad = true;
                         } else if (lane == 0) {
-                            acc.qual += l;
+                            uint32_t l = (uint32_t)(yclose - 1 - ystart);
+                            if (l && lds8[wbase + (uint32_t)ystart + l - 1] == '\r') --l;
+                            Pv = so_pack((uint32_t)ystart, l, lc);
+                            if (kind == 1u) { ++acc_rec; acc_bases += l; }
+                            else acc_qual += l;
                         }
+                    } else {
+                        kind = 0;
                     }
                 }
             }
-            // ---- the tile's line: record starts (the lanes wrote them), first and last four entries, count, alignment
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             {
-                uint32_t rv = tline[lane];
-                if (lane >= FR_EDGE + 4 && lane < FR_EDGE + 8) rv = lst[(int)lane - (int)(FR_EDGE + 8)];
-                if (tile_bad) ++n_over;
-                prv = lane == FR_CNT ? (run & 0xFFFFu) : lane == FR_CNT + 1 ? (run >> 16) : lane == FR_HYP ? (tile_bad ? 7u : hyp) : rv;
+                const bool cnt = !(z.dbg & 2u) && !span_bad;
+                fz_lines<true, NSL>(PBs, nfill_s, Pv, kind == 1u ? 1u : 0u, true, L, lds8, S, T, span_bad, cnt);
+                fz_lines<false, NSL>(PBq, nfill_q, Pv, kind == 3u ? 1u : 0u, true, L, lds8, S, T, span_bad, cnt);
             }
-            ptile = tile;
-            pending = true;
-            __builtin_amdgcn_wave_barrier();
+            if (span_bad) ++n_over;
         }
-        if (pending) __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + ptile * FR_STRIDE + lane);
+        if (pending) __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
     }
     if (lane == 0 && n_over) atomicAdd(&z.out->spec_fail, (unsigned long long)n_over);
 
     // ---- per-block partial histogram, per-wave totals
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * SO_WORDS;
+    uint32_t *__restrict__ dst = z.scratch + (uint64_t)blockIdx.x * SO_WORDS;
     for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) dst[i] = hist[i];
-    unsigned long long sc[5] = {acc.rec, acc.bases, acc.qual, 0, 0};
+    unsigned long long sc[5] = {acc_rec, acc_bases, acc_qual, 0, 0};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         unsigned long long v = sc[j];
@@ -423,34 +570,22 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(StatsArgs a, FusedArg
         sc[4] = sc[0] - T.not_dnan;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
-            if (sc[j]) atomicAdd(&a.scalars[j], sc[j]);
+            if (sc[j]) atomicAdd(&z.scalars[j], sc[j]);
     }
 }
 
-// k_stats_commit: adds what k_scan_stats left in scratch to the caller's arrays — per-block partial histograms
-// (bank-scheduled layout), the exact path's 64-bit counters and the scalars — if and only if the scan's
-// finalize kernel kept the fast path's result (DevOut::stats_commit).
+// k_stats_commit: adds what k_scan_stats left in scratch — per-block partial histograms (bank-scheduled layout)
+// and the totals — to the caller's arrays if and only if the scan's finalize kernel kept the fast path's result
+// (DevOut::stats_commit).
 __global__ __launch_bounds__(256) void k_stats_commit(const DevOut *__restrict__ out, const uint32_t *__restrict__ scratch,
-                                                      uint32_t n_blocks, uint32_t lc, uint32_t lmax, uint32_t words,
-                                                      const unsigned long long *__restrict__ src_qual,
-                                                      const unsigned long long *__restrict__ src_base,
+                                                      uint32_t n_blocks, uint32_t lc, uint32_t words,
                                                       const unsigned long long *__restrict__ src_scalars,
                                                       unsigned long long *__restrict__ qual_hist,
                                                       unsigned long long *__restrict__ base_hist,
                                                       unsigned long long *__restrict__ scalars) {
     if (!out->stats_commit) return;
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.y == 0) {  // the 64-bit side arrays (out-of-window bytes, columns beyond the LDS rows), once
-        for (uint32_t i = id; i < lmax * 256u; i += gridDim.x * blockDim.x) {
-            const unsigned long long v = src_qual[i];
-            if (v) atomicAdd(&qual_hist[i], v);
-        }
-        for (uint32_t i = id; i < lmax * 8u; i += gridDim.x * blockDim.x) {
-            const unsigned long long v = src_base[i];
-            if (v) atomicAdd(&base_hist[i], v);
-        }
-        if (id < FQH_NSCALARS && src_scalars[id]) atomicAdd(&scalars[id], src_scalars[id]);
-    }
+    if (blockIdx.y == 0 && id < FQH_NSCALARS && src_scalars[id]) atomicAdd(&scalars[id], src_scalars[id]);
     if (id >= words) return;
     const bool isq = id >= SO_SBYTES / 4;
     const uint32_t r = isq ? id - SO_SBYTES / 4 : id;
@@ -469,17 +604,17 @@ __global__ __launch_bounds__(256) void k_stats_commit(const DevOut *__restrict__
 
 uint32_t stats_blocks(int n_cu);
 
-// can the single-pass kernel take this call's lmax?  (columns beyond the 256 bank-scheduled rows have no LDS here)
+// can the single-pass kernel take this call's lmax?  (its histogram has the 256 bank-scheduled rows and nothing else)
 bool scan_stats_supports(uint32_t lmax) { return lmax >= 1 && lmax <= SO_LC_MAX; }
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu) {
-    const uint64_t want = (n_tiles + FZ_WAVES - 1) / FZ_WAVES;
+    const uint64_t want = ((n_tiles + FZ_SPAN - 1) / FZ_SPAN + FZ_WAVES - 1) / FZ_WAVES;
     const uint32_t cus = stats_blocks(n_cu);
     return (uint32_t)(want < cus ? (want ? want : 1) : cus);
 }
 size_t scan_stats_scratch_bytes(int n_cu) { return (size_t)stats_blocks(n_cu) * SO_WORDS * sizeof(uint32_t); }
 
 template <uint32_t NSL>
-static hipError_t launch_scan_stats_n(hipStream_t s, const StatsArgs &a, FusedArgs z, uint32_t blocks) {
+static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t blocks) {
     z.wave_base = SO_SBYTES + ((NSL + 1) / 2) * 16384u;
     const size_t lds = (size_t)z.wave_base + (size_t)FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK;
     static_assert(SO_SBYTES + ((NSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK <= SO_LDS_MAX, "LDS budget");
@@ -494,30 +629,28 @@ static hipError_t launch_scan_stats_n(hipStream_t s, const StatsArgs &a, FusedAr
         if (e != hipSuccess) return e;
         set = true;
     }
-    hipLaunchKernelGGL((k_scan_stats<NSL>), dim3(blocks), dim3(FZ_THREADS), lds, s, a, z);
+    hipLaunchKernelGGL((k_scan_stats<NSL>), dim3(blocks), dim3(FZ_THREADS), lds, s, z);
     return hipSuccess;
 }
 
-// a: buf, len, lmax, scratch (scan_stats_scratch_bytes), qual_hist / base_hist / scalars = ZEROED side arrays of
-// lmax * 256, lmax * 8 and FQH_NSCALARS u64 (not the caller's: see k_stats_commit)
-hipError_t launch_scan_stats(hipStream_t s, StatsArgs a, FusedArgs z, int n_cu) {
-    a.lc = a.lmax < SO_LC_MAX ? a.lmax : SO_LC_MAX;
-    a.lx = 0;
-    a.listw = 0;
-    a.dbg = 0;
+// z: buf, len, n_tiles, the fast path's outputs, lmax, scratch (scan_stats_scratch_bytes), scalars = ZEROED side
+// array of FQH_NSCALARS u64 (not the caller's: see k_stats_commit)
+hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
+    z.lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
+    z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
     const uint32_t blocks = scan_stats_blocks(z.n_tiles, n_cu);
-    const uint32_t nsl = (a.lc + 31) / 32;
-    hipError_t e = nsl <= 5 ? launch_scan_stats_n<5>(s, a, z, blocks) : launch_scan_stats_n<8>(s, a, z, blocks);
+    const uint32_t nsl = (z.lc + 31) / 32;
+    hipError_t e = nsl <= 5 ? launch_scan_stats_n<5>(s, z, blocks) : launch_scan_stats_n<8>(s, z, blocks);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
-void launch_stats_commit(hipStream_t s, const DevOut *out, const StatsArgs &a, uint32_t blocks,
+void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, uint32_t blocks,
                          unsigned long long *qual_hist, unsigned long long *base_hist, unsigned long long *scalars) {
-    const uint32_t lc = a.lmax < SO_LC_MAX ? a.lmax : SO_LC_MAX;
+    const uint32_t lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
     const uint32_t nsl = (lc + 31) / 32;
     const uint32_t words = (SO_SBYTES + ((nsl <= 5 ? 5u : 8u) + 1) / 2 * 16384u) / 4;
     hipLaunchKernelGGL(k_stats_commit, dim3((words + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
-                       a.scratch, blocks, lc, a.lmax, words, a.qual_hist, a.base_hist, a.scalars, qual_hist, base_hist, scalars);
+                       z.scratch, blocks, lc, words, z.scalars, qual_hist, base_hist, scalars);
 }
 
 }  // namespace fqh

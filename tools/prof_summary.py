@@ -23,7 +23,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             acc[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
         print("== pmc:", os.path.basename(d))
         for k, cs in acc.items():
-            if "k_index" in k or "k_emit" in k or "k_stats" in k or "k_read" in k:
+            if "k_index" in k or "k_emit" in k or "k_stats" in k or "k_read" in k or "k_scan" in k:
                 print("  ", k)
                 for c, v in cs.items():
                     print("      %-28s n=%3d mean %.6g" % (c, len(v), sum(v) / len(v)))

@@ -48,25 +48,77 @@ constexpr uint32_t FZ_GROUP = 4096;                 // bytes per group: 64 conti
 constexpr uint32_t FZ_TAIL = 512;                   // bytes of the previous group kept in front of the group
 constexpr uint32_t FZ_POST = 512;                   // bytes after the span, for the span's last line
 constexpr uint32_t FZ_DATA = FZ_TAIL + FZ_GROUP + FZ_POST;
-constexpr uint32_t FZ_GLIST = 188;                  // line starts per group that can be staged
-constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 128 + (4 + FZ_GLIST) * 2;  // 5632
+constexpr uint32_t FZ_GLIST = 187;                  // line starts per group that can be staged (+ one virtual entry)
+constexpr uint32_t FZ_RS = 192;                    // record starts of a tile staged in LDS (4 x 187 entries / 4, rounded)
+constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 16 + FZ_RS * 2 + (4 + FZ_GLIST + 1) * 2;  // 5904
 constexpr uint32_t FZ_SLACK = 512;                  // a batch reads up to 32 NSL + 32 bytes past a line's start
 static_assert(FZ_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesses");
 
 typedef uint32_t fz_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 
+// A line as one lane knows it: bits 0-8 its length (columns), bit 12 "there is a line", bits 16-28 the LDS position y of
+// its first byte in the wave's data area.  The low 16 bits are the shape key.
+constexpr uint32_t FZ_P_ACT = 0x1000u;
+
 struct FzLane {              // what a lane needs to read and count lines; constant over the kernel
-    uint32_t wbase;          // LDS address of y = 0 of the wave's data area (wave-uniform)
-    uint32_t m, m4, g8;      // lane % 8, 4 * that, lane / 8
+    uint32_t wm4;            // LDS address of the wave's data area + 4 * (lane % 8)
+    uint32_t m, g8, g16;     // lane % 8, lane / 8, 16 * (lane / 8)
     SoLane c;                // the bank schedule's selectors and slot offsets
 };
 
+template <uint32_t NSL>
+struct FzBatch {             // eight lines in flight: this lane's dword of each step of its line
+    uint32_t P;
+    uint32_t w[NSL];
+};
+
+// What a lane derives from the shape of its line and its place in the group of eight; kept across batches and worked
+// out again only when a line of another shape turns up.  Two modes.  Uniform (every line of the batch that ends in a
+// partial dword has it at the same step `tus`, the rule with reads of one length): that dword is counted in step tus
+// along with everything else — cm[tus] is its byte mask for the check, tv[] the values of its four atomics.  Ragged:
+// cm[] covers whole dwords only and the partial dwords get their own pass (tb, tv, tu).
+template <uint32_t NSL>
+struct FzShape {
+    uint32_t key;            // low 16 bits of the P it was derived from
+    uint32_t cm[NSL];        // check mask of this lane's dword at step u; also the value of its atomics (0 / ~0) in all steps but tus
+    uint32_t tv[4];          // value of the k-th atomic (~0: byte k ^ (g & 3) counts) at step tus / in the pass of the partial dwords
+    uint32_t tb, tu;         // ragged mode: byte mask of the lane's partial dword (0: none) and its step
+    uint32_t mode;           // wave-uniform: bits 0-7 tus (0xFF: ragged), bit 8: some line ends in a partial dword
+};
+template <uint32_t NSL>
+__device__ __forceinline__ void fz_shape(FzShape<NSL> &S, uint32_t P, uint32_t m) {
+    S.key = P & 0xFFFFu;
+    const uint32_t len = P & 0x1FFu;
+    const uint32_t nfull4 = len & ~3u, nbt = len & 3u;
+    const uint32_t tu = nfull4 >> 5, mt = (nfull4 >> 2) & 7u, g3 = (__lane_id() >> 3) & 3u;
+    const unsigned long long tl = __ballot(nbt != 0);
+    uint32_t tus = 0xFFu;
+    if (tl) {
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tu, (int)(__ffsll((long long)tl) - 1));
+        if (__ballot(nbt != 0 && tu != t0) == 0) tus = t0;
+    } else {
+        tus = NSL;  // no partial dword anywhere: no step is special
+    }
+    const bool uni = tus != 0xFFu;
+    const int tt = (int)nfull4 - (int)(4u * m);
+    const uint32_t pmask = (nbt && m == mt) ? (1u << (8u * nbt)) - 1u : 0u;  // this lane's partial dword (at step tu)
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u)
+        S.cm[u] = tt > (int)(32u * u) ? 0xFFFFFFFFu : (uni && tu == u) ? pmask : 0u;
+    const bool whole_at_tus = uni && tus < NSL && tt > (int)(32u * tus);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        S.tv[k] = (whole_at_tus || (nbt && m == mt && (k ^ g3) < nbt)) ? 0xFFFFFFFFu : 0u;
+    S.tb = uni ? 0u : pmask;
+    S.tu = nbt ? tu : 0u;
+    S.mode = tus | (tl ? 0x100u : 0u);
+}
+
 // this lane's dword of every step of its line: two aligned dwords (ds_read2_b32, immediate offsets) and one shift
 template <uint32_t NSL>
-__device__ __forceinline__ void fz_fetch(SoBatch<NSL> &B, const FzLane &L, const uint8_t *lds8) {
-    const uint32_t ys = B.P >> SO_P_SREL;
-    const uint32_t la = L.wbase + (ys & ~3u) + L.m4;
-    const uint32_t sh = ys & 3u;
+__device__ __forceinline__ void fz_fetch(FzBatch<NSL> &B, const FzLane &L, const uint8_t *lds8) {
+    const uint32_t la = L.wm4 + ((B.P >> 16) & ~3u);
+    const uint32_t sh = (B.P >> 16) & 3u;
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
         const fz_u32x2 v = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + 32u * u);
@@ -74,33 +126,30 @@ __device__ __forceinline__ void fz_fetch(SoBatch<NSL> &B, const FzLane &L, const
     }
 }
 
-// Count one batch: so_count (stats_dev.h) without its exact path — anything that one would handle (a byte outside
-// the alphabet / window, a line longer than the rows) sets `bad` and counts nothing.
+template <bool IS_SEQ, uint32_t OFF>
+__device__ __forceinline__ void fz_sub4(const SoLane &c, uint32_t pb, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[0]), v0);
+    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[1]), v1);
+    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[2]), v2);
+    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[3]), v3);
+}
+
+// Count one batch: pass 1 checks every byte the batch counts, pass 2 adds them — one v_perm_b32 and one ds_sub_u32 per
+// byte (stats_dev.h).  No exact path: a byte outside the alphabet / window sets `bad` and nothing is counted.
 template <bool IS_SEQ, uint32_t NSL>
-__device__ __forceinline__ void fz_count(SoBatch<NSL> &B, SoShape<NSL> &S, const FzLane &L, SoTotals &T, bool &bad) {
+__device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const FzLane &L, SoTotals &T, bool &bad) {
     const SoLane &c = L.c;
-    const uint32_t P = B.P;
-    if (__ballot((P & 0xFFFFu) != S.key) != 0) so_shape<NSL>(S, P, L.m);
+    if (__ballot((B.P & 0xFFFFu) != S.key) != 0) fz_shape<NSL>(S, B.P, L.m);
     constexpr uint32_t RB = IS_SEQ ? 2048u : 16384u;
     constexpr uint32_t REGION = IS_SEQ ? 0u : SO_SBYTES;
-    const uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.any);
-    const bool tails = (any & 1u) != 0;
-    if (any & 2u) {  // a line longer than the histogram's rows
-        bad = true;
-        return;
-    }
+    const uint32_t mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.mode);
+    const uint32_t tus = mode & 0xFFu;
+    const bool ragged_tails = tus == 0xFFu;
     uint32_t chk = 0, orw = 0, pt = 0;
-    const uint32_t tus = (any >> 8) & 0xFFu;
-    if (tails) {
+    if (ragged_tails) {  // lines of different lengths in one batch: each lane picks the step of its line's partial dword
         uint32_t x = B.w[0];
-        if (tus < NSL) {
 #pragma unroll
-            for (uint32_t u = 1; u < NSL; ++u)
-                if (tus == u) x = B.w[u];
-        } else {
-#pragma unroll
-            for (uint32_t u = 1; u < NSL; ++u) x = S.tu == u ? B.w[u] : x;
-        }
+        for (uint32_t u = 1; u < NSL; ++u) x = S.tu == u ? B.w[u] : x;
         if (IS_SEQ) {
             pt = x & 0x07070707u;
             chk |= (x ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pt)) & S.tb;
@@ -112,7 +161,7 @@ __device__ __forceinline__ void fz_count(SoBatch<NSL> &B, SoShape<NSL> &S, const
     }
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
-        const uint32_t w = B.w[u], f = S.full[u];
+        const uint32_t w = B.w[u], f = S.cm[u];
         if (IS_SEQ) {
             const uint32_t bins = w & 0x07070707u;
             chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;
@@ -130,27 +179,24 @@ __device__ __forceinline__ void fz_count(SoBatch<NSL> &B, SoShape<NSL> &S, const
     }
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
-        const uint32_t pb = B.w[u], f = S.full[u];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ad = __builtin_amdgcn_perm(c.slots, pb, c.sel[k]);
-            switch (u) {  // (the row block and slot half go into the instruction's immediate offset)
-            case 0: lds_sub<REGION>(ad, f); break;
-            case 1: lds_sub<REGION + 128u>(ad, f); break;
-            case 2: lds_sub<REGION + RB>(ad, f); break;
-            case 3: lds_sub<REGION + RB + 128u>(ad, f); break;
-            case 4: lds_sub<REGION + 2 * RB>(ad, f); break;
-            case 5: lds_sub<REGION + 2 * RB + 128u>(ad, f); break;
-            case 6: lds_sub<REGION + 3 * RB>(ad, f); break;
-            default: lds_sub<REGION + 3 * RB + 128u>(ad, f); break;
-            }
+        const uint32_t pb = B.w[u], f = S.cm[u];
+        const bool sp = u == tus;  // (wave-uniform) the step that also holds the partial last dwords
+        const uint32_t v0 = sp ? S.tv[0] : f, v1 = sp ? S.tv[1] : f, v2 = sp ? S.tv[2] : f, v3 = sp ? S.tv[3] : f;
+        switch (u) {  // (the row block and slot half go into the instruction's immediate offset)
+        case 0: fz_sub4<IS_SEQ, REGION>(c, pb, v0, v1, v2, v3); break;
+        case 1: fz_sub4<IS_SEQ, REGION + 128u>(c, pb, v0, v1, v2, v3); break;
+        case 2: fz_sub4<IS_SEQ, REGION + RB>(c, pb, v0, v1, v2, v3); break;
+        case 3: fz_sub4<IS_SEQ, REGION + RB + 128u>(c, pb, v0, v1, v2, v3); break;
+        case 4: fz_sub4<IS_SEQ, REGION + 2 * RB>(c, pb, v0, v1, v2, v3); break;
+        case 5: fz_sub4<IS_SEQ, REGION + 2 * RB + 128u>(c, pb, v0, v1, v2, v3); break;
+        case 6: fz_sub4<IS_SEQ, REGION + 3 * RB>(c, pb, v0, v1, v2, v3); break;
+        default: fz_sub4<IS_SEQ, REGION + 3 * RB + 128u>(c, pb, v0, v1, v2, v3); break;
         }
     }
-    if (tails) {
-        const uint32_t tu = tus < NSL ? tus : S.tu;
-        const uint32_t off = REGION + ((tu & 1u) << 7) + (tu >> 1) * RB;
+    if (ragged_tails) {
+        const uint32_t off = REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lds_sub<0>(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off, S.tf[k]);
+        for (int k = 0; k < 4; ++k) lds_sub<0>(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off, S.tv[k]);
     }
     if (IS_SEQ) {  // sequence lines with an 'N' (bit 3 is set in 'N' only): the 8 lanes of a line OR their flags
         const unsigned long long bn = __ballot((orw & 0x08080808u) != 0);
@@ -158,36 +204,34 @@ __device__ __forceinline__ void fz_count(SoBatch<NSL> &B, SoShape<NSL> &S, const
     }
 }
 
-// The lines that ended in this group join the batch in progress.  Pnew: lane i holds the packed word of new line i
-// (i < n).  Position q = nfill + i of the running sequence of lines: batch q / 8, slot q % 8.  Full batches are
-// counted; what is left (fewer than eight lines) stays in PB for the next call; flush counts that as well.
+// The lines of one kind that ended in this chunk of entries join the batch in progress.  Pent: lane j holds the packed
+// word of the line that entry j of the chunk closes; this kind's are at lanes l0, l0 + 4, .. (n of them).  Position
+// q = nfill + i of the running sequence of lines: batch q / 8, slot q % 8.  Full batches are counted; fewer than eight
+// lines stay in PB for the next call; flush counts them as well.
 template <bool IS_SEQ, uint32_t NSL>
-__device__ __forceinline__ void fz_lines(SoBatch<NSL> &PB, uint32_t &nfill, uint32_t Pnew, uint32_t n, bool flush,
-                                         const FzLane &L, const uint8_t *lds8, SoShape<NSL> &S, SoTotals &T, bool &bad,
+__device__ __forceinline__ void fz_lines(FzBatch<NSL> &PB, uint32_t &nfill, uint32_t Pent, uint32_t l0, uint32_t n, bool flush,
+                                         const FzLane &L, const uint8_t *lds8, FzShape<NSL> &S, SoTotals &T, bool &bad,
                                          bool do_count) {
     const uint32_t q0 = nfill;
     const uint32_t total = q0 + n;
     const uint32_t nb = total >> 3;
-    int lo_i = -(int)q0;
-    for (uint32_t b = 0; b <= nb; ++b, lo_i += 8) {
-        const int i = lo_i + (int)L.g8;
-        const bool isnew = i >= 0 && i < (int)n;
-        uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * i, (int)Pnew);
-        if (!isnew) Pn = 0;
+    const uint32_t rem = total & 7u;
+    const uint32_t nit = nb + ((rem && flush) ? 1u : 0u);  // batches to count
+    int i0 = -(int)q0;  // slot g8 of batch b takes new line i = 8 b - q0 + g8, held by lane l0 + 4 i
+    for (uint32_t b = 0; b <= nb; ++b, i0 += 8) {
+        const uint32_t i = (uint32_t)(i0 + (int)L.g8);  // (negative wraps: the unsigned compare rejects it)
+        const bool isnew = i < n;
+        const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * l0 + 16u * (uint32_t)i0 + L.g16), (int)Pent);
         if (b == 0) {
-            if (L.g8 >= q0) PB.P = Pn;  // (slots below q0 keep the lines they hold)
+            if (L.g8 >= q0) PB.P = isnew ? Pn : 0u;  // (slots below q0 keep the lines they hold)
         } else {
-            PB.P = Pn;
+            PB.P = isnew ? Pn : 0u;
         }
         if (isnew) fz_fetch<NSL>(PB, L, lds8);
-        if (b < nb && do_count) fz_count<IS_SEQ, NSL>(PB, S, L, T, bad);
+        if (b < nit && do_count) fz_count<IS_SEQ, NSL>(PB, S, L, T, bad);
     }
-    nfill = total & 7u;
-    if (flush) {
-        if (nfill && do_count) fz_count<IS_SEQ, NSL>(PB, S, L, T, bad);
-        nfill = 0;
-        PB.P = 0;
-    }
+    nfill = flush ? 0u : rem;
+    if (flush) PB.P = 0;
 }
 
 // 16 bytes at buf + off of the partial tile at the end of the buffer; bytes at or beyond len read as 0
@@ -208,11 +252,12 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wbase = wb0 + wv * FZ_WAVE_BYTES;  // LDS address of y = 0 of the wave's data area
     FzLane L;
-    L.wbase = wb0 + wv * FZ_WAVE_BYTES;
     L.m = lane & 7u;
-    L.m4 = L.m * 4u;
+    L.wm4 = wbase + L.m * 4u;
     L.g8 = lane >> 3;
+    L.g16 = L.g8 * 16u;
     L.c.slots = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
@@ -220,7 +265,6 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
         L.c.sel[k] = 0x0C0C0004u + k + (j << 8);
         L.c.slots |= ((L.m + 8u * j) * 4u) << (8u * k);
     }
-    const uint32_t wbase = L.wbase;
     uint8_t *const wptr = lds8 + wbase + FZ_TAIL + 16u * lane;      // chunk 64 j + lane of the group: + 1024 j
     const uint32_t rbase = wbase + FZ_TAIL + 64u * lane;            // this lane's 64 contiguous bytes
     const uint8_t *const rptr = lds8 + rbase;
@@ -229,12 +273,13 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
     const uint32_t kro = (4u - rot) & 3u;                           // rotate the 64-bit mask right by 16 kro bits
     const bool swp = (kro & 2u) != 0;
     const uint32_t s16 = (kro & 1u) * 16u;
-    uint16_t *const tline = reinterpret_cast<uint16_t *>(lds8 + wbase + FZ_DATA);  // the tile's line, 64 u16
-    uint16_t *const lst = tline + 64 + 4;  // the group's entries; lst[-4 .. -1]: the last four before the group
+    uint16_t *const tedge = reinterpret_cast<uint16_t *>(lds8 + wbase + FZ_DATA);  // the tile's first four entries
+    uint16_t *const trs = tedge + 8;       // the tile's record starts (FZ_RS of them)
+    uint16_t *const lst = trs + FZ_RS + 4; // the group's entries; lst[-4 .. -1]: the last four before the group
 
     uint32_t acc_rec = 0, acc_bases = 0, acc_qual = 0;  // per lane (a wave never reads 4 GiB)
     SoTotals T = {0, 0};
-    SoShape<NSL> S = {};
+    FzShape<NSL> S = {};
     S.key = 0xFFFFFFFFu;
 
     const uint8_t *__restrict__ const buf = z.buf;
@@ -263,7 +308,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
     if (span < n_spans) {
         uint4 n0, n1, n2, n3;
         fetch_group(span * FZ_SPAN, 0, n0, n1, n2, n3);
-        uint32_t pb = span ? buf[((uint64_t)(span * FZ_SPAN) << WT_SHIFT) - 1] : 0u;  // the byte before the span
+        // the byte before the span, kept in a vector register until the span starts (no wait right behind the load)
+        uint32_t pbv = span ? buf[((uint64_t)(span * FZ_SPAN) << WT_SHIFT) - 1] : 0u;
         bool pending = false;  // the previous tile's line is still in a register
         uint32_t ptile = 0, prv = 0;
         for (; span < n_spans; span += nw) {
@@ -272,47 +318,60 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
             const uint32_t t1 = t0 + FZ_SPAN < n_tiles ? t0 + FZ_SPAN : n_tiles;
             uint32_t srun = 0;       // entries of the span before the current group
             uint32_t tot = 0;        // entries of the current group
-            uint32_t prev = (t0 && pb == '\n') ? 1u : 0u;
+            uint32_t prev;           // the byte before the group is a newline
+            {
+                uint32_t x = pbv;
+                asm volatile("v_mov_b32 %0, %0" : "+v"(x));  // (opaque: keeps the compiler from moving the value to a scalar at the load)
+                prev = (t0 && (uint32_t)__builtin_amdgcn_readfirstlane((int)x) == '\n') ? 1u : 0u;
+            }
             uint32_t hyp = 7;        // the span's alignment: entries hyp, hyp + 4, .. (counted from the span's first) start records
             bool span_bad = false;
-            SoBatch<NSL> PBs, PBq;   // the batches in progress
+            FzBatch<NSL> PBs, PBq;   // the batches in progress
             PBs.P = 0;
             PBq.P = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < NSL; ++u) PBs.w[u] = PBq.w[u] = 0;
             uint32_t nfill_s = 0, nfill_q = 0;
             uint2 post = make_uint2(0, 0);
-            uint32_t last_ng = 1, last_bytes = 0;
-            bool last_full = true;
             for (uint32_t tile = t0; tile < t1; ++tile) {
                 const uint64_t tb = (uint64_t)tile << WT_SHIFT;
                 const bool full = tile < n_full;
                 const uint32_t tile_bytes = full ? WT_BYTES : (uint32_t)(len - tb);
                 const uint32_t ng = full ? WT_BYTES / FZ_GROUP : (tile_bytes + FZ_GROUP - 1) / FZ_GROUP;
-                last_ng = ng;
-                last_bytes = tile_bytes;
-                last_full = full;
+                const bool last_t = tile + 1 == t1;
                 uint32_t run = 0;            // entries of the tile before the current group
                 uint32_t have = 0, bad = 0;  // bit r: some / some failing window of five entries starting at r (mod 4), tile-relative
                 uint32_t hyp_t = hyp < 4 ? (hyp - srun - tot) & 3u : 7u;  // the same alignment counted from the tile's first entry
                 __builtin_amdgcn_wave_barrier();
-                tline[lane] = 0;
+                trs[lane] = 0;  // (unused slots of the tile's line are 0)
 #pragma unroll 1
                 for (uint32_t g = 0; g < ng; ++g) {
+                    const bool last_g = g + 1 == ng;
                     __builtin_amdgcn_wave_barrier();
                     *reinterpret_cast<uint4 *>(wptr) = n0;
                     *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
                     *reinterpret_cast<uint4 *>(wptr + 2048) = n2;
                     *reinterpret_cast<uint4 *>(wptr + 3072) = n3;
-                    {  // the next group: of this tile, of the span's next tile, or of the wave's next span
-                        const bool last_g = g + 1 == ng;
-                        const bool last_t = tile + 1 == t1;
-                        if (last_g && last_t) {
-                            pb = buf[((uint64_t)(nspan * FZ_SPAN) << WT_SHIFT) - (nspan ? 1 : 0)];
-                            const uint64_t pe = tb + tile_bytes + 8u * lane;   // the bytes after the span
-                            if (pe + 8 <= len) post = *reinterpret_cast<const uint2 *>(buf + pe);
-                            else post = make_uint2(0, 0);
+                    int ppos = -1;  // position of the first newline in the bytes after the span
+                    if (last_g && last_t && full) {  // those bytes (loaded three groups ago) go behind the group
+                        *reinterpret_cast<uint2 *>(lds8 + wbase + FZ_TAIL + FZ_GROUP + 8u * lane) = post;
+                        const uint32_t f0 = eq_flags(post.x, 0x0A0A0A0Au), f1 = eq_flags(post.y, 0x0A0A0A0Au);
+                        const unsigned long long bm = __ballot((f0 | f1) != 0);
+                        if (bm) {
+                            const uint32_t first = (uint32_t)__ffsll((long long)bm) - 1u;
+                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, (int)first);
+                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane((int)f1, (int)first);
+                            const uint32_t byte = g0 ? ((uint32_t)__ffs(g0) - 1u) / 8u : 4u + ((uint32_t)__ffs(g1) - 1u) / 8u;
+                            ppos = (int)(8u * first + byte);
                         }
-                        fetch_group(last_g ? (last_t ? nspan * FZ_SPAN : tile + 1) : tile, last_g ? 0u : g + 1, n0, n1, n2, n3);
                     }
+                    // the next group: of this tile, of the span's next tile, or of the wave's next span
+                    if (last_t && g == 0) {  // (early: the bytes after the span are needed in the span's last group)
+                        const uint64_t pe = tb + tile_bytes + 8u * lane;
+                        if (pe + 8 <= len) post = *reinterpret_cast<const uint2 *>(buf + pe);
+                    }
+                    if (last_g && last_t) pbv = buf[((uint64_t)(nspan * FZ_SPAN) << WT_SHIFT) - (nspan ? 1 : 0)];
+                    fetch_group(last_g ? (last_t ? nspan * FZ_SPAN : tile + 1) : tile, last_g ? 0u : g + 1, n0, n1, n2, n3);
                     if (g == 0 && pending)  // a whole group before the next wait on vmcnt
                         __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -357,16 +416,10 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
                     run += tot;   // the previous group's entries are behind us now
                     srun += tot;
                     if (g == 0) run = 0;  // (they belonged to the previous tile)
-                    tot = gtot;
-                    if (tot > FZ_GLIST) {  // lines shorter than ~22 bytes on average: left to the exact path
-                        span_bad = true;
-                        run += gtot;
-                        srun += gtot;
-                        tot = 0;
-                        continue;
-                    }
+                    if (gtot > FZ_GLIST) span_bad = true;  // lines shorter than ~22 bytes on average: left to the exact path
+                    tot = gtot < FZ_GLIST ? gtot : FZ_GLIST;
                     const uint32_t ebase = g * FZ_GROUP + lane * 64u;
-                    {
+                    if (pre + cl <= FZ_GLIST) {  // (a lane whose entries would leave the list writes none: the span is bad anyway)
                         uint16_t *dst = lst + pre;
                         while (ls_lo) {
                             const uint32_t q = __ffs(ls_lo) - 1;
@@ -381,86 +434,100 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
                             *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
                         }
                     }
+                    const int gofs = (int)FZ_TAIL - (int)(g * FZ_GROUP);  // tile offset -> y (position in the wave's data area)
+                    // ---- the span's last group: its last line ends in another wavefront's span (or with the buffer); the
+                    // 512 bytes after the span close it, as one more (virtual) entry behind the group's
+                    uint32_t totv = tot;
+                    if (last_g && last_t && !(z.dbg & 16u)) {
+                        const int yend = (int)FZ_TAIL + (int)(tile_bytes - g * FZ_GROUP);  // y of the first byte after the span
+                        const bool last_nl = full ? prev != 0 : buf[len - 1] == '\n';
+                        int yclose = -1;
+                        if (last_nl) {
+                            yclose = yend;
+                        } else if (full) {
+                            if (ppos >= 0) yclose = yend + ppos + 1;
+                            else if (tb + tile_bytes + FZ_POST <= len) span_bad = true;  // a line that goes on for more than 512 bytes after the span
+                            // (else: no '\n' before the end of the buffer: not a line the parser delivers)
+                        }
+                        if (yclose >= 0) {
+                            if (lane == 0) lst[tot] = (uint16_t)((uint32_t)(yclose - gofs) & 0x3FFFu);
+                            totv = tot + 1;
+                        }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    // ---- windows of five entries that end in this group (src/records.rs:141,155,233 under each alignment)
-                    if (!(z.dbg & 8u))
-                        for (uint32_t p = lane; p < tot; p += 64) {
-                            const uint32_t ti = run + p;
-                            if (ti < 4) {
-                                tline[FR_EDGE + ti] = lst[p];  // the tile's first four entries
-                                continue;
+                    // ---- one lane per entry, 64 entries at a time: the window of five entries that ends at it (src/records.rs:141,
+                    // 155,233 under each alignment), and the line it closes (the one entry p - 1 starts)
+#pragma unroll 1
+                    for (uint32_t c0 = 0; c0 < totv; c0 += 64) {
+                        const uint32_t p = c0 + lane;
+                        const uint32_t ti = run + p;
+                        uint32_t Pent = 0;      // the line entry p closes
+                        uint32_t e4 = 0;
+                        uint32_t l = 0;
+                        if (p < totv) {
+                            e4 = lst[p];
+                            const uint32_t e3 = lst[(int)p - 1];
+                            if (p < tot && !(z.dbg & 8u)) {
+                                if (ti < 4) {
+                                    tedge[ti] = (uint16_t)e4;  // the tile's first four entries
+                                } else {
+                                    const uint32_t e0 = lst[(int)p - 4], e1 = lst[(int)p - 3], e2 = lst[(int)p - 2];
+                                    const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
+                                                    ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
+                                    have |= 1u << (ti & 3u);
+                                    bad |= ok ? 0u : 1u << (ti & 3u);
+                                }
                             }
-                            const uint32_t e0 = lst[(int)p - 4], e1 = lst[(int)p - 3], e2 = lst[(int)p - 2], e3 = lst[(int)p - 1], e4 = lst[p];
-                            const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
-                                            ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
-                            have |= 1u << (ti & 3u);
-                            bad |= ok ? 0u : 1u << (ti & 3u);
-                        }
-                    if (tile == t0 && g == 0) {  // the span's first group must single out the alignment it is counted under
-                        uint32_t cons = 0;
-#pragma unroll
-                        for (uint32_t r = 0; r < 4; ++r)
-                            if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
-                        if (cons && !(cons & (cons - 1))) hyp = hyp_t = (uint32_t)__ffs(cons) - 1;
-                        else span_bad = true;
-                    }
-                    if (!span_bad && tot && !(z.dbg & 1u)) {
-                        // ---- one lane per line that ends in this group.  Entry p closes the line that entry p - 1 starts.
-                        // Lines, counted from the span's first entry: hyp (mod 4) header, + 1 sequence, + 2 separator, + 3 quality.
-                        const uint32_t pq = (hyp - srun) & 3u;         // these entries start a record and close a quality line
-                        const uint32_t ps = (pq + 2u) & 3u;            // these close a sequence line
-                        const int gofs = (int)FZ_TAIL - (int)(g * FZ_GROUP);  // tile offset -> y (the wave's data area)
-                        uint32_t P_s = 0, P_q = 0;
-                        bool far = false;
-                        {
-                            const uint32_t p = ps + 4u * lane;
-                            if (p < tot && (srun | p) != 0) {
-                                const int n = (int)(lst[p] & 0x3FFFu);
-                                uint32_t l = ((uint32_t)(n - (int)lst[(int)p - 1]) & 0x3FFFu) - 1u;   // raw line, without its '\n'
-                                const int ys = n + gofs - 1 - (int)l;
-                                if (ys < 0) far = true;
-                                else {
+                            if ((srun | p) != 0) {  // (the span's first entry closes a line that is not this wave's)
+                                l = ((e4 - e3) & 0x3FFFu) - 1u;  // raw line, without its '\n'
+                                int yc = (int)(e4 & 0x3FFFu) + gofs;
+                                if (p >= tot && yc < (int)FZ_TAIL) yc += (int)WT_BYTES;  // (the virtual entry's offset may have wrapped)
+                                const int ys = yc - 1 - (int)l;
+                                if (ys < 0 || l > lc) {
+                                    span_bad = true;  // began before the kept tail (longer than ~500 bytes), or longer than the rows
+                                } else {
                                     if (l && lds8[wbase + (uint32_t)ys + l - 1] == '\r') --l;  // trim_winline, src/records.rs:66-73
-                                    P_s = so_pack((uint32_t)ys, l, lc);
-                                    ++acc_rec;
-                                    acc_bases += l;
+                                    Pent = l | FZ_P_ACT | ((uint32_t)ys << 16);
                                 }
                             }
+                        }
+                        span_bad = __ballot(span_bad) != 0;
+                        if (tile == t0 && g == 0 && c0 == 0) {  // the span's first entries must single out the alignment it is counted under
+                            uint32_t cons = 0;
+#pragma unroll
+                            for (uint32_t r = 0; r < 4; ++r)
+                                if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
+                            if (cons && !(cons & (cons - 1))) hyp = hyp_t = (uint32_t)__ffs(cons) - 1;
+                            else span_bad = true;
                         }
                         {
-                            const uint32_t p = pq + 4u * lane;
-                            if (p < tot) {
-                                const uint32_t e = lst[p] & 0x3FFFu;
-                                // record start k of the tile: the first FR_N in the tile's line, then a second line, then the list area
-                                if (run + p >= hyp_t) {
-                                    const uint32_t k = (run + p - hyp_t) >> 2;
-                                    if (k < FR_N) tline[k] = (uint16_t)e;
-                                    else if (k < FR_N + FR2_N) z.fast_rs[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + (k - FR_N)] = (uint16_t)e;
-                                    else z.list[(uint64_t)tile * z.list_cap + 8 + k] = (uint16_t)e;
-                                }
-                                if ((srun | p) != 0) {
-                                    uint32_t l = ((e - (uint32_t)lst[(int)p - 1]) & 0x3FFFu) - 1u;
-                                    const int ys = (int)e + gofs - 1 - (int)l;
-                                    if (ys < 0) far = true;
-                                    else {
-                                        if (l && lds8[wbase + (uint32_t)ys + l - 1] == '\r') --l;
-                                        P_q = so_pack((uint32_t)ys, l, lc);
-                                        acc_qual += l;
-                                    }
-                                }
+                            // lines, counted from the span's first entry: hyp (mod 4) header, + 1 sequence, + 2 separator, + 3 quality;
+                            // entry p closes line srun + p - 1.  (Runs whatever span_bad says: nothing of a bad span is used, and
+                            // a region that is skipped conditionally costs a wait for the loads in flight, see DESIGN.md.)
+                            const uint32_t kd = (srun + p - 1u - hyp) & 3u;
+                            if (Pent) {
+                                if (kd == 1u) { ++acc_rec; acc_bases += l; }
+                                if (kd == 3u) acc_qual += l;
                             }
+                            if (kd == 3u && p < tot && ti >= hyp_t) {  // a record starts here: record start k of the tile
+                                const uint32_t k = (ti - hyp_t) >> 2;
+                                if (k < FZ_RS) trs[k] = (uint16_t)(e4 & 0x3FFFu);
+                            }
+                            const uint32_t cnt_c = totv - c0 < 64 ? totv - c0 : 64u;
+                            const uint32_t pq = (hyp - srun - c0) & 3u;  // lanes pq, pq + 4, ..: entries that close a quality line
+                            uint32_t ps = (pq + 2u) & 3u;                // lanes ps, ps + 4, ..: entries that close a sequence line
+                            uint32_t pq0 = pq;
+                            if ((srun | c0) == 0) {  // (the span's very first entry closes nothing of ours)
+                                if (ps == 0) ps = 4;
+                                if (pq0 == 0) pq0 = 4;
+                            }
+                            const uint32_t nls = cnt_c > ps ? (cnt_c - ps + 3) >> 2 : 0u, nlq = cnt_c > pq0 ? (cnt_c - pq0 + 3) >> 2 : 0u;
+                            const bool flush = last_g && last_t && c0 + 64 >= totv;
+                            const bool cnt = !(z.dbg & 2u);
+                            fz_lines<true, NSL>(PBs, nfill_s, Pent, ps, nls, flush, L, lds8, S, T, span_bad, cnt);
+                            fz_lines<false, NSL>(PBq, nfill_q, Pent, pq0, nlq, flush, L, lds8, S, T, span_bad, cnt);
                         }
-                        if (__ballot(far)) span_bad = true;  // a line that began before the kept tail (longer than ~500 bytes)
-                        uint32_t nls = tot > ps ? (tot - ps + 3) >> 2 : 0u, nlq = tot > pq ? (tot - pq + 3) >> 2 : 0u;
-                        uint32_t Ps2 = P_s, Pq2 = P_q;
-                        if (srun == 0) {  // the span's very first entry closes a line that is not this wave's: lane 0 of its kind is empty
-                            if (ps == 0 && nls) { Ps2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * lane + 4u), (int)P_s); --nls; }
-                            if (pq == 0 && nlq) { Pq2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * lane + 4u), (int)P_q); --nlq; }
-                        }
-                        const bool cnt = !(z.dbg & 2u);
-                        fz_lines<true, NSL>(PBs, nfill_s, Ps2, nls, false, L, lds8, S, T, span_bad, cnt);
-                        fz_lines<false, NSL>(PBq, nfill_q, Pq2, nlq, false, L, lds8, S, T, span_bad, cnt);
                     }
                     // ---- the next group finds this one's last 512 bytes and last four entries in front of its own
                     __builtin_amdgcn_wave_barrier();
@@ -484,10 +551,21 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
                         if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
                     if (trun < 8 || hyp_t > 3 || cons != (1u << hyp_t)) span_bad = true;
                 }
-                // ---- the tile's line: record starts (the lanes wrote them), first and last four entries, count, alignment
+                // ---- the tile's line: record starts (the lanes staged them), first and last four entries, count, alignment;
+                // record starts beyond the line's FR_N go to a second line and to the list area (reads shorter than ~140 bp)
                 {
-                    uint32_t rv = tline[lane];
+                    uint32_t rv = lane < FR_N ? (uint32_t)trs[lane] : 0u;
+                    if (lane >= FR_EDGE && lane < FR_EDGE + 4) rv = tedge[lane - FR_EDGE];
                     if (lane >= FR_EDGE + 4 && lane < FR_EDGE + 8) rv = lst[(int)lane - (int)(FR_EDGE + 8)];
+                    const uint32_t nrs = trun > hyp_t ? (trun - hyp_t + 3) >> 2 : 0u;  // record starts of the tile
+                    if (nrs > FR_N && hyp_t < 4) {
+                        z.fast_rs[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + lane] = trs[FR_N + lane];
+                        if (nrs > FR_N + FR2_N)
+                            for (uint32_t k = FR_N + FR2_N + lane; k < nrs && k < FZ_RS; k += 64) z.list[(uint64_t)tile * z.list_cap + 8 + k] = trs[k];
+                        __builtin_amdgcn_wave_barrier();
+                        trs[64 + lane] = 0;
+                        trs[128 + lane] = 0;
+                    }
                     if (span_bad) ++n_over;
                     prv = lane == FR_CNT ? (trun & 0xFFFFu) : lane == FR_CNT + 1 ? (trun >> 16) : lane == FR_HYP ? (span_bad ? 7u : hyp_t) : rv;
                 }
@@ -495,58 +573,6 @@ __global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
                 pending = true;
                 __builtin_amdgcn_wave_barrier();
             }
-            srun += tot;  // entries of the whole span
-            // ---- the span's last line ends in another wavefront's span (or with the buffer): close it with the bytes
-            // after the span, then count what is left in the batches
-            uint32_t Pv = 0;
-            uint32_t kind = 0;
-            if (!span_bad && srun && !(z.dbg & 16u)) {
-                kind = (srun - 1u - hyp) & 3u;
-                if (kind == 1u || kind == 3u) {
-                    const int yend = (int)(FZ_TAIL + last_bytes - (last_ng - 1) * FZ_GROUP);  // y of the first byte after the span
-                    const bool last_nl = last_full ? prev != 0 : buf[len - 1] == '\n';
-                    int yclose = -1;
-                    if (last_nl) {
-                        yclose = yend;
-                    } else if (last_full) {
-                        __builtin_amdgcn_wave_barrier();
-                        *reinterpret_cast<uint2 *>(lds8 + wbase + FZ_TAIL + FZ_GROUP + 8u * lane) = post;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        const uint32_t f0 = eq_flags(post.x, 0x0A0A0A0Au), f1 = eq_flags(post.y, 0x0A0A0A0Au);
-                        const unsigned long long bm = __ballot((f0 | f1) != 0);
-                        if (bm) {
-                            const uint32_t first = (uint32_t)__ffsll((long long)bm) - 1u;
-                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, (int)first);
-                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane((int)f1, (int)first);
-                            const uint32_t byte = g0 ? ((uint32_t)__ffs(g0) - 1u) / 8u : 4u + ((uint32_t)__ffs(g1) - 1u) / 8u;
-                            yclose = yend + (int)(8u * first + byte) + 1;
-                        } else if (((uint64_t)(t1 - 1) << WT_SHIFT) + last_bytes + FZ_POST <= len) {
-                            span_bad = true;  // a line that goes on for more than 512 bytes after the span
-                        }  // (else: no '\n' before the end of the buffer: not a line the parser delivers)
-                    }
-                    if (yclose >= 0) {
-                        const int ystart = (int)FZ_TAIL + (int)(lst[-1] & 0x3FFFu) - (int)((last_ng - 1) * FZ_GROUP);
-                        if (ystart < 0) {
-                            span_bad = true;
-                        } else if (lane == 0) {
-                            uint32_t l = (uint32_t)(yclose - 1 - ystart);
-                            if (l && lds8[wbase + (uint32_t)ystart + l - 1] == '\r') --l;
-                            Pv = so_pack((uint32_t)ystart, l, lc);
-                            if (kind == 1u) { ++acc_rec; acc_bases += l; }
-                            else acc_qual += l;
-                        }
-                    } else {
-                        kind = 0;
-                    }
-                }
-            }
-            {
-                const bool cnt = !(z.dbg & 2u) && !span_bad;
-                fz_lines<true, NSL>(PBs, nfill_s, Pv, kind == 1u ? 1u : 0u, true, L, lds8, S, T, span_bad, cnt);
-                fz_lines<false, NSL>(PBq, nfill_q, Pv, kind == 3u ? 1u : 0u, true, L, lds8, S, T, span_bad, cnt);
-            }
-            if (span_bad) ++n_over;
         }
         if (pending) __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
     }

@@ -41,8 +41,10 @@
 
 namespace fqh {
 
-constexpr uint32_t FZ_THREADS = 768;
-constexpr uint32_t FZ_WAVES = FZ_THREADS / 64;
+#ifndef FQH_FZ_W5
+#define FQH_FZ_W5 16
+#endif
+constexpr uint32_t FZ_WAVES_MAX = 16;              // wavefronts per block: 16 with up to 160 rows, 12 with 256 (LDS)
 constexpr uint32_t FZ_SPAN = 4;                     // tiles a wavefront walks in one go
 constexpr uint32_t FZ_GROUP = 4096;                 // bytes per group: 64 contiguous bytes per lane
 constexpr uint32_t FZ_TAIL = 512;                   // bytes of the previous group kept in front of the group
@@ -81,7 +83,7 @@ template <uint32_t NSL>
 struct FzShape {
     uint32_t key;            // low 16 bits of the P it was derived from
     uint32_t cm[NSL];        // check mask of this lane's dword at step u; also the value of its atomics (0 / ~0) in all steps but tus
-    uint32_t tv[4];          // value of the k-th atomic (~0: byte k ^ (g & 3) counts) at step tus / in the pass of the partial dwords
+    uint32_t tv[4];          // what the k-th atomic ADDS (1: byte k ^ (g & 3) counts) at step tus / in the pass of the partial dwords
     uint32_t tb, tu;         // ragged mode: byte mask of the lane's partial dword (0: none) and its step
     uint32_t mode;           // wave-uniform: bits 0-7 tus (0xFF: ragged), bit 8: some line ends in a partial dword
 };
@@ -108,7 +110,7 @@ __device__ __forceinline__ void fz_shape(FzShape<NSL> &S, uint32_t P, uint32_t m
     const bool whole_at_tus = uni && tus < NSL && tt > (int)(32u * tus);
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
-        S.tv[k] = (whole_at_tus || (nbt && m == mt && (k ^ g3) < nbt)) ? 0xFFFFFFFFu : 0u;
+        S.tv[k] = (whole_at_tus || (nbt && m == mt && (k ^ g3) < nbt)) ? 1u : 0u;
     S.tb = uni ? 0u : pmask;
     S.tu = nbt ? tu : 0u;
     S.mode = tus | (tl ? 0x100u : 0u);
@@ -126,12 +128,14 @@ __device__ __forceinline__ void fz_fetch(FzBatch<NSL> &B, const FzLane &L, const
     }
 }
 
-template <bool IS_SEQ, uint32_t OFF>
-__device__ __forceinline__ void fz_sub4(const SoLane &c, uint32_t pb, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
-    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[0]), v0);
-    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[1]), v1);
-    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[2]), v2);
-    lds_sub<OFF>(__builtin_amdgcn_perm(c.slots, pb, c.sel[3]), v3);
+// four atomics of one step: ds_sub_u32 of v_k at the address byte k of the bins gives, `off` in the instruction's immediate
+template <bool IS_SEQ>
+__device__ __forceinline__ void fz_sub4_at(const uint32_t off, const SoLane &c, uint32_t pb, uint32_t v0, uint32_t v1, uint32_t v2,
+                                           uint32_t v3) {
+    (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[0]) + off), v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[1]) + off), v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[2]) + off), v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[3]) + off), v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // Count one batch: pass 1 checks every byte the batch counts, pass 2 adds them — one v_perm_b32 and one ds_sub_u32 per
@@ -180,23 +184,26 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
         const uint32_t pb = B.w[u], f = S.cm[u];
-        const bool sp = u == tus;  // (wave-uniform) the step that also holds the partial last dwords
-        const uint32_t v0 = sp ? S.tv[0] : f, v1 = sp ? S.tv[1] : f, v2 = sp ? S.tv[2] : f, v3 = sp ? S.tv[3] : f;
-        switch (u) {  // (the row block and slot half go into the instruction's immediate offset)
-        case 0: fz_sub4<IS_SEQ, REGION>(c, pb, v0, v1, v2, v3); break;
-        case 1: fz_sub4<IS_SEQ, REGION + 128u>(c, pb, v0, v1, v2, v3); break;
-        case 2: fz_sub4<IS_SEQ, REGION + RB>(c, pb, v0, v1, v2, v3); break;
-        case 3: fz_sub4<IS_SEQ, REGION + RB + 128u>(c, pb, v0, v1, v2, v3); break;
-        case 4: fz_sub4<IS_SEQ, REGION + 2 * RB>(c, pb, v0, v1, v2, v3); break;
-        case 5: fz_sub4<IS_SEQ, REGION + 2 * RB + 128u>(c, pb, v0, v1, v2, v3); break;
-        case 6: fz_sub4<IS_SEQ, REGION + 3 * RB>(c, pb, v0, v1, v2, v3); break;
-        default: fz_sub4<IS_SEQ, REGION + 3 * RB + 128u>(c, pb, v0, v1, v2, v3); break;
+        // (the row block and slot half go into the instruction's immediate offset)
+        constexpr uint32_t OFFS[8] = {REGION, REGION + 128u, REGION + RB, REGION + RB + 128u, REGION + 2 * RB, REGION + 2 * RB + 128u,
+                                      REGION + 3 * RB, REGION + 3 * RB + 128u};
+        if (u == tus) {  // (wave-uniform) the step that also holds the partial last dwords: per-byte values.  ADDs of 0 / 1, so
+            // that the compiler cannot merge the two arms into one with four v_mov / v_cndmask per step in front of it
+            const uint32_t o = OFFS[u < 8 ? u : 7];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + o), S.tv[k],
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            fz_sub4_at<IS_SEQ>(OFFS[u < 8 ? u : 7], c, pb, f, f, f, f);
         }
     }
     if (ragged_tails) {
         const uint32_t off = REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lds_sub<0>(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off, S.tv[k]);
+        for (int k = 0; k < 4; ++k)
+            (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off), S.tv[k],
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (IS_SEQ) {  // sequence lines with an 'N' (bit 3 is set in 'N' only): the 8 lanes of a line OR their flags
         const unsigned long long bn = __ballot((orw & 0x08080808u) != 0);
@@ -239,8 +246,9 @@ __device__ __attribute__((noinline)) uint4 fz_load16_tail(const uint8_t *__restr
     return load16(buf, off, len);
 }
 
-template <uint32_t NSL>
-__global__ __launch_bounds__(FZ_THREADS) void k_scan_stats(FusedArgs z) {
+template <uint32_t NSL, uint32_t FZ_WAVES>
+__global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
+    constexpr uint32_t FZ_THREADS = FZ_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const uint32_t lc = z.lc;
     const uint32_t wb0 = z.wave_base;  // bytes of histogram in front of the waves' areas
@@ -633,13 +641,13 @@ uint32_t stats_blocks(int n_cu);
 // can the single-pass kernel take this call's lmax?  (its histogram has the 256 bank-scheduled rows and nothing else)
 bool scan_stats_supports(uint32_t lmax) { return lmax >= 1 && lmax <= SO_LC_MAX; }
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu) {
-    const uint64_t want = ((n_tiles + FZ_SPAN - 1) / FZ_SPAN + FZ_WAVES - 1) / FZ_WAVES;
+    const uint64_t want = ((n_tiles + FZ_SPAN - 1) / FZ_SPAN + FZ_WAVES_MAX - 1) / FZ_WAVES_MAX;
     const uint32_t cus = stats_blocks(n_cu);
     return (uint32_t)(want < cus ? (want ? want : 1) : cus);
 }
 size_t scan_stats_scratch_bytes(int n_cu) { return (size_t)stats_blocks(n_cu) * SO_WORDS * sizeof(uint32_t); }
 
-template <uint32_t NSL>
+template <uint32_t NSL, uint32_t FZ_WAVES>
 static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t blocks) {
     z.wave_base = SO_SBYTES + ((NSL + 1) / 2) * 16384u;
     const size_t lds = (size_t)z.wave_base + (size_t)FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK;
@@ -650,12 +658,12 @@ static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t block
                   "garbage addresses must stay inside the allocation");
     static bool set = false;
     if (!set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_stats<NSL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_stats<NSL, FZ_WAVES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         set = true;
     }
-    hipLaunchKernelGGL((k_scan_stats<NSL>), dim3(blocks), dim3(FZ_THREADS), lds, s, z);
+    hipLaunchKernelGGL((k_scan_stats<NSL, FZ_WAVES>), dim3(blocks), dim3(FZ_WAVES * 64), lds, s, z);
     return hipSuccess;
 }
 
@@ -666,7 +674,7 @@ hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
     z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
     const uint32_t blocks = scan_stats_blocks(z.n_tiles, n_cu);
     const uint32_t nsl = (z.lc + 31) / 32;
-    hipError_t e = nsl <= 5 ? launch_scan_stats_n<5>(s, z, blocks) : launch_scan_stats_n<8>(s, z, blocks);
+    hipError_t e = nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks) : launch_scan_stats_n<8, 12>(s, z, blocks);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

@@ -50,9 +50,9 @@ constexpr uint32_t FZ_GROUP = 4096;                 // bytes per group: 64 conti
 constexpr uint32_t FZ_TAIL = 512;                   // bytes of the previous group kept in front of the group
 constexpr uint32_t FZ_POST = 512;                   // bytes after the span, for the span's last line
 constexpr uint32_t FZ_DATA = FZ_TAIL + FZ_GROUP + FZ_POST;
-constexpr uint32_t FZ_GLIST = 187;                  // line starts per group that can be staged (+ one virtual entry)
-constexpr uint32_t FZ_RS = 192;                    // record starts of a tile staged in LDS (4 x 187 entries / 4, rounded)
-constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 16 + FZ_RS * 2 + (4 + FZ_GLIST + 1) * 2;  // 5904
+constexpr uint32_t FZ_GLIST = 251;                  // line starts per group that can be staged (+ one virtual entry)
+constexpr uint32_t FZ_RS = 256;                    // record starts of a tile staged in LDS (4 x 251 entries / 4, rounded)
+constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 16 + FZ_RS * 2 + (4 + FZ_GLIST + 1) * 2;  // 6160
 constexpr uint32_t FZ_SLACK = 512;                  // a batch reads up to 32 NSL + 32 bytes past a line's start
 static_assert(FZ_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesses");
 
@@ -114,18 +114,6 @@ __device__ __forceinline__ void fz_shape(FzShape<NSL> &S, uint32_t P, uint32_t m
     S.tb = uni ? 0u : pmask;
     S.tu = nbt ? tu : 0u;
     S.mode = tus | (tl ? 0x100u : 0u);
-}
-
-// this lane's dword of every step of its line: two aligned dwords (ds_read2_b32, immediate offsets) and one shift
-template <uint32_t NSL>
-__device__ __forceinline__ void fz_fetch(FzBatch<NSL> &B, const FzLane &L, const uint8_t *lds8) {
-    const uint32_t la = L.wm4 + ((B.P >> 16) & ~3u);
-    const uint32_t sh = (B.P >> 16) & 3u;
-#pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) {
-        const fz_u32x2 v = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + 32u * u);
-        B.w[u] = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
-    }
 }
 
 // four atomics of one step: ds_sub_u32 of v_k at the address byte k of the bins gives, `off` in the instruction's immediate
@@ -211,34 +199,61 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
     }
 }
 
-// The lines of one kind that ended in this chunk of entries join the batch in progress.  Pent: lane j holds the packed
-// word of the line that entry j of the chunk closes; this kind's are at lanes l0, l0 + 4, .. (n of them).  Position
-// q = nfill + i of the running sequence of lines: batch q / 8, slot q % 8.  Full batches are counted; fewer than eight
-// lines stay in PB for the next call; flush counts them as well.
-template <bool IS_SEQ, uint32_t NSL>
-__device__ __forceinline__ void fz_lines(FzBatch<NSL> &PB, uint32_t &nfill, uint32_t Pent, uint32_t l0, uint32_t n, bool flush,
-                                         const FzLane &L, const uint8_t *lds8, FzShape<NSL> &S, SoTotals &T, bool &bad,
-                                         bool do_count) {
-    const uint32_t q0 = nfill;
-    const uint32_t total = q0 + n;
-    const uint32_t nb = total >> 3;
-    const uint32_t rem = total & 7u;
-    const uint32_t nit = nb + ((rem && flush) ? 1u : 0u);  // batches to count
-    int i0 = -(int)q0;  // slot g8 of batch b takes new line i = 8 b - q0 + g8, held by lane l0 + 4 i
-    for (uint32_t b = 0; b <= nb; ++b, i0 += 8) {
-        const uint32_t i = (uint32_t)(i0 + (int)L.g8);  // (negative wraps: the unsigned compare rejects it)
-        const bool isnew = i < n;
-        const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * l0 + 16u * (uint32_t)i0 + L.g16), (int)Pent);
-        if (b == 0) {
-            if (L.g8 >= q0) PB.P = isnew ? Pn : 0u;  // (slots below q0 keep the lines they hold)
-        } else {
-            PB.P = isnew ? Pn : 0u;
-        }
-        if (isnew) fz_fetch<NSL>(PB, L, lds8);
-        if (b < nit && do_count) fz_count<IS_SEQ, NSL>(PB, S, L, T, bad);
+// The lines that ended in this chunk of entries join the batches in progress, one per kind (sequence, quality).  Pent:
+// lane j holds the packed word of the line that entry j of the chunk closes; a kind's lines are at lanes l0, l0 + 4, ..
+// (n of them).  Position q = nfill + i of a kind's running sequence of lines: batch q / 8, slot q % 8.  Full batches are
+// counted; fewer than eight lines stay in the kind's batch for the next call; flush counts them as well.
+// Order of the LDS traffic of one iteration: the reads of both kinds' lines and the lookups of the NEXT iteration's
+// lines first, the atomics of both kinds behind them — LDS operations of a wave complete in order, and a read that is
+// issued behind 24 atomics waits for all of them.
+template <uint32_t NSL>
+struct FzRaw {
+    fz_u32x2 v[NSL];
+};
+template <uint32_t NSL>
+__device__ __forceinline__ void fz_issue(const FzBatch<NSL> &B, FzRaw<NSL> &R, const FzLane &L, const uint8_t *lds8) {
+    const uint32_t la = L.wm4 + ((B.P >> 16) & ~3u);
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) R.v[u] = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + 32u * u);
+}
+template <uint32_t NSL>
+__device__ __forceinline__ void fz_align(FzBatch<NSL> &B, const FzRaw<NSL> &R) {
+    const uint32_t sh = (B.P >> 16) & 3u;
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) B.w[u] = __builtin_amdgcn_alignbyte(R.v[u].y, R.v[u].x, sh);
+}
+struct FzKind {          // one kind's lines of the chunk
+    uint32_t l0, n;      // lanes l0, l0 + 4, ..: n lines
+};
+template <uint32_t NSL>
+__device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKind ks, FzBatch<NSL> &PBq, uint32_t &nfq, FzKind kq,
+                                          uint32_t Pent, bool flush, const FzLane &L, const uint8_t *lds8, FzShape<NSL> &S,
+                                          SoTotals &T, bool &bad, bool do_count) {
+    const uint32_t q0s = nfs, tots = q0s + ks.n, nbs = tots >> 3, rems = tots & 7u, nits = nbs + ((rems && flush) ? 1u : 0u);
+    const uint32_t q0q = nfq, totq = q0q + kq.n, nbq = totq >> 3, remq = totq & 7u, nitq = nbq + ((remq && flush) ? 1u : 0u);
+    const uint32_t nbm = nbs > nbq ? nbs : nbq;
+    int is0 = -(int)q0s, iq0 = -(int)q0q;  // slot g8 of batch b takes new line i = 8 b - q0 + g8, held by lane l0 + 4 i
+    uint32_t Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)is0 + L.g16), (int)Pent);
+    uint32_t Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)iq0 + L.g16), (int)Pent);
+    for (uint32_t b = 0; b <= nbm; ++b, is0 += 8, iq0 += 8) {
+        const bool act_s = b <= nbs, act_q = b <= nbq;  // (wave-uniform) the kind still assembles a batch in this iteration
+        const bool news = act_s && (uint32_t)(is0 + (int)L.g8) < ks.n;  // (a negative index wraps: the unsigned compare rejects it)
+        const bool newq = act_q && (uint32_t)(iq0 + (int)L.g8) < kq.n;
+        if (act_s && (b != 0 || L.g8 >= q0s)) PBs.P = news ? Pns : 0u;  // (slots below q0 of the first batch keep their lines)
+        if (act_q && (b != 0 || L.g8 >= q0q)) PBq.P = newq ? Pnq : 0u;
+        FzRaw<NSL> Rs, Rq;
+        if (news) fz_issue<NSL>(PBs, Rs, L, lds8);
+        if (newq) fz_issue<NSL>(PBq, Rq, L, lds8);
+        Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)(is0 + 8) + L.g16), (int)Pent);
+        Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)(iq0 + 8) + L.g16), (int)Pent);
+        if (news) fz_align<NSL>(PBs, Rs);
+        if (act_s && b < nits && do_count) fz_count<true, NSL>(PBs, S, L, T, bad);
+        if (newq) fz_align<NSL>(PBq, Rq);
+        if (act_q && b < nitq && do_count) fz_count<false, NSL>(PBq, S, L, T, bad);
     }
-    nfill = flush ? 0u : rem;
-    if (flush) PB.P = 0;
+    nfs = flush ? 0u : rems;
+    nfq = flush ? 0u : remq;
+    if (flush) PBs.P = PBq.P = 0;
 }
 
 // 16 bytes at buf + off of the partial tile at the end of the buffer; bytes at or beyond len read as 0
@@ -492,11 +507,12 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                 int yc = (int)(e4 & 0x3FFFu) + gofs;
                                 if (p >= tot && yc < (int)FZ_TAIL) yc += (int)WT_BYTES;  // (the virtual entry's offset may have wrapped)
                                 const int ys = yc - 1 - (int)l;
-                                if (ys < 0 || l > lc) {
-                                    span_bad = true;  // began before the kept tail (longer than ~500 bytes), or longer than the rows
+                                if (ys < 0) {
+                                    span_bad = true;  // began before the kept tail (longer than ~500 bytes)
                                 } else {
                                     if (l && lds8[wbase + (uint32_t)ys + l - 1] == '\r') --l;  // trim_winline, src/records.rs:66-73
-                                    Pent = l | FZ_P_ACT | ((uint32_t)ys << 16);
+                                    if (l > lc) span_bad = true;  // longer than the histogram's rows
+                                    else Pent = l | FZ_P_ACT | ((uint32_t)ys << 16);
                                 }
                             }
                         }
@@ -533,8 +549,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             const uint32_t nls = cnt_c > ps ? (cnt_c - ps + 3) >> 2 : 0u, nlq = cnt_c > pq0 ? (cnt_c - pq0 + 3) >> 2 : 0u;
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
                             const bool cnt = !(z.dbg & 2u);
-                            fz_lines<true, NSL>(PBs, nfill_s, Pent, ps, nls, flush, L, lds8, S, T, span_bad, cnt);
-                            fz_lines<false, NSL>(PBq, nfill_q, Pent, pq0, nlq, flush, L, lds8, S, T, span_bad, cnt);
+                            fz_lines2<NSL>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, cnt);
                         }
                     }
                     // ---- the next group finds this one's last 512 bytes and last four entries in front of its own
@@ -573,6 +588,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         __builtin_amdgcn_wave_barrier();
                         trs[64 + lane] = 0;
                         trs[128 + lane] = 0;
+                        trs[192 + lane] = 0;
                     }
                     if (span_bad) ++n_over;
                     prv = lane == FR_CNT ? (trun & 0xFFFFu) : lane == FR_CNT + 1 ? (trun >> 16) : lane == FR_HYP ? (span_bad ? 7u : hyp_t) : rv;

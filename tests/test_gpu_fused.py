@@ -1,0 +1,180 @@
+"""GPU parity tests of the single-pass route (k_scan_stats, fqh_stats / fqh_scan_stats on a whole file): one read of
+the input gives record offsets AND histograms, the way the reference's Parser::each hands each record to the closure
+that reads seq()/qual() (src/lib.rs:226-237, src/records.rs:75-90).  Every case is compared bit-for-bit with the
+oracle; the cases also pin WHICH route ran: the single pass where it applies, the exact two-pass route where the
+kernel must decline (bytes outside the alphabet, lmax below the read length, parse errors, long reads)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALPH = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    yield torch, pkg
+
+
+def make(rng, nrec, seqlen, crlf=0.0, plus_id=False, hdr=None, qlo=33, qhi=75):
+    out = []
+    for i in range(nrec):
+        n = seqlen(i) if callable(seqlen) else seqlen
+        e = b"\r\n" if rng.random() < crlf else b"\n"
+        h = hdr(i) if hdr else b"r%d 1:N:0" % i
+        seq = rng.choice(ALPH, n, p=[.2475, .2475, .2475, .2475, .01]).tobytes()
+        qual = rng.integers(qlo, qhi, n).astype(np.uint8).tobytes()
+        out.append(b"@" + h + e + seq + e + b"+" + (h if plus_id else b"") + e + qual + e)
+    return b"".join(out)
+
+
+def run(env, fqref, data, lmax, want_fused, offsets=False):
+    torch, pkg = env
+    # a context of its own: list sizes and the fast path's back-off stick to a context
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        return run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets)
+    finally:
+        ctx.close()
+
+
+def run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets):
+    dev = torch.device("cuda:0")
+    a = np.frombuffer(data, dtype=np.uint8)
+    d = torch.empty(max(a.size, 16), dtype=torch.uint8, device=dev)
+    d[:a.size].copy_(torch.from_numpy(a.copy()))
+    qh = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+    bh = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+    sc = torch.zeros(8, dtype=torch.int64, device=dev)
+    # the histograms are ADDED to: start from a known non-zero state to see that a discarded pass leaves no trace
+    qh += 3
+    bh += 5
+    sc += 7
+    ctx.set_spec(True)  # (forget any back-off an earlier case left in the context)
+    rs = None
+    if offsets:
+        rs = torch.zeros(a.size // 4 + 16, dtype=torch.int64, device=dev)
+        s, c, st = ctx.scan_stats(d.data_ptr(), a.size, lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr(),
+                                  d_rec_start=rs.data_ptr(), cap=rs.numel())
+        assert st == pkg.OK
+    else:
+        s, c = ctx.stats(d.data_ptr(), a.size, lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    fused = ctx.last_scan_fast()
+    r, oq, ob, osc = fqref.stats(a, lmax)
+    assert (s.parse_status, s.n_records) == (r.status, r.n_records)
+    assert np.array_equal(sc.cpu().numpy().astype(np.uint64) - 7, osc), (sc.cpu().numpy() - 7, osc)
+    assert np.array_equal(qh.cpu().numpy().astype(np.uint64).reshape(lmax, 256) - 3, oq)
+    assert np.array_equal(bh.cpu().numpy().astype(np.uint64).reshape(lmax, 8) - 5, ob)
+    if offsets:
+        r2, off = fqref.offsets(a)
+        assert np.array_equal(rs.cpu().numpy()[: r2.n_records].astype(np.uint64), off)
+    if want_fused is not None:
+        assert fused == want_fused, "route: single pass kept = %s, expected %s" % (fused, want_fused)
+    return s
+
+
+@pytest.mark.parametrize("nrec", [1, 7, 49, 50, 55, 199, 200, 204, 397, 398, 1000, 3177])
+def test_sizes_around_tiles_and_spans(env, fqref, nrec):
+    """330-byte records: buffers that end inside the first tile, at / around tile (16 KiB) and span (64 KiB) edges."""
+    rng = np.random.default_rng(nrec)
+    data = make(rng, nrec, 150, hdr=lambda i: b"SYN.%012d 1:N:0:1" % i)
+    assert len(data) == 330 * nrec
+    # (a last tile with fewer than four line starts is not something the fast path proves: exact route)
+    tail = len(data) % 16384
+    run(env, fqref, data, 150, want_fused=nrec >= 3 and (tail == 0 or tail > 1400))
+
+
+@pytest.mark.parametrize("shape", ["fixed150", "fixed100", "fixed36", "fixed250", "ragged", "ragged4", "crlf", "plusid",
+                                   "qual_at_plus", "empty_reads"])
+def test_single_pass_shapes(env, fqref, shape):
+    rng = np.random.default_rng(abs(hash(shape)) % 1000)
+    lmaxes = (150,)
+    kw = {}
+    if shape == "fixed150":
+        seqlen, nrec, lmaxes = 150, 5000, (150, 151, 160, 256)
+    elif shape == "fixed100":
+        seqlen, nrec, lmaxes = 100, 6000, (100, 128)
+    elif shape == "fixed36":
+        seqlen, nrec, lmaxes = 36, 20000, (36, 64)       # > 64 line starts per 4 KiB group: several chunks of entries
+    elif shape == "fixed250":
+        seqlen, nrec, lmaxes = 250, 4000, (250, 256)     # the 256-row variant of the kernel
+    elif shape == "ragged":
+        seqlen, nrec, lmaxes = (lambda i: int(rng.integers(1, 151))), 8000, (150, 160)   # batches of lines of different lengths
+    elif shape == "ragged4":
+        seqlen, nrec, lmaxes = (lambda i: int(rng.choice([148, 149, 150, 151, 152, 4, 3, 1]))), 8000, (152,)
+    elif shape == "crlf":
+        seqlen, nrec, kw = 150, 5000, {"crlf": 0.3}       # trim_winline in the kernel (src/records.rs:66-73)
+    elif shape == "plusid":
+        seqlen, nrec, kw = 150, 5000, {"plus_id": True}
+    elif shape == "qual_at_plus":
+        seqlen, nrec, kw = 150, 5000, {"qlo": 43, "qhi": 65}   # quality lines full of '+' and '@'
+    else:
+        seqlen, nrec = (lambda i: 0 if i % 5 == 0 else 150), 6000  # empty sequence / quality lines are accepted
+    data = make(rng, nrec, seqlen, **kw)
+    for lmax in lmaxes:
+        run(env, fqref, data, lmax, want_fused=True)
+    run(env, fqref, data, lmaxes[0], want_fused=True, offsets=True)
+
+
+@pytest.mark.parametrize("shape", ["lowercase", "qual_high", "lmax_short", "long_reads", "mismatch", "truncated", "no_final_nl"])
+def test_declined_inputs_take_the_exact_route(env, fqref, shape):
+    """Whatever the single pass cannot prove or count sends the call to the exact two-pass route; the arrays the
+    caller passed get exactly the oracle's counts (nothing of the discarded pass leaks into them)."""
+    rng = np.random.default_rng(11)
+    data = bytearray(make(rng, 4000, 150))
+    lmax = 150
+    if shape == "lowercase":
+        pos = data.index(b"\n", 700000) + 1   # some line start far into the file; flip a base of the next sequence line
+        k = data.index(b"\n", pos) + 5
+        data[k] = ord("a")
+    elif shape == "qual_high":
+        k = len(data) - 20
+        data[k] = 126                         # '~' is outside the kernel's window '!'..'`' (and a valid quality byte)
+    elif shape == "lmax_short":
+        lmax = 100                            # columns 100..149 go to the overflow counters: exact route
+    elif shape == "long_reads":
+        data = bytearray(make(rng, 600, 700))  # lines longer than the tail the kernel keeps
+        lmax = 256
+    elif shape == "mismatch":
+        k = data.index(b"\n", 900000)
+        del data[k - 3]                       # one quality (or sequence) byte less: length mismatch somewhere
+    elif shape == "truncated":
+        del data[-100:]
+    elif shape == "no_final_nl":
+        del data[-1:]
+    run(env, fqref, bytes(data), lmax, want_fused=False)
+
+
+def test_medium_synthetic_parity_and_determinism(env, fqref):
+    """256 MiB of the benchmark's synthetic input: single pass == oracle, and two runs give identical arrays."""
+    torch, pkg = env
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda:0")
+    n = (256 << 20) // 330 * 330
+    d = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    ctx.synth_fill(d.data_ptr(), 0, n)
+    host = d[:n].cpu().numpy()
+    res = []
+    for _ in range(2):
+        qh = torch.zeros(150 * 256, dtype=torch.int64, device=dev)
+        bh = torch.zeros(150 * 8, dtype=torch.int64, device=dev)
+        sc = torch.zeros(8, dtype=torch.int64, device=dev)
+        rs = torch.zeros(n // 300 + 16, dtype=torch.int64, device=dev)
+        ctx.set_spec(True)
+        s, c, st = ctx.scan_stats(d.data_ptr(), n, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr(),
+                                  d_rec_start=rs.data_ptr(), cap=rs.numel())
+        assert ctx.last_scan_fast() and s.parse_status == pkg.OK and s.n_records == n // 330
+        res.append((qh.cpu().numpy(), bh.cpu().numpy(), sc.cpu().numpy(), rs.cpu().numpy()[: n // 330 + 1]))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    r, oq, ob, osc = fqref.stats(host, 150)
+    assert np.array_equal(res[0][0].astype(np.uint64).reshape(150, 256), oq)
+    assert np.array_equal(res[0][1].astype(np.uint64).reshape(150, 8), ob)
+    assert np.array_equal(res[0][2].astype(np.uint64), osc)
+    assert np.array_equal(res[0][3].astype(np.uint64), np.arange(n // 330 + 1, dtype=np.uint64) * 330)
+    ctx.close()

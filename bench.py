@@ -41,8 +41,10 @@ def main():
                          "gets the tail of the previous rank's shard in front of its own, one all_reduce of the "
                          "histograms) and a check of the global totals; one extra JSON line, not part of the metric")
     ap.add_argument("--stream-gib", type=float, default=0.0,
-                    help="configs[3]: stream this many GiB from pinned host memory through fqh_stream_* "
-                         "(a record-aligned pinned region is replayed) and report the PCIe-inclusive rate")
+                    help="configs[3] (N = 1) / configs[4] (N > 1): stream this many GiB (in total) from pinned host memory "
+                         "through fqh_stream_* (a pinned block is replayed) and report the PCIe-inclusive rate; N > 1: "
+                         "byte-range shards, every rank phase-free through its own ring, one exchange + stitch + all_reduce")
+    ap.add_argument("--slot-mib", type=int, default=256, help="ring slot size of the streamed modes")
     args = ap.parse_args()
 
     import numpy as np
@@ -73,6 +75,13 @@ def main():
     assert world == n_gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+
+    if args.stream_gib > 0 and world > 1:
+        sharded_stream(args, pkg, torch, dist, dev, rank, world, backend)
+        dist.destroy_process_group()
+        return
+    if args.stream_gib > 0 and not args.bytes:
+        args.bytes = (args.slot_mib << 20) + (1 << 20)  # (the streamed mode only needs one slot's worth of synthetic bytes)
 
     shard = args.bytes if args.bytes else SHARD
     total_records = (world * shard) // RECLEN
@@ -134,7 +143,7 @@ def main():
     if args.stream_gib > 0:
         # configs[3]: host -> pinned ring -> hipMemcpyAsync (side stream) -> scan, double buffered.
         import ctypes as C
-        slot = 256 << 20
+        slot = args.slot_mib << 20
         region_recs = (slot // RECLEN)
         region = region_recs * RECLEN  # record-aligned, so replaying it keeps the stream valid FASTQ
         host_src = buf[:region].cpu().numpy()  # pageable source; the ring slots themselves are pinned
@@ -347,6 +356,135 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def numa_pin(torch, dev_index):
+    """Best effort: run this process (and first-touch its pinned ring) on the NUMA node of its GPU.  -> node or None."""
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
+def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
+    """configs[4]: byte-range sharded AND host-streamed.  The file is the endless repetition of one pinned block (a slot's
+    worth of synthetic records), cut at multiples of a shard size that is NOT a multiple of the record size: every cut
+    falls inside a record.  Each rank streams its range phase-free (fastq-rs_amd/sharded.py), then: one all_gather of 8
+    words + the tail bytes per rank, the phase check, the one-record stitch, one all_reduce of counts + histograms."""
+    import ctypes as C
+    import importlib
+    import numpy as np
+    sharded = importlib.import_module("fastq_rs_amd.sharded")
+    node = numa_pin(torch, dev.index)
+    LMAX = 150
+    blk = (args.slot_mib << 20) // 2640 * 2640          # multiple of the record size (330) and of 16
+    total = int(args.stream_gib * (1 << 30))
+    shard = max(blk, total // world // blk * blk) + 997  # cuts inside records
+    file_len = world * shard // RECLEN * RECLEN          # (the last rank's range is a few bytes shorter)
+    lo, hi = rank * shard, min((rank + 1) * shard, file_len)
+    ctx = pkg.Ctx(dev.index)
+    # the block, generated on the GPU, and its image in host memory
+    d_blk = torch.empty(blk + 16, dtype=torch.uint8, device=dev)
+    ctx.synth_fill(d_blk.data_ptr(), 0, blk)
+    h_blk = d_blk[:blk].cpu().numpy()
+    filled = {}
+
+    def read_into(addr, off, n):
+        d = off % blk
+        if n == 0 or filled.get(addr) == d:   # a ring slot that already holds the block at this rotation
+            return
+        done = 0
+        while done < n:
+            k = min(n - done, blk - (off + done) % blk)
+            C.memmove(addr + done, h_blk.ctypes.data + (off + done) % blk, k)
+            done += k
+        if n == blk:
+            filled[addr] = d
+
+    hist = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
+    sc, qh, bh = hist[:8], hist[8: 8 + LMAX * 256], hist[8 + LMAX * 256:]
+    window = torch.empty(sharded.ALIGN_WINDOW + 16, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(4 * pkg.BUFSIZE + 16, dtype=torch.uint8, device=dev)
+    TAILCAP = 2 * pkg.BUFSIZE
+    xdev = dev if backend == "nccl" else torch.device("cpu")
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    res = sharded.stream_shard(ctx, read_into, lo, hi, file_len, blk, stats=(LMAX, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()),
+                               d_window=window.data_ptr())
+    t_stream = time.perf_counter() - t0
+    # ---- the one exchange: 8 words + the tail bytes of every rank
+    mine = np.zeros(64 + TAILCAP, dtype=np.uint8)
+    mine[:64] = np.array(res.summary_words(), dtype=np.int64).view(np.uint8)
+    assert len(res.tail) <= TAILCAP
+    mine[64: 64 + len(res.tail)] = np.frombuffer(res.tail, dtype=np.uint8)
+    t_in = torch.from_numpy(mine).to(xdev)
+    t_all = torch.empty(world * mine.size, dtype=torch.uint8, device=xdev)
+    dist.all_gather_into_tensor(t_all, t_in)
+    rows = t_all.cpu().numpy().reshape(world, mine.size)
+    words = [[int(x) for x in rows[r, :64].view(np.int64)] for r in range(world)]
+    bad = sharded.check_phases(words)
+    st_status, st_recs = pkg.OK, 0
+    if rank:
+        prev_tail = rows[rank - 1, 64: 64 + words[rank - 1][5]].tobytes()
+        st_status, st_recs = sharded.stitch(ctx, prev_tail, res.head, LMAX, scratch.data_ptr(), qh.data_ptr(), bh.data_ptr(),
+                                            sc.data_ptr())
+    counts = torch.tensor([res.n_records + st_recs, 1 if (res.status != pkg.OK or st_status != pkg.OK) else 0], dtype=torch.int64,
+                          device=dev)
+    both = torch.cat([counts, hist]).to(xdev)
+    dist.all_reduce(both)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt, t_stream], dtype=torch.float64, device=xdev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0].item())
+    rates = torch.zeros(world, dtype=torch.float64, device=xdev)
+    rates[rank] = (hi - lo) / 1e9 / t_stream
+    dist.all_reduce(rates)
+    tot = both.cpu().numpy()
+    # ---- what the totals must be: the block's own histograms, times the repetitions, plus the last partial block
+    reps, rem = divmod(file_len, blk)
+    exp = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
+    one = torch.zeros_like(exp)
+    ctx.stats(d_blk.data_ptr(), blk, LMAX, one[8: 8 + LMAX * 256].data_ptr(), one[8 + LMAX * 256:].data_ptr(), one[:8].data_ptr())
+    exp += one * reps
+    if rem:
+        ctx.stats(d_blk.data_ptr(), rem, LMAX, exp[8: 8 + LMAX * 256].data_ptr(), exp[8 + LMAX * 256:].data_ptr(), exp[:8].data_ptr())
+    exp = exp.cpu().numpy()
+    ok_hist = bool((tot[2:] == exp).all())
+    if rank == 0:
+        print(json.dumps({
+            "mode": "sharded-stream",
+            "workload": "configs[4]: %.2f GiB in %d byte-range shards of %d B (cuts inside records), each streamed from pinned "
+                        "host memory through a 3 x %d MiB ring (one pinned block replayed), phase-free; one all_gather "
+                        "(8 words + tail bytes per rank), phase check, one-record stitch, one all_reduce" % (
+                            file_len / 2**30, world, shard, blk >> 20),
+            "n_gpus": world, "backend": backend, "bytes_per_gpu": shard, "seconds": round(dt, 4),
+            "gbs_pcie_inclusive_aggregate": round(file_len / 1e9 / dt, 2),
+            "gbs_per_rank_streaming": [round(float(x), 2) for x in rates.cpu().numpy()],
+            "records": int(tot[0]), "records_per_s": round(int(tot[0]) / dt, 1), "numa_node_rank0": node,
+            "check": {"records_expected": file_len // RECLEN, "errors": int(tot[1]), "phases_ok": not bad,
+                      "histograms_ok": ok_hist}}), flush=True)
+    assert not bad, bad
+    assert int(tot[1]) == 0 and int(tot[0]) == file_len // RECLEN, (tot[:2], file_len // RECLEN)
+    assert ok_hist
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ NSCALARS = 8
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
-    "fqh_shard_prescan", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
+    "fqh_shard_prescan", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
@@ -104,6 +104,8 @@ def lib():
                                         C.POINTER(Carry)]
         L.fqh_rescan_launch.argtypes = [vp, i32, C.POINTER(Carry), vp, u64]
         L.fqh_shard_prescan.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64 * 4)]
+        L.fqh_shard_align.argtypes = [vp, vp, u64, i32, C.POINTER(u32), C.POINTER(u64)]
+        L.fqh_stream_carry.argtypes = [vp, C.POINTER(Carry)]
         L.fqh_invalidate.argtypes = [vp]
         L.fqh_stats.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp,
                                 C.POINTER(Summary), C.POINTER(Carry)]
@@ -215,6 +217,13 @@ class Ctx:
         nn, ns, back = C.c_uint64(), C.c_uint64(), (C.c_uint64 * 4)()
         self._chk(self._L.fqh_shard_prescan(self._h, d_buf, length, C.byref(nn), C.byref(ns), C.byref(back)))
         return nn.value, ns.value, [int(x) for x in back]
+
+    def shard_align(self, d_buf, length, prev_is_newline):
+        """-> (phase, first_record_offset) of a shard that starts anywhere; raises FqhError(E_HEADER / E_ARG) if the window
+        does not settle it."""
+        ph, off = C.c_uint32(), C.c_uint64()
+        self._chk(self._L.fqh_shard_align(self._h, d_buf, length, 1 if prev_is_newline else 0, C.byref(ph), C.byref(off)))
+        return ph.value, off.value
 
     def rescan_launch(self, is_final=True, carry=None, d_rec_start=None, cap=0):
         self._chk(self._L.fqh_rescan_launch(self._h, 1 if is_final else 0,
@@ -337,3 +346,8 @@ class Stream:
 
     def release(self):
         self.ctx._chk(self._L.fqh_stream_release(self._h))
+
+    def carry(self):
+        c = Carry()
+        self.ctx._chk(self._L.fqh_stream_carry(self._h, C.byref(c)))
+        return c

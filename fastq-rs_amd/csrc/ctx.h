@@ -72,6 +72,7 @@ struct fqh_ctx {
     fqh_carry carry_in = {};
     bool whole_file = false;
     bool skip_emit = false;  // shard prescan: only the byte scan, the prefix and the chunk-end summary
+    bool head_unchecked = false;  // fqh_shard_align: the record in progress at the chunk start is not validated
     // fast path: prove validity with a quarter of the list traffic; any doubt -> exact rerun
     bool spec_enabled = true;   // false: exact path only (callers that need full line lists, FQH_SPEC=0)
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...

@@ -231,6 +231,13 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
 
 static fqh_status ensure_full_index(fqh_ctx *ctx);
 
+// The cached tile index describes the BYTES of the last scanned buffer: every writer of this library that touches
+// them drops it.  (Writes the library cannot see — the caller's own kernels, a reused allocator block — need
+// fqh_invalidate; see include/fastq_hip.h.)
+static void drop_index_if_overlaps(fqh_ctx *ctx, const void *d_dst, uint64_t bytes) {
+    const uint8_t *lo = (const uint8_t *)d_dst, *hi = lo + bytes;
+    if (ctx->last_valid && lo < ctx->args.buf + ctx->args.len && hi > ctx->args.buf) ctx->last_valid = false;
+}
 static bool carry_is_zero(const fqh_carry &c) {
     return c.base_offset == 0 && c.nl_count == 0 && c.back[0] == 0 && c.back[1] == 0 && c.back[2] == 0 && c.back[3] == 0;
 }
@@ -309,7 +316,9 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
             }
         }
     }
-    if (a.rec_start && s.n_records + 1 > a.cap && s.parse_status == FQH_OK) {
+    // (whatever the parse status: the emit kernels clamp their writes to cap, so a caller that walks
+    // d_rec_start[0 .. n_records] of a chunk with an error AND more records than cap would read past it)
+    if (a.rec_start && s.n_records + 1 > a.cap) {
         ctx->last_summary = s;
         if (out) *out = s;
         return fail(ctx, FQH_E_CAPACITY, "d_rec_start capacity < n_records + 1");
@@ -356,6 +365,7 @@ static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     a.v_start = (c.back[0] == 0 && len > 0) ? 1u : 0u;
     a.bufsize = ctx->bufsize;
     a.max_walk = ctx->bufsize ? (uint32_t)(ctx->bufsize / WT_BYTES + 3) : 0xFFFFFFFFu;
+    a.head_unchecked = ctx->head_unchecked ? 1u : 0u;
     a.n_tiles = (len + WT_BYTES - 1) / WT_BYTES;
     a.n_blocks = (a.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     a.rec_start = d_rec_start;
@@ -517,6 +527,71 @@ fqh_status fqh_shard_prescan(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, u
     *n_newlines = s.n_newlines;
     *n_line_starts = s.n_line_starts;
     for (int i = 0; i < 4; ++i) back0[i] = c.back[i];
+    return FQH_OK;
+}
+
+fqh_status fqh_shard_align(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int prev_is_newline, uint32_t *phase,
+                           uint64_t *first_record_offset) {
+    if (!ctx || !phase || !first_record_offset || !len) return FQH_E_ARG;
+    *phase = 0xFFFFFFFFu;
+    *first_record_offset = 0;
+    // index the window once (phase-free), then run only the emit / validate step under each of the four phases
+    uint64_t nn = 0, ns = 0, back0[4];
+    fqh_status st = fqh_shard_prescan(ctx, d_buf, len, &nn, &ns, back0);
+    if (st != FQH_OK) return st;
+    int found = -1, n_ok = 0;
+    uint64_t off = 0;
+    uint64_t recs[4] = {0, 0, 0, 0}, offs[4] = {0, 0, 0, 0};
+    bool clean[4] = {false, false, false, false};
+    const uint32_t keep_skip = ctx->spec_skip, keep_backoff = ctx->spec_backoff;  // (three of the four probes fail by design)
+    for (uint32_t phi = 0; phi < 4; ++phi) {
+        fqh_carry c = {};
+        c.base_offset = 1ull << 40;  // (anywhere: only differences to it are used)
+        c.nl_count = phi;
+        // distances to the line starts before the window: unknown.  Anything consistent will do, the record in
+        // progress is not validated (head_unchecked); back[0] == 0 says "a line starts at offset 0"
+        c.back[0] = prev_is_newline ? 0 : 1;
+        for (int i = 1; i < 4; ++i) c.back[i] = c.back[i - 1] + 1;
+        ctx->head_unchecked = true;
+        st = do_scan_launch(ctx, d_buf, len, 0, &c, (uint64_t *)ctx->d_misc, 2, true);
+        fqh_summary s = {};
+        if (st == FQH_OK) st = do_scan_finish(ctx, &s, nullptr);
+        ctx->head_unchecked = false;
+        if (st != FQH_OK && st != FQH_E_CAPACITY) return st;
+        const bool aligned = phi == 0 && prev_is_newline;  // the window begins with a record: nothing is in progress
+        if (!aligned) {  // the record in progress must end inside the window
+            if (s.n_records < 1) continue;
+            uint64_t rs[2] = {0, 0};
+            HIPCHK(ctx, hipMemcpyAsync(rs, ctx->d_misc, sizeof rs, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            offs[phi] = rs[1] - c.base_offset;
+        }
+        recs[phi] = s.n_records + (aligned ? 1 : 0);  // (counted alike: the unvalidated head record, or one for free)
+        clean[phi] = s.parse_status == FQH_OK;
+        if (clean[phi]) {
+            ++n_ok;
+            found = (int)phi;
+        }
+    }
+    ctx->last_valid = false;
+    ctx->spec_skip = keep_skip;
+    ctx->spec_backoff = keep_backoff;
+    if (n_ok > 1) return fail(ctx, FQH_E_ARG, "fqh_shard_align: more than one line phase validates (window too small)");
+    if (n_ok == 0) {
+        // The window holds a parse error.  Under the true phase the records in front of it still validate; under a wrong
+        // one the first record after the head fails at once.  Take the phase that gets furthest, if it stands out: the
+        // stream then reports the error where it is, and the ranks' phase check at the end guards the choice.
+        for (uint32_t phi = 0; phi < 4; ++phi)
+            if (found < 0 || recs[phi] > recs[found]) found = (int)phi;
+        bool stands_out = true;
+        for (uint32_t phi = 0; phi < 4; ++phi)
+            if ((int)phi != found && recs[phi] + 1 >= recs[found]) stands_out = false;
+        if (!stands_out || recs[found] < 3)
+            return fail(ctx, FQH_E_HEADER, "fqh_shard_align: no line phase validates (a parse error at the window's start, or not FASTQ)");
+    }
+    off = offs[found];
+    *phase = (uint32_t)found;
+    *first_record_offset = off;
     return FQH_OK;
 }
 
@@ -853,6 +928,7 @@ fqh_status fqh_last_timing(fqh_ctx *ctx, fqh_timing *out) {
 fqh_status fqh_synth_fill(fqh_ctx *ctx, uint8_t *d_out, uint64_t byte_off, uint64_t len, uint64_t seed) {
     if (!ctx || (len && !d_out)) return FQH_E_ARG;
     if (len && ((uintptr_t)d_out & 15)) return fail(ctx, FQH_E_ARG, "d_out must be 16-byte aligned");
+    drop_index_if_overlaps(ctx, d_out, len);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     launch_synth(ctx->stream, d_out, byte_off, len, seed);
     HIPCHK(ctx, hipGetLastError());
@@ -894,6 +970,7 @@ fqh_status fqh_dev_free(fqh_ctx *ctx, void *d_ptr) {
 }
 fqh_status fqh_memcpy_h2d(fqh_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes) {
     if (!ctx) return FQH_E_ARG;
+    drop_index_if_overlaps(ctx, d_dst, bytes);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -908,6 +985,7 @@ fqh_status fqh_memcpy_d2h(fqh_ctx *ctx, void *h_dst, const void *d_src, uint64_t
 }
 fqh_status fqh_memset(fqh_ctx *ctx, void *d_dst, int value, uint64_t bytes) {
     if (!ctx) return FQH_E_ARG;
+    drop_index_if_overlaps(ctx, d_dst, bytes);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -37,6 +37,8 @@ struct ScanArgs {
     uint32_t v_start;   // 1 if a line starts at chunk offset 0 (back[0]==0 && len>0)
     uint64_t bufsize;   // 0 = unlimited
     uint32_t max_walk;  // tiles a predecessor search may cross before the record is "too long"
+    uint32_t head_unchecked;  // the record in progress at the chunk start began at unknown distances (a shard whose line
+                              // phase is being probed, fqh_shard_align): its length rule and length are not checked
     // tile index
     const uint16_t *list;
     uint32_t list_cap;

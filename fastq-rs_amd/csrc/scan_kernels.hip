@@ -159,6 +159,7 @@ __device__ __forceinline__ void close_record(const ScanArgs &a, uint64_t t, uint
     const bool ok = collect_prev(a, t, i, p);
     const unsigned long long rec = (l >> 2) - 1;  // the record that just ended
     unsigned long long reclen;
+    if (a.head_unchecked && rec == (a.nl_count >> 2)) return;  // began before the chunk, at distances nobody knows yet
     if (ok) {
         // newlines: nl0=p[2]-1 nl1=p[1]-1 nl2=p[0]-1 nl3=S-1; raw line lengths nl3-nl2 vs nl1-nl0
         if ((S - p[0]) != (p[1] - p[2])) {
@@ -1024,7 +1025,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
             if ((l & 3) == 2 && !(cls[k] & 2u)) fail = true;
         }
         // length rule and length of the record that ends at entry rr (needs >= 1 earlier record line)
-        if (lbase0 + rr >= 4) {
+        if (lbase0 + rr >= 4 && !a.head_unchecked) {
             if ((S[4] - S[3]) != (S[2] - S[1])) fail = true;
             const unsigned long long reclen = (unsigned long long)(S[4] - S[0]);
             if (reclen > max_len) max_len = reclen;

@@ -31,6 +31,7 @@ struct fqh_stream {
     fqh_carry carry = {};
     uint64_t records_done = 0;
     bool ended = false;
+    bool saved_spec = true;  // the context's fast-path setting at creation (restored by fqh_stream_destroy)
     fqh::BufferReplay replay;
     // FQH_STREAM_STATS
     uint32_t lmax = 0;
@@ -77,6 +78,7 @@ void fqh_stream_destroy(fqh_stream *st) {
         if (s.copied) (void)hipEventDestroy(s.copied);
     }
     if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
+    st->ctx->spec_enabled = st->saved_spec;
     delete st;
 }
 
@@ -90,11 +92,15 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
     st->n_slots = n_slots;
     st->flags = flags;
     st->slot_bytes = (slot_bytes + 15) & ~(uint64_t)15;
-    // room for the partial trailing record of the previous slot: a record longer than BUFSIZE is an
-    // error in the reference, so two BUFSIZEs always suffice
-    st->reserve = 2 * (uint64_t)FQH_BUFSIZE;
+    // room for the partial trailing record of the previous slot: a record longer than the context's BUFSIZE is an
+    // error in the reference, so two of them always suffice; without a limit (bufsize 0) records of up to 16 MiB
+    // (or a slot, if that is less) are kept contiguous and anything longer is FQH_E_CAPACITY, not "too long"
+    const uint64_t two = 2 * (uint64_t)FQH_BUFSIZE;
+    const uint64_t want = ctx->bufsize ? 2 * ctx->bufsize : (st->slot_bytes < (16u << 20) ? st->slot_bytes : (uint64_t)(16u << 20));
+    st->reserve = ((want > two ? want : two) + 15) & ~(uint64_t)15;
     st->slots.resize(n_slots);
     st->replay.reset(ctx->bufsize);
+    st->saved_spec = ctx->spec_enabled;
     if (flags & (FQH_STREAM_INDEX | FQH_STREAM_STATS)) ctx->spec_enabled = false;  // every chunk needs complete line lists
     fqh_status rc = FQH_OK;
     do {
@@ -180,7 +186,9 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         break;
     }
     const uint64_t n = sum.n_records;
-    // boundaries (and index) back to the host
+    // boundaries (and index) back to the host (n + 1 <= rec_cap: the scan returns FQH_E_CAPACITY otherwise, whatever
+    // the parse status, and the loop above has grown the arrays and rescanned)
+    if (n + 1 > s.rec_cap) return FQH_E_CAPACITY;
     HIPCHK(ctx, hipMemcpyAsync(s.h_rec, s.d_rec, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     if ((st->flags & FQH_STREAM_INDEX) && n) {
         rc = grow_idx(st, s, n);
@@ -232,9 +240,14 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     const uint64_t tail = known_end - s.h_rec[n];
     if (c.parse_status == FQH_OK && !s.is_final) {
         if (tail > st->reserve) {
+            if (!ctx->bufsize || tail + 15 < ctx->bufsize) {  // the reference would accept it; the ring cannot hold it
+                ctx->err = "fqh_stream: a record in progress is longer than the lead area of the ring (bufsize 0: 16 MiB or one slot)";
+                return FQH_E_CAPACITY;
+            }
             c.parse_status = FQH_E_TOO_LONG;  // cannot be kept contiguous; the reference rejects it as well
             c.err_record = st->records_done + n;
             c.err_offset = s.h_rec[n];
+            c.err_need = tail;
         } else {
             fqh_stream::Slot &nx = st->slots[(st->col + 1) % st->n_slots];
             if (tail) memcpy(nx.h + st->reserve - tail, s.h + st->reserve + s.n_new - tail, tail);
@@ -251,6 +264,12 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     s.state = 3;
     ++st->col;
     *out = c;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_carry(fqh_stream *st, fqh_carry *out) {
+    if (!st || !out) return FQH_E_ARG;
+    *out = st->carry;
     return FQH_OK;
 }
 

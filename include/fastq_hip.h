@@ -129,7 +129,22 @@ fqh_status fqh_carry_combine(const fqh_carry *prev, uint64_t len, uint64_t n_new
                              fqh_carry *next);
 fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, uint64_t *d_rec_start,
                              uint64_t cap);
-/* Forget the cached tile index (call after overwriting a buffer that was scanned). */
+/* Where does the first record of a byte-range shard begin, and at which line phase does the shard start?  For hosts
+ * that cannot wait for the shards in front of theirs (the host-streamed sharded mode, BASELINE configs[4]: each rank
+ * streams its own range and the ranks talk once, at the end).  d_buf[0..len) is a window at the shard's start (a few
+ * MiB; the byte before it is a newline or not: prev_is_newline).  The four possible phases (newlines in front of
+ * the shard, mod 4) are tried on the window's tile index; the record in progress at the window's start is left
+ * unvalidated (it belongs to the stitch with the previous shard), every other record of the window is validated in
+ * the reference's order (src/records.rs:201-247).  *phase = the one phase under which the window parses,
+ * *first_record_offset = where the record in progress ends (0 if the shard begins with a record).  FQH_E_HEADER: no
+ * phase validates; FQH_E_ARG: several do (window too small to tell).  The ranks confirm the phase at the end against
+ * the true newline count of the shards in front of them (fqh_carry.nl_count of their streams, fqh_stream_carry). */
+fqh_status fqh_shard_align(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int prev_is_newline, uint32_t *phase,
+                           uint64_t *first_record_offset);
+/* Forget the cached tile index.  The index describes the BYTES of the last scanned buffer; fqh_memcpy_h2d, fqh_memset and
+ * fqh_synth_fill drop it themselves when they write into that buffer, writes the library cannot see (the caller's
+ * own kernels, an allocator that hands the same address out again) need this call before fqh_stats /
+ * fqh_index_records / fqh_rescan_launch on the same (pointer, length, carry). */
 fqh_status fqh_invalidate(fqh_ctx *ctx);
 
 /* Full IdxRecord-style index of the records found by the LAST fqh_scan on this context (same
@@ -234,6 +249,9 @@ fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap);
 fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final);
 fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out);
 fqh_status fqh_stream_release(fqh_stream *st); /* done with the chunk of the last collect */
+/* Parser state behind the last collected chunk (nl_count = newlines the stream has seen: what the next shard's phase is
+ * checked against in the sharded mode). */
+fqh_status fqh_stream_carry(fqh_stream *st, fqh_carry *out);
 
 /* Timing of the kernels of the last launch/finish pair, measured with HIP events on the
  * launch stream: total and per-kernel milliseconds (index, prefix, emit, stats). */

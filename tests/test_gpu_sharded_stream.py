@@ -1,0 +1,151 @@
+"""configs[4] on one GPU: a file cut into byte-range shards at arbitrary offsets, every shard streamed through its own
+pinned ring phase-free (fastq-rs_amd/sharded.py: fqh_shard_align + fqh_stream_*), one exchange, the one-record
+stitch at every cut, one sum — must equal the oracle's sequential Parser::each + histogram loop over the whole file
+(the reference gathers per-worker results the same way, src/lib.rs:553-559).  The "ranks" run one after the other in
+this process; the multi-process form of the same protocol is bench.py --gpus N --stream-gib G
+(tests/test_gpu_sharded_stream.py::test_bench_sharded_streamed_three_ranks_one_gpu)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import fuzzgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    import importlib
+    sharded = importlib.import_module("fastq_rs_amd.sharded")
+    return torch, pkg, sharded
+
+
+def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16):
+    torch, pkg, sharded = env
+    dev = torch.device("cuda:0")
+    n = len(data)
+    host = (C.c_uint8 * n).from_buffer_copy(data)
+
+    def read_into(addr, off, nbytes):
+        C.memmove(addr, C.addressof(host) + off, nbytes)
+
+    bounds = [0] + list(cuts) + [n]
+    hist = torch.zeros(8 + lmax * 264, dtype=torch.int64, device=dev)
+    sc, qh, bh = hist[:8], hist[8: 8 + lmax * 256], hist[8 + lmax * 256:]
+    window = torch.empty(sharded.ALIGN_WINDOW + 16, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(4 * pkg.BUFSIZE + 16, dtype=torch.uint8, device=dev)
+    results = []
+    for r in range(len(bounds) - 1):  # every "rank" has a context (a GPU) of its own; they share the histograms here
+        ctx = pkg.Ctx(0)
+        res = sharded.stream_shard(ctx, read_into, bounds[r], bounds[r + 1], n, slot_bytes,
+                                   stats=(lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()), d_window=window.data_ptr())
+        results.append(res)
+        ctx.close()
+    # ---- the exchange (lists instead of an all_gather), the phase check, the stitches
+    words = [res.summary_words() for res in results]
+    status, n_records, err_rank = pkg.OK, 0, None
+    bad_phase = sharded.check_phases(words)
+    ctx = pkg.Ctx(0)
+    for r, res in enumerate(results):
+        if r:
+            st, k = sharded.stitch(ctx, results[r - 1].tail, res.head, lmax, scratch.data_ptr(), qh.data_ptr(), bh.data_ptr(),
+                                   sc.data_ptr())
+            if st != pkg.OK:
+                status, err_rank = st, r
+                break
+            n_records += k
+        if any(b[0] == r for b in bad_phase):
+            status, err_rank = pkg.E_HEADER, r
+            break
+        n_records += res.n_records
+        if res.status != pkg.OK:
+            status, err_rank = res.status, r
+            break
+    ctx.close()
+    return status, n_records, hist.cpu().numpy().astype(np.uint64), results
+
+
+def cut_points(rng, data, k):
+    """k cuts: inside lines, right behind a newline, at a record start, and two close together."""
+    n = len(data)
+    cuts = sorted(set(int(x) for x in rng.integers(n // 10, n - n // 10, k)))
+    nl = data.find(b"\n", cuts[0])
+    cuts[0] = nl + 1                                  # a line start
+    at = data.find(b"\n@", cuts[-1])
+    if at > 0:
+        cuts[-1] = at + 1                             # (very likely) a record start
+    return sorted(set(cuts))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_sharded_streamed_equals_whole_file_oracle(env, fqref, seed):
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(700 + seed)
+    lmax = 150
+    recs = []
+    for i in range(12000):
+        L = 150 if seed < 2 else int(rng.integers(1, 151))
+        e = b"\r\n" if (seed == 3 and i % 4 == 0) else b"\n"
+        seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L, p=[.2475, .2475, .2475, .2475, .01]).tobytes()
+        qual = rng.integers(33, 75, L).astype(np.uint8).tobytes()   # '+' and '@' among the quality bytes
+        recs.append(b"@r%d/1" % i + e + seq + e + b"+" + e + qual + e)
+    data = b"".join(recs)
+    cuts = cut_points(rng, data, 3 + seed % 2)
+    status, n_records, hist, results = run_sharded(env, data, cuts, lmax, slot_bytes=(1 << 16) if seed % 2 else (1 << 20))
+    r, oq, ob, osc = fqref.stats(data, lmax)
+    assert (status, n_records) == (r.status, r.n_records) == (pkg.OK, 12000)
+    assert np.array_equal(hist[:8], osc), (hist[:8], osc)
+    assert np.array_equal(hist[8: 8 + lmax * 256].reshape(lmax, 256), oq)
+    assert np.array_equal(hist[8 + lmax * 256:].reshape(lmax, 8), ob)
+    # the ranks' pieces tile the file: head + streamed records + tail of every rank
+    assert sum(len(x.head) + len(x.tail) for x in results) == sum(
+        len(results[i].tail) + len(results[i + 1].head) for i in range(len(results) - 1))
+
+
+@pytest.mark.parametrize("kind", ["truncated", "mismatch", "header"])
+def test_sharded_streamed_reports_the_first_error(env, fqref, kind):
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(31)
+    data = bytearray(fuzzgen.valid_file(rng, 6000, maxlen=150, crlf=False))
+    if kind == "truncated":
+        del data[-7:]
+    elif kind == "mismatch":
+        k = data.index(b"\n+", len(data) * 2 // 3)
+        del data[k - 1]          # one base less in a sequence line of the last shard
+    else:
+        k = data.index(b"\n@", len(data) // 2)
+        data[k + 1] = ord("x")   # a header that does not start with '@', in a middle shard
+    data = bytes(data)
+    cuts = [len(data) // 4 + 3, len(data) // 2 - 40, len(data) * 3 // 4 + 11]
+    status, n_records, hist, results = run_sharded(env, data, cuts, 150)
+    r = fqref.count(data)
+    assert r.status != pkg.OK
+    assert status != pkg.OK
+    if kind != "header":  # (an error in a shard's alignment window is reported at the shard's start: see sharded.py)
+        assert (status, n_records) == (r.status, r.n_records)
+
+
+def test_bench_sharded_streamed_three_ranks_one_gpu():
+    """bench.py --gpus 3 --stream-gib G: three processes (gloo, all on cuda:0), real cuts inside records, totals
+    checked inside bench.py against the generator's; here: the JSON line is there and says so."""
+    env = dict(os.environ, FQH_BENCH_BACKEND="gloo", FQH_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--stream-gib", "0.75", "--slot-mib", "32"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(lines[-1])
+    assert j["mode"] == "sharded-stream" and j["n_gpus"] == 3 and j["check"]["phases_ok"] and j["check"]["histograms_ok"]
+    assert j["records"] == j["check"]["records_expected"]

@@ -119,6 +119,23 @@ def test_stream_too_long_and_truncation(fqref, env):
     assert (status, len(recs)) == (res.status, res.n_records) == (pkg.E_TRUNCATED, 50)
 
 
+def test_stream_dense_records_with_trailing_error(fqref, env):
+    """Records of 6-8 bytes (more of them per slot than the per-slot boundary arrays hold at first) AND a parse error in the
+    same chunk: the boundaries of every record before the error come back, none past the arrays (the capacity
+    check used to be skipped whenever the chunk carried a parse error)."""
+    torch, pkg = env
+    rng = np.random.default_rng(9)
+    recs = [b"@\n" + (b"A" * k) + b"\n+\n" + (b"I" * k) + b"\n" for k in rng.integers(0, 2, 5000)]
+    for tail in (b"@x\nAC", b"@x\nAC\n+\nI\n", b"x\n"):
+        data = b"".join(recs) + tail
+        res, idx = fqref.index(data)
+        assert res.status != pkg.OK and res.n_records == 5000
+        for slot in (4096, 1 << 16):
+            status, got, bounds = stream_all(pkg, data, slot)
+            assert (status, len(got)) == (res.status, res.n_records), (tail, slot)
+            assert bounds[: res.n_records] == [int(x) for x in idx[:, 0]]
+
+
 def test_stream_fuzzing_bufsize(fqref, env):
     """cfg(fuzzing) BUFSIZE=64 (src/lib.rs:126-127): the too-long replay runs across slot boundaries."""
     torch, pkg = env

@@ -35,7 +35,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=4096)
-    ap.add_argument("--variants", default="", help="tuning: comma list of k_index variants to A/B (interleaved rounds)")
     ap.add_argument("--shard-stats", action="store_true",
                     help="N > 1 only, after the timed steps: per-position histograms over the shards (every rank "
                          "gets the tail of the previous rank's shard in front of its own, one all_reduce of the "
@@ -181,23 +180,6 @@ def main():
                           "seconds": round(dt, 3), "records": recs}), flush=True)
         st.close(); sctx.close()
         return
-    if args.variants:
-        vs = [int(x) for x in args.variants.split(",")]
-        res = {v: [] for v in vs}
-        for rnd in range(6):
-            for v in vs:
-                pkg.lib().fqh_debug_set_index_variant(v)
-                for _ in range(3):
-                    ctx.scan(buf.data_ptr(), nbytes, True, None, rec_start.data_ptr(), cap)
-                    t = ctx.timing()
-                    res[v].append((t.index_ms, t.emit_ms))
-        ceil = sorted(ctx.read_ceiling(buf.data_ptr(), nbytes)[1] for _ in range(6))
-        print("read ceiling: min %.3f med %.3f ms (%.0f GB/s at min)" % (ceil[0], ceil[3], nbytes / 1e6 / ceil[0]))
-        for v in vs:
-            im = sorted(x[0] for x in res[v]); em = sorted(x[1] for x in res[v])
-            print("variant %d: index min %.3f med %.3f ms (%.0f GB/s at min) | emit min %.3f med %.3f" %
-                  (v, im[0], im[len(im) // 2], nbytes / 1e6 / im[0], em[0], em[len(em) // 2]), flush=True)
-        return
     for _ in range(args.warmup):
         s = step()
     index_ms.clear()
@@ -224,14 +206,16 @@ def main():
     k_ms = float(np.mean(index_ms))
     achieved = nbytes / 1e9 / (k_ms / 1e3)
 
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (only valid
-    # for the workload it was measured on)
-    traffic = None
+    # From the committed rocprofv3 passes of the same command (tools/prof.sh -> profiles/round2_rocprof.json; only valid
+    # for the workload they were measured on): HBM bytes per launch of the dominant kernel (PMC), and its duration as
+    # rocprofv3 --kernel-trace saw it, next to the HIP-event figure of THIS run.
+    traffic = rp = None
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tj = json.load(f)["k_index_fast"]
-        if tj["workload_bytes"] == nbytes:
-            traffic = tj["bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "round2_rocprof.json")) as f:
+            pj = json.load(f)
+        if pj.get("workload_bytes") == nbytes:
+            rp = pj["k_index_fast"]
+            traffic = rp.get("hbm_bytes_per_launch")
     except Exception:
         pass
     out = {
@@ -255,7 +239,13 @@ def main():
         "hbm_roofline_frac_whole_step": round(gbs / world / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": "k_index_fast", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "kernel_ms": round(k_ms, 4),
+                     "traffic": traffic, "traffic_source": "profiles/round2_rocprof.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                           "same command)" if traffic else None,
+                     "kernel_ms": round(k_ms, 4), "kernel_ms_source": "HIP events on the launch stream, this run, mean of the timed steps",
+                     "kernel_ms_min": round(float(np.min(index_ms)), 4), "kernel_ms_max": round(float(np.max(index_ms)), 4),
+                     "kernel_ms_rocprof_avg": rp.get("avg_ms") if rp else None,
+                     "kernel_ms_rocprof_min": rp.get("min_ms") if rp else None,
+                     "kernel_ms_rocprof_max": rp.get("max_ms") if rp else None,
                      "algorithmic_bytes_per_launch": nbytes},
     }
 
@@ -267,47 +257,86 @@ def main():
         cs, ms2 = ctx.read_ceiling(buf.data_ptr(), nbytes)
         out["read_ceiling_gbs"] = round(nbytes / 1e9 / (min(ms, ms2) / 1e3), 1)
         if not args.no_stats:
+            # configs[2]: the histograms, end to end.  A COLD fqh_stats (nothing cached from the scan above: the single pass
+            # reads the input once for offsets, validation and histograms), wall time around the blocking call.
             qh = torch.zeros(150 * 256, dtype=torch.int64, device=dev)
             bh = torch.zeros(150 * 8, dtype=torch.int64, device=dev)
             sc = torch.zeros(8, dtype=torch.int64, device=dev)
-            best = None
-            for _ in range(3):
-                qh.zero_(); bh.zero_(); sc.zero_()
-                ctx.stats_launch(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
-                ctx.stats_finish()
-                tt = ctx.timing()
-                best = tt.stats_ms if best is None else min(best, tt.stats_ms)
-            assert int(sc[0].item()) == total_records
-            assert int(qh.sum().item()) == total_records * 150 and int(bh.sum().item()) == total_records * 150
-            out["stats"] = {"workload": "configs[2]: per-position quality + base histograms, same buffer",
-                            "kernel": "k_stats_oct", "kernel_ms": round(best, 3),
-                            "gbs": round(nbytes / 1e9 / (best / 1e3), 1),
-                            "frac_of_hbm_peak": round(nbytes / 1e9 / (best / 1e3) / HBM_PEAK_GBS, 4)}
+
+            def timed(fn, reps=4):
+                best = None
+                for _ in range(reps):
+                    qh.zero_(); bh.zero_(); sc.zero_()
+                    ctx.invalidate()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    w = (time.perf_counter() - t1) * 1e3
+                    tt = ctx.timing()
+                    if best is None or w < best[0]:
+                        best = (w, tt.index_ms, tt.total_ms, ctx.last_scan_fast())
+                    assert int(sc[0].item()) == total_records
+                    assert int(qh.sum().item()) == total_records * 150 and int(bh.sum().item()) == total_records * 150
+                return best
+
+            one = timed(lambda: ctx.stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()))
+            both = timed(lambda: ctx.scan_stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr(),
+                                                d_rec_start=rec_start.data_ptr(), cap=cap))
+            ctx.set_single_pass(False)
+            two = timed(lambda: ctx.stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()), reps=2)
+            ctx.set_single_pass(True)
+            out["stats"] = {
+                "workload": "configs[2]: per-position quality + base histograms, same buffer, cold call (fqh_stats)",
+                "route": "single pass: k_scan_stats reads the input once for offsets, validation and histograms" if one[3]
+                         else "two passes (the single pass was not kept)",
+                "kernel": "k_scan_stats", "input_reads": 1 if one[3] else 2,
+                "end_to_end_ms": round(one[0], 3), "kernel_ms": round(one[1], 3), "all_kernels_ms": round(one[2], 3),
+                "gbs_end_to_end": round(nbytes / 1e6 / one[0], 1),
+                "frac_of_hbm_peak_end_to_end": round(nbytes / 1e6 / one[0] / HBM_PEAK_GBS, 4),
+                "scan_offsets_and_histograms_end_to_end_ms": round(both[0], 3),
+                "two_pass_route_end_to_end_ms": round(two[0], 3),
+                "bound": "vector ALU issue, then LDS atomics (DESIGN.md 5b); HBM is read once"}
         if not args.no_cpu_baseline:
             from oracle import fqref  # the oracle as timed CPU baseline (kind "port"), never the product
-            sample = min(nbytes, args.cpu_sample_mib << 20) // RECLEN * RECLEN
+            # SURVEY 8(d) cfg 0: examples/fastq-count.rs on a 2 GiB file on a ramdisk: the oracle's Parser::each reads the
+            # file through its 68 KiB Buffer, one read(2) per refill, 1 thread (the reference scan is single-threaded)
+            sample = min(nbytes, 2 << 30) // RECLEN * RECLEN
             host = buf[:sample].cpu().numpy()
+            path = "/dev/shm/fqh_bench_%d.fastq" % os.getpid()
             best = None
-            for _ in range(3):
-                t1 = time.perf_counter()
-                r = fqref.count(host)
-                d1 = time.perf_counter() - t1
-                best = d1 if best is None else min(best, d1)
+            try:
+                host.tofile(path)
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    r = fqref.count_file(path)
+                    d1 = time.perf_counter() - t1
+                    best = d1 if best is None else min(best, d1)
+            finally:
+                if os.path.exists(path):
+                    os.remove(path)
             assert r.status == 0 and r.n_records == sample // RECLEN
+            model = "unknown"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+            except Exception:
+                pass
             out["cpu_baseline"] = {"value": round(sample / 1e9 / best, 3), "unit": "GB/s", "cores": 1,
                                    "kind": "port",
-                                   "sample": "oracle Parser::each count over the first %d MiB of the same "
-                                             "buffer, best of 3, 1 thread (the reference scan is "
-                                             "single-threaded); host has %d cores" % (sample >> 20, os.cpu_count())}
+                                   "sample": "configs[0]: the oracle's fastq-count (Parser::each through the 68 KiB Buffer, "
+                                             "one read(2) per refill) over a %.2f GiB file of the same synthetic bytes on "
+                                             "/dev/shm, best of 3, 1 thread; host: %s, %d logical cores"
+                                             % (sample / 2**30, model, os.cpu_count())}
             hs = min(sample, 512 << 20) // RECLEN * RECLEN
             t1 = time.perf_counter()
             fqref.stats(host[:hs], 150)
             d1 = time.perf_counter() - t1
             out["cpu_baseline"]["stats_gbs"] = round(hs / 1e9 / d1, 3)
             # the histogram loop the way parallel_each would run it: record-aligned pieces on worker threads
-            # (ctypes releases the GIL), SURVEY.md 8(d) cfg 0
+            # (ctypes releases the GIL), all cores
             from concurrent.futures import ThreadPoolExecutor
-            nthr = max(1, min(32, (os.cpu_count() or 1)))
+            nthr = max(1, os.cpu_count() or 1)
             per = (sample // RECLEN + nthr - 1) // nthr * RECLEN
             pieces = [host[i:i + per] for i in range(0, sample, per)]
             with ThreadPoolExecutor(nthr) as ex:

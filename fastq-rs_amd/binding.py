@@ -8,16 +8,17 @@ LIB_PATH = os.path.join(_HERE, "libfastq_hip.so")
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
-           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "BUFSIZE", "NSCALARS", "EXPORTS"]
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "EXPORTS"]
 
 OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY = range(10)
 BUFSIZE = 68 * 1024
 NSCALARS = 8
+OPT_FAST_PATH, OPT_SINGLE_PASS = 1, 2
 
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
-    "fqh_set_stream", "fqh_set_bufsize", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
+    "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
     "fqh_shard_prescan", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
@@ -121,8 +122,8 @@ def lib():
         L.fqh_record_flags.argtypes = [vp, vp, u64, u64, vp, u64, vp]
         L.fqh_gather_records.argtypes = [vp, vp, u64, u64, vp, u64, vp, C.c_uint8, C.c_uint8, vp, u64,
                                          C.POINTER(u64), C.POINTER(u64)]
-        L.fqh_debug_last_scan_fast.argtypes = [vp]
-        L.fqh_debug_set_spec.argtypes = [vp, i32]
+        L.fqh_last_scan_fast.argtypes = [vp]
+        L.fqh_set_option.argtypes = [vp, i32, i32]
         L.fqh_stream_create.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
         L.fqh_stream_destroy.argtypes = [vp]
         L.fqh_stream_destroy.restype = None
@@ -289,11 +290,15 @@ class Ctx:
 
     def last_scan_fast(self):
         """Test hook: did the last scan complete on the fast path (no exact rerun)?"""
-        return bool(self._L.fqh_debug_last_scan_fast(self._h))
+        return bool(self._L.fqh_last_scan_fast(self._h))
 
     def set_spec(self, on):
         """Test hook: (re-)enable or disable the fast path for this context."""
-        self._L.fqh_debug_set_spec(self._h, 1 if on else 0)
+        self._chk(self._L.fqh_set_option(self._h, OPT_FAST_PATH, 1 if on else 0))
+
+    def set_single_pass(self, on):
+        """Whole-file statistics in the scan's own pass over the input (default) or as a second pass."""
+        self._chk(self._L.fqh_set_option(self._h, OPT_SINGLE_PASS, 1 if on else 0))
 
     def timing(self):
         t = Timing()

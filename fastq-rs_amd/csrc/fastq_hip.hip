@@ -604,20 +604,21 @@ fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, ui
     return do_scan_launch(ctx, buf, len, is_final, in, d_rec_start, cap, true);
 }
 
-// test hooks, not part of the public header
-extern "C" int fqh_debug_last_scan_fast(fqh_ctx *ctx) { return ctx && ctx->used_spec ? 1 : 0; }
-extern "C" void fqh_debug_set_spec(fqh_ctx *ctx, int on) {
-    if (!ctx) return;
-    ctx->spec_enabled = on != 0;
-    ctx->spec_skip = ctx->spec_backoff = 0;
+int fqh_last_scan_fast(fqh_ctx *ctx) { return ctx && ctx->used_spec ? 1 : 0; }
+fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
+    if (!ctx) return FQH_E_ARG;
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is pending");
+    switch (option) {
+    case FQH_OPT_FAST_PATH:
+        ctx->spec_enabled = value != 0;
+        ctx->spec_skip = ctx->spec_backoff = 0;
+        return FQH_OK;
+    case FQH_OPT_SINGLE_PASS:
+        ctx->fused_enabled = value != 0;
+        return FQH_OK;
+    }
+    return fail(ctx, FQH_E_ARG, "unknown option");
 }
-// copies the fast path's per-tile record (128 u16) of tile t to the host (tests / tools only)
-extern "C" int fqh_debug_fast_record(fqh_ctx *ctx, uint64_t t, uint16_t *out128) {
-    if (!ctx || !ctx->fast_rs || t >= ctx->tiles_cap) return -1;
-    (void)hipStreamSynchronize(ctx->stream);
-    return (int)hipMemcpy(out128, ctx->fast_rs + t * 64, 128, hipMemcpyDeviceToHost);
-}
-
 fqh_status fqh_invalidate(fqh_ctx *ctx) {
     if (!ctx) return FQH_E_ARG;
     ctx->last_valid = false;

@@ -96,6 +96,19 @@ fqh_status fqh_set_stream(fqh_ctx *ctx, void *hip_stream);
  * src/lib.rs:126-127; 0 = no limit). */
 fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
 
+/* Knobs (defaults in brackets; the environment variables FQH_SPEC / FQH_FUSED set the same at fqh_create):
+ *   FQH_OPT_FAST_PATH [1]   fqh_scan first tries to PROVE the input valid with a quarter of the index traffic
+ *                            and reruns the exact path on any doubt; 0 = exact path only.  Setting it
+ *                           also clears the back-off the context keeps after failed attempts.
+ *   FQH_OPT_SINGLE_PASS [1] whole-file fqh_stats / fqh_scan_stats count in the scan's own pass over the input
+ *                           (k_scan_stats); 0 = always the exact scan followed by the histogram kernel.
+ * fqh_last_scan_fast: did the last finished scan (or single-pass statistics call) keep the fast path's result (1), or
+ * was it rerun on the exact path (0)?  Results are identical either way; this is for benchmarks and tests. */
+#define FQH_OPT_FAST_PATH 1
+#define FQH_OPT_SINGLE_PASS 2
+fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
+int fqh_last_scan_fast(fqh_ctx *ctx);
+
 /* Record scan.  d_buf[0..len) are device-resident bytes; `in` (NULL = start of file) describes
  * where in the file they sit.  Writes d_rec_start[0..n_records]: [0] = file offset of the record in
  * progress at the chunk start, [i] = file offset just past the i-th record that ends in this chunk

@@ -8,18 +8,32 @@
  */
 #include "fqref.h"
 
+#include <errno.h>
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 /* ------------------------------------------------------------------------------------------ */
 /* Reader: std::io::Cursor<&[u8]> — read() copies min(dest.len(), remaining) bytes.            */
 /* max_read > 0 additionally caps one read() (a legal Read impl may return short reads).       */
+/* fd >= 0: std::fs::File instead (examples/fastq-count.rs:8-13 opens the path, parse_path hands the file to the   */
+/* parser for plain input, src/lib.rs:190): one read(2) per Buffer::read_into, ErrorKind::Interrupted retried      */
+/* (src/buffer.rs:85-97).                                                                                          */
 typedef struct {
     const uint8_t *data;
     uint64_t len, pos, max_read;
+    int fd;
 } reader_t;
 
 static uint64_t reader_read(reader_t *r, uint8_t *dest, uint64_t n) {
+    if (r->fd >= 0) {
+        for (;;) {
+            ssize_t k = read(r->fd, dest, n);
+            if (k >= 0) return (uint64_t)k;
+            if (errno != EINTR) return 0;
+        }
+    }
     uint64_t avail = r->len - r->pos;
     if (n > avail) n = avail;
     if (r->max_read && n > r->max_read) n = r->max_read;
@@ -129,9 +143,23 @@ static int from_buffer(const uint8_t *buf, uint64_t n, rec_t *out, int *err) {
 
 /* ------------------------------------------------------------------------------------------ */
 /* Parser::each / RecordRefIter::advance — src/lib.rs:221-239, 255-303                         */
+static void each_reader(reader_t rd, uint64_t bufsize, fqref_cb cb, void *user, fqref_result *res);
 void fqref_each(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
                 fqref_cb cb, void *user, fqref_result *res) {
-    reader_t rd = {data, len, 0, max_read};
+    reader_t rd = {data, len, 0, max_read, -1};
+    each_reader(rd, bufsize, cb, user, res);
+}
+/* examples/fastq-count.rs:6-24 on a plain file: parse_path -> Parser::new(file) -> each(|_| total += 1).  Returns -1 if
+ * the file cannot be opened. */
+int fqref_count_file(const char *path, uint64_t bufsize, fqref_result *res) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    reader_t rd = {NULL, 0, 0, 0, fd};
+    each_reader(rd, bufsize, NULL, NULL, res);
+    close(fd);
+    return 0;
+}
+static void each_reader(reader_t rd, uint64_t bufsize, fqref_cb cb, void *user, fqref_result *res) {
     buf_t b;
     buf_init(&b, bufsize);
     uint64_t consumed = 0; /* global offset of b.data[b.start] */
@@ -268,7 +296,7 @@ void fqref_stats(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t m
 void fqref_record_sets(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
                        uint32_t n_threads, uint64_t *set_sizes, uint64_t cap_sets, uint64_t *n_sets,
                        uint64_t *worker_counts, fqref_result *res) {
-    reader_t rd = {data, len, 0, max_read};
+    reader_t rd = {data, len, 0, max_read, -1};
     buf_t b;
     buf_init(&b, bufsize);
     memset(res, 0, sizeof *res);

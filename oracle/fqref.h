@@ -63,6 +63,8 @@ void fqref_each(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t ma
                 fqref_cb cb, void *user, fqref_result *res);
 
 /* Convenience loops on top of fqref_each. */
+/* the same over a file on disk (one read(2) per Buffer refill): examples/fastq-count.rs; -1 if it cannot be opened */
+int fqref_count_file(const char *path, uint64_t bufsize, fqref_result *res);
 void fqref_count(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,
                  fqref_result *res);
 /* Writes up to cap index entries; res->n_records is the true count. */

@@ -43,6 +43,7 @@ def lib():
         L = C.CDLL(so)
         u8p, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
         L.fqref_count.argtypes = [u8p, u64, u64, u64, C.POINTER(Result)]
+        L.fqref_count_file.argtypes = [C.c_char_p, u64, C.POINTER(Result)]
         L.fqref_index.argtypes = [u8p, u64, u64, u64, C.c_void_p, u64, C.POINTER(Result)]
         L.fqref_offsets.argtypes = [u8p, u64, u64, u64, C.c_void_p, u64, C.POINTER(Result)]
         L.fqref_stats.argtypes = [u8p, u64, u64, u64, u32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -71,6 +72,14 @@ def count(data, bufsize=BUFSIZE, max_read=0):
     a, p, n = _buf(data)
     r = Result()
     lib().fqref_count(p, n, bufsize, max_read, C.byref(r))
+    return r
+
+
+def count_file(path, bufsize=BUFSIZE):
+    """examples/fastq-count.rs on a plain file: the parser reads it through its 68 KiB Buffer, one read(2) per refill."""
+    r = Result()
+    if lib().fqref_count_file(os.fsencode(path), bufsize, C.byref(r)) != 0:
+        raise OSError("cannot open %s" % path)
     return r
 
 

@@ -187,6 +187,36 @@ static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) 
     return 0;
 }
 
+// --zip FILE1 FILE2 FLAGS BUFSIZE SLOT: each_zipped (src/lib.rs:577-609) with a scripted callback: call i returns the
+// advance flags FLAGS[i % len] ('0'..'3': bit 0 parser 1, bit 1 parser 2).  Prints "call <head1|-> <head2|->" per call,
+// then "zipped <finished1> <finished2> <error|ok>".
+static int zip(const char *file1, const char *file2, const char *flags, uint64_t bufsize, uint64_t slot) {
+    auto slurp = [](const char *f) {
+        std::ifstream in(f, std::ios::binary);
+        return std::string((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    };
+    const std::string d1 = slurp(file1), d2 = slurp(file2), fl = flags;
+    Options o;
+    o.bufsize = bufsize;
+    o.slot_bytes = slot;
+    Parser<MemReader> p1(MemReader(d1), o), p2(MemReader(d2), o);
+    std::string err = "ok";
+    std::pair<bool, bool> fin{false, false};
+    size_t i = 0;
+    try {
+        fin = each_zipped(p1, p2, [&](const std::optional<RefRecord> &a, const std::optional<RefRecord> &b) {
+            auto str = [](fastq::bytes_view v) { return std::string((const char *)v.data(), v.size()); };
+            const std::string h1 = a ? str(a->head()) : "-", h2 = b ? str(b->head()) : "-";
+            printf("call %s %s\n", h1.c_str(), h2.c_str());
+            const int f = fl.empty() ? 3 : fl[i % fl.size()] - '0';
+            ++i;
+            return std::make_pair((f & 1) != 0, (f & 2) != 0);
+        });
+    } catch (const Error &e) { err = e.what(); }
+    printf("zipped %d %d %s\n", fin.first ? 1 : 0, fin.second ? 1 : 0, err.c_str());
+    return 0;
+}
+
 // --plain FILE: the reader chain of parse_path without a Parser (no GPU needed): prints the number
 // of plain bytes and their FNV-1a hash, or the error.
 static int plain(const char *file) {
@@ -211,6 +241,7 @@ static int plain(const char *file) {
 
 int main(int argc, char **argv) {
     if (argc >= 3 && !strcmp(argv[1], "--plain")) return plain(argv[2]);
+    if (argc >= 7 && !strcmp(argv[1], "--zip")) return zip(argv[2], argv[3], argv[4], strtoull(argv[5], 0, 0), strtoull(argv[6], 0, 0));
     if (argc >= 5 && !strcmp(argv[1], "--dump"))
         return dump(argv[2], atoi(argv[3]), strtoull(argv[4], 0, 0), argc > 5 ? strtoull(argv[5], 0, 0) : (1 << 20));
 #define RUN(t) do { t(); printf("ok %s\n", #t); fflush(stdout); } while (0)

@@ -159,42 +159,97 @@ int fqref_count_file(const char *path, uint64_t bufsize, fqref_result *res) {
     close(fd);
     return 0;
 }
-static void each_reader(reader_t rd, uint64_t bufsize, fqref_cb cb, void *user, fqref_result *res) {
+/* RecordRefIter — src/lib.rs:241-304: advance() consumes the previous record and parses the next one (refilling the
+ * Buffer as needed), get() is Some(record) unless the input has ended. */
+typedef struct {
+    reader_t rd;
     buf_t b;
-    buf_init(&b, bufsize);
-    uint64_t consumed = 0; /* global offset of b.data[b.start] */
-    uint64_t cur_len = 0;  /* current_length.take() */
-    int have_cur = 0;
-    memset(res, 0, sizeof *res);
+    uint64_t consumed; /* global offset of b.data[b.start] */
+    uint64_t cur_len;  /* current_length.take() */
+    int have_cur;      /* get() would return Some */
+    rec_t rec;
+    uint64_t n_records;
+} iter_t;
+
+static void iter_init(iter_t *it, reader_t rd, uint64_t bufsize) {
+    memset(it, 0, sizeof *it);
+    it->rd = rd;
+    buf_init(&it->b, bufsize);
+}
+/* returns 0 or the FQREF_E_* of the io::Error advance() returns */
+static int iter_advance(iter_t *it) {
+    buf_t *b = &it->b;
+    if (it->have_cur) { b->start += it->cur_len; it->consumed += it->cur_len; it->have_cur = 0; } /* :258-260 */
     for (;;) {
-        /* advance() */
-        if (have_cur) { b.start += cur_len; consumed += cur_len; have_cur = 0; } /* :258-260 */
-        rec_t rec;
-        int got = 0, at_end = 0;
-        while (!got && !at_end) {
-            int err;
-            int r = from_buffer(b.data + b.start, buf_len(&b), &rec, &err);   /* :262 */
-            if (err) { res->status = err; goto done; }                         /* :263 */
-            if (r == R_EMPTY) {                                                /* :264-275 */
-                buf_clean(&b);
-                if (buf_read_into(&b, &rd) == 0) at_end = 1;
-            } else if (r == R_INCOMPLETE) {                                    /* :276-294 */
-                buf_clean(&b);
-                if (buf_n_free(&b) == 0) { res->status = FQREF_E_TOO_LONG; goto done; }
-                if (buf_read_into(&b, &rd) == 0) { res->status = FQREF_E_TRUNCATED; goto done; }
-            } else {                                                           /* :295-300 */
-                got = 1;
-            }
+        int err;
+        int r = from_buffer(b->data + b->start, buf_len(b), &it->rec, &err);  /* :262 */
+        if (err) return err;                                                  /* :263 */
+        if (r == R_EMPTY) {                                                   /* :264-275 */
+            buf_clean(b);
+            if (buf_read_into(b, &it->rd) == 0) return 0;                     /* end of input: get() == None */
+        } else if (r == R_INCOMPLETE) {                                       /* :276-294 */
+            buf_clean(b);
+            if (buf_n_free(b) == 0) return FQREF_E_TOO_LONG;
+            if (buf_read_into(b, &it->rd) == 0) return FQREF_E_TRUNCATED;
+        } else {                                                              /* :295-300 */
+            it->cur_len = it->rec.end;
+            it->have_cur = 1;
+            it->n_records++;
+            return 0;
         }
-        if (at_end) goto done;                 /* get() == None -> Ok(true)   :229 */
-        cur_len = rec.end; have_cur = 1;
-        fqref_idx idx = {consumed, rec.head, rec.seq, rec.sep, rec.qual};
-        res->n_records++;
-        res->bytes_consumed = consumed + rec.end;
-        if (cb && !cb(user, b.data + b.start, &idx)) { res->stopped = 1; goto done; } /* :231-234 */
     }
-done:
-    free(b.data);
+}
+
+static void each_reader(reader_t rd, uint64_t bufsize, fqref_cb cb, void *user, fqref_result *res) {
+    iter_t it;
+    iter_init(&it, rd, bufsize);
+    memset(res, 0, sizeof *res);
+    for (;;) {                                   /* Parser::each, src/lib.rs:221-239 */
+        int err = iter_advance(&it);
+        if (err) { res->status = err; break; }
+        if (!it.have_cur) break;                 /* get() == None -> Ok(true)   :229 */
+        fqref_idx idx = {it.consumed, it.rec.head, it.rec.seq, it.rec.sep, it.rec.qual};
+        res->n_records++;
+        res->bytes_consumed = it.consumed + it.rec.end;
+        if (cb && !cb(user, it.b.data + it.b.start, &idx)) { res->stopped = 1; break; } /* :231-234 */
+    }
+    free(it.b.data);
+}
+
+/* each_zipped — src/lib.rs:577-609.  The callback is replaced by a script: call i returns the advance flags
+ * flags[i % nflags] (bit 0: advance parser 1, bit 1: advance parser 2).  trace[2 i], trace[2 i + 1] = the (0-based) index
+ * of the record each parser showed the callback in call i, or UINT64_MAX for None.  *status = the error an advance()
+ * returned (0: none), fin[0..1] = the returned (bool, bool). */
+void fqref_each_zipped(const uint8_t *d1, uint64_t l1, const uint8_t *d2, uint64_t l2, uint64_t bufsize,
+                       const uint8_t *flags, uint64_t nflags, uint64_t *trace, uint64_t cap, uint64_t *ncalls,
+                       int32_t fin[2], int32_t *status) {
+    reader_t r1 = {d1, l1, 0, 0, -1}, r2 = {d2, l2, 0, 0, -1};
+    iter_t i1, i2;
+    iter_init(&i1, r1, bufsize);
+    iter_init(&i2, r2, bufsize);
+    int f1 = 0, f2 = 0;
+    uint64_t n = 0;
+    *status = 0;
+    int err = iter_advance(&i1);                                   /* :589 */
+    if (!err) err = iter_advance(&i2);                             /* :590 */
+    while (!err) {
+        const int v1 = !f1 && i1.have_cur, v2 = !f2 && i2.have_cur; /* :593-594 */
+        f1 = !v1; f2 = !v2;                                        /* :595 */
+        if (n < cap) {
+            trace[2 * n] = v1 ? i1.n_records - 1 : UINT64_MAX;
+            trace[2 * n + 1] = v2 ? i2.n_records - 1 : UINT64_MAX;
+        }
+        const uint8_t fl = nflags ? flags[n % nflags] : 3;         /* callback(val1, val2) :596 */
+        ++n;
+        if ((fl & 3) == 0 || (f1 && f2)) break;                    /* :598-600 */
+        if ((fl & 1) && !f1) err = iter_advance(&i1);              /* :601-603 */
+        if (!err && (fl & 2) && !f2) err = iter_advance(&i2);      /* :604-606 */
+    }
+    *status = err;
+    *ncalls = n;
+    fin[0] = f1; fin[1] = f2;
+    free(i1.b.data);
+    free(i2.b.data);
 }
 
 /* ------------------------------------------------------------------------------------------ */

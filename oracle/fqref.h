@@ -63,6 +63,10 @@ void fqref_each(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t ma
                 fqref_cb cb, void *user, fqref_result *res);
 
 /* Convenience loops on top of fqref_each. */
+/* each_zipped (src/lib.rs:577-609) with a scripted callback: see fqref.c */
+void fqref_each_zipped(const uint8_t *d1, uint64_t l1, const uint8_t *d2, uint64_t l2, uint64_t bufsize,
+                       const uint8_t *flags, uint64_t nflags, uint64_t *trace, uint64_t cap, uint64_t *ncalls,
+                       int32_t fin[2], int32_t *status);
 /* the same over a file on disk (one read(2) per Buffer refill): examples/fastq-count.rs; -1 if it cannot be opened */
 int fqref_count_file(const char *path, uint64_t bufsize, fqref_result *res);
 void fqref_count(const uint8_t *data, uint64_t len, uint64_t bufsize, uint64_t max_read,

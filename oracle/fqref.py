@@ -44,6 +44,8 @@ def lib():
         u8p, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
         L.fqref_count.argtypes = [u8p, u64, u64, u64, C.POINTER(Result)]
         L.fqref_count_file.argtypes = [C.c_char_p, u64, C.POINTER(Result)]
+        L.fqref_each_zipped.argtypes = [u8p, u64, u8p, u64, u64, u8p, u64, C.c_void_p, u64, C.POINTER(u64),
+                                        C.POINTER(C.c_int32 * 2), C.POINTER(C.c_int32)]
         L.fqref_index.argtypes = [u8p, u64, u64, u64, C.c_void_p, u64, C.POINTER(Result)]
         L.fqref_offsets.argtypes = [u8p, u64, u64, u64, C.c_void_p, u64, C.POINTER(Result)]
         L.fqref_stats.argtypes = [u8p, u64, u64, u64, u32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -81,6 +83,19 @@ def count_file(path, bufsize=BUFSIZE):
     if lib().fqref_count_file(os.fsencode(path), bufsize, C.byref(r)) != 0:
         raise OSError("cannot open %s" % path)
     return r
+
+
+def each_zipped(data1, data2, flags, bufsize=BUFSIZE):
+    """each_zipped (src/lib.rs:577-609) with the callback scripted by `flags` (bytes, 2 bits each, cycled).
+    -> (status, (finished1, finished2), trace[ncalls, 2] of record indices, UINT64_MAX = None)."""
+    a1, p1, n1 = _buf(data1)
+    a2, p2, n2 = _buf(data2)
+    af, pf, nf = _buf(flags)
+    cap = n1 // 6 + n2 // 6 + 8
+    trace = np.zeros((cap, 2), dtype=np.uint64)
+    ncalls, fin, st = C.c_uint64(0), (C.c_int32 * 2)(), C.c_int32(0)
+    lib().fqref_each_zipped(p1, n1, p2, n2, bufsize, pf, nf, trace.ctypes.data, cap, C.byref(ncalls), C.byref(fin), C.byref(st))
+    return st.value, (bool(fin[0]), bool(fin[1])), trace[: ncalls.value]
 
 
 def index(data, bufsize=BUFSIZE, max_read=0):

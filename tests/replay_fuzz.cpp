@@ -1,0 +1,105 @@
+// replay_fuzz.cpp — differential fuzz of csrc/replay.h (the host-side replay of the reference's Buffer arithmetic, which
+// decides "Fastq record is too long" and cuts RecordSets) against the oracle's streaming restatement, at the
+// reference's own fuzzing BUFSIZE of 64 (src/lib.rs:126-127) and at 69632.  TEST INFRASTRUCTURE: built by
+// tests/test_replay_fuzz.py with -fsanitize=address,undefined, links oracle/libfqref.so, needs no GPU.
+//
+// Inputs are valid records of random sizes (many around BUFSIZE), optionally cut short at the end; the record
+// boundaries a scan would deliver come from the oracle run with an unlimited buffer; they are fed to BufferReplay in
+// random chunkings, as fqh_stream_* does.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../fastq-rs_amd/csrc/replay.h"
+extern "C" {
+#include "../oracle/fqref.h"
+}
+
+static std::string record(std::mt19937_64 &rng, uint64_t total) {  // a valid record of exactly `total` bytes (>= 6)
+    // "@" + h + "\n" + s + "\n+\n" + q + "\n" with |s| == |q|: total = 6 + |h| + 2 |s|
+    uint64_t body = total - 6, s = (body / 2 > 0) ? rng() % (body / 2 + 1) : 0, h = body - 2 * s;
+    std::string r = "@" + std::string(h, 'h') + "\n" + std::string(s, 'A') + "\n+\n" + std::string(s, 'I') + "\n";
+    return r;
+}
+
+int main(int argc, char **argv) {
+    const uint64_t iters = argc > 1 ? strtoull(argv[1], 0, 0) : 2000;
+    std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], 0, 0) : 12345);
+    uint64_t fails = 0, tripped_cases = 0;
+    for (uint64_t it = 0; it < iters; ++it) {
+        const uint64_t B = (it % 4 == 3) ? 69632 : 64;
+        std::string data;
+        const int nrec = 1 + (int)(rng() % 40);
+        for (int i = 0; i < nrec; ++i) {
+            uint64_t len;
+            const uint64_t r = rng() % 60;
+            if (r < 50) len = 6 + rng() % (B / 2);
+            else if (r < 59) len = B - 20 + rng() % 21;    // around the alignment-dependent band (B - 15 .. B)
+            else len = B + 1 + rng() % B;                    // certainly too long
+            if (len < 6) len = 6;
+            data += record(rng, len);
+        }
+        bool truncated = false;
+        if (rng() % 5 == 0 && data.size() > 3) {  // cut inside the last record: a truncated tail
+            data.resize(data.size() - 1 - rng() % 3);
+            truncated = true;
+        }
+        const uint8_t *p = (const uint8_t *)data.data();
+        // what the scan delivers: all record boundaries (unlimited buffer), and the status before the too-long rule
+        fqref_result big;
+        std::vector<uint64_t> rs(data.size() / 6 + 2);
+        fqref_offsets(p, data.size(), ((data.size() + 15) & ~(uint64_t)15) + 2 * 69632, 0, rs.data(), rs.size(), &big);  // (a buffer the whole input fits)
+        const uint64_t n = big.n_records;
+        rs.resize(n + 1);
+        rs[n] = big.bytes_consumed;
+        // the reference
+        fqref_result want;
+        fqref_count(p, data.size(), B, 0, &want);
+        // the replay, fed in random chunks of boundaries
+        fqh::BufferReplay rp;
+        rp.reset(B);
+        uint64_t which = 0, done = 0;
+        bool trip = false;
+        while (!trip) {
+            const uint64_t take = (rng() % 3 == 0) ? n - done : (n - done ? rng() % (n - done + 1) : 0);
+            const bool last = done + take == n;
+            const uint64_t known_end = last ? data.size() : rs[done + take] + (rng() % 2 ? 0 : (rs[done + take + (done + take < n ? 1 : 0)] - rs[done + take]) / 2);
+            const uint64_t need = (last && truncated) ? 0 : fqh::BufferReplay::NO_BAD;
+            trip = rp.step(rs.data() + done, done, take, last ? data.size() : known_end, last, need, &which);
+            done += take;
+            if (last) break;
+        }
+        const bool want_trip = want.status == FQREF_E_TOO_LONG;
+        bool ok = trip == want_trip && (!trip || which == want.n_records);
+        if (!trip && ok) ok = want.n_records == n && (want.status == 0 || want.status == FQREF_E_TRUNCATED);
+        // RecordSets: sizes of the yielded sets
+        std::vector<uint64_t> sizes(data.size() / 8 + 16), got;
+        uint64_t nsets = 0;
+        fqref_result ws;
+        fqref_record_sets(p, data.size(), B, 0, 1, sizes.data(), sizes.size(), &nsets, nullptr, &ws);
+        fqh::BufferReplay rq;
+        rq.reset(B, true);
+        uint64_t w2 = 0;
+        bool fin = false;
+        const bool t2 = rq.step(rs.data(), 0, n, data.size(), true, truncated ? 0 : fqh::BufferReplay::NO_BAD, &w2, &got, &fin);
+        if ((ws.status == FQREF_E_TOO_LONG) != t2) ok = false;
+        if (got.size() > nsets) ok = false;  // (a set under construction when an error hits is dropped by the reference)
+        for (size_t i = 0; i < got.size() && i < nsets; ++i)
+            if (got[i] != sizes[i]) ok = false;
+        if (ws.status == 0 && got.size() != nsets) ok = false;
+        tripped_cases += trip;
+        if (!ok) {
+            ++fails;
+            if (fails < 5)
+                fprintf(stderr, "MISMATCH it=%llu B=%llu n=%llu trip=%d which=%llu want status=%d n=%llu sets got=%zu want=%llu t2=%d wsstatus=%d\n",
+                        (unsigned long long)it, (unsigned long long)B, (unsigned long long)n, trip, (unsigned long long)which, want.status,
+                        (unsigned long long)want.n_records, got.size(), (unsigned long long)nsets, t2, ws.status);
+        }
+    }
+    printf("replay_fuzz: %llu inputs, %llu too-long cases, %llu mismatches\n", (unsigned long long)iters,
+           (unsigned long long)tripped_cases, (unsigned long long)fails);
+    return fails ? 1 : 0;
+}

@@ -34,6 +34,17 @@ def test_reference_unit_tests_against_cpp_mirror(gpu_ok):
         assert "ok %s\n" % t in out.stdout
 
 
+def test_cpp_mirror_under_asan_ubsan_and_tsan(gpu_ok):
+    """The same mirrored unit tests, built with AddressSanitizer + UBSan and with ThreadSanitizer (the queues of
+    parallel_each and thread_reader, the ring's state machine): no report.  (TSan needs ASLR off on this kernel.)"""
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="ignore_noninstrumented_modules=1 report_signal_unsafe=0")
+    for exe, pre in (("host_tests_asan", []), ("host_tests_tsan", ["setarch", "x86_64", "-R"])):
+        out = subprocess.run(pre + [os.path.join(BIN, exe)], capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, exe + out.stdout[-2000:] + out.stderr[-4000:]
+        assert "all host tests passed" in out.stdout
+        assert "Sanitizer" not in out.stderr, out.stderr[-4000:]
+
+
 SETS_MSG = {4: "Truncated input file.", 5: "Fastq record is too long."}
 
 
@@ -83,6 +94,46 @@ def test_each_sets_parallel_each_equal_oracle(gpu_ok, fqref, tmp_path, seed):
         assert w_err == want_err
         if rs.status == 0:
             assert w_counts == ",".join(str(int(x)) for x in workers) + ","
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_each_zipped_equals_oracle(gpu_ok, fqref, tmp_path, seed):
+    """each_zipped (src/lib.rs:577-609): two files of different lengths, a scripted callback with random advance flags
+    (single reads interleaved in paired data are skipped that way); every callback's pair of records, the returned
+    (bool, bool) and the error of a bad file equal the oracle's restatement."""
+    rng = np.random.default_rng(900 + seed)
+    n1, n2 = int(rng.integers(50, 400)), int(rng.integers(50, 400))
+    mk = lambda n, tag: b"".join(fuzzgen.valid_record(rng, i, maxlen=60).replace(b"@r", b"@" + tag, 1) for i in range(n))
+    d1, d2 = mk(n1, b"a"), mk(n2, b"b")
+    if seed == 3:
+        d2 = d2[:-9]                      # truncated second file: the error surfaces when its iterator gets there
+    if seed == 4:
+        d1 = fuzzgen.mutate(rng, d1, 1)
+    flags = "".join(str(int(x)) for x in rng.choice([1, 2, 3, 3, 3], int(rng.integers(1, 40)))) if seed else "3"
+    if seed == 2:
+        flags += "0"                      # the callback stops the walk
+    (tmp_path / "a.fq").write_bytes(d1)
+    (tmp_path / "b.fq").write_bytes(d2)
+    for bufsize, slot in ((fqref.BUFSIZE, 1 << 16), (fqref.BUFSIZE, 1 << 20)):
+        out = subprocess.run([os.path.join(BIN, "host_tests"), "--zip", str(tmp_path / "a.fq"), str(tmp_path / "b.fq"), flags,
+                              str(bufsize), str(slot)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = out.stdout.strip().split("\n")
+        st, fin, trace = fqref.each_zipped(d1, d2, bytes(int(c) for c in flags), bufsize=bufsize)
+        _, i1 = fqref.index(d1, bufsize=bufsize)
+        _, i2 = fqref.index(d2, bufsize=bufsize)
+        NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+        want = []
+        for a, b in trace:
+            h1 = "-" if a == NONE else fqref.accessors(d1, i1[int(a)])[0].decode("latin-1")
+            h2 = "-" if b == NONE else fqref.accessors(d2, i2[int(b)])[0].decode("latin-1")
+            want.append("call %s %s" % (h1, h2))
+        assert lines[:-1] == want
+        z = lines[-1].split(" ", 3)
+        if st == 0:
+            assert z == ["zipped", str(int(fin[0])), str(int(fin[1])), "ok"]
+        else:
+            assert z[3] == fqref.strerror(st)
 
 
 def test_fastq_count_cli(gpu_ok, fqref, tmp_path):

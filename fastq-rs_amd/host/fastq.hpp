@@ -25,6 +25,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -574,12 +575,15 @@ class DynReader {
 // `niffler >= 2.4.0`, unpinned and not vendored => parity unpinned here): niffler reads the first five
 // bytes, fails with FileTooShort when there are fewer, matches the magic numbers below and then replays
 // those bytes in front of the stream.
-enum class Compression { No, Gzip, Bzip2, Lzma, Zstd };
+enum class Compression { No, Gzip, Bzip2, Lzma, Zstd, Lz4 };
 inline Compression sniff_compression(const uint8_t *b5) {
     if (b5[0] == 0x1f && b5[1] == 0x8b) return Compression::Gzip;
     if (b5[0] == 0x42 && b5[1] == 0x5a) return Compression::Bzip2;
     if (b5[0] == 0xfd && b5[1] == 0x37 && b5[2] == 0x7a && b5[3] == 0x58 && b5[4] == 0x5a) return Compression::Lzma;
     if (b5[0] == 0x28 && b5[1] == 0xb5 && b5[2] == 0x2f && b5[3] == 0xfd) return Compression::Zstd;
+    // (the crate's documentation names lz4 next to gzip, src/lib.rs:137-141 and README.md:39-45: its numbers were taken
+    // with an lz4 file; the LZ4 frame magic, little endian 0x184D2204)
+    if (b5[0] == 0x04 && b5[1] == 0x22 && b5[2] == 0x4d && b5[3] == 0x18) return Compression::Lz4;
     return Compression::No;
 }
 
@@ -654,11 +658,144 @@ class GzReader {
 };
 #endif
 
+
+// LZ4 frame decoder on the host (the published LZ4 Frame format 1.6.x and LZ4 block format: no dependency, the image has
+// no lz4 headers).  Concatenated frames and skippable frames are accepted like `lz4 -d` does; blocks may depend on the
+// previous ones (a 64 KiB window is kept); checksums are skipped, not verified.  Runs on the thread_reader thread.
+template <class Reader>
+class Lz4Reader {
+  public:
+    explicit Lz4Reader(Reader r) : r_(std::move(r)), in_(1 << 16) {}
+    size_t read(uint8_t *dst, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            if (out_pos_ == out_.size()) {
+                if (done_ || !next_block()) break;
+                continue;
+            }
+            const size_t k = std::min(n - got, out_.size() - out_pos_);
+            memcpy(dst + got, out_.data() + out_pos_, k);
+            out_pos_ += k;
+            got += k;
+            if (got) break;  // (a Read may return short: hand over what one block gave)
+        }
+        return got;
+    }
+
+  private:
+    bool fill(uint8_t *p, size_t n, bool eof_ok = false) {  // exactly n bytes, or (eof_ok) nothing at all
+        size_t have = 0;
+        while (have < n) {
+            if (in_pos_ == in_len_) {
+                in_len_ = r_.read(in_.data(), in_.size());
+                in_pos_ = 0;
+                if (in_len_ == 0) {
+                    if (have == 0 && eof_ok) return false;
+                    throw Error(ErrorKind::InvalidData, "unexpected end of lz4 stream");
+                }
+            }
+            const size_t k = std::min(n - have, in_len_ - in_pos_);
+            memcpy(p + have, in_.data() + in_pos_, k);
+            in_pos_ += k;
+            have += k;
+        }
+        return true;
+    }
+    static uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+    bool next_block() {  // decodes the next data block into out_ (behind the kept window); false at the end of input
+        for (;;) {
+            if (!in_frame_) {
+                uint8_t m[4];
+                if (!fill(m, 4, true)) { done_ = true; return false; }
+                const uint32_t magic = le32(m);
+                if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame
+                    uint8_t sz[4];
+                    fill(sz, 4);
+                    std::vector<uint8_t> skip(le32(sz));
+                    if (!skip.empty()) fill(skip.data(), skip.size());
+                    continue;
+                }
+                if (magic != 0x184D2204u) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: bad frame magic");
+                uint8_t fb[2];
+                fill(fb, 2);
+                if ((fb[0] >> 6) != 1) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: unsupported frame version");
+                independent_ = (fb[0] >> 5) & 1;
+                block_checksum_ = (fb[0] >> 4) & 1;
+                const bool content_size = (fb[0] >> 3) & 1;
+                content_checksum_ = (fb[0] >> 2) & 1;
+                const bool dict_id = fb[0] & 1;
+                uint8_t rest[13];
+                fill(rest, (content_size ? 8 : 0) + (dict_id ? 4 : 0) + 1);  // + header checksum
+                in_frame_ = true;
+                window_.clear();
+            }
+            uint8_t bs[4];
+            fill(bs, 4);
+            const uint32_t word = le32(bs);
+            if (word == 0) {  // EndMark
+                if (content_checksum_) { uint8_t c[4]; fill(c, 4); }
+                in_frame_ = false;
+                continue;
+            }
+            const bool stored = (word >> 31) != 0;
+            const uint32_t size = word & 0x7FFFFFFFu;
+            if (size > (4u << 20)) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: block size");
+            blk_.resize(size);
+            if (size) fill(blk_.data(), size);
+            if (block_checksum_) { uint8_t c[4]; fill(c, 4); }
+            // out_ = [window (up to 64 KiB of earlier output) | this block's output]; out_pos_ starts behind the window
+            out_.assign(window_.begin(), window_.end());
+            const size_t base = out_.size();
+            if (stored) out_.insert(out_.end(), blk_.begin(), blk_.end());
+            else decode_block(base);
+            out_pos_ = base;
+            if (!independent_) {
+                const size_t keep = std::min<size_t>(out_.size(), 65536);
+                window_.assign(out_.end() - keep, out_.end());
+            }
+            if (out_.size() > base) return true;
+        }
+    }
+    void decode_block(size_t base) {  // LZ4 block format: token, literals, 2-byte offset, match length
+        const uint8_t *p = blk_.data(), *end = p + blk_.size();
+        auto bad = [] { throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: block data"); };
+        (void)base;
+        while (p < end) {
+            const uint32_t tok = *p++;
+            size_t lit = tok >> 4;
+            if (lit == 15) {
+                uint8_t b;
+                do { if (p >= end) bad(); b = *p++; lit += b; } while (b == 255);
+            }
+            if ((size_t)(end - p) < lit) bad();
+            out_.insert(out_.end(), p, p + lit);
+            p += lit;
+            if (p >= end) break;  // the last sequence is literals only
+            if (end - p < 2) bad();
+            const size_t off = p[0] | (p[1] << 8);
+            p += 2;
+            size_t len = (tok & 15) + 4;
+            if ((tok & 15) == 15) {
+                uint8_t b;
+                do { if (p >= end) bad(); b = *p++; len += b; } while (b == 255);
+            }
+            if (off == 0 || off > out_.size()) bad();
+            const size_t from = out_.size() - off;
+            out_.reserve(out_.size() + len);
+            for (size_t i = 0; i < len; ++i) out_.push_back(out_[from + i]);  // (may overlap its own output)
+        }
+    }
+    Reader r_;
+    std::vector<uint8_t> in_, blk_, out_, window_;
+    size_t in_pos_ = 0, in_len_ = 0, out_pos_ = 0;
+    bool in_frame_ = false, done_ = false, independent_ = true, block_checksum_ = false, content_checksum_ = false;
+};
+
 // parse_path (src/lib.rs:167-196): open the file (nullopt / "-" = stdin), sniff the compression
 // format, hand the closure a Parser over plain bytes.  Plain input goes straight to the parser;
 // compressed input is decoded on a thread_reader thread with the reference's parameters (4 MiB
-// buffers, queue of 2; src/lib.rs:191).  Gzip is decoded with zlib; bzip2 / xz / zstd are detected
-// but no decoder library is present in this build.
+// buffers, queue of 2; src/lib.rs:191).  Gzip is decoded with zlib, lz4 frames with the decoder above; bzip2 / xz /
+// zstd are detected but no decoder library is present in this build.
 template <class F>
 auto with_plain_reader(const std::optional<std::string> &path, F use) {  // use(DynReader &) sees plain bytes
     FILE *f = stdin;
@@ -693,6 +830,12 @@ auto with_plain_reader(const std::optional<std::string> &path, F use) {  // use(
         });
     }
 #endif
+    if (fmt == Compression::Lz4) {
+        return thread_reader(1 << 22, 2, Lz4Reader<PrefixReader<FileReader>>(std::move(chained)), [&](auto reader) {
+            DynReader dyn(&reader);
+            return use(dyn);
+        });
+    }
     throw Error(ErrorKind::InvalidData,
                 std::string("Niffler failled in compression detection: no decoder in this build for ") +
                     (fmt == Compression::Gzip ? "gzip" : fmt == Compression::Bzip2 ? "bzip2"

@@ -161,7 +161,14 @@ def test_fastq_count_on_gzip_input(gpu_ok, fqref, tmp_path):
     cut = len(data) // 2
     (tmp_path / "in.fq").write_bytes(data)
     (tmp_path / "in.fq.gz").write_bytes(gzip.compress(data[:cut]) + gzip.compress(data[cut:]))
-    for name in ("in.fq", "in.fq.gz"):
+    names = ["in.fq", "in.fq.gz"]
+    try:  # lz4 as well (src/lib.rs:137-141 names it), when the box has a liblz4 to write the test frame with
+        from test_host_parse_path import lz4_frame
+        (tmp_path / "in.fq.lz4").write_bytes(lz4_frame(data[:cut]) + lz4_frame(data[cut:], block_linked=True, block_size_id=4))
+        names.append("in.fq.lz4")
+    except OSError:
+        pass
+    for name in names:
         for extra in ([], ["--threads", "3"]):
             out = subprocess.run([os.path.join(BIN, "fastq_count"), str(tmp_path / name)] + extra,
                                  capture_output=True, text=True, timeout=600)

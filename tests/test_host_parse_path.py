@@ -48,6 +48,63 @@ def test_plain_and_gzip_give_the_same_bytes(host_tests, tmp_path):
         assert plain(host_tests, tmp_path / name) == (0, want), name
 
 
+def lz4_frame(data, level=0, block_linked=False, content_checksum=False, block_size_id=0):
+    """An LZ4 frame made by the system's liblz4 (LZ4F_compressFrame) — an encoder that is not ours."""
+    import ctypes as C
+    L = C.CDLL("liblz4.so.1")
+
+    class FrameInfo(C.Structure):
+        _fields_ = [("blockSizeID", C.c_int), ("blockMode", C.c_int), ("contentChecksumFlag", C.c_int), ("frameType", C.c_int),
+                    ("contentSize", C.c_ulonglong), ("dictID", C.c_uint), ("blockChecksumFlag", C.c_int)]
+
+    class Prefs(C.Structure):
+        _fields_ = [("frameInfo", FrameInfo), ("compressionLevel", C.c_int), ("autoFlush", C.c_uint),
+                    ("favorDecSpeed", C.c_uint), ("reserved", C.c_uint * 3)]
+
+    pr = Prefs()
+    pr.frameInfo.blockSizeID = block_size_id
+    pr.frameInfo.blockMode = 0 if block_linked else 1   # LZ4F_blockLinked = 0, LZ4F_blockIndependent = 1
+    pr.frameInfo.contentChecksumFlag = 1 if content_checksum else 0
+    pr.compressionLevel = level
+    L.LZ4F_compressFrameBound.restype = C.c_size_t
+    L.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.POINTER(Prefs)]
+    L.LZ4F_compressFrame.restype = C.c_size_t
+    L.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(Prefs)]
+    L.LZ4F_isError.argtypes = [C.c_size_t]
+    cap = L.LZ4F_compressFrameBound(len(data), C.byref(pr))
+    out = C.create_string_buffer(cap)
+    n = L.LZ4F_compressFrame(out, cap, data, len(data), C.byref(pr))
+    assert not L.LZ4F_isError(n)
+    return out.raw[:n]
+
+
+def test_lz4_frames_give_the_same_bytes(host_tests, tmp_path):
+    """The crate's documentation names lz4 next to gzip (src/lib.rs:137-141, README.md:39-45).  Frames written by the
+    system's liblz4: linked and independent blocks, 64 KiB and 4 MiB blocks, a content checksum, two frames back to
+    back with a skippable frame between them; the decoder of parse_path gives back the plain bytes."""
+    try:
+        lz4_frame(b"x" * 100)
+    except OSError:
+        pytest.skip("no liblz4.so.1 on this box to write test frames with")
+    rng = np.random.default_rng(78)
+    data = fuzzgen.valid_file(rng, 6000, maxlen=150)
+    want = "plain %d %016x" % (len(data), fnv1a(data))
+    cut = len(data) // 3
+    skippable = bytes([0x53, 0x2a, 0x4d, 0x18, 5, 0, 0, 0]) + b"hello"
+    variants = {
+        "a.lz4": lz4_frame(data),
+        "linked.lz4": lz4_frame(data, block_linked=True, block_size_id=4),
+        "hc.lz4": lz4_frame(data, level=9, block_linked=True, content_checksum=True, block_size_id=7),
+        "multi.lz4": lz4_frame(data[:cut]) + skippable + lz4_frame(data[cut:], block_linked=True, block_size_id=4),
+    }
+    for name, blob in variants.items():
+        (tmp_path / name).write_bytes(blob)
+        assert plain(host_tests, tmp_path / name) == (0, want), name
+    (tmp_path / "trunc.lz4").write_bytes(variants["a.lz4"][: len(variants["a.lz4"]) // 2])
+    rc, out = plain(host_tests, tmp_path / "trunc.lz4")
+    assert rc == 3 and out.startswith("error")
+
+
 def test_sniffing_errors(host_tests, tmp_path):
     data = b"@a\nACGT\n+\nIIII\n" * 100
     (tmp_path / "short").write_bytes(b"@a\nA")                      # niffler: FileTooShort

@@ -22,7 +22,8 @@ EXPORTS = [
     "fqh_shard_prescan", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
-    "fqh_stream_collect", "fqh_stream_release", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
+    "fqh_stream_collect", "fqh_stream_release", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
+    "fqh_allreduce_u64", "fqh_sync", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
 ]
 
@@ -131,6 +132,13 @@ def lib():
         L.fqh_stream_submit.argtypes = [vp, u64, i32]
         L.fqh_stream_collect.argtypes = [vp, C.POINTER(Chunk)]
         L.fqh_stream_release.argtypes = [vp]
+        L.fqh_comm_unique_id.argtypes = [C.c_char_p]
+        L.fqh_comm_create.argtypes = [vp, i32, i32, C.c_char_p, C.POINTER(vp)]
+        L.fqh_comm_destroy.argtypes = [vp]
+        L.fqh_comm_destroy.restype = None
+        L.fqh_allgather.argtypes = [vp, vp, vp, vp, u64]
+        L.fqh_allreduce_u64.argtypes = [vp, vp, vp, u64]
+        L.fqh_sync.argtypes = [vp]
         L.fqh_synth_fill.argtypes = [vp, vp, u64, u64, u64]
         L.fqh_read_ceiling.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(C.c_float)]
         L.fqh_dev_alloc.argtypes = [vp, u64, C.POINTER(vp)]

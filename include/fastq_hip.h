@@ -19,7 +19,7 @@
  *   Record::write (filter loops)    src/records.rs:93-96          fqh_gather_records
  *   Buffer                          src/buffer.rs:1-112           fqh_stream_* (pinned ring)
  *   thread_reader                   src/thread_reader.rs:182-200  fqh_stream_* (copy stream)
- *   parallel_each gather            src/lib.rs:553-559            fqh_reduce_* (RCCL/torch)
+ *   parallel_each gather            src/lib.rs:553-559            fqh_allgather / fqh_allreduce_u64 (RCCL)
  */
 #ifndef FASTQ_HIP_H
 #define FASTQ_HIP_H
@@ -154,6 +154,23 @@ fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, ui
  * the true newline count of the shards in front of them (fqh_carry.nl_count of their streams, fqh_stream_carry). */
 fqh_status fqh_shard_align(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int prev_is_newline, uint32_t *phase,
                            uint64_t *first_record_offset);
+/* The exchange steps of the sharded modes, over RCCL (xGMI) on the context's stream — for hosts without a collective
+ * library of their own (a Rust or C++ driver; bench.py uses torch.distributed, which is the same RCCL).  librccl.so is
+ * bound at run time by the first of these calls.  One rank makes an id (fqh_comm_unique_id) and hands it to the
+ * others by any means; every rank then calls fqh_comm_create on its own context (= its GPU).  fqh_allgather: every
+ * rank contributes bytes_per_rank bytes (the 7 carry words of fqh_shard_prescan, the 8 words + tail of a streamed
+ * shard), d_recv gets all of them in rank order.  fqh_allreduce_u64: element-wise sum in place (counts, scalars,
+ * histograms) — the gather at the end of Parser::parallel_each, src/lib.rs:553-559.  Both are enqueued; fqh_sync waits
+ * for the context's stream. */
+typedef struct fqh_comm fqh_comm;
+#define FQH_COMM_ID_BYTES 128
+fqh_status fqh_comm_unique_id(uint8_t id[FQH_COMM_ID_BYTES]);
+fqh_status fqh_comm_create(fqh_ctx *ctx, int n_ranks, int rank, const uint8_t id[FQH_COMM_ID_BYTES], fqh_comm **out);
+void fqh_comm_destroy(fqh_comm *comm);
+fqh_status fqh_allgather(fqh_ctx *ctx, fqh_comm *comm, const void *d_send, void *d_recv, uint64_t bytes_per_rank);
+fqh_status fqh_allreduce_u64(fqh_ctx *ctx, fqh_comm *comm, uint64_t *d_buf, uint64_t n);
+fqh_status fqh_sync(fqh_ctx *ctx);
+
 /* Forget the cached tile index.  The index describes the BYTES of the last scanned buffer; fqh_memcpy_h2d, fqh_memset and
  * fqh_synth_fill drop it themselves when they write into that buffer, writes the library cannot see (the caller's
  * own kernels, an allocator that hands the same address out again) need this call before fqh_stats /

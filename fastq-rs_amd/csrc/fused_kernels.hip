@@ -399,6 +399,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    // (this group's last 512 bytes, for the next group's tail: read now, written at the group's end)
+                    const uint2 tailv = *reinterpret_cast<const uint2 *>(lds8 + wbase + FZ_GROUP + 8u * lane);
                     uint32_t m_lo, m_hi;
                     {
                         const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u) & 48u));
@@ -443,18 +445,18 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                     tot = gtot < FZ_GLIST ? gtot : FZ_GLIST;
                     const uint32_t ebase = g * FZ_GROUP + lane * 64u;
                     if (pre + cl <= FZ_GLIST) {  // (a lane whose entries would leave the list writes none: the span is bad anyway)
+                        // offsets only; the '@' / '+' bits are added by the per-entry pass below (one LDS round trip there
+                        // instead of one per iteration here)
                         uint16_t *dst = lst + pre;
                         while (ls_lo) {
                             const uint32_t q = __ffs(ls_lo) - 1;
                             ls_lo &= ls_lo - 1;
-                            const uint32_t b = rptr[q];
-                            *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                            *dst++ = (uint16_t)(ebase + q);
                         }
                         while (ls_hi) {
                             const uint32_t q = __ffs(ls_hi) + 31;
                             ls_hi &= ls_hi - 1;
-                            const uint32_t b = rptr[q];
-                            *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                            *dst++ = (uint16_t)(ebase + q);
                         }
                     }
                     const int gofs = (int)FZ_TAIL - (int)(g * FZ_GROUP);  // tile offset -> y (position in the wave's data area)
@@ -486,10 +488,25 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         const uint32_t p = c0 + lane;
                         const uint32_t ti = run + p;
                         uint32_t Pent = 0;      // the line entry p closes
-                        uint32_t e4 = 0;
+                        uint32_t e4 = 0, bcr = 0;
                         uint32_t l = 0;
+                        int yc = 0;
+                        // phase A: the entry, the first byte of the line it starts ('@' / '+': read_header / read_sep look at
+                        // nothing else, src/records.rs:141,155) and the byte in front of the '\n' that closes the line before it
                         if (p < totv) {
                             e4 = lst[p];
+                            yc = (int)(e4 & 0x3FFFu) + gofs;
+                            if (p >= tot && yc < (int)FZ_TAIL) yc += (int)WT_BYTES;  // (the virtual entry's offset may have wrapped)
+                            const uint8_t *at = lds8 + wbase + (uint32_t)yc;
+                            const uint32_t b0 = at[0];
+                            bcr = *(at - 2);
+                            e4 |= (b0 == '@' ? 0x4000u : 0u) | (b0 == '+' ? 0x8000u : 0u);
+                            if (p < tot) lst[p] = (uint16_t)e4;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        // phase B: the window of five entries that ends here, and the line entry p closes
+                        if (p < totv) {
                             const uint32_t e3 = lst[(int)p - 1];
                             if (p < tot && !(z.dbg & 8u)) {
                                 if (ti < 4) {
@@ -501,16 +518,15 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                     have |= 1u << (ti & 3u);
                                     bad |= ok ? 0u : 1u << (ti & 3u);
                                 }
+                                if (tot >= 4 && p + 4 >= tot) lst[(int)p - (int)tot] = (uint16_t)e4;  // the last four go in front of the next group's
                             }
                             if ((srun | p) != 0) {  // (the span's first entry closes a line that is not this wave's)
                                 l = ((e4 - e3) & 0x3FFFu) - 1u;  // raw line, without its '\n'
-                                int yc = (int)(e4 & 0x3FFFu) + gofs;
-                                if (p >= tot && yc < (int)FZ_TAIL) yc += (int)WT_BYTES;  // (the virtual entry's offset may have wrapped)
                                 const int ys = yc - 1 - (int)l;
                                 if (ys < 0) {
                                     span_bad = true;  // began before the kept tail (longer than ~500 bytes)
                                 } else {
-                                    if (l && lds8[wbase + (uint32_t)ys + l - 1] == '\r') --l;  // trim_winline, src/records.rs:66-73
+                                    if (l && bcr == '\r') --l;  // trim_winline, src/records.rs:66-73
                                     if (l > lc) span_bad = true;  // longer than the histogram's rows
                                     else Pent = l | FZ_P_ACT | ((uint32_t)ys << 16);
                                 }
@@ -552,16 +568,15 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             fz_lines2<NSL>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, cnt);
                         }
                     }
-                    // ---- the next group finds this one's last 512 bytes and last four entries in front of its own
+                    // ---- the next group finds this one's last 512 bytes (and, above, its last four entries) in front of its own
                     __builtin_amdgcn_wave_barrier();
-                    {
-                        const uint2 tv = *reinterpret_cast<const uint2 *>(lds8 + wbase + FZ_GROUP + 8u * lane);
+                    if (tot < 4) {  // (rare: the four entries in front of the next group are partly the old ones)
                         const uint32_t hv = lane < 4 ? (uint32_t)lst[(int)tot - 4 + (int)lane] : 0u;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        *reinterpret_cast<uint2 *>(lds8 + wbase + 8u * lane) = tv;
                         if (lane < 4) lst[(int)lane - 4] = (uint16_t)hv;
                     }
+                    *reinterpret_cast<uint2 *>(lds8 + wbase + 8u * lane) = tailv;
                 }
                 const uint32_t trun = run + tot;  // entries of the whole tile
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

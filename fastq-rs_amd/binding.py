@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfastq_hip.so")
+# (FQH_LIB_PATH: a tuning build of the same library, tools/exp_fztime.sh; never a fallback)
+LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.so")
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",

@@ -189,8 +189,8 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
             HIPCHK(ctx, hipMalloc((void **)&ctx->stats_scratch, need));
             ctx->stats_scratch_bytes = need;
         }
-        if (!ctx->side) HIPCHK(ctx, hipMalloc((void **)&ctx->side, FQH_NSCALARS * sizeof(unsigned long long)));
-        HIPCHK(ctx, hipMemsetAsync(ctx->side, 0, FQH_NSCALARS * sizeof(unsigned long long), s));
+        if (!ctx->side) HIPCHK(ctx, hipMalloc((void **)&ctx->side, 2 * FQH_NSCALARS * sizeof(unsigned long long)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->side, 0, 2 * FQH_NSCALARS * sizeof(unsigned long long), s));
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));  // (after the memset: index_ms is the kernel alone)
         fz.buf = a.buf;
         fz.len = a.len;
@@ -203,6 +203,14 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.scratch = ctx->stats_scratch;
         fz.scalars = ctx->side;
         if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fz, ctx->n_cu));
+#ifdef FQH_FZ_TIMING  // tuning builds only: cycles a wave spends per phase of a group (tools/exp_fztime.sh)
+        {
+            unsigned long long t[6];
+            (void)hipMemcpyAsync(t, ctx->side + FQH_NSCALARS, sizeof t, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "FZ_TIMING write+prefetch %llu masks %llu staging %llu entries %llu lines %llu rest %llu\n", t[0], t[1], t[2], t[3], t[4], t[5]);
+        }
+#endif
         ctx->index_full = false;
     } else if (!reuse_index) {
         launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs, a.n_tiles,

@@ -313,6 +313,12 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
     const uint32_t nw = gridDim.x * FZ_WAVES;
     const uint32_t lo = lane * 16u;
     uint32_t n_over = 0;
+#ifdef FQH_FZ_TIMING
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tk = 0;
+#define FZ_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; } while (0)
+#else
+#define FZ_T(i) do { } while (0)
+#endif
 
     // the four 16-byte pieces of this lane for group g of tile t (whole tiles: unconditional loads)
     auto fetch_group = [&](uint32_t t, uint32_t g, uint4 &n0, uint4 &n1, uint4 &n2, uint4 &n3) {
@@ -370,6 +376,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
 #pragma unroll 1
                 for (uint32_t g = 0; g < ng; ++g) {
                     const bool last_g = g + 1 == ng;
+#ifdef FQH_FZ_TIMING
+                    tk = __builtin_readcyclecounter();
+#endif
                     __builtin_amdgcn_wave_barrier();
                     *reinterpret_cast<uint4 *>(wptr) = n0;
                     *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    FZ_T(0);  // LDS write, prefetch issue
                     // (this group's last 512 bytes, for the next group's tail: read now, written at the group's end)
                     const uint2 tailv = *reinterpret_cast<const uint2 *>(lds8 + wbase + FZ_GROUP + 8u * lane);
                     uint32_t m_lo, m_hi;
@@ -438,6 +448,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             gtot += (uint32_t)__popcll(b);
                         }
                     }
+                    FZ_T(1);  // read-back, newline masks, prefix
                     run += tot;   // the previous group's entries are behind us now
                     srun += tot;
                     if (g == 0) run = 0;  // (they belonged to the previous tile)
@@ -459,6 +470,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             *dst++ = (uint16_t)(ebase + q);
                         }
                     }
+                    FZ_T(2);  // staging
                     const int gofs = (int)FZ_TAIL - (int)(g * FZ_GROUP);  // tile offset -> y (position in the wave's data area)
                     // ---- the span's last group: its last line ends in another wavefront's span (or with the buffer); the
                     // 512 bytes after the span close it, as one more (virtual) entry behind the group's
@@ -532,6 +544,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                 }
                             }
                         }
+                        FZ_T(3);  // per-entry pass
                         span_bad = __ballot(span_bad) != 0;
                         if (tile == t0 && g == 0 && c0 == 0) {  // the span's first entries must single out the alignment it is counted under
                             uint32_t cons = 0;
@@ -565,7 +578,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             const uint32_t nls = cnt_c > ps ? (cnt_c - ps + 3) >> 2 : 0u, nlq = cnt_c > pq0 ? (cnt_c - pq0 + 3) >> 2 : 0u;
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
                             const bool cnt = !(z.dbg & 2u);
+                            FZ_T(5);
                             fz_lines2<NSL>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, cnt);
+                            FZ_T(4);  // lines: lookups, reads, counts
                         }
                     }
                     // ---- the next group finds this one's last 512 bytes (and, above, its last four entries) in front of its own
@@ -577,6 +592,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         if (lane < 4) lst[(int)lane - 4] = (uint16_t)hv;
                     }
                     *reinterpret_cast<uint2 *>(lds8 + wbase + 8u * lane) = tailv;
+                    FZ_T(5);  // the rest
                 }
                 const uint32_t trun = run + tot;  // entries of the whole tile
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -616,6 +632,10 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
         if (pending) __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
     }
     if (lane == 0 && n_over) atomicAdd(&z.out->spec_fail, (unsigned long long)n_over);
+#ifdef FQH_FZ_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&z.scalars[8 + i], tph[i]);
+#endif
 
     // ---- per-block partial histogram, per-wave totals
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

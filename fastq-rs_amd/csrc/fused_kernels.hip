@@ -45,7 +45,10 @@ namespace fqh {
 #define FQH_FZ_W5 16
 #endif
 constexpr uint32_t FZ_WAVES_MAX = 16;              // wavefronts per block: 16 with up to 160 rows, 12 with 256 (LDS)
-constexpr uint32_t FZ_SPAN = 4;                     // tiles a wavefront walks in one go
+#ifndef FQH_FZ_SPAN
+#define FQH_FZ_SPAN 4
+#endif
+constexpr uint32_t FZ_SPAN = FQH_FZ_SPAN;                     // tiles a wavefront walks in one go
 constexpr uint32_t FZ_GROUP = 4096;                 // bytes per group: 64 contiguous bytes per lane
 constexpr uint32_t FZ_TAIL = 512;                   // bytes of the previous group kept in front of the group
 constexpr uint32_t FZ_POST = 512;                   // bytes after the span, for the span's last line

@@ -28,12 +28,78 @@ pub struct fqh_chunk {
     pub err_record: u64, pub err_offset: u64, pub err_need: u64,
 }
 
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct fqh_carry { pub base_offset: u64, pub nl_count: u64, pub back: [u64; 4] }
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct fqh_summary {
+    pub n_records: u64, pub bytes_consumed: u64, pub parse_status: i32, pub reserved: i32,
+    pub err_record: u64, pub err_offset: u64, pub n_newlines: u64, pub tail_len: u64,
+    pub max_record_len: u64, pub n_line_starts: u64,
+}
+
+#[repr(C)] pub struct fqh_comm { _p: [u8; 0] }
+pub const FQH_COMM_ID_BYTES: usize = 128;
+pub const FQH_OPT_FAST_PATH: c_int = 1;
+pub const FQH_OPT_SINGLE_PASS: c_int = 2;
+
 #[link(name = "fastq_hip")]
 extern "C" {
     pub fn fqh_create(device: c_int, out: *mut *mut fqh_ctx) -> c_int;
     pub fn fqh_destroy(ctx: *mut fqh_ctx);
     pub fn fqh_strerror(status: c_int) -> *const c_char;
+    pub fn fqh_last_error(ctx: *mut fqh_ctx) -> *const c_char;
+    pub fn fqh_abi_version() -> c_int;
+    pub fn fqh_set_stream(ctx: *mut fqh_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn fqh_set_bufsize(ctx: *mut fqh_ctx, bufsize: u64) -> c_int;
+    pub fn fqh_set_option(ctx: *mut fqh_ctx, option: c_int, value: c_int) -> c_int;
+    pub fn fqh_last_scan_fast(ctx: *mut fqh_ctx) -> c_int;
+
+    // ---- whole buffers in HBM: IdxRecord::from_buffer over every record (src/records.rs:201-247)
+    pub fn fqh_scan(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int, carry_in: *const fqh_carry,
+                    d_rec_start: *mut u64, cap: u64, out: *mut fqh_summary, carry_out: *mut fqh_carry) -> c_int;
+    pub fn fqh_scan_launch(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int, carry_in: *const fqh_carry,
+                           d_rec_start: *mut u64, cap: u64) -> c_int;
+    pub fn fqh_scan_finish(ctx: *mut fqh_ctx, out: *mut fqh_summary, carry_out: *mut fqh_carry) -> c_int;
+    pub fn fqh_index_records(ctx: *mut fqh_ctx, d_index: *mut fqh_idx_record, cap: u64) -> c_int;
+    pub fn fqh_invalidate(ctx: *mut fqh_ctx) -> c_int;
+
+    // ---- the closure of Parser::each that reads seq() / qual() (src/lib.rs:226-237, src/records.rs:75-90)
+    pub fn fqh_stats(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int, carry_in: *const fqh_carry,
+                     lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64,
+                     out: *mut fqh_summary, carry_out: *mut fqh_carry) -> c_int;
+    pub fn fqh_stats_launch(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int, carry_in: *const fqh_carry,
+                            lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64) -> c_int;
+    pub fn fqh_stats_launch_lead(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, lead_len: u64, is_final: c_int,
+                                 carry_in: *const fqh_carry, lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64,
+                                 d_scalars: *mut u64) -> c_int;
+    pub fn fqh_stats_finish(ctx: *mut fqh_ctx, out: *mut fqh_summary, carry_out: *mut fqh_carry) -> c_int;
+    pub fn fqh_scan_stats(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int, carry_in: *const fqh_carry,
+                          d_rec_start: *mut u64, cap: u64, lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64,
+                          d_scalars: *mut u64, out: *mut fqh_summary, carry_out: *mut fqh_carry) -> c_int;
+    pub fn fqh_scan_stats_launch(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int,
+                                 carry_in: *const fqh_carry, d_rec_start: *mut u64, cap: u64, lmax: u32,
+                                 d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64) -> c_int;
+    pub fn fqh_scan_stats_finish(ctx: *mut fqh_ctx, out: *mut fqh_summary, carry_out: *mut fqh_carry) -> c_int;
+
+    // ---- byte-range shards across GPUs (the crate is single-process; nearest: src/lib.rs:553-559)
+    pub fn fqh_shard_prescan(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, n_newlines: *mut u64,
+                             n_line_starts: *mut u64, back_zero_carry: *mut u64) -> c_int;
+    pub fn fqh_carry_combine(prev: *const fqh_carry, len: u64, n_newlines: u64, n_line_starts: u64,
+                             back_zero_carry: *const u64, next: *mut fqh_carry) -> c_int;
+    pub fn fqh_rescan_launch(ctx: *mut fqh_ctx, is_final: c_int, carry_in: *const fqh_carry, d_rec_start: *mut u64,
+                             cap: u64) -> c_int;
+    pub fn fqh_shard_align(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, prev_is_newline: c_int, phase: *mut u32,
+                           first_record_offset: *mut u64) -> c_int;
+    pub fn fqh_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn fqh_comm_create(ctx: *mut fqh_ctx, n_ranks: c_int, rank: c_int, id: *const u8, out: *mut *mut fqh_comm) -> c_int;
+    pub fn fqh_comm_destroy(comm: *mut fqh_comm);
+    pub fn fqh_allgather(ctx: *mut fqh_ctx, comm: *mut fqh_comm, d_send: *const c_void, d_recv: *mut c_void,
+                         bytes_per_rank: u64) -> c_int;
+    pub fn fqh_allreduce_u64(ctx: *mut fqh_ctx, comm: *mut fqh_comm, d_buf: *mut u64, n: u64) -> c_int;
+    pub fn fqh_sync(ctx: *mut fqh_ctx) -> c_int;
+
+    // ---- Buffer + thread_reader (src/buffer.rs, src/thread_reader.rs:182-200): the pinned ring
     pub fn fqh_stream_create(ctx: *mut fqh_ctx, slot_bytes: u64, n_slots: u32, flags: u32,
                              out: *mut *mut fqh_stream) -> c_int;
     pub fn fqh_stream_destroy(st: *mut fqh_stream);
@@ -41,6 +107,7 @@ extern "C" {
     pub fn fqh_stream_submit(st: *mut fqh_stream, nbytes: u64, is_final: c_int) -> c_int;
     pub fn fqh_stream_collect(st: *mut fqh_stream, out: *mut fqh_chunk) -> c_int;
     pub fn fqh_stream_release(st: *mut fqh_stream) -> c_int;
+    pub fn fqh_stream_carry(st: *mut fqh_stream, out: *mut fqh_carry) -> c_int;
     // histograms per delivered record (FQH_STREAM_STATS) and the device-side filter (flags + gather);
     // not needed by Parser itself, bound for consumers that want them
     pub fn fqh_stream_set_stats(st: *mut fqh_stream, lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64,
@@ -50,6 +117,13 @@ extern "C" {
     pub fn fqh_gather_records(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, base_offset: u64,
                               d_index: *const fqh_idx_record, n: u64, d_flags: *const u8, mask: u8, want: u8,
                               d_out: *mut u8, out_cap: u64, n_selected: *mut u64, out_bytes: *mut u64) -> c_int;
+
+    // ---- device memory for hosts without a HIP binding of their own
+    pub fn fqh_dev_alloc(ctx: *mut fqh_ctx, bytes: u64, d_ptr: *mut *mut c_void) -> c_int;
+    pub fn fqh_dev_free(ctx: *mut fqh_ctx, d_ptr: *mut c_void) -> c_int;
+    pub fn fqh_memcpy_h2d(ctx: *mut fqh_ctx, d_dst: *mut c_void, h_src: *const c_void, bytes: u64) -> c_int;
+    pub fn fqh_memcpy_d2h(ctx: *mut fqh_ctx, h_dst: *mut c_void, d_src: *const c_void, bytes: u64) -> c_int;
+    pub fn fqh_memset(ctx: *mut fqh_ctx, d_dst: *mut c_void, value: c_int, bytes: u64) -> c_int;
 }
 
 const FQH_OK: c_int = 0;
@@ -61,6 +135,8 @@ const FQH_STREAM_STATS: u32 = 2;
 /// What `Parser` holds instead of `buffer::Buffer`.
 pub struct GpuScanner<R: Read> {
     reader: R, ctx: *mut fqh_ctx, st: *mut fqh_stream, eof: bool,
+    /// a chunk's parse error waits here while the records in front of it are handed out
+    pending: Option<Error>,
 }
 
 impl<R: Read> GpuScanner<R> {
@@ -74,7 +150,7 @@ impl<R: Read> GpuScanner<R> {
                 fqh_destroy(ctx);
                 return Err(Error::new(ErrorKind::Other, "fqh_stream_create"));
             }
-            Ok(GpuScanner { reader, ctx, st, eof: false })
+            Ok(GpuScanner { reader, ctx, st, eof: false, pending: None })
         }
     }
 
@@ -98,7 +174,9 @@ impl<R: Read> GpuScanner<R> {
                         Err(e) => return Err(e),
                     }
                 }
-                fqh_stream_submit(self.st, n as u64, self.eof as c_int);
+                if fqh_stream_submit(self.st, n as u64, self.eof as c_int) != FQH_OK {
+                    return Err(Error::new(ErrorKind::Other, "fqh_stream_submit"));
+                }
             }
             Ok(())
         }
@@ -106,17 +184,23 @@ impl<R: Read> GpuScanner<R> {
 
     /// One chunk of records: the GPU's replacement for ~hundreds of thousands of
     /// `IdxRecord::from_buffer` calls.  The slices stay valid until the next call.
+    ///
+    /// A chunk that ends in a parse error still carries the `n_records` valid records in front of
+    /// the bad one; `Parser::each` (src/lib.rs:226-237) hands those to the closure before it returns
+    /// the error, so they are returned first and the error by the call after.
     pub fn next_chunk(&mut self) -> Result<Option<(&[u8], &[fqh_idx_record], u64, bool)>> {
+        if let Some(e) = self.pending.take() { return Err(e); }
         self.fill()?;
         unsafe {
             let mut c: fqh_chunk = std::mem::zeroed();
             fqh_stream_release(self.st); // releases the previous chunk, if any
             if fqh_stream_collect(self.st, &mut c) != FQH_OK { return Ok(None); }
             if c.parse_status != FQH_OK {
-                // records before the error were delivered with the previous chunks / this index;
                 // the error text is the crate's own (fqh_strerror returns the exact strings)
                 let msg = std::ffi::CStr::from_ptr(fqh_strerror(c.parse_status)).to_string_lossy().into_owned();
-                return Err(Error::new(ErrorKind::InvalidData, msg));
+                let e = Error::new(ErrorKind::InvalidData, msg);
+                if c.n_records == 0 { return Err(e); }
+                self.pending = Some(e);
             }
             let lead = c.lead_len as usize;
             let bytes = std::slice::from_raw_parts(c.h_data.sub(lead), lead + c.data_len as usize);

@@ -6,9 +6,9 @@
 //
 // What bounds it is the vector ALU (a wave64 VALU operation occupies its SIMD for four cycles: 4.8e9 of them
 // per 16 GiB made the first version take 11 ms), then the LDS atomic unit; HBM comes third.  Hence:
-//   * one block per CU owns the CU's LDS: the bank-scheduled histogram (stats_dev.h) and, behind it, 5.5 KiB per
-//     wavefront: [512 B tail of the previous group | 4 KiB group | 512 B of the bytes after the span | 128 B tile
-//     line | 4 + 188 line-start entries];
+//   * one block per CU owns the CU's LDS: the bank-scheduled histogram (stats_dev.h) and, behind it, 6 160 B per
+//     wavefront: [512 B tail of the previous group | 4 KiB group | 512 B of the bytes after the span | 16 B |
+//     256 record starts of the tile | 4 + 251 + 1 line-start entries];
 //   * a wavefront takes SPANS of four 16 KiB tiles round-robin and walks them 4 KiB at a time like k_index_fast
 //     (16-byte non-temporal loads a group ahead, SWAR newline masks, ballot prefix).  The LDS image is LINEAR; the
 //     lane-contiguous read-back is conflict-free because lane l reads its four 16-byte chunks in the order
@@ -18,15 +18,16 @@
 //     the span is counted under; every tile must confirm it, and k_emit_fast checks each tile's against the true
 //     global line index.  Any doubt sets spec_fail and nothing of this pass is used;
 //   * every line that ENDS in a group is counted from LDS (the tail keeps the 512 bytes in front of the group, so
-//     a line that straddles groups or tiles is contiguous): one lane per line works out start and length
-//     (trim_winline: one '\r'), eight lines make a batch, a lane's dword of each step is one ds_read2_b32 with an
+//     a line that straddles groups or tiles is contiguous): one lane per ENTRY first fetches the class bits of the
+//     entry's window and the byte in front of the newline in one LDS round trip, then works out the line's start and
+//     length (trim_winline: one '\r'); eight lines make a batch, a lane's dword of each step is one ds_read2_b32 with an
 //     immediate offset and one v_alignbyte, then pass 1 / pass 2 of the bank schedule: one v_perm_b32 + one
 //     ds_sub_u32 per byte.  A batch that is not full at the end of a group stays in registers and is filled up by
 //     the next group's lines (batches are 97 % full instead of 77 %);
 //   * the span's last line ends in another wavefront's span: the 512 bytes after the span are read as well and
 //     the line is closed there;
 //   * no exact path in here: a byte outside ACGTN / '!'..'`', a line longer than the histogram's rows or than the
-//     kept tail, more than 188 line starts in 4 KiB — the span is marked bad, spec_fail is set, and the caller
+//     kept tail, more than 251 line starts in 4 KiB — the span is marked bad, spec_fail is set, and the caller
 //     reruns on the exact two-pass route (k_index_t + k_stats_oct), which handles all of it;
 //   * per-block partial histograms and the totals go to scratch; k_stats_commit adds them to the caller's arrays
 //     only if the scan's finalize kernel found no reason to doubt the fast path.

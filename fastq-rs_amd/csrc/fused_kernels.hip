@@ -62,6 +62,13 @@ static_assert(FZ_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesse
 
 typedef uint32_t fz_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 
+// spans of FZ_SPAN tiles; a last partial tile of at most one group belongs to the span in front of it
+__host__ __device__ __forceinline__ uint32_t fz_spans(uint64_t n_tiles, uint64_t len) {
+    const uint64_t tail = len & (WT_BYTES - 1);
+    const uint64_t own = (n_tiles > 1 && tail != 0 && tail <= FZ_GROUP) ? n_tiles - 1 : n_tiles;
+    return (uint32_t)((own + FZ_SPAN - 1) / FZ_SPAN);
+}
+
 // A line as one lane knows it: bits 0-8 its length (columns), bit 12 "there is a line", bits 16-28 the LDS position y of
 // its first byte in the wave's data area.  The low 16 bits are the shape key.
 constexpr uint32_t FZ_P_ACT = 0x1000u;
@@ -313,7 +320,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
     const uint64_t len = z.len;
     const uint32_t n_tiles = (uint32_t)z.n_tiles;
     const uint32_t n_full = (uint32_t)(len >> WT_SHIFT);
-    const uint32_t n_spans = (n_tiles + FZ_SPAN - 1) / FZ_SPAN;
+    // (a partial tile of at most one group at the end of the buffer rides with the span in front of it: too few line
+    // starts to settle an alignment of its own)
+    const uint32_t n_spans = fz_spans(n_tiles, len);
     const uint32_t nw = gridDim.x * FZ_WAVES;
     const uint32_t lo = lane * 16u;
     uint32_t n_over = 0;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
         for (; span < n_spans; span += nw) {
             const uint32_t nspan = span + nw < n_spans ? span + nw : span;  // clamped: the prefetch is unconditional
             const uint32_t t0 = span * FZ_SPAN;
-            const uint32_t t1 = t0 + FZ_SPAN < n_tiles ? t0 + FZ_SPAN : n_tiles;
+            const uint32_t t1 = span + 1 == n_spans ? n_tiles : t0 + FZ_SPAN;
             uint32_t srun = 0;       // entries of the span before the current group
             uint32_t tot = 0;        // entries of the current group
             uint32_t prev;           // the byte before the group is a newline
@@ -602,12 +611,22 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 // ---- the tile must confirm the alignment: still the only consistent one
+                // (the short tile at the end of the buffer cannot: it is counted under the span's alignment, marked FR_SMALL,
+                // and k_finalize_fast validates its records against the true line index)
+                const bool small_t = !full && trun < 8;
                 {
-                    uint32_t cons = 0;
+                    uint32_t cons = 0, badb = 0;
 #pragma unroll
-                    for (uint32_t r = 0; r < 4; ++r)
-                        if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
-                    if (trun < 8 || hyp_t > 3 || cons != (1u << hyp_t)) span_bad = true;
+                    for (uint32_t r = 0; r < 4; ++r) {
+                        const bool b = __ballot((bad >> r) & 1u) != 0;
+                        badb |= b ? 1u << r : 0u;
+                        if (__ballot((have >> r) & 1u) && !b) cons |= 1u << r;
+                    }
+                    if (small_t) {
+                        if (hyp_t > 3 || ((badb >> hyp_t) & 1u)) span_bad = true;
+                    } else if (trun < 8 || hyp_t > 3 || cons != (1u << hyp_t)) {
+                        span_bad = true;
+                    }
                 }
                 // ---- the tile's line: record starts (the lanes staged them), first and last four entries, count, alignment;
                 // record starts beyond the line's FR_N go to a second line and to the list area (reads shorter than ~140 bp)
@@ -615,6 +634,10 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                     uint32_t rv = lane < FR_N ? (uint32_t)trs[lane] : 0u;
                     if (lane >= FR_EDGE && lane < FR_EDGE + 4) rv = tedge[lane - FR_EDGE];
                     if (lane >= FR_EDGE + 4 && lane < FR_EDGE + 8) rv = lst[(int)lane - (int)(FR_EDGE + 8)];
+                    if (small_t) {  // entries 0 .. trun - 1 in order, no record starts
+                        const uint32_t k = lane - FR_EDGE;
+                        rv = (lane >= FR_EDGE && k < trun) ? (k < 4 ? (uint32_t)tedge[k] : (uint32_t)lst[(int)k - (int)trun]) : 0u;
+                    }
                     const uint32_t nrs = trun > hyp_t ? (trun - hyp_t + 3) >> 2 : 0u;  // record starts of the tile
                     if (nrs > FR_N && hyp_t < 4) {
                         z.fast_rs[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + lane] = trs[FR_N + lane];
@@ -626,7 +649,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         trs[192 + lane] = 0;
                     }
                     if (span_bad) ++n_over;
-                    prv = lane == FR_CNT ? (trun & 0xFFFFu) : lane == FR_CNT + 1 ? (trun >> 16) : lane == FR_HYP ? (span_bad ? 7u : hyp_t) : rv;
+                    prv = lane == FR_CNT ? (trun & 0xFFFFu) : lane == FR_CNT + 1 ? (trun >> 16) : lane == FR_HYP ? (span_bad ? 7u : small_t ? (FR_SMALL | hyp_t) : hyp_t) : rv;
                 }
                 ptile = tile;
                 pending = true;

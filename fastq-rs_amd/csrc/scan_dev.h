@@ -122,6 +122,11 @@ __device__ __forceinline__ void index_piece(const uint4 v, const uint64_t off, c
 // measures the same as the 7 that 512 entries allow (tools/exp_ab_env.py FQH_INDEX_BPC 0 6).
 constexpr uint32_t FAST_ENTRIES = 1024;
 constexpr uint32_t FR_N = 52, FR_EDGE = 52, FR_CNT = 60, FR_HYP = 62, FR_STRIDE = 64, FR2_N = 64;
+// [FR_HYP] >= FR_SMALL: the short partial tile at the end of the buffer (fewer than eight line starts — too few for the
+// windows to single out an alignment).  Its entries 0 .. count-1 sit in the eight edge slots in order, nothing of it
+// was validated or emitted by the per-tile kernels: k_finalize_fast does both, with the true line index in hand.
+// Low bits: 0..3 = the alignment k_scan_stats counted the tile's lines under (finalize checks it), 4 = nothing counted.
+constexpr uint32_t FR_SMALL = 8;
 __host__ __device__ __forceinline__ uint64_t fr2_off(uint64_t n_tiles) { return (n_tiles + 64) * FR_STRIDE; }
 
 }  // namespace fqh

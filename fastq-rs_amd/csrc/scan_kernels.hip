@@ -671,8 +671,15 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
     const uint32_t lo = lane * 16;
 
     // evaluate the four alignments over the staged list; rv = this lane's slot of the tile's line
-    auto finish_tile = [&](uint64_t tile, uint32_t run, uint32_t nstaged, uint32_t &rv) {
+    auto finish_tile = [&](uint64_t tile, uint32_t run, uint32_t nstaged, uint32_t &rv, bool tail) {
         uint32_t hyp = 7;
+        if (tail && nstaged == run && run < 8) {  // the short tile at the end of the buffer: left to k_finalize_fast
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            rv = (lane >= FR_EDGE && lane < FR_EDGE + run) ? (uint32_t)lst[lane - FR_EDGE] : 0u;
+            rv = lane == FR_CNT ? run : lane == FR_HYP ? (FR_SMALL | 4u) : rv;
+            return;
+        }
         if (nstaged == run && run >= 8) {  // uniform
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                 }  // else: more than FAST_ENTRIES line starts in a tile: left to the exact path
                 run += tot;
             }
-            finish_tile(tile, run, nstaged, prv);
+            finish_tile(tile, run, nstaged, prv, false);
             prun = run;
             ptile = tile;
             pending = true;
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
             index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, FAST_ENTRIES);
         }
         uint32_t rv;
-        finish_tile(t, run, run <= FAST_ENTRIES ? run : 0u, rv);
+        finish_tile(t, run, run <= FAST_ENTRIES ? run : 0u, rv, true);
         store_tile(t, run, rv);
     }
     if (lane == 0 && n_over) atomicAdd(&out->spec_fail, (unsigned long long)n_over);
@@ -864,8 +871,9 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
         const uint32_t pz = wave_shr1(e.z, pz0), pw = wave_shr1(e.w, pw0);  // previous tile's last four entries
         const unsigned long long lbase = a.nl_count + 1 + bp + tp;
         const uint32_t r = (4u - ((uint32_t)lbase & 3u)) & 3u;             // entry index of the first record start
-        const bool has = cnt != 0;
-        bool bad = has && hyp != r;
+        const bool small = hyp >= FR_SMALL;   // the short tile at the end of the buffer: k_finalize_fast's
+        const bool has = cnt != 0 && !small;
+        bool bad = (has && hyp != r) || (small && T + 1 != a.n_tiles);
         const uint32_t nrs = has && cnt > r ? (cnt - r + 3) >> 2 : 0u;
         const unsigned long long rbase = ((lbase + r) >> 2) - r0;
         if (has && T) {  // the record that ends at entry r started in the previous tile (tile 0: k_finalize_fast)
@@ -986,7 +994,11 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
     const bool lastnl = a.len > 0 && a.buf[a.len - 1] == '\n';
     const uint64_t tl_last = a.n_tiles ? a.n_tiles - 1 : 0;
-    if (!fail && (a.tile_count[0] < 4 || a.tile_count[tl_last] < 4 || E < 8)) fail = true;
+    const uint32_t hyp_last = a.n_tiles ? a.fast_rs[tl_last * FR_STRIDE + FR_HYP] : 7u;
+    const bool small = hyp_last >= FR_SMALL;  // a short tile at the end: all of its (< 8) entries are in its edge slots
+    if (!fail && (a.tile_count[0] < 4 || E < 8)) fail = true;
+    if (!fail && (small ? (a.n_tiles < 2 || a.tile_count[tl_last] >= 8 || a.tile_count[tl_last - 1] < 4) : a.tile_count[tl_last] < 4))
+        fail = true;
     unsigned long long max_len = out->max_len, first_long = out->first_long;
     const unsigned long long r0 = a.nl_count >> 2;
     long long recent[4] = {0, 0, 0, 0};
@@ -1035,12 +1047,50 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         if (a.rec_start && a.cap > 0) a.rec_start[0] = a.base_offset - a.back[a.nl_count & 3];
 
         // ---- chunk end: the last four entries (with their class bits)
-        const uint16_t *el = a.fast_rs + tl_last * FR_STRIDE + FR_EDGE + 4;
         uint32_t le[4];
         long long ls[4];
-        for (int k = 0; k < 4; ++k) {  // k = 0: most recent
-            le[k] = el[3 - k];
-            ls[k] = (long long)((tl_last << WT_SHIFT) + (le[k] & 0x3FFFu));
+        if (!small) {
+            const uint16_t *el = a.fast_rs + tl_last * FR_STRIDE + FR_EDGE + 4;
+            for (int k = 0; k < 4; ++k) {  // k = 0: most recent
+                le[k] = el[3 - k];
+                ls[k] = (long long)((tl_last << WT_SHIFT) + (le[k] & 0x3FFFu));
+            }
+        } else {
+            // the short tail tile: k_emit_fast skipped it.  Its entries behind the previous tile's last four: every
+            // record that ends at one of them has its five line starts in this list (src/records.rs:201-247)
+            const uint32_t cnt = a.tile_count[tl_last];
+            uint32_t ce[12];
+            long long cs[12];
+            const uint16_t *ep = a.fast_rs + (tl_last - 1) * FR_STRIDE + FR_EDGE + 4;
+            const uint16_t *eq = a.fast_rs + tl_last * FR_STRIDE + FR_EDGE;
+            for (uint32_t k = 0; k < 4; ++k) {
+                ce[k] = ep[k];
+                cs[k] = (long long)(((tl_last - 1) << WT_SHIFT) + (ce[k] & 0x3FFFu));
+            }
+            for (uint32_t k = 0; k < cnt; ++k) {
+                ce[4 + k] = eq[k];
+                cs[4 + k] = (long long)((tl_last << WT_SHIFT) + (ce[4 + k] & 0x3FFFu));
+            }
+            const unsigned long long lq0 = a.nl_count + 1 + tile_pref(a, tl_last);  // line index of the tile's entry 0
+            if (!(hyp_last & 4u) && (hyp_last & 3u) != ((4u - ((uint32_t)lq0 & 3u)) & 3u)) fail = true;  // counted under another alignment
+            for (uint32_t j = 0; j < 4 + cnt; ++j) {
+                const unsigned long long l = lq0 + j - 4;
+                if ((l & 3) == 0 && !(ce[j] & 0x4000u)) fail = true;
+                if ((l & 3) == 2 && !(ce[j] & 0x8000u)) fail = true;
+                if (j >= 4 && (l & 3) == 0) {  // a record ends in front of this entry
+                    if ((cs[j] - cs[j - 1]) != (cs[j - 2] - cs[j - 3])) fail = true;
+                    const unsigned long long reclen = (unsigned long long)(cs[j] - cs[j - 4]);
+                    if (reclen > max_len) max_len = reclen;
+                    const unsigned long long rec = (l >> 2) - 1;
+                    if (a.bufsize && reclen + 15 >= a.bufsize && rec < first_long) first_long = rec;
+                    const unsigned long long r = (l >> 2) - r0;
+                    if (a.rec_start && r < a.cap) a.rec_start[r] = a.base_offset + (unsigned long long)cs[j];
+                }
+            }
+            for (uint32_t k = 0; k < 4; ++k) {
+                le[k] = ce[4 + cnt - 1 - k];
+                ls[k] = cs[4 + cnt - 1 - k];
+            }
         }
         n_newlines = E + (lastnl ? 1 : 0);
         T = a.nl_count + n_newlines;

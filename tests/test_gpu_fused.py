@@ -3,6 +3,8 @@ the input gives record offsets AND histograms, the way the reference's Parser::e
 that reads seq()/qual() (src/lib.rs:226-237, src/records.rs:75-90).  Every case is compared bit-for-bit with the
 oracle; the cases also pin WHICH route ran: the single pass where it applies, the exact two-pass route where the
 kernel must decline (bytes outside the alphabet, lmax below the read length, parse errors, long reads)."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -84,15 +86,14 @@ def test_sizes_around_tiles_and_spans(env, fqref, nrec):
     rng = np.random.default_rng(nrec)
     data = make(rng, nrec, 150, hdr=lambda i: b"SYN.%012d 1:N:0:1" % i)
     assert len(data) == 330 * nrec
-    # (a last tile with fewer than four line starts is not something the fast path proves: exact route)
-    tail = len(data) % 16384
-    run(env, fqref, data, 150, want_fused=nrec >= 3 and (tail == 0 or tail > 1400))
+    # (nrec 50, 199, 398: a last tile of a few hundred bytes — fewer than eight line starts — is k_finalize_fast's)
+    run(env, fqref, data, 150, want_fused=nrec >= 3)
 
 
 @pytest.mark.parametrize("shape", ["fixed150", "fixed100", "fixed36", "fixed250", "ragged", "ragged4", "crlf", "plusid",
                                    "qual_at_plus", "empty_reads"])
 def test_single_pass_shapes(env, fqref, shape):
-    rng = np.random.default_rng(abs(hash(shape)) % 1000)
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
     lmaxes = (150,)
     kw = {}
     if shape == "fixed150":
@@ -148,6 +149,67 @@ def test_declined_inputs_take_the_exact_route(env, fqref, shape):
     elif shape == "no_final_nl":
         del data[-1:]
     run(env, fqref, bytes(data), lmax, want_fused=False)
+
+
+@pytest.mark.parametrize("crlf", [0.0, 0.3])
+def test_short_last_tile(env, fqref, crlf):
+    """Files that end a few bytes to a few hundred bytes into a 16 KiB tile: the last tile has 0..7 line starts, which
+    no window of five can vouch for.  The per-tile kernels mark it (FR_SMALL) and k_finalize_fast validates and emits
+    its records; the single pass counts its lines with the span in front of it.  Both routes must keep the fast
+    path, and give the oracle's offsets and histograms."""
+    torch, pkg = env
+    rng = np.random.default_rng(5 + int(crlf * 10))
+    recs = [make(rng, 1, 150 - (k % 3), crlf=crlf, hdr=lambda i: b"q%d" % (k * 7919 % 1000)) for k in range(700)]
+    sizes = np.cumsum([len(r) for r in recs])
+    picked = [k for k in range(120, 700) if sizes[k - 1] % 16384 < 1700]
+    assert len(picked) >= 30
+    for k in picked:
+        data = b"".join(recs[:k])
+        run(env, fqref, data, 150, want_fused=True, offsets=bool(k & 1))
+        # the plain scan on its own takes the same route
+        ctx = pkg.Ctx(0)
+        a = np.frombuffer(data, dtype=np.uint8)
+        d = torch.from_numpy(a.copy()).cuda()
+        rs = torch.zeros(k + 16, dtype=torch.int64, device=d.device)
+        s, c = ctx.scan(d.data_ptr(), a.size, d_rec_start=rs.data_ptr(), cap=rs.numel())[:2]
+        r2, off = fqref.offsets(a)
+        assert ctx.last_scan_fast() and (s.parse_status, s.n_records) == (r2.status, r2.n_records) == (pkg.OK, k)
+        assert np.array_equal(rs.cpu().numpy()[: k + 1].astype(np.uint64), np.append(off, a.size).astype(np.uint64)[: k + 1])
+        ctx.close()
+    # ... and tails of exactly t bytes, for the cuts between and inside the last record's lines
+    for t in (1, 2, 3, 150, 151, 152, 153, 154, 155, 156, 157, 158, 303, 304, 305, 306, 307, 308, 309, 310, 311, 312, 313,
+              600, 620, 640):
+        T0 = 120 * (4 + 151 + 2 + 151)
+        q, r = divmod((t - T0) % 16384, 120)
+        data = make(rng, 120, 150, crlf=0.0, hdr=lambda i: b"h:" + b"p" * (q + (1 if i < r else 0)))
+        assert len(data) % 16384 == t
+        run(env, fqref, data, 150, want_fused=True, offsets=True)
+
+
+def test_short_last_tile_with_errors(env, fqref):
+    """An error inside the short last tile (or in the record that straddles into it) is the exact route's to report."""
+    rng = np.random.default_rng(77)
+    base = make(rng, 120, 150, hdr=lambda i: b"q%d" % i)
+    while len(base) % 16384 > 900 or len(base) % 16384 < 400:
+        base += make(rng, 1, 150, hdr=lambda i: b"x")
+    n = len(base)
+    tail0 = n - n % 16384
+    for kind in ("at", "plus", "len", "trunc", "nonl"):
+        data = bytearray(base)
+        if kind == "at":
+            k = data.rindex(b"\n@") + 1
+            assert k >= tail0
+            data[k] = ord("x")
+        elif kind == "plus":
+            k = data.rindex(b"\n+\n") + 1
+            data[k] = ord("-")
+        elif kind == "len":
+            del data[n - 3]
+        elif kind == "trunc":
+            del data[n - 160:]
+        else:
+            del data[n - 1:]
+        run(env, fqref, bytes(data), 150, want_fused=False)
 
 
 def test_medium_synthetic_parity_and_determinism(env, fqref):

@@ -749,7 +749,13 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
     if (n > skip) {
-        const size_t need = stats_oct_scratch_bytes(lmax, ctx->n_cu);
+        // reads longer than the kernel's 256 LDS rows are counted in several passes, which share one bit per record
+        // and alphabet flag (behind the partial histograms in the scratch)
+        const uint32_t max_line = (uint32_t)std::min<uint64_t>(ctx->last_summary.max_record_len / 2, 0xFFFFFFFFu);
+        const bool passes = std::min(max_line ? max_line : lmax, lmax) > 256;
+        const size_t hist_bytes = stats_oct_scratch_bytes(lmax, ctx->n_cu);
+        const uint64_t flag_words = passes ? (n - skip + 31) / 32 + 1 : 0;
+        const size_t need = hist_bytes + ((size_t)flag_words * 2 + 1) * sizeof(uint32_t);
         if (need > ctx->stats_scratch_bytes) {
             (void)hipFree(ctx->stats_scratch);
             ctx->stats_scratch = nullptr;
@@ -772,7 +778,15 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         sa.block_prefix = ctx->block_prefix;
         sa.n_tiles = ctx->args.n_tiles;
         sa.lmax = lmax;
+        // a delivered record holds its sequence and its quality line, of one length: neither is longer than half of it
+        sa.max_line = max_line;
         sa.scratch = ctx->stats_scratch;
+        if (passes) {
+            sa.flagmap = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->stats_scratch) + hist_bytes);
+            sa.flag_words = flag_words;
+            sa.cr_flag = sa.flagmap + flag_words * 2;
+            HIPCHK(ctx, hipMemsetAsync(sa.flagmap, 0, ((size_t)flag_words * 2 + 1) * sizeof(uint32_t), s));
+        }
         sa.qual_hist = (unsigned long long *)d_qual_hist;
         sa.base_hist = (unsigned long long *)d_base_hist;
         sa.scalars = (unsigned long long *)d_scalars;

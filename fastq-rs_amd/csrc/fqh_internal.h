@@ -69,9 +69,15 @@ struct StatsArgs {
     const uint32_t *tile_prefix;
     const uint64_t *block_prefix;
     uint64_t n_tiles;
-    uint32_t lmax, lc;           // lc = columns kept in LDS
-    uint32_t lx, listw;          // k_stats_oct: extra plain LDS rows lc .. lc + lx (long reads); staged list entries per wave
-    uint32_t *scratch;           // [gridDim.x][lc * 128] per-block partial histograms
+    uint32_t lmax;               // rows of the caller's histograms
+    uint32_t col0, lc;           // this pass of k_stats_oct counts columns col0 .. col0 + lc - 1 (lc <= 256 rows in LDS)
+    uint32_t max_line;           // no line that counts is longer than this (0: unknown); bounds the number of passes
+    uint32_t last;               // this is the pass that holds the last of the caller's rows: it sees sequence lines to their end
+    uint32_t *flagmap;           // several passes: one bit per record that counts, "has an N or worse" in words [0, flag_words),
+    uint64_t flag_words;         //   "has a byte outside ACGTN" behind them (zeroed by the caller); NULL with one pass
+    uint32_t *cr_flag;           // several passes: pass 0 sets it if any line that counts ends in "\r\n"; the others look for '\r' only then
+    uint32_t listw;              // k_stats_oct: staged list entries per wave
+    uint32_t *scratch;           // [gridDim.x][SO_WORDS] per-block partial histograms
     unsigned long long *qual_hist, *base_hist, *scalars;
     uint32_t dbg;                // timing experiments only (FQH_STATS_DBG, k_stats_oct<5, true>): 1 no LDS atomics, 4 no counting,
                                  // 8 generic tile path, 16 no '\\r' probes, 64 sequence lines only, 128 / 256 one / no load per batch,

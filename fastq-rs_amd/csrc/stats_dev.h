@@ -50,8 +50,7 @@ constexpr uint32_t SO_LC_MAX = 256;           // rows kept in LDS
 constexpr uint32_t SO_QBYTES = 4 * 64 * 256;  // quality region: 4 row blocks x 64 bins x 64 slots x 4 B
 constexpr uint32_t SO_SBYTES = 4 * 8 * 256;   // sequence region
 constexpr uint32_t SO_WORDS = (SO_QBYTES + SO_SBYTES) / 4;  // the sequence region comes first: [0, SO_SBYTES)
-constexpr uint32_t SO_LISTW = 512;            // list entries staged in LDS per wave (u16 each); 256 when extra rows need the room
-constexpr uint32_t SO_LX_MAX = 256;           // extra rows (columns 256 .. 511) in a plain [row][72] layout, exact path only
+constexpr uint32_t SO_LISTW = 512;            // list entries staged in LDS per wave (u16 each)
 constexpr uint32_t SO_LDS_MAX = 160 * 1024;
 constexpr uint32_t SO_ADDR_SPAN = 65536 + SO_SBYTES + 128 + 3 * 16384;  // see launch_stats_oct
 
@@ -95,14 +94,11 @@ __device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v) {
     asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(byte_addr), "v"(v), "n"(OFF));
 }
 
-// Columns a.lc .. a.lc + a.lx - 1 (reads longer than the 256 bank-scheduled rows) have plain LDS rows of
-// 72 words (64 quality bins, 8 sequence bins) behind the staged lists; only the exact path touches them.
-__device__ __forceinline__ uint32_t *so_extra(const StatsArgs &a, uint32_t *hist) {
-    return hist + SO_WORDS + (SO_WAVES * a.listw) / 2;
-}
-
-// The exact per-byte statement: columns pos .. of a line of `len` columns held in w.  (lc is the tile's
-// view of the bank-scheduled rows: 0 in tiles that take the exact path for everything.)
+// The exact per-byte statement: columns pos .. of a line of `len` columns held in w, all relative to the pass's first
+// column a.col0.  Only the pass's own columns (< a.lc) are counted: what lies beyond them belongs to a later pass or
+// to the overflow counters, which are plain arithmetic on the line's length; the alphabet flags cover every byte.
+// (lc is the tile's view of the bank-scheduled rows: 0 in tiles that take the exact path for everything; columns the
+// LDS rows do not take — and quality bytes outside '!'..'`' — go to the caller's arrays.)
 template <bool IS_SEQ>
 __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, uint32_t pos, uint32_t len, uint32_t lc,
                                               uint32_t *hist, uint32_t &any_n, uint32_t &any_inv) {
@@ -116,15 +112,13 @@ __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, ui
             const uint32_t bin = valid ? (b & 7u) : 0u;
             any_inv |= valid ? 0u : 1u;
             any_n |= b == 'N' ? 1u : 0u;
+            if (col >= a.lc) continue;
             if (col < lc) atomicAdd(hist + so_word<true>(bin, col), 1u);
-            else if (col - a.lc < a.lx) atomicAdd(so_extra(a, hist) + (col - a.lc) * 72u + 64u + bin, 1u);
-            else if (col < a.lmax) atomicAdd(&a.base_hist[(uint64_t)col * 8 + bin_to_class(bin)], 1ull);
-            else atomicAdd(&a.scalars[IS_SEQ ? 5 : 6], 1ull);  // a column beyond the caller's lmax
+            else atomicAdd(&a.base_hist[(uint64_t)(a.col0 + col) * 8 + bin_to_class(bin)], 1ull);
         } else {
+            if (col >= a.lc) continue;
             if (col < lc && b - 33u < 64u) atomicAdd(hist + so_word<false>(b - 33u, col), 1u);
-            else if (col - a.lc < a.lx && b - 33u < 64u) atomicAdd(so_extra(a, hist) + (col - a.lc) * 72u + (b - 33u), 1u);
-            else if (col < a.lmax) atomicAdd(&a.qual_hist[(uint64_t)col * 256 + b], 1ull);
-            else atomicAdd(&a.scalars[IS_SEQ ? 5 : 6], 1ull);  // a column beyond the caller's lmax
+            else atomicAdd(&a.qual_hist[(uint64_t)(a.col0 + col) * 256 + b], 1ull);
         }
     }
 }
@@ -153,7 +147,19 @@ struct SoAcc {                   // per-lane totals (the lane that owns a line a
 struct SoTotals {
     uint32_t not_dna;            // sequence lines with an 'N' or a byte outside the alphabet
     uint32_t not_dnan;           // sequence lines with a byte outside the alphabet
+    unsigned long long over_s, over_q;  // sequence / quality columns at or beyond the caller's lmax
 };
+// (rare: the caller asked for fewer rows than its reads are long) adds up, over the wave, what each lane's line has
+// beyond lmax columns
+__device__ __forceinline__ unsigned long long so_over(uint32_t len, bool has, uint32_t lmax) {
+    uint32_t v = (has && len > lmax) ? len - lmax : 0u;
+    if (__ballot(v != 0) == 0) return 0;
+    unsigned long long t = v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    return (unsigned long long)__builtin_amdgcn_readfirstlane((int)(uint32_t)t) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t >> 32)) << 32);
+}
 __device__ __forceinline__ uint32_t so_groups(unsigned long long lanes) {  // 8-lane groups with a lane set
     lanes |= lanes >> 4;
     lanes |= lanes >> 2;
@@ -215,7 +221,7 @@ __device__ __forceinline__ void lds_sub(uint32_t byte_addr, uint32_t v) {
 template <bool IS_SEQ, uint32_t NSL, bool DBG>
 __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbase, SoBatch<NSL> &B, SoShape<NSL> &S,
                                          uint32_t lane, uint32_t lc, uint32_t *hist, const SoLane &c, uint32_t my_len,
-                                         uint32_t src4, SoTotals &T, SoAcc &acc, bool trimmed, bool &cr_seen) {
+                                         uint32_t src4, SoTotals &T, SoAcc &acc, bool trimmed, bool &cr_seen, long long lrec) {
     const uint32_t m = lane & 7u, m4 = m * 4u;
     const uint32_t P = B.P;
     if (__ballot((P & 0xFFFFu) != S.key) != 0) so_shape<NSL>(S, P, m);
@@ -340,8 +346,24 @@ __device__ __forceinline__ void so_count(const StatsArgs &a, const uint8_t *tbas
     if (IS_SEQ) {  // lines that are not pure ACGT / ACGTN: the 8 lanes of a line OR their flags
         const unsigned long long bi = __ballot(any_inv != 0), bn = __ballot(any_n != 0) | bi;
         if (bn) {
-            T.not_dna += so_groups(bn);
-            T.not_dnan += so_groups(bi);
+            if (!a.flagmap) {
+                T.not_dna += so_groups(bn);
+                T.not_dnan += so_groups(bi);
+            } else {
+                // several passes look at (different columns of) this line: its record's bit in the two maps says whether an
+                // earlier one has counted it already.  lrec + slot = the record's index among those that count.
+                const uint32_t sh = lane & 56u;
+                const bool gn = ((bn >> sh) & 0xFFull) != 0, gi = ((bi >> sh) & 0xFFull) != 0;
+                bool newn = false, newi = false;
+                if (m == 0 && gn) {
+                    const unsigned long long rec = (unsigned long long)(lrec + (long long)(src4 >> 2));
+                    const uint32_t bit = 1u << (rec & 31u);
+                    newn = !(atomicOr(&a.flagmap[rec >> 5], bit) & bit);
+                    if (gi) newi = !(atomicOr(&a.flagmap[a.flag_words + (rec >> 5)], bit) & bit);
+                }
+                T.not_dna += (uint32_t)__popcll(__ballot(newn));
+                T.not_dnan += (uint32_t)__popcll(__ballot(newi));
+            }
         }
     }
 }

@@ -15,11 +15,18 @@ uint32_t stats_blocks(int n_cu) { return (uint32_t)(n_cu > 0 ? n_cu : 256); }
 
 template <uint32_t NSL, bool DBG>
 __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // sequence + quality regions, the staged lists, the extra rows
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // sequence + quality regions, the staged lists
     const uint32_t lc = a.lc;
-    const uint32_t listw = a.listw;  // 512, or 256 when the extra rows need the room
+    const uint32_t listw = a.listw;
+    // Reads longer than the 256 rows the LDS holds are counted in PASSES of 256 columns (launch_stats_oct): this launch
+    // counts columns col0 .. col0 + lc - 1 of every line and nothing else.  Totals and the columns beyond the caller's
+    // lmax (plain arithmetic on the line lengths) belong to pass 0; every pass flags the sequence lines in which it met
+    // an 'N' or worse (a record's bit in a.flagmap says whether an earlier pass has counted it), and the last pass
+    // looks at what sequence lines hold beyond the caller's rows for that purpose only.
+    const uint32_t col0 = a.col0;
+    const bool pass0 = col0 == 0;
+    auto seg = [&](uint32_t l) -> uint32_t { return l > col0 ? (l - col0 < lc ? l - col0 : lc) : 0u; };
     for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) hist[i] = 0;
-    for (uint32_t i = threadIdx.x; i < a.lx * 72u; i += SO_THREADS) so_extra(a, hist)[i] = 0;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -38,8 +45,10 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         c.slots |= (((lane & 7u) + 8u * j) * 4u) << (8u * k);
     }
     SoAcc acc = {0, 0, 0};
-    SoTotals T = {0, 0};
+    SoTotals T = {0, 0, 0, 0};
     bool cr_seen = false;  // wave-uniform: a line of this wave's tiles ended in "\r\n" -- look for it from the next tile on
+    bool cr_any = false;   // wave-uniform: this wave trimmed a '\r' (pass 0 tells the later passes through a.cr_flag)
+    const bool cr_file = (pass0 || !a.cr_flag) ? true : __builtin_nontemporal_load(a.cr_flag) != 0;
     // DBG (FQH_STATS_DBG & 8192): cycles this wave spent waiting for a tile's words, staging its list, working out
     // its lines, and in its batches (added to qual_hist[0..3] at the end; tools/exp_statsdbg.py prints them)
     unsigned long long dbgt[4] = {0, 0, 0, 0};
@@ -121,10 +130,11 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         const uint32_t e_hi = a.line_hi - lbase < cnt ? (uint32_t)(a.line_hi - lbase) : cnt;
         const uint32_t lb3 = (uint32_t)lbase & 3u;
         const uint8_t *const tbase = a.buf + tb;
+        const uint8_t *const wbase = tbase + col0;  // column col0 of a line that starts at tile offset s: wbase[s]
         // every unconditional load of a line that starts in this tile stays inside the buffer; the
-        // (at most two) tiles at the end of the buffer for which that does not hold take the exact
+        // (few) tiles at the end of the buffer for which that does not hold take the exact
         // path for everything
-        const bool safe = tb + WT_BYTES + 32u * NSL + 8u <= a.len;
+        const bool safe = tb + WT_BYTES + col0 + 32u * NSL + 8u <= a.len;
         const uint32_t lce = safe ? lc : 0u;  // LDS rows in use for this tile: none => every column is exact
 
         // one lane per line: start and raw length of line `sbl` of `kind`; false: no line that counts
@@ -140,6 +150,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         };
         const uint32_t i0s = (1u - lb3) & 3u, i0q = (3u - lb3) & 3u;
         const uint32_t nls = i0s < cnt ? (cnt - i0s + 3) >> 2 : 0u, nlq = i0q < cnt ? (cnt - i0q + 3) >> 2 : 0u;
+        // index, among the records that count, of the record whose sequence line is the tile's first (may be negative)
+        const long long lrec0 = ((long long)(lbase + i0s) - (long long)a.line_lo) >> 2;
 
         if (safe && nls <= 64 && nlq <= 64 && !(DBG && (a.dbg & 8u))) {
             // ---- the usual tile: at most 64 lines of each kind.  Both kinds' lines are worked out at
@@ -149,14 +161,27 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             const bool has_s = line_of(0, lane, s_s, l_s), has_q = line_of(1, lane, s_q, l_q);
             // The byte before each line's '\n' is only looked at (two scattered loads per tile, and their latency before the
             // first batch can be packed) once the wave has met a "\r\n"; until then so_count's exact path does the trimming.
-            const bool probe = cr_seen && !(DBG && (a.dbg & 16u));
+            // (that only works where the line's last byte is one of the bytes the pass counts: a tile with a line longer
+            // than the rows, and every pass but the first, look right away)
+            const bool probe = (pass0 ? (cr_seen || __ballot((has_s && l_s > lce) || (has_q && l_q > lce)) != 0) : cr_file) &&
+                               !(DBG && (a.dbg & 16u));
             const uint32_t cr_s = (probe && has_s && l_s) ? tbase[s_s + l_s - 1] : 0u;
             const uint32_t cr_q = (probe && has_q && l_q) ? tbase[s_q + l_q - 1] : 0u;
             if (cr_s == '\r') --l_s;                                                   // trim_winline, src/records.rs:66-73
             if (cr_q == '\r') --l_q;
-            const uint32_t P_s = has_s ? so_pack(s_s, l_s, lce) : 0u, P_q = has_q ? so_pack(s_q, l_q, lce) : 0u;
-            if (has_s) { ++acc.rec; acc.bases += l_s; }
-            if (has_q) acc.qual += l_q;
+            if (probe && __ballot(cr_s == '\r' || cr_q == '\r') != 0) cr_any = true;
+            const bool trimmed = probe || !pass0;  // (a later pass without probes: pass 0 found no "\r\n" in the file)
+            if (pass0) {
+                if (has_s) { ++acc.rec; acc.bases += l_s; }
+                if (has_q) acc.qual += l_q;
+                T.over_s += so_over(l_s, has_s, a.lmax);
+                T.over_q += so_over(l_q, has_q, a.lmax);
+            }
+            // the columns of this pass; the last pass sees a sequence line to its end (the alphabet flags)
+            l_s = (a.last && l_s > col0) ? l_s - col0 : seg(l_s);
+            l_q = seg(l_q);
+            const uint32_t P_s = (has_s && (pass0 || l_s)) ? so_pack(s_s, l_s, lce) : 0u;
+            const uint32_t P_q = (has_q && (pass0 || l_q)) ? so_pack(s_q, l_q, lce) : 0u;
             if (DBG) { tk3 = __builtin_readcyclecounter(); dbgt[2] += tk3 - tk2; }
             const uint32_t nbs = (nls + 7) >> 3, nbq = (DBG && (a.dbg & 64u)) ? 0u : (nlq + 7) >> 3;  // 64: sequence lines only
             // Batch f = 2 k + kind: the k-th eight sequence lines, then the k-th eight quality lines -- the lines of (nearly) the
@@ -182,23 +207,23 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                 if (DBG && (a.dbg & 384u)) {  // 128: only the first step's load, 256: none
 #pragma unroll
                     for (uint32_t u = 0; u < NSL; ++u) B.w[u] = o;
-                    if (a.dbg & 128u) B.w[0] = load4_fast(tbase + o);
+                    if (a.dbg & 128u) B.w[0] = load4_fast(wbase + o);
                     return;
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(tbase + (o + 32 * u));
+                for (uint32_t u = 0; u < NSL; ++u) B.w[u] = load4_fast(wbase + (o + 32 * u));
                 if (DBG && (a.dbg & 16384u)) {  // the same loads once more, one byte on: what does a load that hits cost?
 #pragma unroll
-                    for (uint32_t u = 0; u < NSL; ++u) B.w[u] ^= load4_fast(tbase + (o + 32 * u + 1));
+                    for (uint32_t u = 0; u < NSL; ++u) B.w[u] ^= load4_fast(wbase + (o + 32 * u + 1));
                 }
             };
             auto count_s = [&](uint32_t f, SoBatch<NSL> &B) {  // f even
                 if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
-                so_count<true, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_s, 32u * (f >> 1) + 4u * g8, T, acc, probe, cr_seen);
+                so_count<true, NSL, DBG>(a, wbase, B, S, lane, lce, hist, c, l_s, 32u * (f >> 1) + 4u * g8, T, acc, trimmed, cr_seen, lrec0);
             };
             auto count_q = [&](uint32_t f, SoBatch<NSL> &B) {  // f odd
                 if (DBG && (a.dbg & 4u)) { acc.rec += B.w[0] == 0x12345u; return; }
-                so_count<false, NSL, DBG>(a, tbase, B, S, lane, lce, hist, c, l_q, 32u * (f >> 1) + 4u * g8, T, acc, probe, cr_seen);
+                so_count<false, NSL, DBG>(a, wbase, B, S, lane, lce, hist, c, l_q, 32u * (f >> 1) + 4u * g8, T, acc, trimmed, cr_seen, 0);
             };
             // The fetches are unconditional inside the loops (the index is clamped instead) so that the
             // compiler's s_waitcnt for the batch it needs leaves the next one's loads in flight.
@@ -226,20 +251,34 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
             const uint32_t nlines = kind ? nlq : nls;
             if (!nlines) continue;
             for (uint32_t sb = 0; sb < nlines; sb += 64) {
-                uint32_t my_P = 0, my_len = 0;
+                uint32_t my_P = 0, my_len = 0, full_len = 0;
+                bool mine = false, crl = false;
                 {
                     uint32_t s_rel = 0, len = 0;
                     if (sb + lane < nlines && line_of(kind, sb + lane, s_rel, len)) {
-                        if (len && tbase[s_rel + len - 1] == '\r') --len;              // trim_winline, src/records.rs:66-73
-                        my_len = len;
-                        my_P = so_pack(s_rel, len, lce);
-                        if (kind == 0) {
-                            ++acc.rec;
-                            acc.bases += len;
-                        } else {
-                            acc.qual += len;
+                        if (len && tbase[s_rel + len - 1] == '\r') {                   // trim_winline, src/records.rs:66-73
+                            --len;
+                            crl = true;
                         }
+                        mine = true;
+                        full_len = len;
+                        if (pass0) {
+                            if (kind == 0) {
+                                ++acc.rec;
+                                acc.bases += len;
+                            } else {
+                                acc.qual += len;
+                            }
+                        }
+                        len = (kind == 0 && a.last && len > col0) ? len - col0 : seg(len);
+                        my_len = len;
+                        my_P = (pass0 || len) ? so_pack(s_rel, len, lce) : 0u;
                     }
+                }
+                if (__ballot(crl) != 0) cr_any = true;
+                if (pass0) {
+                    if (kind == 0) T.over_s += so_over(full_len, mine, a.lmax);
+                    else T.over_q += so_over(full_len, mine, a.lmax);
                 }
                 const uint32_t nbat = ((nlines - sb < 64 ? nlines - sb : 64u) + 7) >> 3;
                 SoBatch<NSL> B0;
@@ -248,27 +287,27 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
                     const uint32_t o = (B0.P >> SO_P_SREL) + m4;
                     if (safe) {
 #pragma unroll
-                        for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = load4_fast(tbase + (o + 32 * u));
+                        for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = load4_fast(wbase + (o + 32 * u));
                     } else {  // lce == 0: every column goes through the exact path, which loads for itself
 #pragma unroll
                         for (uint32_t u = 0; u < NSL; ++u) B0.w[u] = 0;
                     }
-                    if (kind == 0) so_count<true, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc, true, cr_seen);
-                    else so_count<false, NSL, DBG>(a, tbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc, true, cr_seen);
+                    if (kind == 0) so_count<true, NSL, DBG>(a, wbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc, true, cr_seen, lrec0 + sb);
+                    else so_count<false, NSL, DBG>(a, wbase, B0, S, lane, lce, hist, c, my_len, 32u * b + 4u * g8, T, acc, true, cr_seen, 0);
                 }
             }
         }
     }
+    if (pass0 && a.cr_flag && (cr_any || cr_seen) && lane == 0) atomicOr(a.cr_flag, 1u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the inline ds_add of lds_add
     __syncthreads();
-    uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * (SO_WORDS + a.lx * 72u);
+    uint32_t *__restrict__ dst = a.scratch + (uint64_t)blockIdx.x * SO_WORDS;
     for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) dst[i] = hist[i];
-    for (uint32_t i = threadIdx.x; i < a.lx * 72u; i += SO_THREADS) dst[SO_WORDS + i] = so_extra(a, hist)[i];
     if (DBG && (a.dbg & 8192u) && lane == 0)
         for (int j = 0; j < 4; ++j) atomicAdd(&a.qual_hist[j], dbgt[j]);
     // per-line totals: rec / bases / qual were summed by the lane that owned the line; the two
     // "not DNA" counts are wave-uniform
-    unsigned long long sc[5] = {acc.rec, acc.bases, acc.qual, 0, 0};
+    unsigned long long sc[7] = {acc.rec, acc.bases, acc.qual, 0, 0, T.over_s, T.over_q};  // [5], [6]: bytes at positions >= lmax
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         unsigned long long v = sc[j];
@@ -277,53 +316,39 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         sc[j] = v;
     }
     if (lane == 0) {
+        // [3], [4]: records whose sequence is pure ACGT / ACGTN = all of them (pass 0) less the flagged ones (any pass)
         sc[3] = sc[0] - T.not_dna;
         sc[4] = sc[0] - T.not_dnan;
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < 7; ++j)
             if (sc[j]) atomicAdd(&a.scalars[j], sc[j]);
     }
 }
 
-// Sum the per-block partial histograms into the caller's u64 arrays (coalesced reads).
+// Sum the per-block partial histograms of one pass into the caller's u64 arrays (coalesced reads): LDS row r is
+// column col0 + r.
 __global__ __launch_bounds__(256) void k_stats_reduce_oct(const uint32_t *__restrict__ scratch, uint32_t n_blocks,
-                                                          uint32_t lc, uint32_t lx,
+                                                          uint32_t lc, uint32_t col0,
                                                           unsigned long long *__restrict__ qual_hist,
                                                           unsigned long long *__restrict__ base_hist) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t words = SO_WORDS + lx * 72u;
-    if (id >= words) return;
-    bool isq;
-    uint32_t bin, row;
-    if (id < SO_WORDS) {  // bank-scheduled rows
-        isq = id >= SO_SBYTES / 4;
-        const uint32_t r = isq ? id - SO_SBYTES / 4 : id;
-        const uint32_t rb = isq ? r >> 12 : r >> 9;
-        bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
-        row = rb * 64 + so_row6(r & 63u);
-        if (row >= lc) return;
-    } else {              // plain rows lc .. lc + lx - 1: 64 quality bins, 8 sequence bins
-        const uint32_t r = id - SO_WORDS;
-        row = lc + r / 72u;
-        isq = r % 72u < 64u;
-        bin = isq ? r % 72u : r % 72u - 64u;
-    }
+    if (id >= SO_WORDS) return;
+    const bool isq = id >= SO_SBYTES / 4;
+    const uint32_t r = isq ? id - SO_SBYTES / 4 : id;
+    const uint32_t rb = isq ? r >> 12 : r >> 9;
+    const uint32_t bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
+    const uint32_t row = rb * 64 + so_row6(r & 63u);
+    if (row >= lc) return;
     const uint32_t b0 = blockIdx.y * RED_GROUP;
     const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
     unsigned long long s = 0;
-    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * words + id];
+    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * SO_WORDS + id];
     if (!s) return;
-    if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
-    else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+    if (isq) atomicAdd(&qual_hist[(uint64_t)(col0 + row) * 256 + 33 + bin], s);
+    else atomicAdd(&base_hist[(uint64_t)(col0 + row) * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
 }
 
-uint32_t stats_oct_lc(uint32_t lmax) { return lmax < SO_LC_MAX ? lmax : SO_LC_MAX; }
-static uint32_t stats_oct_lx(uint32_t lmax) {
-    return lmax > SO_LC_MAX ? (lmax - SO_LC_MAX < SO_LX_MAX ? lmax - SO_LC_MAX : SO_LX_MAX) : 0u;
-}
-size_t stats_oct_scratch_bytes(uint32_t lmax, int n_cu) {
-    return (size_t)stats_blocks(n_cu) * (SO_WORDS + stats_oct_lx(lmax) * 72u) * sizeof(uint32_t);
-}
+size_t stats_oct_scratch_bytes(uint32_t, int n_cu) { return (size_t)stats_blocks(n_cu) * SO_WORDS * sizeof(uint32_t); }
 template <uint32_t NSL, bool DBG>
 static hipError_t launch_stats_oct_n(hipStream_t s, const StatsArgs &a, uint32_t blocks, size_t lds) {
     // Lanes without a whole dword subtract 0 at the address their bytes happen to form: any bin byte
@@ -341,34 +366,38 @@ static hipError_t launch_stats_oct_n(hipStream_t s, const StatsArgs &a, uint32_t
     return hipSuccess;
 }
 hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
-    a.lc = stats_oct_lc(a.lmax);
 #ifdef FQH_TUNING  // timing variant of the kernel (tools/exp_statsdbg.py); not part of the product library
     static const uint32_t dbg = getenv("FQH_STATS_DBG") ? (uint32_t)atoi(getenv("FQH_STATS_DBG")) : 0u;
 #else
     const uint32_t dbg = 0;
 #endif
     a.dbg = dbg;
-    a.lx = stats_oct_lx(a.lmax);
-    a.listw = a.lx ? 256u : SO_LISTW;
-    size_t lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * a.listw * sizeof(uint16_t) +
-                 (size_t)a.lx * 72 * sizeof(uint32_t);
-    if (lds > SO_LDS_MAX) {  // cannot happen with the constants above; keep the kernel launchable anyway
-        a.lx = 0;
-        lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * a.listw * sizeof(uint16_t);
-    }
+    a.listw = SO_LISTW;
+    const size_t lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * a.listw * sizeof(uint16_t);
     const uint32_t blocks = stats_blocks(n_cu);
-    const uint32_t nsl = (a.lc + 31) / 32;  // steps that hold LDS rows
-    hipError_t e =
+    // one pass per 256 columns, as far as the caller's rows and the longest line go (reads of up to 256 bp: one)
+    const uint32_t span = (a.max_line && a.max_line < a.lmax) ? a.max_line : a.lmax;
+    if (span <= SO_LC_MAX) {  // one pass
+        a.flagmap = nullptr;
+        a.cr_flag = nullptr;
+    }
+    for (uint32_t col0 = 0; col0 == 0 || col0 < span; col0 += SO_LC_MAX) {
+        a.col0 = col0;
+        a.lc = a.lmax - col0 < SO_LC_MAX ? a.lmax - col0 : SO_LC_MAX;
+        a.last = col0 + SO_LC_MAX >= span ? 1u : 0u;
+        const uint32_t nsl = (a.lc + 31) / 32;  // steps that hold LDS rows
+        hipError_t e =
 #ifdef FQH_TUNING
-                   dbg        ? launch_stats_oct_n<5, true>(s, a, blocks, lds) :  // timing experiments: 150-bp shape only
+                       dbg        ? (nsl <= 5 ? launch_stats_oct_n<5, true>(s, a, blocks, lds) : launch_stats_oct_n<8, true>(s, a, blocks, lds)) :  // timing experiments
 #endif
-                   nsl <= 2   ? launch_stats_oct_n<2, false>(s, a, blocks, lds)
-                   : nsl <= 4 ? launch_stats_oct_n<4, false>(s, a, blocks, lds)
-                   : nsl <= 5 ? launch_stats_oct_n<5, false>(s, a, blocks, lds)
-                              : launch_stats_oct_n<8, false>(s, a, blocks, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stats_reduce_oct, dim3((SO_WORDS + a.lx * 72u + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP),
-                       dim3(256), 0, s, a.scratch, blocks, a.lc, a.lx, a.qual_hist, a.base_hist);
+                       nsl <= 2   ? launch_stats_oct_n<2, false>(s, a, blocks, lds)
+                       : nsl <= 4 ? launch_stats_oct_n<4, false>(s, a, blocks, lds)
+                       : nsl <= 5 ? launch_stats_oct_n<5, false>(s, a, blocks, lds)
+                                  : launch_stats_oct_n<8, false>(s, a, blocks, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_stats_reduce_oct, dim3((SO_WORDS + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s,
+                           a.scratch, blocks, a.lc, a.col0, a.qual_hist, a.base_hist);
+    }
     return hipGetLastError();
 }
 

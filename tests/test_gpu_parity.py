@@ -227,6 +227,38 @@ def test_stats_long_reads_and_odd_bytes(fqref, gpu):
         assert np.array_equal(gq, qh) and np.array_equal(gb, bh) and np.array_equal(gs, sc)
 
 
+@pytest.mark.parametrize("shape", ["clean", "crlf", "dirty", "hifi", "mixed"])
+def test_stats_kilobase_reads(fqref, gpu, shape):
+    """Reads of 2 - 5 kbp (and a mix with short ones): k_stats_oct counts them in passes of 256 columns, every pass in
+    LDS; the caller's lmax may be smaller than the reads (overflow counters), larger, or no multiple of anything."""
+    rng = np.random.default_rng({"clean": 1, "crlf": 2, "dirty": 3, "hifi": 4, "mixed": 5}[shape])
+    recs = []
+    for i in range(260):
+        n = int(rng.integers(2000, 5001))
+        if shape == "mixed" and i % 3:
+            n = int(rng.integers(0, 300))
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes()
+        qual = rng.integers(33, 75, n).astype(np.uint8).tobytes()
+        if shape == "hifi":
+            qual = rng.choice(np.frombuffer(b"~!5I", dtype=np.uint8), n).tobytes()   # '~' = Q93 lies outside the LDS window
+        if shape == "dirty" and i % 4 == 0 and n:
+            sa = bytearray(seq)
+            for k in rng.integers(0, n, 3):
+                sa[int(k)] = int(rng.choice(list(b"Nnx.")))
+            sa[n - 1] = ord("N") if i % 8 == 0 else sa[n - 1]     # an 'N' in the line's last column, far beyond the first pass
+            seq = bytes(sa)
+        e = b"\r\n" if (shape == "crlf" and i % 2 == 0) else b"\n"
+        recs.append(b"@m%d/ccs" % i + e + seq + e + b"+" + e + qual + e)
+    data = b"".join(recs)
+    for lmax in (5000, 4097, 1000, 256, 257, 6000):
+        r, qh, bh, sc = fqref.stats(data, lmax)
+        s, gq, gb, gs = gpu.stats(data, lmax)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (0, 260)
+        assert np.array_equal(gs, sc), (shape, lmax, gs, sc)
+        assert np.array_equal(gb, bh), (shape, lmax, np.argwhere(gb != bh)[:5])
+        assert np.array_equal(gq, qh), (shape, lmax, np.argwhere(gq != qh)[:5])
+
+
 @pytest.mark.parametrize("shape", ["fixed150", "fixed36", "ragged", "binned", "crlf", "dirty", "len4k"])
 def test_stats_fast_path_shapes(fqref, gpu, shape):
     """Multi-tile buffers (so that the whole-dword LDS path runs, not only the exact one): fixed and

@@ -1,4 +1,4 @@
-"""tools/exp_longreads.py — histogram kernel on 300 bp reads (columns 256..299 live in the extra LDS rows)."""
+"""tools/exp_longreads.py L — histogram kernel (k_stats_oct, passes of 256 columns) and the scan on reads of L bp."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,14 +7,15 @@ pkg = g.load_package()
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(1)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-nrec = 4096
+nrec = max(256, 4096 * 300 // max(L, 300))
 seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (nrec, L))
 qual = rng.integers(35, 74, (nrec, L)).astype(np.uint8)
 recs = []
 for i in range(nrec):
     recs.append(b"@r%07d\n" % i + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n")
 block = b"".join(recs)
-reps = (2 << 30) // len(block)
+GIB = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+reps = int(GIB * (1 << 30)) // len(block)
 n = reps * len(block)
 hb = torch.from_numpy(np.frombuffer(block, dtype=np.uint8).copy()).to(dev)
 buf = hb.repeat(reps).contiguous()
@@ -27,8 +28,12 @@ for _ in range(3):
     ctx.stats_launch(buf.data_ptr(), n, L, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()); ctx.stats_finish()
     t = ctx.timing().stats_ms
     best = t if best is None else min(best, t)
-assert int(sc[0]) == reps * nrec and int(qh.sum()) == reps * nrec * L and int(bh.sum()) == reps * nrec * L
+assert os.environ.get("FQH_STATS_DBG") or (int(sc[0]) == reps * nrec and int(qh.sum()) == reps * nrec * L and int(bh.sum()) == reps * nrec * L)
 print("read length %d: histograms %.2f GiB in %.3f ms = %.0f GB/s" % (L, n / 2**30, best, n / 1e6 / best))
+if int(os.environ.get("FQH_STATS_DBG", "0")) & 8192:  # (tuning build) cycles per wave and launch in the kernel's sections, all passes
+    print("  cycles per wave: words %.0f  staging %.0f  lines %.0f  batches %.0f" % tuple(int(x) / 4096.0 for x in qh[:4]))
+if len(sys.argv) > 3:
+    sys.exit(0)
 ctx2 = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
 rs = torch.empty(reps * nrec + 16, dtype=torch.int64, device=dev)
 ts = []

@@ -76,7 +76,6 @@ struct StatsArgs {
     uint32_t *flagmap;           // several passes: one bit per record that counts, "has an N or worse" in words [0, flag_words),
     uint64_t flag_words;         //   "has a byte outside ACGTN" behind them (zeroed by the caller); NULL with one pass
     uint32_t *cr_flag;           // several passes: pass 0 sets it if any line that counts ends in "\r\n"; the others look for '\r' only then
-    uint32_t listw;              // k_stats_oct: staged list entries per wave
     uint32_t *scratch;           // [gridDim.x][SO_WORDS] per-block partial histograms
     unsigned long long *qual_hist, *base_hist, *scalars;
     uint32_t dbg;                // timing experiments only (FQH_STATS_DBG, k_stats_oct<5, true>): 1 no LDS atomics, 4 no counting,

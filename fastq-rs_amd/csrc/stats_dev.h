@@ -50,7 +50,9 @@ constexpr uint32_t SO_LC_MAX = 256;           // rows kept in LDS
 constexpr uint32_t SO_QBYTES = 4 * 64 * 256;  // quality region: 4 row blocks x 64 bins x 64 slots x 4 B
 constexpr uint32_t SO_SBYTES = 4 * 8 * 256;   // sequence region
 constexpr uint32_t SO_WORDS = (SO_QBYTES + SO_SBYTES) / 4;  // the sequence region comes first: [0, SO_SBYTES)
-constexpr uint32_t SO_LISTW = 512;            // list entries staged in LDS per wave (u16 each)
+constexpr uint32_t SO_LISTW = 256;            // list entries per tile slot in LDS (u16 each), 256-column variant; the rest is read from memory
+constexpr uint32_t SO_LISTW_REG = 512;        // ... staged per wave by the other variants
+constexpr uint32_t SO_SLOT_BYTES = 2 * SO_LISTW + 256;  // a tile's slot in LDS: its list entries and 64 words of bookkeeping
 constexpr uint32_t SO_LDS_MAX = 160 * 1024;
 constexpr uint32_t SO_ADDR_SPAN = 65536 + SO_SBYTES + 128 + 3 * 16384;  // see launch_stats_oct
 

@@ -17,7 +17,7 @@ template <uint32_t NSL, bool DBG>
 __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // sequence + quality regions, the staged lists
     const uint32_t lc = a.lc;
-    const uint32_t listw = a.listw;
+    const uint32_t listw = NSL >= 8 ? SO_LISTW : SO_LISTW_REG;  // list entries of a tile kept in LDS; the rest is read from memory
     // Reads longer than the 256 rows the LDS holds are counted in PASSES of 256 columns (launch_stats_oct): this launch
     // counts columns col0 .. col0 + lc - 1 of every line and nothing else.  Totals and the columns beyond the caller's
     // lmax (plain arithmetic on the line lengths) belong to pass 0; every pass flags the sequence lines in which it met
@@ -32,7 +32,14 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // a scalar: so is the tile
     const uint32_t m4 = (lane & 7u) * 4u, g8 = lane >> 3;
-    uint16_t *const wl = reinterpret_cast<uint16_t *>(hist + SO_WORDS) + wv * listw;  // this wave's staged list
+    // Two ways of having a tile's words at hand a tile ahead (DMA below).  Without: the wave's staged list sits right
+    // behind the histogram.  With: two tile slots per wave, [listw list entries (u16) | 64 words, six of them the
+    // tile's], BEHIND every address a lane that counts nothing can form (such a lane subtracts 0 wherever its bytes
+    // point, SO_ADDR_SPAN): the slots are filled by LDS-DMA, and a read-modify-write of the LDS, even of +0, is not
+    // atomic against that (found the hard way: lists that lost entries whenever a batch had idle lanes).
+    constexpr bool DMA = NSL >= 8;
+    uint8_t *const wslot = DMA ? reinterpret_cast<uint8_t *>(hist) + SO_ADDR_SPAN + wv * (2u * SO_SLOT_BYTES)
+                               : reinterpret_cast<uint8_t *>(hist + SO_WORDS) + wv * (2u * SO_LISTW_REG);
     // The address registers assume the histogram starts at LDS address 0 (it is the kernel's only
     // LDS object); a shared-memory pointer is its LDS address in the low 32 bits.
     if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();
@@ -55,19 +62,36 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
     SoShape<NSL> S = {};
     S.key = 0xFFFFFFFFu;  // no P has this key: the first batch works the shape out
 
-    // What a wave needs to know about a tile before it can start on it, loaded one tile ahead (the
-    // per-tile chain count -> prefix -> list -> '\r' bytes -> first dwords is otherwise paid in full,
-    // 256 times per wave: 2.5 of the kernel's 6 ms).
+    // What a wave needs to know about a tile before it can start on it is loaded one tile ahead (the per-tile chain
+    // count -> prefix -> list -> '\r' bytes -> first dwords is otherwise paid in full, 256 times per wave: 2.5 of the
+    // kernel's 6 ms): six words — 0 the tile's count, 1 its prefix, 2 the next tile's count, 3 that tile's first entry,
+    // 4-5 the block prefix — and the first listw list entries.
+    //   * Reads of up to 160 bp (NSL <= 5): into registers (one for the six words, four for the list), staged with two
+    //     ds_write when the tile's turn comes.
+    //   * The 256-column variant has no registers to spare: held in registers, these words were the first thing the
+    //     allocator spilled, and a spill waits for the very load it was meant to hide (3 000 cycles per tile).  There
+    //     they go STRAIGHT INTO LDS (global_load_lds), into the slot the wave is not working from.  (Not for the other
+    //     variants: next to LDS-DMA the compiler waits vmcnt(0) for every ordinary load, which costs the 150 bp shape
+    //     the overlap of a batch's loads with the batch before it: 3.7 instead of 3.2 ms.)
     struct TilePre {
-        uint32_t meta;  // lane 0: the tile's count, 1: its prefix, 2: the next tile's count, 3: that tile's first
-                        // entry, 4-5: the block prefix -- six words, one load, one register
+        uint32_t meta;
         uint2 l0, l1;   // list entries 4 lane .. 4 lane + 3 and 256 + 4 lane .. + 3
     };
-    auto prefetch = [&](uint64_t t, TilePre &P) {
+    TilePre nextP;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    auto prefetch = [&](uint64_t t, uint32_t slot) {
         const uint64_t tc = t < a.n_tiles ? t : a.n_tiles - 1;  // clamped: the loads are unconditional
-        const uint16_t *__restrict__ tl = a.list + tc * a.list_cap;
-        P.l0 = *reinterpret_cast<const uint2 *>(tl + lane * 4);
-        P.l1 = *reinterpret_cast<const uint2 *>(tl + 256 + lane * 4);  // list_cap >= 512
+        uint8_t *const dst = wslot + slot * SO_SLOT_BYTES;
+        if constexpr (DMA) {
+            const uint32_t *__restrict__ tl = reinterpret_cast<const uint32_t *>(a.list + tc * a.list_cap) + lane;  // list_cap >= 512
+            __builtin_amdgcn_global_load_lds((gptr_t)tl, (lptr_t)dst, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(tl + 64), (lptr_t)(dst + 256), 4, 0, 0);
+        } else {
+            const uint16_t *__restrict__ tl = a.list + tc * a.list_cap;
+            nextP.l0 = *reinterpret_cast<const uint2 *>(tl + lane * 4);
+            nextP.l1 = *reinterpret_cast<const uint2 *>(tl + 256 + lane * 4);  // list_cap >= 512
+        }
         const uint64_t t1 = tc + 1 < a.n_tiles ? tc + 1 : tc;
         const uint32_t *mp = a.tile_count + tc;
         if (lane == 1) mp = a.tile_prefix + tc;
@@ -75,40 +99,63 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_oct(StatsArgs a) {
         if (lane == 3) mp = reinterpret_cast<const uint32_t *>(a.list + t1 * a.list_cap);  // (list_cap is even)
         if (lane == 4 || lane == 5)
             mp = reinterpret_cast<const uint32_t *>(a.block_prefix + (tc >> SCAN_SHIFT)) + (lane - 4);
-        P.meta = *mp;
+        if constexpr (DMA) __builtin_amdgcn_global_load_lds((gptr_t)mp, (lptr_t)(dst + 2u * SO_LISTW), 4, 0, 0);
+        else nextP.meta = *mp;
     };
     const uint64_t tstride = (uint64_t)gridDim.x * SO_WAVES;
     uint64_t tile = (uint64_t)blockIdx.x * SO_WAVES + wv;
-    TilePre nextP;
-    if (tile < a.n_tiles && a.len >= 4) prefetch(tile, nextP);
+    uint32_t slot = 0;
+    if (tile < a.n_tiles && a.len >= 4) prefetch(tile, 0);
     if (DBG && (a.dbg & 65536u) && wv >= 8) tile = a.n_tiles;  // half the waves idle: does the other half get faster?
     for (; tile < a.n_tiles && a.len >= 4; tile += tstride) {
-        const TilePre cur = nextP;
         unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
         if (DBG) tk0 = __builtin_readcyclecounter();
-        prefetch(tile + tstride, nextP);
-        // (six lanes hold the tile's six words: as scalars, the tile's bookkeeping runs on the scalar unit)
-        uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 0);
+        uint16_t *const wl = reinterpret_cast<uint16_t *>(wslot + (DMA ? slot * SO_SLOT_BYTES : 0u));
+        uint32_t cnt, cur_tp, cur_cnt1, cur_first1;
+        unsigned long long cur_bp;
+        TilePre cur;
+        if constexpr (DMA) {
+            // the slot's loads were issued a whole tile ago (nothing orders an LDS read behind them but this wait)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t *const mw = reinterpret_cast<const uint32_t *>(wslot + slot * SO_SLOT_BYTES + 2u * SO_LISTW);
+            const uint4 m03 = *reinterpret_cast<const uint4 *>(mw);
+            const uint2 m45 = *reinterpret_cast<const uint2 *>(mw + 4);
+            // (as scalars, the tile's bookkeeping runs on the scalar unit)
+            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)m03.x);
+            cur_tp = (uint32_t)__builtin_amdgcn_readfirstlane((int)m03.y);
+            cur_cnt1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m03.z);
+            cur_first1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m03.w);
+            cur_bp = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)m45.x) |
+                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)m45.y) << 32);
+            slot ^= 1u;
+            prefetch(tile + tstride, slot);
+        } else {
+            cur = nextP;
+            prefetch(tile + tstride, 0);
+            // (six lanes hold the tile's six words: as scalars, the tile's bookkeeping runs on the scalar unit)
+            cnt = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 0);
+            cur_tp = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 1);
+            cur_cnt1 = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 2);
+            cur_first1 = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 3);
+            cur_bp = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 4) |
+                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 5) << 32);
+        }
         cnt = cnt < a.list_cap ? cnt : a.list_cap;
         if (cnt == 0) continue;
-        const uint32_t cur_tp = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 1);
-        const uint32_t cur_cnt1 = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 2);
-        const uint32_t cur_first1 = (uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 3);
-        const unsigned long long cur_bp =
-            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 4) |
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cur.meta, 5) << 32);
         const unsigned long long lbase = a.nl_count + 1 + cur_bp + cur_tp;
         if (lbase >= a.line_hi || lbase + cnt <= a.line_lo) continue;
         if (DBG && (a.dbg & 1024u)) { acc.rec += cnt; continue; }  // only the walk over the tiles' words
         if (DBG) { tk1 = __builtin_readcyclecounter(); dbgt[0] += tk1 - tk0; }
         const uint16_t *__restrict__ tl = a.list + tile * a.list_cap;
         const uint64_t tb = tile << WT_SHIFT;
-        // stage the list
-        __builtin_amdgcn_wave_barrier();
-        *reinterpret_cast<uint2 *>(wl + lane * 4) = cur.l0;
-        if (listw > 256) *reinterpret_cast<uint2 *>(wl + 256 + lane * 4) = cur.l1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (!DMA) {  // stage the list
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<uint2 *>(wl + lane * 4) = cur.l0;
+            *reinterpret_cast<uint2 *>(wl + 256 + lane * 4) = cur.l1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         if (DBG) { tk2 = __builtin_readcyclecounter(); dbgt[1] += tk2 - tk1; }
         // start of the first line after this tile (ends the tile's last line), tile-relative
         uint64_t next_first = a.valid_end;
@@ -372,8 +419,7 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
     const uint32_t dbg = 0;
 #endif
     a.dbg = dbg;
-    a.listw = SO_LISTW;
-    const size_t lds = (size_t)SO_WORDS * sizeof(uint32_t) + (size_t)SO_WAVES * a.listw * sizeof(uint16_t);
+    const size_t lds = (size_t)SO_ADDR_SPAN + (size_t)SO_WAVES * 2 * SO_SLOT_BYTES;
     const uint32_t blocks = stats_blocks(n_cu);
     // one pass per 256 columns, as far as the caller's rows and the longest line go (reads of up to 256 bp: one)
     const uint32_t span = (a.max_line && a.max_line < a.lmax) ? a.max_line : a.lmax;

@@ -89,6 +89,9 @@ def main():
     hi = min((rank + 1) * shard, file_len)
     nbytes = hi - lo
 
+    # one real stream for the library's kernels and for the collectives (the device-side exchange is ordered by the
+    # stream alone; torch's default stream is the null stream, which the library would replace by a stream of its own)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     ctx = pkg.Ctx(dev.index, stream=torch.cuda.current_stream().cuda_stream)
     LEAD = 2 * pkg.BUFSIZE  # room in front of the shard for the tail of the previous rank's shard (--shard-stats)
     store = torch.empty(LEAD + nbytes + 16, dtype=torch.uint8, device=dev)
@@ -103,7 +106,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # N > 1: small exchanges go through preallocated pinned host staging (no per-step allocations)
+    # N > 1: the exchange stays on the device (fqh_shard_prescan_launch / fqh_shard_rescan_launch): the byte scan, an
+    # all_gather of 8 words per rank, the fold of the carries + the emit step, an all_reduce of the counts — all
+    # enqueued on one stream, one host wait at the end of the step.  If a shard cannot keep the fast path, every rank's
+    # finish says so (E_AGAIN) and the step runs the host recipe (prescan, exchange through pinned staging,
+    # fqh_carry_combine on the host, rescan).
+    W = pkg.SHARD_WORDS
+    words = torch.zeros(W, dtype=torch.int64, device=dev)
+    all_words = torch.zeros(world * W, dtype=torch.int64, device=dev) if world > 1 else None
     gather_in = torch.zeros(7, dtype=torch.int64, device=dev)
     gather_all = torch.zeros(world * 7, dtype=torch.int64, device=dev) if world > 1 else None
     h_in = torch.zeros(7, dtype=torch.int64).pin_memory() if world > 1 else None
@@ -111,13 +121,11 @@ def main():
     h_counts = torch.zeros(2, dtype=torch.int64).pin_memory() if world > 1 else None
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
     index_ms = []
+    host_steps = [0]
 
-    def step():
-        if world == 1:
-            s, c, st = ctx.scan(buf.data_ptr(), nbytes, True, None, rec_start.data_ptr(), cap)
-            index_ms.append(ctx.timing().index_ms)
-            return s
+    def step_host():
         # 1) shard-local byte scan (phase-free), 2) carry exchange, 3) emit with the true carry
+        host_steps[0] += 1
         nn, ns, back0 = ctx.shard_prescan(buf.data_ptr(), nbytes)
         index_ms.append(ctx.timing().index_ms)
         h_in[0], h_in[1], h_in[2] = nbytes, nn, ns
@@ -137,6 +145,28 @@ def main():
         h_counts[1] = 1 if s.parse_status != pkg.OK else 0
         counts.copy_(h_counts, non_blocking=True)
         dist.all_reduce(counts)
+        return s
+
+    def step():
+        if world == 1:
+            s, c, st = ctx.scan(buf.data_ptr(), nbytes, True, None, rec_start.data_ptr(), cap)
+            index_ms.append(ctx.timing().index_ms)
+            return s
+        if os.environ.get("FQH_BENCH_HOST_PROTOCOL") == "1":
+            return step_host()
+        ctx.shard_prescan_launch(buf.data_ptr(), nbytes, words.data_ptr())
+        dist.all_gather_into_tensor(all_words, words)
+        ctx.shard_rescan_launch(is_last, all_words.data_ptr(), world, rank, rec_start.data_ptr(), cap, counts.data_ptr())
+        dist.all_reduce(counts)
+        try:
+            s, c, st = ctx.scan_finish()
+        except pkg.FqhError as e:
+            if e.status != pkg.E_AGAIN:
+                raise
+            if os.environ.get("FQH_BENCH_DEBUG") and host_steps[0] == 0:
+                print("rank %d: E_AGAIN, gathered words %s" % (rank, all_words.cpu().numpy().reshape(world, W).tolist()), file=sys.stderr, flush=True)
+            return step_host()
+        index_ms.append(ctx.timing().index_ms)
         return s
 
     if args.stream_gib > 0:
@@ -234,7 +264,10 @@ def main():
         "config": {"workload": "configs[1]: %d x %.3f GiB synthetic 150 bp FASTQ resident in HBM, "
                                "record-offset scan + count + validation" % (world, nbytes / 2**30),
                    "bytes_per_gpu": nbytes, "records_total": total_records,
-                   "sharding": "byte-range, cuts at multiples of %d" % shard if world > 1 else "none"},
+                   "sharding": "byte-range, cuts at multiples of %d" % shard if world > 1 else "none",
+                   "exchange": ("on the device: all_gather of 8 words per rank, fold + emit, all_reduce of the counts, one "
+                                "host wait per step (%d of %d timed+warmup steps fell back to the host recipe)"
+                                % (host_steps[0], args.steps + args.warmup)) if world > 1 else "none"},
         "records_per_s": round(total_records / (dt / args.steps), 1),
         "hbm_roofline_frac_whole_step": round(gbs / world / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": "k_index_fast", "achieved": round(achieved, 1),

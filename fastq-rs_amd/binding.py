@@ -9,9 +9,10 @@ LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.s
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
-           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "EXPORTS"]
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "EXPORTS"]
 
-OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY = range(10)
+OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY, E_AGAIN = range(11)
+SHARD_WORDS = 8
 BUFSIZE = 68 * 1024
 NSCALARS = 8
 OPT_FAST_PATH, OPT_SINGLE_PASS = 1, 2
@@ -20,7 +21,7 @@ OPT_FAST_PATH, OPT_SINGLE_PASS = 1, 2
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
-    "fqh_shard_prescan", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
+    "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
@@ -108,6 +109,8 @@ def lib():
         L.fqh_rescan_launch.argtypes = [vp, i32, C.POINTER(Carry), vp, u64]
         L.fqh_shard_prescan.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64 * 4)]
         L.fqh_shard_align.argtypes = [vp, vp, u64, i32, C.POINTER(u32), C.POINTER(u64)]
+        L.fqh_shard_prescan_launch.argtypes = [vp, vp, u64, vp]
+        L.fqh_shard_rescan_launch.argtypes = [vp, i32, vp, i32, i32, vp, u64, vp]
         L.fqh_stream_carry.argtypes = [vp, C.POINTER(Carry)]
         L.fqh_invalidate.argtypes = [vp]
         L.fqh_stats.argtypes = [vp, vp, u64, i32, C.POINTER(Carry), u32, vp, vp, vp,
@@ -227,6 +230,16 @@ class Ctx:
         nn, ns, back = C.c_uint64(), C.c_uint64(), (C.c_uint64 * 4)()
         self._chk(self._L.fqh_shard_prescan(self._h, d_buf, length, C.byref(nn), C.byref(ns), C.byref(back)))
         return nn.value, ns.value, [int(x) for x in back]
+
+    def shard_prescan_launch(self, d_buf, length, d_words):
+        """The byte scan of a shard, enqueued; its SHARD_WORDS words go to d_words (device) for the all-gather."""
+        self._chk(self._L.fqh_shard_prescan_launch(self._h, d_buf, length, d_words))
+
+    def shard_rescan_launch(self, is_final, d_all_words, n_ranks, rank, d_rec_start=None, cap=0, d_counts=None):
+        """Fold of the gathered words + emit under the true carry, enqueued; end with scan_finish() (raises FqhError with
+        status E_AGAIN on every rank if a shard left the fast path: take the host recipe then)."""
+        self._chk(self._L.fqh_shard_rescan_launch(self._h, 1 if is_final else 0, d_all_words, n_ranks, rank, d_rec_start, cap,
+                                                  d_counts))
 
     def shard_align(self, d_buf, length, prev_is_newline):
         """-> (phase, first_record_offset) of a shard that starts anywhere; raises FqhError(E_HEADER / E_ARG) if the window

@@ -16,6 +16,9 @@ void launch_emit(hipStream_t, const ScanArgs &, DevOut *, int);
 void launch_finalize(hipStream_t, const ScanArgs &, DevOut *);
 size_t stats_oct_scratch_bytes(uint32_t, int);
 hipError_t launch_stats_oct(hipStream_t, StatsArgs, int);
+void launch_shard_words(hipStream_t, const DevOut *, const DevOut *, uint64_t, uint64_t *);
+void launch_carry_fold(hipStream_t, const uint64_t *, int, int, DevCarry *, DevCarry *, DevOut *);
+void launch_shard_counts(hipStream_t, const DevOut *, const DevOut *, const DevCarry *, uint64_t *);
 bool scan_stats_supports(uint32_t lmax);
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu);
 size_t scan_stats_scratch_bytes(int n_cu);
@@ -55,6 +58,9 @@ struct fqh_ctx {
     DevOut *h_out = nullptr;      // pinned
     DevOut *h_init = nullptr;     // pinned reset image
     uint64_t *d_misc = nullptr;   // 8 u64 of scratch
+    DevCarry *d_carry = nullptr;  // device-side shard protocol: the folded carry, and its pinned twin the host reads at finish
+    DevCarry *h_carry = nullptr;
+    bool dev_carry = false;       // the launch in flight took its carry from d_carry
     fqh_idx_record *idx = nullptr;
     size_t idx_cap = 0;
     uint64_t *tmp_rec = nullptr;

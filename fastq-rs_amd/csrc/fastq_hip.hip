@@ -39,6 +39,7 @@ const char *fqh_strerror(fqh_status s) {
     case FQH_E_DEVICE: return "HIP device error";
     case FQH_E_ARG: return "invalid argument";
     case FQH_E_CAPACITY: return "output capacity too small";
+    case FQH_E_AGAIN: return "a shard left the fast path: use the host recipe";
     }
     return "unknown";
 }
@@ -100,6 +101,8 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->block_prefix);
     (void)hipFree(ctx->d_out);
     (void)hipFree(ctx->d_misc);
+    (void)hipFree(ctx->d_carry);
+    if (ctx->h_carry) (void)hipHostFree(ctx->h_carry);
     (void)hipFree(ctx->idx);
     (void)hipFree(ctx->tmp_rec);
     (void)hipFree(ctx->stats_scratch);
@@ -374,6 +377,7 @@ static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     a.bufsize = ctx->bufsize;
     a.max_walk = ctx->bufsize ? (uint32_t)(ctx->bufsize / WT_BYTES + 3) : 0xFFFFFFFFu;
     a.head_unchecked = ctx->head_unchecked ? 1u : 0u;
+    a.prescan = ctx->skip_emit ? 1u : 0u;
     a.n_tiles = (len + WT_BYTES - 1) / WT_BYTES;
     a.n_blocks = (a.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     a.rec_start = d_rec_start;
@@ -400,6 +404,23 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->dout_clean = true;  // the finalize kernel has run
+    if (ctx->dev_carry) {  // the carry was folded on the device (fqh_shard_rescan_launch): the host learns it here
+        ctx->dev_carry = false;
+        const DevCarry hc = *ctx->h_carry;
+        ScanArgs &a = ctx->args;
+        a.dcarry = nullptr;
+        a.base_offset = hc.base_offset;
+        a.nl_count = hc.nl_count;
+        for (int i = 0; i < 4; ++i) a.back[i] = hc.back[i];
+        a.v_start = (hc.back[0] == 0 && a.len > 0) ? 1u : 0u;
+        ctx->carry_in.base_offset = hc.base_offset;
+        ctx->carry_in.nl_count = hc.nl_count;
+        for (int i = 0; i < 4; ++i) ctx->carry_in.back[i] = hc.back[i];
+        if (hc.any_fail) {
+            ctx->last_valid = false;
+            return fail(ctx, FQH_E_AGAIN, "a shard's byte scan left the fast path: run fqh_shard_prescan / fqh_carry_combine / fqh_rescan_launch");
+        }
+    }
     if (ctx->used_spec && ctx->h_out->spec_fail) {
         // the fast path could not prove the input valid (a real error, lines longer than a few KiB,
         // or a degenerate layout): run the exact path, and keep later scans of this context on it for a
@@ -535,6 +556,50 @@ fqh_status fqh_shard_prescan(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, u
     *n_newlines = s.n_newlines;
     *n_line_starts = s.n_line_starts;
     for (int i = 0; i < 4; ++i) back0[i] = c.back[i];
+    return FQH_OK;
+}
+
+fqh_status fqh_shard_prescan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t *d_words) {
+    if (!ctx || !d_words) return FQH_E_ARG;
+    ctx->skip_emit = true;
+    fqh_status st = do_scan_launch(ctx, d_buf, len, 0, nullptr, nullptr, 0);
+    ctx->skip_emit = false;
+    if (st != FQH_OK) return st;
+    launch_shard_words(ctx->stream, &ctx->d_out[0], ctx->h_out, len, d_words);
+    HIPCHK(ctx, hipGetLastError());
+    return FQH_OK;  // (the launch stays pending: fqh_shard_rescan_launch continues it, fqh_scan_finish ends it)
+}
+
+fqh_status fqh_shard_rescan_launch(fqh_ctx *ctx, int is_final, const uint64_t *d_all_words, int n_ranks, int rank,
+                                   uint64_t *d_rec_start, uint64_t cap, uint64_t *d_counts) {
+    if (!ctx || !d_all_words || n_ranks < 1 || rank < 0 || rank >= n_ranks) return FQH_E_ARG;
+    if (!ctx->pending || ctx->dev_carry) return fail(ctx, FQH_E_ARG, "fqh_shard_rescan_launch continues a fqh_shard_prescan_launch");
+    if (d_rec_start && cap == 0) return fail(ctx, FQH_E_ARG, "cap is 0");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_carry) HIPCHK(ctx, hipMalloc((void **)&ctx->d_carry, sizeof(DevCarry)));
+    if (!ctx->h_carry) HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_carry, sizeof(DevCarry), hipHostMallocDefault));
+    hipStream_t s = ctx->stream;
+    launch_carry_fold(s, d_all_words, n_ranks, rank, ctx->d_carry, ctx->h_carry, &ctx->d_out[0]);
+    ScanArgs &a = ctx->args;  // the prescan's: buffer and tile index
+    a.is_final = is_final ? 1 : 0;
+    a.rec_start = d_rec_start;
+    a.cap = d_rec_start ? cap : 0;
+    a.dcarry = ctx->d_carry;
+    a.prescan = 0;
+    ctx->whole_file = false;  // (the "too long" rule of a sharded file is the driver's, as for chunks)
+    ctx->dev_carry = true;
+    ctx->dout_clean = false;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+    if (ctx->used_spec) {
+        launch_emit_fast(s, a, &ctx->d_out[0], ctx->n_cu);
+        launch_finalize_fast(s, a, &ctx->d_out[0]);
+    } else {
+        launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
+        launch_finalize(s, a, &ctx->d_out[0]);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+    if (d_counts) launch_shard_counts(s, &ctx->d_out[0], ctx->h_out, ctx->d_carry, d_counts);
+    HIPCHK(ctx, hipGetLastError());
     return FQH_OK;
 }
 

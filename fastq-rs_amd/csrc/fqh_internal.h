@@ -54,7 +54,18 @@ struct ScanArgs {
     fqh_idx_record *idx;
     uint64_t idx_cap;
     struct DevOut *mirror;         // pinned host copy of the results, written by the finalize kernel (nullable)
+    uint32_t prescan;              // fqh_shard_prescan*: no emit, nothing that depends on the line phase is validated
+    const struct DevCarry *dcarry; // the carry-in lives in device memory (the device-side shard protocol: k_carry_fold wrote it
+                                   // on this stream); the emit / finalize kernels then take it from there
 };
+
+// A carry in device (or pinned host) memory, laid out as fqh_carry, and what the shard exchange found out.
+struct DevCarry {
+    uint64_t base_offset, nl_count;
+    uint64_t back[4];
+    uint64_t any_fail;             // some rank's prescan left the fast path: the exchanged words are not to be used
+};
+constexpr uint32_t SHARD_WORDS = 8;  // FQH_SHARD_WORDS: len, newlines, line starts, back_zero_carry[4], "left the fast path"
 
 // Arguments of the line-parallel histogram kernels (stats_kernels.hip: k_stats_oct, k_stats_lines).
 struct StatsArgs {

@@ -93,6 +93,14 @@ __global__ __launch_bounds__(1024) void k_prefix_top(uint64_t *__restrict__ bloc
 
 // ---------------------------------------------------------------------------------------------
 // helpers on the tile index
+// The carry-in of a launch whose carry was worked out on the device (fqh_shard_rescan_launch).
+__device__ __forceinline__ void load_carry(ScanArgs &a) {
+    if (!a.dcarry) return;
+    a.base_offset = a.dcarry->base_offset;
+    a.nl_count = a.dcarry->nl_count;
+    for (int i = 0; i < 4; ++i) a.back[i] = a.dcarry->back[i];
+    a.v_start = (a.back[0] == 0 && a.len > 0) ? 1u : 0u;
+}
 __device__ __forceinline__ uint64_t tile_pref(const ScanArgs &a, uint64_t t) {
     return a.block_prefix[t >> SCAN_SHIFT] + a.tile_prefix[t];
 }
@@ -256,6 +264,7 @@ constexpr uint32_t EMIT_G = 4;
 constexpr uint32_t EMIT_WORDS = 1280;  // staged entries per wave; more -> generic path
 
 __global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ out) {
+    load_carry(a);
     __shared__ uint32_t stage_all[4][EMIT_WORDS + 4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
@@ -458,6 +467,7 @@ __device__ __forceinline__ void publish_and_reset(const ScanArgs &a, DevOut *out
 }
 
 __global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
+    load_carry(a);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
     const bool lastnl = a.len > 0 && a.buf[a.len - 1] == '\n';
@@ -835,6 +845,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // store per lane, in rounds of 16 loads then 16 stores.  ~25 instructions per tile instead of ~110.
 template <uint32_t EMIT_ROUND>
 __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
+    load_carry(a);
     __shared__ uint16_t stage_all[4][EMIT_ROUND * 64];
     uint16_t *const stage = stage_all[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
@@ -989,6 +1000,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
 // rule, carry-out and summary.  Needs at least four line starts in the first and in the last tile;
 // otherwise, or on any violation, it sets spec_fail.
 __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
+    load_carry(a);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     bool fail = out->spec_fail != 0 || a.n_tiles == 0;
     const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
@@ -996,6 +1008,9 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     const uint64_t tl_last = a.n_tiles ? a.n_tiles - 1 : 0;
     const uint32_t hyp_last = a.n_tiles ? a.fast_rs[tl_last * FR_STRIDE + FR_HYP] : 7u;
     const bool small = hyp_last >= FR_SMALL;  // a short tile at the end: all of its (< 8) entries are in its edge slots
+    // a shard's prescan runs under a made-up carry (the shard begins the file): what it is asked for are the newline
+    // count and the last line starts; what depends on the line phase is validated by the rescan under the true carry
+    const bool chk = !a.prescan;
     if (!fail && (a.tile_count[0] < 4 || E < 8)) fail = true;
     if (!fail && (small ? (a.n_tiles < 2 || a.tile_count[tl_last] >= 8 || a.tile_count[tl_last - 1] < 4) : a.tile_count[tl_last] < 4))
         fail = true;
@@ -1009,7 +1024,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         if (a.v_start) {
             const unsigned long long l = a.nl_count;
             const uint8_t b = a.buf[0];
-            if (((l & 3) == 0 && b != '@') || ((l & 3) == 2 && b != '+')) fail = true;
+            if (((l & 3) == 0 && b != '@') || ((l & 3) == 2 && b != '+')) fail = chk;
         }
         const uint32_t rr = (4u - ((uint32_t)lbase0 & 3u)) & 3u;  // first entry of tile 0 that starts a record
         long long S[5];   // line starts rr-4 .. rr of tile 0, chunk-relative
@@ -1033,12 +1048,12 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
             const int j = (int)rr - 4 + k;
             if (j < 0) continue;
             const unsigned long long l = lbase0 + j;
-            if ((l & 3) == 0 && !(cls[k] & 1u)) fail = true;
-            if ((l & 3) == 2 && !(cls[k] & 2u)) fail = true;
+            if ((l & 3) == 0 && !(cls[k] & 1u)) fail = chk;
+            if ((l & 3) == 2 && !(cls[k] & 2u)) fail = chk;
         }
         // length rule and length of the record that ends at entry rr (needs >= 1 earlier record line)
         if (lbase0 + rr >= 4 && !a.head_unchecked) {
-            if ((S[4] - S[3]) != (S[2] - S[1])) fail = true;
+            if ((S[4] - S[3]) != (S[2] - S[1])) fail = chk;
             const unsigned long long reclen = (unsigned long long)(S[4] - S[0]);
             if (reclen > max_len) max_len = reclen;
             const unsigned long long rec = ((lbase0 + rr) >> 2) - 1;
@@ -1072,13 +1087,13 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
                 cs[4 + k] = (long long)((tl_last << WT_SHIFT) + (ce[4 + k] & 0x3FFFu));
             }
             const unsigned long long lq0 = a.nl_count + 1 + tile_pref(a, tl_last);  // line index of the tile's entry 0
-            if (!(hyp_last & 4u) && (hyp_last & 3u) != ((4u - ((uint32_t)lq0 & 3u)) & 3u)) fail = true;  // counted under another alignment
+            if (!(hyp_last & 4u) && (hyp_last & 3u) != ((4u - ((uint32_t)lq0 & 3u)) & 3u)) fail = chk;  // counted under another alignment
             for (uint32_t j = 0; j < 4 + cnt; ++j) {
                 const unsigned long long l = lq0 + j - 4;
-                if ((l & 3) == 0 && !(ce[j] & 0x4000u)) fail = true;
-                if ((l & 3) == 2 && !(ce[j] & 0x8000u)) fail = true;
+                if ((l & 3) == 0 && !(ce[j] & 0x4000u)) fail = chk;
+                if ((l & 3) == 2 && !(ce[j] & 0x8000u)) fail = chk;
                 if (j >= 4 && (l & 3) == 0) {  // a record ends in front of this entry
-                    if ((cs[j] - cs[j - 1]) != (cs[j - 2] - cs[j - 3])) fail = true;
+                    if ((cs[j] - cs[j - 1]) != (cs[j - 2] - cs[j - 3])) fail = chk;
                     const unsigned long long reclen = (unsigned long long)(cs[j] - cs[j - 4]);
                     if (reclen > max_len) max_len = reclen;
                     const unsigned long long rec = (l >> 2) - 1;
@@ -1103,13 +1118,13 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
             // a group starting at l was validated in its tile only if its fifth line start exists as an entry
             const bool group_done = (l & 3) == 0 ? (l + 4 <= l_last) : ((l & ~3ull) + 4 <= l_last);
             if (group_done) continue;
-            if ((l & 3) == 0 && !(le[k] & 0x4000u)) fail = true;
-            if ((l & 3) == 2 && !(le[k] & 0x8000u)) fail = true;
+            if ((l & 3) == 0 && !(le[k] & 0x4000u)) fail = chk;
+            if ((l & 3) == 2 && !(le[k] & 0x8000u)) fail = chk;
         }
         if (lastnl) {
             const unsigned long long lv = a.nl_count + 1 + E;  // a line would start at offset len
             if ((lv & 3) == 0) {  // a record ends exactly at the chunk end: lines lv-4 .. lv-1 = the last four entries
-                if ((((long long)a.len - ls[0]) != (ls[1] - ls[2]))) fail = true;
+                if ((((long long)a.len - ls[0]) != (ls[1] - ls[2]))) fail = chk;
                 const unsigned long long reclen = (unsigned long long)((long long)a.len - ls[3]);
                 if (reclen > max_len) max_len = reclen;
                 const unsigned long long rec = (lv >> 2) - 1;
@@ -1122,7 +1137,7 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
             recent[0] = ls[0]; recent[1] = ls[1]; recent[2] = ls[2]; recent[3] = ls[3];
         }
         const unsigned long long col = (unsigned long long)((long long)a.len - recent[0]);
-        if (a.is_final && ((T & 3) != 0 || col > 0)) fail = true;  // truncated: the exact path reports it
+        if (a.is_final && ((T & 3) != 0 || col > 0)) fail = chk;  // truncated: the exact path reports it
     }
     out->spec_fail = fail ? 1 : 0;
     out->stats_commit = fail ? 0 : 1;
@@ -1140,6 +1155,68 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
     out->err_need = 0;
     out->tail_len = (unsigned long long)((long long)a.len - recent[T & 3]);
     publish_and_reset(a, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The shard exchange without host hops: what a rank contributes, the fold over the ranks in front
+// of it, and what it contributes to the sum at the end.  One thread each.
+__global__ void k_shard_words(const DevOut *__restrict__ out, const DevOut *__restrict__ mirror, uint64_t len,
+                              unsigned long long *__restrict__ w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    w[0] = len;
+    w[1] = out->n_newlines;
+    w[2] = out->total_entries + out->lastnl;
+    for (int i = 0; i < 4; ++i) {  // (as resolve() builds the carry-out of a chunk that began the file)
+        const long long v = (long long)len - out->recent[i];
+        w[3 + i] = v < 0 ? 0ull : ((unsigned long long)v > len ? len : (unsigned long long)v);
+    }
+    // (the finalize kernel has reset the accumulators behind the copy it published)
+    w[7] = (mirror->spec_fail || mirror->overflow) ? 1ull : 0ull;
+}
+// fqh_carry_combine over the rows of the ranks in front of `rank` (src of the host version: fastq_hip.hip)
+__global__ void k_carry_fold(const unsigned long long *__restrict__ all, int n_ranks, int rank, DevCarry *__restrict__ dc,
+                             DevCarry *__restrict__ hc, DevOut *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevCarry c = {};
+    for (int r = 0; r < n_ranks; ++r) c.any_fail |= all[r * SHARD_WORDS + 7];
+    for (int r = 0; r < rank; ++r) {
+        const unsigned long long *w = all + r * SHARD_WORDS;
+        const unsigned long long len = w[0], nls = w[2];
+        DevCarry n = {};
+        n.any_fail = c.any_fail;
+        n.base_offset = c.base_offset + len;
+        n.nl_count = c.nl_count + w[1];
+        int k = 0;
+        for (; k < 4 && (unsigned long long)k < nls; ++k) n.back[k] = w[3 + k];
+        if (len == 0) {
+            for (int i = 0; i < 4; ++i) n.back[i] = c.back[i];
+        } else {
+            for (int j = 0; k < 4; ++k, ++j) {
+                const unsigned long long v = c.back[j < 4 ? j : 3] + len;
+                n.back[k] = v > n.base_offset ? n.base_offset : v;
+            }
+        }
+        c = n;
+    }
+    *dc = c;
+    *hc = c;  // pinned: the host reads it after the stream has drained (fqh_scan_finish)
+    if (c.any_fail) out->spec_fail = 1;  // nothing of this launch is used
+}
+__global__ void k_shard_counts(const DevOut *__restrict__ out, const DevOut *__restrict__ mirror, const DevCarry *__restrict__ dc,
+                               unsigned long long *__restrict__ counts) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    counts[0] = out->n_records;
+    // (a fast path that failed under the true carry: the host reruns the exact path in fqh_scan_finish, after the sum)
+    counts[1] = (out->final_key != NOKEY || mirror->spec_fail || mirror->overflow || dc->any_fail) ? 1ull : 0ull;
+}
+void launch_shard_words(hipStream_t s, const DevOut *out, const DevOut *mirror, uint64_t len, uint64_t *d_words) {
+    hipLaunchKernelGGL(k_shard_words, dim3(1), dim3(64), 0, s, out, mirror, len, (unsigned long long *)d_words);
+}
+void launch_carry_fold(hipStream_t s, const uint64_t *d_all, int n_ranks, int rank, DevCarry *dc, DevCarry *hc, DevOut *out) {
+    hipLaunchKernelGGL(k_carry_fold, dim3(1), dim3(64), 0, s, (const unsigned long long *)d_all, n_ranks, rank, dc, hc, out);
+}
+void launch_shard_counts(hipStream_t s, const DevOut *out, const DevOut *mirror, const DevCarry *dc, uint64_t *d_counts) {
+    hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(64), 0, s, out, mirror, dc, (unsigned long long *)d_counts);
 }
 
 void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *list, uint32_t list_cap,

@@ -42,6 +42,8 @@ pub struct fqh_summary {
 pub const FQH_COMM_ID_BYTES: usize = 128;
 pub const FQH_OPT_FAST_PATH: c_int = 1;
 pub const FQH_OPT_SINGLE_PASS: c_int = 2;
+pub const FQH_SHARD_WORDS: usize = 8;
+pub const FQH_E_AGAIN: c_int = 10;
 
 #[link(name = "fastq_hip")]
 extern "C" {
@@ -85,6 +87,9 @@ extern "C" {
     // ---- byte-range shards across GPUs (the crate is single-process; nearest: src/lib.rs:553-559)
     pub fn fqh_shard_prescan(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, n_newlines: *mut u64,
                              n_line_starts: *mut u64, back_zero_carry: *mut u64) -> c_int;
+    pub fn fqh_shard_prescan_launch(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, d_words: *mut u64) -> c_int;
+    pub fn fqh_shard_rescan_launch(ctx: *mut fqh_ctx, is_final: c_int, d_all_words: *const u64, n_ranks: c_int, rank: c_int,
+                                   d_rec_start: *mut u64, cap: u64, d_counts: *mut u64) -> c_int;
     pub fn fqh_carry_combine(prev: *const fqh_carry, len: u64, n_newlines: u64, n_line_starts: u64,
                              back_zero_carry: *const u64, next: *mut fqh_carry) -> c_int;
     pub fn fqh_rescan_launch(ctx: *mut fqh_ctx, is_final: c_int, carry_in: *const fqh_carry, d_rec_start: *mut u64,

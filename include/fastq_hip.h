@@ -45,7 +45,8 @@ typedef enum {
     FQH_E_IO = 6,
     FQH_E_DEVICE = 7,       /* HIP runtime error; fqh_last_error() has the text */
     FQH_E_ARG = 8,
-    FQH_E_CAPACITY = 9      /* rec_start / index capacity too small; summary.n_records is exact */
+    FQH_E_CAPACITY = 9,     /* rec_start / index capacity too small; summary.n_records is exact */
+    FQH_E_AGAIN = 10        /* fqh_shard_rescan_launch: some shard left the fast path; take the host recipe */
 } fqh_status;
 
 /* Parser state at a byte boundary of the input: everything a scan of the NEXT chunk needs to be
@@ -142,6 +143,20 @@ fqh_status fqh_carry_combine(const fqh_carry *prev, uint64_t len, uint64_t n_new
                              fqh_carry *next);
 fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, uint64_t *d_rec_start,
                              uint64_t cap);
+/* The same recipe with the exchange ON THE DEVICE — no host hop between the byte scan and the emit step (the host
+ * recipe costs two: 0.14 ms of a 3 ms step).  fqh_shard_prescan_launch enqueues step 1 and writes this rank's
+ * FQH_SHARD_WORDS words (len, newlines, line starts, back_zero_carry[4], "left the fast path") to d_words; the host
+ * enqueues an all-gather of them on the same stream (fqh_allgather, or any collective library on the context's
+ * stream); fqh_shard_rescan_launch enqueues the fold of the rows in front of `rank` (fqh_carry_combine, on the device),
+ * the emit / validate step under the carry it gives, and — if d_counts is not NULL — writes (records, 1 if this
+ * shard has a parse error or the recipe cannot be used) there for the sum over the ranks; fqh_scan_finish ends the
+ * launch as usual (summary, carry-out).  It returns FQH_E_AGAIN on EVERY rank when some rank's byte scan could not
+ * keep the fast path (its words are not to be used): the ranks then run the host recipe above.  A parse error inside
+ * a shard is reported by that shard's fqh_scan_finish as usual; the word d_counts[1] tells the other ranks. */
+#define FQH_SHARD_WORDS 8
+fqh_status fqh_shard_prescan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t *d_words);
+fqh_status fqh_shard_rescan_launch(fqh_ctx *ctx, int is_final, const uint64_t *d_all_words, int n_ranks, int rank,
+                                   uint64_t *d_rec_start, uint64_t cap, uint64_t *d_counts);
 /* Where does the first record of a byte-range shard begin, and at which line phase does the shard start?  For hosts
  * that cannot wait for the shards in front of theirs (the host-streamed sharded mode, BASELINE configs[4]: each rank
  * streams its own range and the ranks talk once, at the end).  d_buf[0..len) is a window at the shard's start (a few

@@ -52,5 +52,21 @@ def test_shard_protocol_over_the_c_abi_with_rccl(fqref):
     r, oq, ob, osc = fqref.stats(buf[:n].cpu().numpy(), 150)
     assert np.array_equal(after[2:10].astype(np.uint64), osc)
     assert np.array_equal(after[10: 10 + 150 * 256].astype(np.uint64).reshape(150, 256), oq)
+    # the same exchange without the host in between: words -> all-gather -> fold + emit -> sum, one wait at the end
+    # (fqh_allgather runs on the context's stream: the three steps are ordered by it)
+    W = pkg.SHARD_WORDS
+    w1 = torch.zeros(W, dtype=torch.int64, device=dev)
+    wall = torch.zeros(W, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    rs.zero_()
+    torch.cuda.synchronize()
+    ctx.shard_prescan_launch(buf.data_ptr(), n, w1.data_ptr())
+    ctx._chk(L.fqh_allgather(ctx._h, comm, w1.data_ptr(), wall.data_ptr(), 8 * W))
+    ctx.shard_rescan_launch(True, wall.data_ptr(), 1, 0, rs.data_ptr(), rs.numel(), cnt.data_ptr())
+    ctx._chk(L.fqh_allreduce_u64(ctx._h, comm, cnt.data_ptr(), 2))
+    s2, c2, st2 = ctx.scan_finish()
+    assert (s2.parse_status, s2.n_records, s2.n_newlines) == (pkg.OK, 40000, 160000)
+    assert cnt.cpu().tolist() == [40000, 0] and wall.cpu().tolist() == [n, nn, ns] + back0 + [0]
+    assert np.array_equal(rs.cpu().numpy()[:40001], np.arange(40001) * 330)
     L.fqh_comm_destroy(comm)
     ctx.close()

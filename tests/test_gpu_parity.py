@@ -424,6 +424,97 @@ def test_sharded_two_stage_protocol(fqref, torch, pkg, seed):
     assert starts[: res.n_records] == [int(x) for x in idx[:, 0]]
 
 
+@pytest.mark.parametrize("kind", ["reads150", "ragged", "short_shard", "error_in_shard", "long_reads"])
+def test_sharded_protocol_on_the_device(fqref, torch, pkg, kind):
+    """The same protocol with the exchange on the device: fqh_shard_prescan_launch writes a rank's 8 words to device
+    memory, (here: straight into its row of the gathered array; across GPUs: an all-gather), fqh_shard_rescan_launch folds
+    the rows in front of the rank and emits under that carry — no host hop in between.  Result == whole-file oracle;
+    a shard that cannot keep the fast path makes every rank's finish return E_AGAIN (the host recipe then runs)."""
+    rng = np.random.default_rng(5)
+    alph = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i in range(9000 if kind != "long_reads" else 400):
+        L = 150 if kind in ("reads150", "error_in_shard") else int(rng.integers(1, 200))
+        if kind == "long_reads":
+            L = 9000   # fewer than eight line starts per 16 KiB tile: not something the fast path proves
+        recs.append(b"@r%d\n" % i + rng.choice(alph, L).tobytes() + b"\n+\n" + rng.integers(33, 74, L).astype(np.uint8).tobytes() + b"\n")
+    data = bytearray(b"".join(recs))
+    n = len(data)
+    nsh = 4
+    cuts = [0] + sorted(int(x) for x in rng.integers(n // 8, n - n // 8, nsh - 1)) + [n]
+    if kind == "short_shard":
+        cuts[2] = cuts[1] + 37          # a shard inside one line
+    if kind == "error_in_shard":
+        k = data.index(b"\n+\n", cuts[2] + 5000)
+        data[k + 1] = ord("-")          # in the third shard
+    data = bytes(data)
+    res, idx = fqref.index(data, bufsize=1 << 22)
+    dev = torch.device("cuda:0")
+    W = pkg.SHARD_WORDS
+    stream = torch.cuda.Stream(device=dev)   # ONE stream for all the "ranks": nothing else orders their kernels here
+    torch.cuda.set_stream(stream)
+    all_words = torch.zeros(nsh * W, dtype=torch.int64, device=dev)
+    counts = torch.zeros(nsh * 2, dtype=torch.int64, device=dev)
+    ctxs, bufs, outs = [], [], []
+    for r, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        c = pkg.Ctx(0, stream=stream.cuda_stream, bufsize=0)
+        d = torch.empty(max(b - a, 16), dtype=torch.uint8, device=dev)
+        d[: b - a].copy_(torch.from_numpy(np.frombuffer(data[a:b], dtype=np.uint8).copy()))
+        c.shard_prescan_launch(d.data_ptr(), b - a, all_words[r * W:].data_ptr())
+        ctxs.append(c); bufs.append((d, b - a))
+    for r, c in enumerate(ctxs):
+        cap = bufs[r][1] // 6 + 3
+        rs = torch.zeros(cap, dtype=torch.int64, device=dev)
+        c.shard_rescan_launch(r == nsh - 1, all_words.data_ptr(), nsh, r, rs.data_ptr(), cap, counts[2 * r:].data_ptr())
+        outs.append(rs)
+    again, starts, total, status = 0, [], 0, pkg.OK
+    for r, c in enumerate(ctxs):
+        try:
+            s, cout, st = c.scan_finish()
+        except pkg.FqhError as e:
+            assert e.status == pkg.E_AGAIN
+            again += 1
+            continue
+        offs = outs[r].cpu().numpy()
+        if status == pkg.OK:
+            if not starts:
+                starts.append(int(offs[0]))
+            starts += [int(x) for x in offs[1: s.n_records + 1]]
+            total += s.n_records
+            if s.parse_status != pkg.OK:
+                status = s.parse_status
+                assert (s.err_record, s.err_offset) == (res.err_record, res.err_offset)
+        assert int(counts[2 * r]) == s.n_records or s.parse_status != pkg.OK
+    if kind in ("long_reads", "short_shard", "error_in_shard"):
+        # (a shard of 37 bytes has no four line starts to show; a tile with a broken record settles no alignment)
+        assert again == nsh       # every rank learns it from the gathered words
+        carry, starts, total, status = None, [], 0, pkg.OK
+        for r, c in enumerate(ctxs):   # the host recipe, on the same contexts
+            nn, ns, back0 = c.shard_prescan(bufs[r][0].data_ptr(), bufs[r][1])
+            c.rescan_launch(r == nsh - 1, carry, outs[r].data_ptr(), outs[r].numel())
+            s, cout, st = c.scan_finish()
+            carry = pkg.carry_combine(carry, bufs[r][1], nn, ns, back0)
+            if status == pkg.OK:
+                offs = outs[r].cpu().numpy()
+                if not starts:
+                    starts.append(int(offs[0]))
+                starts += [int(x) for x in offs[1: s.n_records + 1]]
+                total += s.n_records
+                if s.parse_status != pkg.OK:
+                    status = s.parse_status
+                    assert (s.err_record, s.err_offset) == (res.n_records, res.bytes_consumed)  # the failing record: the one after the last good one
+        assert (status, total) == (res.status, res.n_records)
+        assert starts[: res.n_records] == [int(x) for x in idx[: res.n_records, 0]]
+    else:
+        assert again == 0
+        assert (status, total) == (res.status, res.n_records) == (pkg.OK, len(recs))
+        assert starts[: res.n_records] == [int(x) for x in idx[: res.n_records, 0]]
+        assert int(counts[1::2].sum()) == 0 and int(counts[0::2].sum()) == res.n_records
+    for c in ctxs:
+        c.close()
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_sharded_histograms_with_tail_exchange(fqref, torch, pkg, seed):
     """bench.py --shard-stats on one GPU: byte-range shards cut anywhere; every shard gets the tail of the

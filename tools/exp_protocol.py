@@ -1,5 +1,6 @@
-"""tools/exp_protocol.py — host-side overhead of the N > 1 step (prescan, all_gather, carry combine,
-rescan, all_reduce) against the plain scan, on one GPU with an RCCL group of size 1."""
+"""tools/exp_protocol.py — overhead of the N > 1 step against the plain scan, on one GPU with an RCCL group of size 1:
+the host recipe (prescan, all_gather, carry combine on the host, rescan, all_reduce: two host hops) and the device
+recipe (fqh_shard_prescan_launch, all_gather, fqh_shard_rescan_launch, all_reduce: one wait at the end)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -9,6 +10,7 @@ pkg = g.load_package()
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 nbytes = (16 << 30) // 330 * 330
+torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # (a real stream: the library replaces the null stream by one of its own)
 ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
 buf = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
 ctx.synth_fill(buf.data_ptr(), 0, nbytes)
@@ -28,7 +30,17 @@ def proto():
     s, c, st = ctx.scan_finish()
     counts[0] = s.n_records; counts[1] = 0
     dist.all_reduce(counts)
-for name, fn in (("plain", plain), ("protocol", proto), ("plain", plain), ("protocol", proto)):
+W = pkg.SHARD_WORDS
+words = torch.zeros(W, dtype=torch.int64, device=dev)
+allw = torch.zeros(W, dtype=torch.int64, device=dev)
+def proto_dev():
+    ctx.shard_prescan_launch(buf.data_ptr(), nbytes, words.data_ptr())
+    dist.all_gather_into_tensor(allw, words)
+    ctx.shard_rescan_launch(True, allw.data_ptr(), 1, 0, rs.data_ptr(), cap, counts.data_ptr())
+    dist.all_reduce(counts)
+    s, c, st = ctx.scan_finish()
+    assert s.n_records == nbytes // 330
+for name, fn in (("plain", plain), ("host recipe", proto), ("device recipe", proto_dev), ("plain", plain), ("host recipe", proto), ("device recipe", proto_dev)):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): fn()

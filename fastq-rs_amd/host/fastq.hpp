@@ -169,6 +169,11 @@ struct Options {
     uint64_t slot_bytes = 32ull << 20;  // pinned ring slot (the GPU-side "BUFSIZE")
     uint32_t n_slots = 3;
     uint64_t bufsize = BUFSIZE;         // the reference's BUFSIZE, for its "too long" rule (64 = cfg(fuzzing))
+    // Pipes and sockets: the reference delivers records as soon as a 68 KiB refill holds one (src/lib.rs:255-303); the
+    // ring waits for a whole slot.  With low_latency a slot is submitted as it is when the reader comes back with less than
+    // was asked for and nothing else is on its way to the GPU (the consumer would only wait).  Results are the same;
+    // a chunk then costs a GPU round trip per read() of the pipe, so it is off for files.
+    bool low_latency = false;
 };
 
 namespace detail {
@@ -344,9 +349,11 @@ class Parser {
             if (st != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
             uint64_t n = 0;
             while (n < cap) {
-                size_t got = reader_.read(dst + n, (size_t)(cap - n));
+                const size_t want = (size_t)(cap - n);
+                size_t got = reader_.read(dst + n, want);
                 if (got == 0) { eof_ = true; break; }
                 n += got;
+                if (opt_.low_latency && got < want && in_flight_ == 0) break;  // what there is, now
             }
             if (fqh_stream_submit(h_.st, n, eof_ ? 1 : 0) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
             ++in_flight_;

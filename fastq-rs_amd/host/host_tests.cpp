@@ -154,6 +154,13 @@ static void zipped_and_thread_reader() {  // each_zipped lib.rs:577-609, thread_
     CHECK(n == 20000);
 }
 
+// a pipe: read() comes back with at most 3001 bytes at a time
+struct DribbleReader {
+    MemReader m;
+    explicit DribbleReader(const std::string &s) : m(s) {}
+    size_t read(uint8_t *dst, size_t n) { return m.read(dst, n < 3001 ? n : 3001); }
+};
+
 static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) {
     std::ifstream f(file, std::ios::binary);
     std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -167,6 +174,16 @@ static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) 
         try { p.each([&](const RefRecord &r) { ++n; bases += r.seq().size(); return true; }); }
         catch (const Error &e) { err = e.what(); }
         printf("each %zu %zu %s\n", n, bases, err.c_str());
+    }
+    {   // each over a pipe, chunks submitted as the reads come in (Options::low_latency): the same records
+        Options ol = o;
+        ol.low_latency = true;
+        Parser<DribbleReader> p(DribbleReader(d), ol);
+        size_t n = 0, bases = 0;
+        std::string err = "ok";
+        try { p.each([&](const RefRecord &r) { ++n; bases += r.seq().size(); return true; }); }
+        catch (const Error &e) { err = e.what(); }
+        printf("pipe %zu %zu %s\n", n, bases, err.c_str());
     }
     {   // record_sets
         Parser<MemReader> p(MemReader(d), o);

@@ -23,6 +23,7 @@
 // boundaries exactly.  A Reader is anything with `size_t read(uint8_t *dst, size_t n)` returning 0
 // at end of input (std::io::Read); it may throw.
 #pragma once
+#include <dlfcn.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -489,8 +490,8 @@ class FileReader {  // std::fs::File / stdin
 };
 
 // thread_reader (src/thread_reader.rs:182-200): `queuelen` recycled buffers of `bufsize` bytes are
-// filled by a background thread; the consumer sees a Reader.  A reader exception is rethrown in the
-// consumer as BrokenPipe-style Error after the thread has been joined.
+// filled by a background thread; the consumer sees a Reader.  A reader's error reaches the consumer's read() as it
+// is (the reference forwards the io::Result of every read in its BufferMessage).
 template <class Reader>
 class ThreadReader {
   public:
@@ -508,7 +509,12 @@ class ThreadReader {
             std::unique_lock<std::mutex> lk(m_);
             if (have_cur_) { empty_.push_back(std::move(cur_)); have_cur_ = false; cv_.notify_all(); }
             cv_.wait(lk, [&] { return !full_.empty() || failed_; });
-            if (full_.empty()) throw Error(ErrorKind::BrokenPipe, "reader thread died");
+            if (full_.empty()) {
+                // the reader's own error, as the BufferMessage carries the io::Result of its read()
+                // (src/thread_reader.rs:134-137); BrokenPipe only if the thread went away without one
+                if (err_) std::rethrow_exception(err_);
+                throw Error(ErrorKind::BrokenPipe, "reader thread died");
+            }
             auto m = std::move(full_.front());
             full_.pop_front();
             cur_ = std::move(m.first);
@@ -536,6 +542,7 @@ class ThreadReader {
             size_t got = 0;
             try { got = reader_.read(b.data(), bufsize_); } catch (...) {
                 std::lock_guard<std::mutex> lk(m_);
+                err_ = std::current_exception();
                 failed_ = true;
                 cv_.notify_all();
                 return;
@@ -555,6 +562,7 @@ class ThreadReader {
     std::vector<uint8_t> cur_;
     size_t cur_len_ = 0, cur_pos_ = 0;
     bool have_cur_ = false, stop_ = false, failed_ = false;
+    std::exception_ptr err_;
     std::thread th_;
 };
 
@@ -665,6 +673,155 @@ class GzReader {
 };
 #endif
 
+
+// bzip2, xz and zstd — the other formats niffler sniffs for parse_path (src/lib.rs:173-190).  The image ships the
+// run-time libraries (libbz2.so.1, liblzma.so.5, libzstd.so.1) but no headers: the three streaming decoders are bound
+// with dlopen, through the few stable declarations of their public C interfaces restated here.  A box without the
+// library gets niffler's "no decoder" error for that format.  Concatenated streams / frames are decoded back to back,
+// as bzip2 -d, xz -d and zstd -d do.  Runs on the thread_reader thread.
+namespace codec {
+inline void *open_lib(const char *a, const char *b) {
+    void *h = dlopen(a, RTLD_NOW | RTLD_LOCAL);
+    if (!h && b) h = dlopen(b, RTLD_NOW | RTLD_LOCAL);
+    return h;
+}
+template <class T>
+inline bool sym(void *h, const char *name, T &fn) {
+    fn = reinterpret_cast<T>(dlsym(h, name));
+    return fn != nullptr;
+}
+
+struct Bz2 {  // bzlib.h 1.0: bz_stream, BZ2_bzDecompress{Init,,End}; BZ_OK 0, BZ_STREAM_END 4
+    struct Stream {
+        char *next_in; unsigned avail_in, total_in_lo32, total_in_hi32;
+        char *next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+        void *state; void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
+    };
+    int (*init)(Stream *, int, int) = nullptr;
+    int (*run)(Stream *) = nullptr;
+    int (*end)(Stream *) = nullptr;
+    Stream z{};
+    bool live = false;
+    static const char *name() { return "bzip2"; }
+    bool load() {
+        void *h = open_lib("libbz2.so.1", "libbz2.so.1.0");
+        return h && sym(h, "BZ2_bzDecompressInit", init) && sym(h, "BZ2_bzDecompress", run) && sym(h, "BZ2_bzDecompressEnd", end);
+    }
+    bool start() { memset(&z, 0, sizeof z); live = init(&z, 0, 0) == 0; return live; }
+    void stop() { if (live) end(&z); live = false; }
+    // -> 0 progress, 1 stream ended, -1 corrupt
+    int step(const uint8_t *&in, size_t &n_in, uint8_t *&out, size_t &n_out) {
+        z.next_in = (char *)in; z.avail_in = (unsigned)(n_in < 0x40000000u ? n_in : 0x40000000u);
+        z.next_out = (char *)out; z.avail_out = (unsigned)(n_out < 0x40000000u ? n_out : 0x40000000u);
+        const unsigned ai = z.avail_in, ao = z.avail_out;
+        const int rc = run(&z);
+        in += ai - z.avail_in; n_in -= ai - z.avail_in;
+        out += ao - z.avail_out; n_out -= ao - z.avail_out;
+        return rc == 4 ? 1 : rc == 0 ? 0 : -1;
+    }
+};
+
+struct Xz {  // lzma/base.h 5.2: lzma_stream (136 bytes on LP64), lzma_stream_decoder, lzma_code, lzma_end
+    struct Stream {
+        const uint8_t *next_in; size_t avail_in; uint64_t total_in;
+        uint8_t *next_out; size_t avail_out; uint64_t total_out;
+        const void *allocator; void *internal;
+        void *reserved_ptr[4]; uint64_t reserved_int1, reserved_int2; size_t reserved_int3, reserved_int4;
+        int reserved_enum1, reserved_enum2;
+        uint64_t slack[8];  // (room, should a later 5.x grow the struct)
+    };
+    int (*init)(Stream *, uint64_t, uint32_t) = nullptr;
+    int (*run)(Stream *, int) = nullptr;
+    void (*end)(Stream *) = nullptr;
+    Stream z{};
+    bool live = false;
+    static const char *name() { return "xz"; }
+    bool load() {
+        void *h = open_lib("liblzma.so.5", nullptr);
+        return h && sym(h, "lzma_stream_decoder", init) && sym(h, "lzma_code", run) && sym(h, "lzma_end", end);
+    }
+    bool start() { memset(&z, 0, sizeof z); live = init(&z, UINT64_MAX, 0) == 0; return live; }  // one .xz stream per start
+    void stop() { if (live) end(&z); live = false; }
+    int step(const uint8_t *&in, size_t &n_in, uint8_t *&out, size_t &n_out) {
+        z.next_in = in; z.avail_in = n_in; z.next_out = out; z.avail_out = n_out;
+        const int rc = run(&z, 0 /* LZMA_RUN */);
+        in = z.next_in; n_in = z.avail_in; out = z.next_out; n_out = z.avail_out;
+        return rc == 1 /* LZMA_STREAM_END */ ? 1 : (rc == 0 || rc == 10 /* LZMA_BUF_ERROR: no progress possible yet */) ? 0 : -1;
+    }
+};
+
+struct Zstd {  // zstd.h 1.4: ZSTD_DStream, ZSTD_inBuffer / ZSTD_outBuffer, ZSTD_decompressStream (0: a frame is complete)
+    struct Buf { void *p; size_t size, pos; };
+    void *(*create)() = nullptr;
+    size_t (*destroy)(void *) = nullptr;
+    size_t (*init)(void *) = nullptr;
+    size_t (*run)(void *, Buf *, Buf *) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    void *d = nullptr;
+    static const char *name() { return "zstd"; }
+    bool load() {
+        void *h = open_lib("libzstd.so.1", nullptr);
+        return h && sym(h, "ZSTD_createDStream", create) && sym(h, "ZSTD_freeDStream", destroy) && sym(h, "ZSTD_initDStream", init) &&
+               sym(h, "ZSTD_decompressStream", run) && sym(h, "ZSTD_isError", is_error);
+    }
+    bool start() {
+        if (!d) d = create();
+        return d && !is_error(init(d));
+    }
+    void stop() { if (d) destroy(d); d = nullptr; }
+    int step(const uint8_t *&in, size_t &n_in, uint8_t *&out, size_t &n_out) {
+        Buf o = {out, n_out, 0}, i = {(void *)in, n_in, 0};
+        const size_t rc = run(d, &o, &i);
+        in += i.pos; n_in -= i.pos; out += o.pos; n_out -= o.pos;
+        if (is_error(rc)) return -1;
+        return rc == 0 ? 1 : 0;
+    }
+};
+}  // namespace codec
+
+template <class Codec, class Reader>
+class CodecReader {
+  public:
+    explicit CodecReader(Reader r) : r_(std::move(r)), in_(1 << 16) {
+        if (!c_.load()) throw Error(ErrorKind::InvalidData, std::string("Niffler failled in compression detection: no decoder library on this machine for ") + Codec::name());
+    }
+    CodecReader(CodecReader &&o) noexcept : r_(std::move(o.r_)), in_(std::move(o.in_)), c_(o.c_) {
+        if (o.started_) std::terminate();  // (a decoder's state holds pointers into itself: only a fresh reader moves)
+    }
+    CodecReader(const CodecReader &) = delete;
+    ~CodecReader() { c_.stop(); }
+    size_t read(uint8_t *dst, size_t n) {
+        started_ = true;
+        uint8_t *out = dst;
+        size_t left = n;
+        while (left == n && !done_) {  // until some output exists or the input is exhausted at a stream boundary
+            if (avail_ == 0 && !in_eof_) {
+                avail_ = r_.read(in_.data(), in_.size());
+                pos_ = in_.data();
+                if (avail_ == 0) in_eof_ = true;
+            }
+            if (!in_stream_) {  // between streams: more input => the next stream, none => EOF
+                if (avail_ == 0) { done_ = true; break; }
+                if (!c_.start()) throw Error(ErrorKind::Other, std::string(Codec::name()) + " decoder init failed");
+                in_stream_ = true;
+            }
+            if (avail_ == 0) throw Error(ErrorKind::InvalidData, std::string("unexpected end of ") + Codec::name() + " stream");
+            const uint8_t *ip = pos_;
+            const int rc = c_.step(ip, avail_, out, left);
+            pos_ = ip;
+            if (rc < 0) throw Error(ErrorKind::InvalidData, std::string("corrupt ") + Codec::name() + " stream");
+            if (rc == 1) { c_.stop(); in_stream_ = false; }
+        }
+        return n - left;
+    }
+  private:
+    Reader r_;
+    std::vector<uint8_t> in_;
+    Codec c_;
+    const uint8_t *pos_ = nullptr;
+    size_t avail_ = 0;
+    bool started_ = false, in_eof_ = false, in_stream_ = false, done_ = false;
+};
 
 // LZ4 frame decoder on the host (the published LZ4 Frame format 1.6.x and LZ4 block format: no dependency, the image has
 // no lz4 headers).  Concatenated frames and skippable frames are accepted like `lz4 -d` does; blocks may depend on the
@@ -839,6 +996,24 @@ auto with_plain_reader(const std::optional<std::string> &path, F use) {  // use(
 #endif
     if (fmt == Compression::Lz4) {
         return thread_reader(1 << 22, 2, Lz4Reader<PrefixReader<FileReader>>(std::move(chained)), [&](auto reader) {
+            DynReader dyn(&reader);
+            return use(dyn);
+        });
+    }
+    if (fmt == Compression::Bzip2) {
+        return thread_reader(1 << 22, 2, CodecReader<codec::Bz2, PrefixReader<FileReader>>(std::move(chained)), [&](auto reader) {
+            DynReader dyn(&reader);
+            return use(dyn);
+        });
+    }
+    if (fmt == Compression::Lzma) {
+        return thread_reader(1 << 22, 2, CodecReader<codec::Xz, PrefixReader<FileReader>>(std::move(chained)), [&](auto reader) {
+            DynReader dyn(&reader);
+            return use(dyn);
+        });
+    }
+    if (fmt == Compression::Zstd) {
+        return thread_reader(1 << 22, 2, CodecReader<codec::Zstd, PrefixReader<FileReader>>(std::move(chained)), [&](auto reader) {
             DynReader dyn(&reader);
             return use(dyn);
         });

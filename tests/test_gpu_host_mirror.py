@@ -170,6 +170,16 @@ def test_fastq_count_on_gzip_input(gpu_ok, fqref, tmp_path):
         names.append("in.fq.lz4")
     except OSError:
         pass
+    import bz2, lzma  # the other formats niffler sniffs: decoded by the system's libraries, bound at run time
+    (tmp_path / "in.fq.bz2").write_bytes(bz2.compress(data))
+    (tmp_path / "in.fq.xz").write_bytes(lzma.compress(data[:cut], format=lzma.FORMAT_XZ) + lzma.compress(data[cut:], format=lzma.FORMAT_XZ))
+    names += ["in.fq.bz2", "in.fq.xz"]
+    try:
+        from test_host_parse_path import zstd_frame
+        (tmp_path / "in.fq.zst").write_bytes(zstd_frame(data))
+        names.append("in.fq.zst")
+    except OSError:
+        pass
     for name in names:
         for extra in ([], ["--threads", "3"]):
             out = subprocess.run([os.path.join(BIN, "fastq_count"), str(tmp_path / name)] + extra,

@@ -105,15 +105,60 @@ def test_lz4_frames_give_the_same_bytes(host_tests, tmp_path):
     assert rc == 3 and out.startswith("error")
 
 
+def zstd_frame(data, level=3):
+    """A zstd frame made by the system's libzstd (ZSTD_compress)."""
+    import ctypes as C
+    L = C.CDLL("libzstd.so.1")
+    L.ZSTD_compressBound.restype = C.c_size_t
+    L.ZSTD_compressBound.argtypes = [C.c_size_t]
+    L.ZSTD_compress.restype = C.c_size_t
+    L.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    L.ZSTD_isError.argtypes = [C.c_size_t]
+    cap = L.ZSTD_compressBound(len(data))
+    out = C.create_string_buffer(cap)
+    n = L.ZSTD_compress(out, cap, data, len(data), level)
+    assert not L.ZSTD_isError(n)
+    return out.raw[:n]
+
+
+def test_bzip2_xz_zstd_give_the_same_bytes(host_tests, tmp_path):
+    """The other formats niffler sniffs (src/lib.rs:173-190): decoded by the system's libbz2 / liblzma / libzstd, bound
+    at run time.  Files written by Python's bz2 / lzma modules and by libzstd: one stream, and two back to back."""
+    import lzma
+    rng = np.random.default_rng(79)
+    data = fuzzgen.valid_file(rng, 6000, maxlen=150)
+    want = "plain %d %016x" % (len(data), fnv1a(data))
+    cut = len(data) // 3
+    variants = {
+        "a.bz2": bz2.compress(data),
+        "multi.bz2": bz2.compress(data[:cut], 1) + bz2.compress(data[cut:]),
+        "a.xz": lzma.compress(data, format=lzma.FORMAT_XZ),
+        "multi.xz": lzma.compress(data[:cut], format=lzma.FORMAT_XZ, preset=1) + lzma.compress(data[cut:], format=lzma.FORMAT_XZ),
+    }
+    try:
+        variants["a.zst"] = zstd_frame(data)
+        variants["multi.zst"] = zstd_frame(data[:cut], 1) + zstd_frame(data[cut:], 19)
+    except OSError:
+        pass   # no libzstd.so.1 on this box to write test frames with
+    for name, blob in variants.items():
+        (tmp_path / name).write_bytes(blob)
+        assert plain(host_tests, tmp_path / name) == (0, want), name
+    for name in ("a.bz2", "a.xz", "a.zst"):
+        if name in variants:
+            (tmp_path / ("trunc." + name)).write_bytes(variants[name][: len(variants[name]) // 2])
+            rc, out = plain(host_tests, tmp_path / ("trunc." + name))
+            assert rc == 3 and out.startswith("error"), name
+            (tmp_path / ("junk." + name)).write_bytes(variants[name][:64] + b"\x00junk" * 50)
+            rc, out = plain(host_tests, tmp_path / ("junk." + name))
+            assert rc == 3 and out.startswith("error"), name
+
+
 def test_sniffing_errors(host_tests, tmp_path):
     data = b"@a\nACGT\n+\nIIII\n" * 100
     (tmp_path / "short").write_bytes(b"@a\nA")                      # niffler: FileTooShort
     rc, out = plain(host_tests, tmp_path / "short")
     assert rc == 3 and "less than five bytes" in out
-    (tmp_path / "x.bz2").write_bytes(bz2.compress(data))            # detected, no decoder in this build
-    rc, out = plain(host_tests, tmp_path / "x.bz2")
-    assert rc == 3 and "bzip2" in out
-    (tmp_path / "x.xz").write_bytes(bytes([0xfd, 0x37, 0x7a, 0x58, 0x5a, 0]) + b"junk")
+    (tmp_path / "x.xz").write_bytes(bytes([0xfd, 0x37, 0x7a, 0x58, 0x5a, 0]) + b"junk")   # the magic, then nothing xz
     rc, out = plain(host_tests, tmp_path / "x.xz")
     assert rc == 3 and "xz" in out
     (tmp_path / "x.zst").write_bytes(bytes([0x28, 0xb5, 0x2f, 0xfd, 0]) + b"junk")

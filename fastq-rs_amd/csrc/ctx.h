@@ -58,6 +58,7 @@ struct fqh_ctx {
     DevOut *h_out = nullptr;      // pinned
     DevOut *h_init = nullptr;     // pinned reset image
     uint64_t *d_misc = nullptr;   // 8 u64 of scratch
+    uint16_t *list_dummy = nullptr;  // 1 KiB: where k_index_fast's list-area writes go while the context has no line lists
     DevCarry *d_carry = nullptr;  // device-side shard protocol: the folded carry, and its pinned twin the host reads at finish
     DevCarry *h_carry = nullptr;
     bool dev_carry = false;       // the launch in flight took its carry from d_carry
@@ -84,6 +85,7 @@ struct fqh_ctx {
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...
     uint32_t spec_backoff = 0;  // ... 1, 2, 4 .. 64 of them, doubling with every failure in a row
     bool index_full = true;     // the tile index in the workspace holds complete line lists
+    bool fast_needs_list = false;  // an input of this context had tiles denser than the fast path's two lines: keep the line lists allocated
     bool dout_clean = false;    // d_out[0]'s accumulators were reset by the last finalize kernel (no init copy needed)
     bool used_spec = false;     // the scan in flight runs the fast path
     fqh_summary last_summary = {};

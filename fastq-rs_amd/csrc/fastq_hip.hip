@@ -70,6 +70,7 @@ fqh_status fqh_create(int device, fqh_ctx **out) {
         ctx->stream = ctx->own_stream;
         if (hipMalloc((void **)&ctx->d_out, 2 * sizeof(DevOut)) != hipSuccess) { st = FQH_E_DEVICE; break; }
         if (hipMalloc((void **)&ctx->d_misc, 64) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        if (hipMalloc((void **)&ctx->list_dummy, 1024) != hipSuccess) { st = FQH_E_DEVICE; break; }
         if (hipHostMalloc((void **)&ctx->h_out, sizeof(DevOut), hipHostMallocDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }
         if (hipHostMalloc((void **)&ctx->h_init, sizeof(DevOut), hipHostMallocDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }
         memset(ctx->h_init, 0, sizeof(DevOut));
@@ -101,6 +102,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->block_prefix);
     (void)hipFree(ctx->d_out);
     (void)hipFree(ctx->d_misc);
+    (void)hipFree(ctx->list_dummy);
     (void)hipFree(ctx->d_carry);
     if (ctx->h_carry) (void)hipHostFree(ctx->h_carry);
     (void)hipFree(ctx->idx);
@@ -132,8 +134,11 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
-static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles) {
-    const size_t need_list = (size_t)n_tiles * ctx->list_cap;
+// with_list: the line lists (1 KiB per 16 KiB tile).  The exact path writes them; the fast path only needs them for tiles with
+// more record starts than a tile's two lines hold (reads shorter than ~50 bp), so a context that only ever sees the fast
+// path on ordinary reads never allocates them.
+static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_list) {
+    const size_t need_list = with_list ? (size_t)n_tiles * ctx->list_cap : 0;
     if (need_list > ctx->list_elems) {
         (void)hipFree(ctx->list);
         ctx->list = nullptr;
@@ -165,9 +170,10 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles) {
 static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     ScanArgs &a = ctx->args;
     hipStream_t s = ctx->stream;
-    fqh_status st = ensure_workspace(ctx, a.n_tiles);
+    const bool with_list = !fast || ctx->fast_needs_list;
+    fqh_status st = ensure_workspace(ctx, a.n_tiles, with_list);
     if (st != FQH_OK) return st;
-    a.list = ctx->list;
+    a.list = with_list ? ctx->list : nullptr;
     a.list_cap = ctx->list_cap;
     a.tile_count = ctx->tile_count;
     a.fast_rs = ctx->fast_rs;
@@ -198,7 +204,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.buf = a.buf;
         fz.len = a.len;
         fz.n_tiles = a.n_tiles;
-        fz.list = ctx->list;
+        fz.list = const_cast<uint16_t *>(a.list);
         fz.list_cap = ctx->list_cap;
         fz.fast_rs = ctx->fast_rs;
         fz.out = &ctx->d_out[0];
@@ -216,8 +222,10 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
 #endif
         ctx->index_full = false;
     } else if (!reuse_index) {
-        launch_index(s, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs, a.n_tiles,
-                     &ctx->d_out[0], ctx->n_cu, fast);
+        // (the fast path without a line-list workspace: what a tile with more than 116 record starts would put there goes
+        // to a 1 KiB dummy — list_cap 0 — and k_emit_fast reports such a tile, need_list)
+        launch_index(s, a.buf, a.len, a.list ? const_cast<uint16_t *>(a.list) : ctx->list_dummy, a.list ? ctx->list_cap : 0u,
+                     ctx->tile_count, ctx->fast_rs, a.n_tiles, &ctx->d_out[0], ctx->n_cu, fast);
         ctx->index_full = !fast;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
@@ -421,6 +429,15 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
             return fail(ctx, FQH_E_AGAIN, "a shard's byte scan left the fast path: run fqh_shard_prescan / fqh_carry_combine / fqh_rescan_launch");
         }
     }
+    if (ctx->used_spec && ctx->h_out->spec_fail && ctx->h_out->need_list && !ctx->fast_needs_list) {
+        // not a doubt about the input: a tile holds more record starts than its two lines take (reads shorter than ~50 bp)
+        // and this context has no line-list workspace yet.  Allocate it and run the fast path again; it stays.
+        ctx->fast_needs_list = true;
+        fqh_status st = enqueue_scan(ctx, false, true);
+        if (st != FQH_OK) return st;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->dout_clean = true;
+    }
     if (ctx->used_spec && ctx->h_out->spec_fail) {
         // the fast path could not prove the input valid (a real error, lines longer than a few KiB,
         // or a degenerate layout): run the exact path, and keep later scans of this context on it for a
@@ -472,7 +489,7 @@ static fqh_status ensure_full_index(fqh_ctx *ctx) {
     if (ctx->index_full) return FQH_OK;
     const ScanArgs &a = ctx->args;
     for (;;) {
-        fqh_status st = ensure_workspace(ctx, a.n_tiles);
+        fqh_status st = ensure_workspace(ctx, a.n_tiles, true);
         if (st != FQH_OK) return st;
         HIPCHK(ctx, hipMemcpyAsync(&ctx->d_out[1], ctx->h_init, sizeof(DevOut), hipMemcpyHostToDevice, ctx->stream));
         launch_index(ctx->stream, a.buf, a.len, ctx->list, ctx->list_cap, ctx->tile_count, ctx->fast_rs,

@@ -114,6 +114,8 @@ struct DevOut {
     long long err_start;            // chunk-relative start of the failing record
     unsigned long long err_need;    // bytes of the failing record needed to see its error (0: n/a)
     unsigned long long tail_len;
+    unsigned long long need_list;    // fast path without a line-list workspace: a tile has more record starts than its two lines hold
+                                     // (reads shorter than ~50 bp): rerun the fast path with the workspace (reset by finalize)
     unsigned long long stats_commit; // written by k_finalize_fast: 1 = the fast path's result stands (k_stats_commit may add
                                      // what k_scan_stats counted to the caller's histograms), 0 = it is discarded
 };

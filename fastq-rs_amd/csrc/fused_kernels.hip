@@ -641,8 +641,14 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                     const uint32_t nrs = trun > hyp_t ? (trun - hyp_t + 3) >> 2 : 0u;  // record starts of the tile
                     if (nrs > FR_N && hyp_t < 4) {
                         z.fast_rs[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + lane] = trs[FR_N + lane];
-                        if (nrs > FR_N + FR2_N)
-                            for (uint32_t k = FR_N + FR2_N + lane; k < nrs && k < FZ_RS; k += 64) z.list[(uint64_t)tile * z.list_cap + 8 + k] = trs[k];
+                        if (nrs > FR_N + FR2_N) {
+                            if (z.list) {
+                                for (uint32_t k = FR_N + FR2_N + lane; k < nrs && k < FZ_RS; k += 64) z.list[(uint64_t)tile * z.list_cap + 8 + k] = trs[k];
+                            } else {  // (no line-list workspace yet: the host reruns with it)
+                                span_bad = true;
+                                if (lane == 0) z.out->need_list = 1;
+                            }
+                        }
                         __builtin_amdgcn_wave_barrier();
                         trs[64 + lane] = 0;
                         trs[128 + lane] = 0;

@@ -93,14 +93,27 @@ __global__ __launch_bounds__(1024) void k_prefix_top(uint64_t *__restrict__ bloc
 
 // ---------------------------------------------------------------------------------------------
 // helpers on the tile index
-// The carry-in of a launch whose carry was worked out on the device (fqh_shard_rescan_launch).
-__device__ __forceinline__ void load_carry(ScanArgs &a) {
-    if (!a.dcarry) return;
-    a.base_offset = a.dcarry->base_offset;
-    a.nl_count = a.dcarry->nl_count;
-    for (int i = 0; i < 4; ++i) a.back[i] = a.dcarry->back[i];
-    a.v_start = (a.back[0] == 0 && a.len > 0) ? 1u : 0u;
-}
+// The carry-in of a launch whose carry was worked out on the device (fqh_shard_rescan_launch): the DEVC variants of the
+// emit / finalize kernels work on a copy of their arguments in LDS with the carry filled in.  (Not on the by-value
+// argument itself: a kernel that writes to its argument struct and indexes it gets it in scratch memory — 200 to 400
+// bytes per lane, which the runtime multiplies by a full device of lanes — and the plain variants would pay for it too.)
+// (COPY: the single-thread finalize kernels index their arguments with run-time subscripts; from the LDS copy that costs
+// an LDS read, from the by-value argument the whole struct went to scratch.)
+#define FQH_ARGS_WITH_CARRY(DEVC, COPY, a_in)                                                   \
+    __shared__ ScanArgs a_sh_;                                                                   \
+    if (DEVC || COPY) {                                                                          \
+        if (threadIdx.x == 0) {                                                                  \
+            a_sh_ = a_in;                                                                        \
+            if (DEVC) {                                                                          \
+                a_sh_.base_offset = a_in.dcarry->base_offset;                                    \
+                a_sh_.nl_count = a_in.dcarry->nl_count;                                          \
+                for (int i_ = 0; i_ < 4; ++i_) a_sh_.back[i_] = a_in.dcarry->back[i_];           \
+                a_sh_.v_start = (a_sh_.back[0] == 0 && a_in.len > 0) ? 1u : 0u;                  \
+            }                                                                                    \
+        }                                                                                        \
+        __syncthreads();                                                                         \
+    }                                                                                            \
+    const ScanArgs &a = (DEVC || COPY) ? a_sh_ : a_in;
 __device__ __forceinline__ uint64_t tile_pref(const ScanArgs &a, uint64_t t) {
     return a.block_prefix[t >> SCAN_SHIFT] + a.tile_prefix[t];
 }
@@ -263,8 +276,9 @@ __device__ void emit_tile_generic(const ScanArgs &a, uint64_t t, uint32_t cnt, u
 constexpr uint32_t EMIT_G = 4;
 constexpr uint32_t EMIT_WORDS = 1280;  // staged entries per wave; more -> generic path
 
-__global__ __launch_bounds__(256) void k_emit(ScanArgs a, DevOut *__restrict__ out) {
-    load_carry(a);
+template <bool DEVC>
+__global__ __launch_bounds__(256) void k_emit(ScanArgs a_in, DevOut *__restrict__ out) {
+    FQH_ARGS_WITH_CARRY(DEVC, false, a_in)
     __shared__ uint32_t stage_all[4][EMIT_WORDS + 4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
@@ -464,10 +478,12 @@ __device__ __forceinline__ void publish_and_reset(const ScanArgs &a, DevOut *out
     out->max_len = 0;
     out->overflow = 0;
     out->spec_fail = 0;
+    out->need_list = 0;
 }
 
-__global__ void k_finalize(ScanArgs a, DevOut *__restrict__ out) {
-    load_carry(a);
+template <bool DEVC>
+__global__ void k_finalize(ScanArgs a_in, DevOut *__restrict__ out) {
+    FQH_ARGS_WITH_CARRY(DEVC, true, a_in)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
     const bool lastnl = a.len > 0 && a.buf[a.len - 1] == '\n';
@@ -843,9 +859,9 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // the record that straddles into it (five line starts out of the two tiles' 16-byte edge blocks).
 // Phase B, one iteration per tile: readlane the three scalars, one 2-byte load and one 8-byte
 // store per lane, in rounds of 16 loads then 16 stores.  ~25 instructions per tile instead of ~110.
-template <uint32_t EMIT_ROUND>
-__global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restrict__ out) {
-    load_carry(a);
+template <uint32_t EMIT_ROUND, bool DEVC>
+__global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a_in, DevOut *__restrict__ out) {
+    FQH_ARGS_WITH_CARRY(DEVC, false, a_in)
     __shared__ uint16_t stage_all[4][EMIT_ROUND * 64];
     uint16_t *const stage = stage_all[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
@@ -913,6 +929,10 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
                 }
             }
         }
+        if (!a.list && nrs > FR_N + FR2_N) {  // the tile's later record starts went to a list area this launch does not have
+            bad = true;                        // (k_index_fast wrote them to a dummy): the host reruns with the workspace
+            out->need_list = 1;
+        }
         fail |= bad ? 1u : 0u;
         const uint32_t n_emit = bad ? 0u : nrs;   // a failed tile stores nothing (the result is discarded anyway)
         // ---- phase B: rounds of 16 tiles: 16 loads, then 16 stores.  Stores share vmcnt with loads on
@@ -944,7 +964,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
                 const unsigned long long vbase = a.base_offset + ((t0 + i) << WT_SHIFT);
                 const bool cap_ok = rb + n <= a.cap;
                 uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rb : nullptr;
-                const uint16_t *__restrict__ tl = a.list + (t0 + i) * a.list_cap + 8;
+                const uint16_t *__restrict__ tl = a.list ? a.list + (t0 + i) * a.list_cap + 8 : nullptr;
                 if (n <= FR_N) {  // the common case: everything is in the tile's line
                     const uint32_t oprev = wave_shr1(o, 0u);
                     if (lane < n) {
@@ -968,7 +988,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
                     const uint32_t oo = m < FR_N ? o
                                         : m >= n ? 0u
                                         : m < FR_N + FR2_N ? (uint32_t)a.fast_rs[fr2_off(a.n_tiles) + (t0 + i) * FR2_N + (m - FR_N)]
-                                                           : (uint32_t)tl[m];
+                                                           : (tl ? (uint32_t)tl[m] : 0u);
                     const uint32_t oprev = wave_shr1(oo, carry);
                     carry = (uint32_t)__builtin_amdgcn_readlane((int)oo, 63);
                     if (m < n) {
@@ -999,8 +1019,13 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a, DevOut *__restric
 // chunk start (validated with the carry), the lines after the last complete in-tile group, the EOF
 // rule, carry-out and summary.  Needs at least four line starts in the first and in the last tile;
 // otherwise, or on any violation, it sets spec_fail.
-__global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
-    load_carry(a);
+template <bool DEVC>
+__global__ void k_finalize_fast(ScanArgs a_in, DevOut *__restrict__ out) {
+    // (one thread works; its small arrays live in LDS: as private arrays they were 400 bytes of scratch per lane, and the
+    // runtime sizes a queue's scratch for a full device of such lanes: 200 MB for the sake of this kernel)
+    __shared__ long long sh_ll[4 + 5 + 4 + 12];
+    __shared__ uint32_t sh_u32[5 + 4 + 12];
+    FQH_ARGS_WITH_CARRY(DEVC, true, a_in)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     bool fail = out->spec_fail != 0 || a.n_tiles == 0;
     const unsigned long long E = a.n_tiles ? a.block_prefix[a.n_blocks] : 0ull;
@@ -1016,7 +1041,8 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         fail = true;
     unsigned long long max_len = out->max_len, first_long = out->first_long;
     const unsigned long long r0 = a.nl_count >> 2;
-    long long recent[4] = {0, 0, 0, 0};
+    long long *const recent = sh_ll;
+    for (int i = 0; i < 4; ++i) recent[i] = 0;
     unsigned long long n_newlines = 0, T = a.nl_count;
     if (!fail) {
         // ---- chunk start: the virtual line start at offset 0 and the record in progress
@@ -1027,8 +1053,8 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
             if (((l & 3) == 0 && b != '@') || ((l & 3) == 2 && b != '+')) fail = chk;
         }
         const uint32_t rr = (4u - ((uint32_t)lbase0 & 3u)) & 3u;  // first entry of tile 0 that starts a record
-        long long S[5];   // line starts rr-4 .. rr of tile 0, chunk-relative
-        uint32_t cls[5];  // bit 0 '@', bit 1 '+' where known from this chunk (entries); 3 = not checkable here
+        long long *const S = sh_ll + 4;   // [5] line starts rr-4 .. rr of tile 0, chunk-relative
+        uint32_t *const cls = sh_u32;     // [5] bit 0 '@', bit 1 '+' where known from this chunk (entries); 3 = not checkable here
         for (int k = 0; k < 5; ++k) {
             const int j = (int)rr - 4 + k;
             if (j >= 0) {
@@ -1062,8 +1088,8 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
         if (a.rec_start && a.cap > 0) a.rec_start[0] = a.base_offset - a.back[a.nl_count & 3];
 
         // ---- chunk end: the last four entries (with their class bits)
-        uint32_t le[4];
-        long long ls[4];
+        uint32_t *const le = sh_u32 + 5;   // [4]
+        long long *const ls = sh_ll + 9;   // [4]
         if (!small) {
             const uint16_t *el = a.fast_rs + tl_last * FR_STRIDE + FR_EDGE + 4;
             for (int k = 0; k < 4; ++k) {  // k = 0: most recent
@@ -1074,8 +1100,8 @@ __global__ void k_finalize_fast(ScanArgs a, DevOut *__restrict__ out) {
             // the short tail tile: k_emit_fast skipped it.  Its entries behind the previous tile's last four: every
             // record that ends at one of them has its five line starts in this list (src/records.rs:201-247)
             const uint32_t cnt = a.tile_count[tl_last];
-            uint32_t ce[12];
-            long long cs[12];
+            uint32_t *const ce = sh_u32 + 9;   // [12]
+            long long *const cs = sh_ll + 13;  // [12]
             const uint16_t *ep = a.fast_rs + (tl_last - 1) * FR_STRIDE + FR_EDGE + 4;
             const uint16_t *eq = a.fast_rs + tl_last * FR_STRIDE + FR_EDGE;
             for (uint32_t k = 0; k < 4; ++k) {
@@ -1176,31 +1202,36 @@ __global__ void k_shard_words(const DevOut *__restrict__ out, const DevOut *__re
 // fqh_carry_combine over the rows of the ranks in front of `rank` (src of the host version: fastq_hip.hip)
 __global__ void k_carry_fold(const unsigned long long *__restrict__ all, int n_ranks, int rank, DevCarry *__restrict__ dc,
                              DevCarry *__restrict__ hc, DevOut *__restrict__ out) {
+    __shared__ DevCarry cs[2];  // (in LDS, not in scratch: see FQH_ARGS_WITH_CARRY)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    DevCarry c = {};
-    for (int r = 0; r < n_ranks; ++r) c.any_fail |= all[r * SHARD_WORDS + 7];
+    DevCarry *c = &cs[0], *n = &cs[1];
+    *c = DevCarry{};
+    unsigned long long any_fail = 0;
+    for (int r = 0; r < n_ranks; ++r) any_fail |= all[r * SHARD_WORDS + 7];
     for (int r = 0; r < rank; ++r) {
         const unsigned long long *w = all + r * SHARD_WORDS;
         const unsigned long long len = w[0], nls = w[2];
-        DevCarry n = {};
-        n.any_fail = c.any_fail;
-        n.base_offset = c.base_offset + len;
-        n.nl_count = c.nl_count + w[1];
+        *n = DevCarry{};
+        n->base_offset = c->base_offset + len;
+        n->nl_count = c->nl_count + w[1];
         int k = 0;
-        for (; k < 4 && (unsigned long long)k < nls; ++k) n.back[k] = w[3 + k];
+        for (; k < 4 && (unsigned long long)k < nls; ++k) n->back[k] = w[3 + k];
         if (len == 0) {
-            for (int i = 0; i < 4; ++i) n.back[i] = c.back[i];
+            for (int i = 0; i < 4; ++i) n->back[i] = c->back[i];
         } else {
             for (int j = 0; k < 4; ++k, ++j) {
-                const unsigned long long v = c.back[j < 4 ? j : 3] + len;
-                n.back[k] = v > n.base_offset ? n.base_offset : v;
+                const unsigned long long v = c->back[j < 4 ? j : 3] + len;
+                n->back[k] = v > n->base_offset ? n->base_offset : v;
             }
         }
+        DevCarry *t = c;
         c = n;
+        n = t;
     }
-    *dc = c;
-    *hc = c;  // pinned: the host reads it after the stream has drained (fqh_scan_finish)
-    if (c.any_fail) out->spec_fail = 1;  // nothing of this launch is used
+    c->any_fail = any_fail;
+    *dc = *c;
+    *hc = *c;  // pinned: the host reads it after the stream has drained (fqh_scan_finish)
+    if (any_fail) out->spec_fail = 1;  // nothing of this launch is used
 }
 __global__ void k_shard_counts(const DevOut *__restrict__ out, const DevOut *__restrict__ mirror, const DevCarry *__restrict__ dc,
                                unsigned long long *__restrict__ counts) {
@@ -1246,13 +1277,18 @@ void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     if (a.n_tiles) {
         const uint64_t ngroups = (a.n_tiles + 63) >> 6;  // 64 tiles per wavefront and round
         uint64_t blocks = (ngroups + 3) / 4;
-        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * 4;
+#ifndef FQH_EMIT_BPC
+#define FQH_EMIT_BPC 4
+#endif
+        const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * FQH_EMIT_BPC;
         if (blocks > maxb) blocks = maxb;
-        hipLaunchKernelGGL((k_emit_fast<16>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        if (a.dcarry) hipLaunchKernelGGL((k_emit_fast<16, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        else hipLaunchKernelGGL((k_emit_fast<16, false>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
     }
 }
 void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {
-    hipLaunchKernelGGL(k_finalize_fast, dim3(1), dim3(64), 0, s, a, out);
+    if (a.dcarry) hipLaunchKernelGGL(k_finalize_fast<true>, dim3(1), dim3(64), 0, s, a, out);
+    else hipLaunchKernelGGL(k_finalize_fast<false>, dim3(1), dim3(64), 0, s, a, out);
 }
 void launch_prefix(hipStream_t s, uint32_t *tile_count, const uint16_t *fast_rs, uint32_t *tile_prefix,
                    uint64_t *block_prefix, uint64_t n_tiles, uint64_t n_blocks) {
@@ -1271,16 +1307,18 @@ void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     static int occ = 0;
     if (!occ) {
         int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_emit, 256, 0) != hipSuccess || o < 1) o = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_emit<false>, 256, 0) != hipSuccess || o < 1) o = 4;
         occ = o > 8 ? 8 : o;
     }
     uint64_t blocks = ((a.n_tiles + EMIT_G - 1) / EMIT_G + 3) / 4;
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ;
     if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(k_emit, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+    if (a.dcarry) hipLaunchKernelGGL(k_emit<true>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+    else hipLaunchKernelGGL(k_emit<false>, dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
 }
 void launch_finalize(hipStream_t s, const ScanArgs &a, DevOut *out) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, s, a, out);
+    if (a.dcarry) hipLaunchKernelGGL(k_finalize<true>, dim3(1), dim3(64), 0, s, a, out);
+    else hipLaunchKernelGGL(k_finalize<false>, dim3(1), dim3(64), 0, s, a, out);
 }
 
 }  // namespace fqh

@@ -212,6 +212,38 @@ def test_short_last_tile_with_errors(env, fqref):
         run(env, fqref, bytes(data), 150, want_fused=False)
 
 
+def test_line_list_workspace_is_allocated_on_demand(env, fqref):
+    """The fast path writes one or two 128-byte lines per 16 KiB tile; the 1 KiB-per-tile line lists are the exact path's
+    (and the fast path's overflow area for reads shorter than ~50 bp).  A context that only sees ordinary reads on the
+    fast path never allocates them: 6 % of the input size stays free."""
+    torch, pkg = env
+    dev = torch.device("cuda:0")
+    n = (2 << 30) // 330 * 330
+    d = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.synth_fill(d.data_ptr(), 0, n)
+    rs = torch.zeros(n // 300 + 16, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    s, c, st = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())
+    assert s.n_records == n // 330 and ctx.last_scan_fast()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < (100 << 20), used          # two lines per tile = 32 MiB + change; the line lists alone would be 128 MiB
+    # 36 bp reads: ~150 records per tile, more than a tile's two lines hold: the context gets its line lists, keeps the fast path
+    rng = np.random.default_rng(3)
+    short = make(rng, 60000, 36)
+    a = np.frombuffer(short, dtype=np.uint8)
+    d2 = torch.from_numpy(a.copy()).to(dev)
+    s2, c2, st2 = ctx.scan(d2.data_ptr(), a.size, True, None, rs.data_ptr(), rs.numel())
+    r2, off = fqref.offsets(a)
+    assert (s2.parse_status, s2.n_records) == (r2.status, r2.n_records) == (pkg.OK, 60000) and ctx.last_scan_fast()
+    assert np.array_equal(rs.cpu().numpy()[:60000].astype(np.uint64), off)
+    s, c, st = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())   # (now with the lists: 128 MiB more)
+    assert s.n_records == n // 330 and ctx.last_scan_fast()
+    assert free0 - torch.cuda.mem_get_info()[0] > (128 << 20)
+    ctx.close()
+
+
 def test_medium_synthetic_parity_and_determinism(env, fqref):
     """256 MiB of the benchmark's synthetic input: single pass == oracle, and two runs give identical arrays."""
     torch, pkg = env

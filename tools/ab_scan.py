@@ -28,4 +28,8 @@ for rnd in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20): step(L, h)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20 * 1e3
-        print("%-40s %.3f ms per step  %.0f GB/s" % (os.path.basename(path), dt, n / 1e6 / dt), flush=True)
+        t = (C.c_float * 5)()
+        L.fqh_last_timing.argtypes = [C.c_void_p, C.c_void_p]
+        L.fqh_last_timing(h, t)
+        print("%-40s %.3f ms per step  %.0f GB/s   (last step: index %.3f prefix %.3f emit+finalize %.3f)" % (
+            os.path.basename(path), dt, n / 1e6 / dt, t[1], t[2], t[3]), flush=True)

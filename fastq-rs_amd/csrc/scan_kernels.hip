@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "scan_dev.h"
 
@@ -861,17 +862,21 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // store per lane, in rounds of 16 loads then 16 stores.  ~25 instructions per tile instead of ~110.
 template <uint32_t EMIT_ROUND, bool DEVC>
 __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a_in, DevOut *__restrict__ out) {
-    FQH_ARGS_WITH_CARRY(DEVC, false, a_in)
+    // (the arguments stay where they are — pointers read back from an LDS copy are flat pointers, and a flat access makes
+    // every later s_waitcnt a vmcnt(0) lgkmcnt(0); of the carry this kernel needs two words, read from device memory)
+    const ScanArgs &a = a_in;
+    const unsigned long long carry_nl = DEVC ? a_in.dcarry->nl_count : a_in.nl_count;
+    const unsigned long long carry_base = DEVC ? a_in.dcarry->base_offset : a_in.base_offset;
     __shared__ uint16_t stage_all[4][EMIT_ROUND * 64];
     uint16_t *const stage = stage_all[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const uint64_t ngroups = (a.n_tiles + 63) >> 6;
-    const unsigned long long r0 = a.nl_count >> 2;
+    const unsigned long long r0 = carry_nl >> 2;
     const uint32_t bufsize32 = a.bufsize > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)a.bufsize;
     unsigned long long first_long = NOKEY;
     uint32_t maxlen32 = 0, fail = 0;
-    for (uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < ngroups; g += nwaves) {
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); g < ngroups; g += nwaves) {
         const uint64_t t0 = g << 6;
         // ---- phase A: lane = tile t0 + lane
         const uint64_t T = t0 + lane;
@@ -896,7 +901,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a_in, DevOut *__rest
         }
         cprev = wave_shr1(cnt, c0);
         const uint32_t pz = wave_shr1(e.z, pz0), pw = wave_shr1(e.w, pw0);  // previous tile's last four entries
-        const unsigned long long lbase = a.nl_count + 1 + bp + tp;
+        const unsigned long long lbase = carry_nl + 1 + bp + tp;
         const uint32_t r = (4u - ((uint32_t)lbase & 3u)) & 3u;             // entry index of the first record start
         const bool small = hyp >= FR_SMALL;   // the short tile at the end of the buffer: k_finalize_fast's
         const bool has = cnt != 0 && !small;
@@ -941,6 +946,57 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a_in, DevOut *__rest
         // the previous round's stores have had a whole load latency to land.
         const uint32_t ntl = (uint32_t)(a.n_tiles - t0 < 64 ? a.n_tiles - t0 : 64);
         const uint16_t *const rs0 = a.fast_rs + t0 * FR_STRIDE + lane;
+        // ---- the streamlined phase B: every tile of the group keeps its record starts in its one line, all of them fit
+        // the caller's array, and no record the fast path can validate reaches the Buffer's limit (such a record would
+        // hold a whole tile with at most four line starts, which fails the fast path in k_index_fast already: the
+        // per-record "too long" test only matters for limits below two tiles).  Then a tile costs three v_readlane, one
+        // 8-byte store with a scalar base and the record-length maximum: ~16 instructions, no branch, no LDS.  The
+        // phase is bound by instruction issue (vector and scalar unit each ~55 % busy with the generic loop below), not
+        // by its 550 MB of traffic.
+        const bool no_long = bufsize32 == 0 || bufsize32 > 2 * WT_BYTES + 15;
+        if (no_long && __ballot(n_emit > FR_N || (n_emit != 0 && a.rec_start != nullptr && rbase + n_emit > a.cap)) == 0) {
+            const uint64_t p0 = (uint64_t)(uintptr_t)(a.rec_start + rbase);   // lane = tile here: where its records go
+            const uint32_t plo = (uint32_t)p0, phi = (uint32_t)(p0 >> 32);
+            const unsigned long long vbase0 = carry_base + (t0 << WT_SHIFT);
+            auto phase_b = [&](auto store_tag) {
+                constexpr bool STORE = decltype(store_tag)::value;
+                uint32_t qa[EMIT_ROUND], qb[EMIT_ROUND];
+                auto body = [&](uint32_t i, uint32_t o) {
+                    const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_emit, (int)i);
+                    if (lane < n) {
+                        if (STORE) {
+                            const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)plo, (int)i);
+                            const uint32_t ph = (uint32_t)__builtin_amdgcn_readlane((int)phi, (int)i);
+                            const unsigned long long vb = vbase0 + ((unsigned long long)i << WT_SHIFT);
+                            // (an explicit global pointer: rebuilt from integers it would be a flat one, and flat stores count on lgkmcnt too)
+                            typedef __attribute__((address_space(1))) uint64_t g_u64;
+                            g_u64 *dst = reinterpret_cast<g_u64 *>(((uint64_t)ph << 32) | pl) + lane;
+                            __builtin_nontemporal_store((uint64_t)(vb + o), dst);
+                        }
+                        const uint32_t reclen = o - wave_shr1(o, o);  // lane 0: 0 (the record that ends there was measured in phase A)
+                        maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+                    }
+                };
+#pragma unroll
+                for (uint32_t j = 0; j < EMIT_ROUND; ++j) qa[j] = rs0[j * FR_STRIDE];  // (the array has 64 tiles of slack)
+#pragma unroll 1
+                for (uint32_t ib = 0; ib < 64; ib += 2 * EMIT_ROUND) {
+#pragma unroll
+                    for (uint32_t j = 0; j < EMIT_ROUND; ++j) qb[j] = rs0[(ib + EMIT_ROUND + j) * FR_STRIDE];
+#pragma unroll
+                    for (uint32_t j = 0; j < EMIT_ROUND; ++j) body(ib + j, qa[j]);
+                    if (ib + 2 * EMIT_ROUND < 64) {
+#pragma unroll
+                        for (uint32_t j = 0; j < EMIT_ROUND; ++j) qa[j] = rs0[(ib + 2 * EMIT_ROUND + j) * FR_STRIDE];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < EMIT_ROUND; ++j) body(ib + EMIT_ROUND + j, qb[j]);
+                }
+            };
+            if (a.rec_start) phase_b(std::true_type{});
+            else phase_b(std::false_type{});
+            continue;
+        }
         for (uint32_t ib = 0; ib < ntl; ib += EMIT_ROUND) {
             uint32_t q[EMIT_ROUND];
 #pragma unroll
@@ -961,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a_in, DevOut *__rest
                 if (n == 0) continue;
                 const unsigned long long rb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(rbase >> 32), (int)i) << 32) |
                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rbase, (int)i);
-                const unsigned long long vbase = a.base_offset + ((t0 + i) << WT_SHIFT);
+                const unsigned long long vbase = carry_base + ((t0 + i) << WT_SHIFT);
                 const bool cap_ok = rb + n <= a.cap;
                 uint64_t *__restrict__ rs = a.rec_start ? a.rec_start + rb : nullptr;
                 const uint16_t *__restrict__ tl = a.list ? a.list + (t0 + i) * a.list_cap + 8 : nullptr;
@@ -1008,6 +1064,7 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a_in, DevOut *__rest
     }
     const unsigned long long fl = wave_min_u64(first_long);
     const unsigned long long ml = wave_max_u64(maxlen32);
+    if (bufsize32 > 2 * WT_BYTES + 15 && ml + 15 >= bufsize32) fail = 1;  // (cannot happen, see the streamlined phase B: left to the exact path if it does)
     if (lane == 0) {
         if (fl != NOKEY) atomicMin(&out->first_long, fl);
         if (ml) atomicMax(&out->max_len, ml);
@@ -1280,10 +1337,13 @@ void launch_emit_fast(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
 #ifndef FQH_EMIT_BPC
 #define FQH_EMIT_BPC 4
 #endif
+#ifndef FQH_EMIT_ROUND
+#define FQH_EMIT_ROUND 16
+#endif
         const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * FQH_EMIT_BPC;
         if (blocks > maxb) blocks = maxb;
-        if (a.dcarry) hipLaunchKernelGGL((k_emit_fast<16, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
-        else hipLaunchKernelGGL((k_emit_fast<16, false>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        if (a.dcarry) hipLaunchKernelGGL((k_emit_fast<FQH_EMIT_ROUND, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
+        else hipLaunchKernelGGL((k_emit_fast<FQH_EMIT_ROUND, false>), dim3((uint32_t)blocks), dim3(256), 0, s, a, out);
     }
 }
 void launch_finalize_fast(hipStream_t s, const ScanArgs &a, DevOut *out) {

@@ -9,7 +9,7 @@ buf = torch.empty(n + 4096, dtype=torch.uint8, device=dev)
 cap = n // 300 + 16
 rs = torch.empty(cap, dtype=torch.int64, device=dev)
 libs = []
-for path in sys.argv[1:3]:
+for path in sys.argv[1:]:
     L = C.CDLL(os.path.abspath(path))
     h = C.c_void_p()
     L.fqh_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

@@ -296,7 +296,7 @@ def main():
             bh = torch.zeros(150 * 8, dtype=torch.int64, device=dev)
             sc = torch.zeros(8, dtype=torch.int64, device=dev)
 
-            def timed(fn, reps=4):
+            def timed(fn, reps=6):
                 best = None
                 for _ in range(reps):
                     qh.zero_(); bh.zero_(); sc.zero_()

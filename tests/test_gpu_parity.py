@@ -721,3 +721,58 @@ def test_full_size_16gib_properties(fqref, gpu, torch):
             assert np.array_equal(b3.cpu().numpy().astype(np.uint64).reshape(150, 8), ob)
             assert np.array_equal(s3.cpu().numpy().astype(np.uint64), osc)
     assert bool(torch.equal(tq, qh)) and bool(torch.equal(tb, bh)) and bool(torch.equal(ts, sc))
+
+
+def test_fast_emit_routes(fqref, torch, pkg):
+    """k_emit_fast has a streamlined per-tile loop (every tile of a 64-tile group keeps its record starts in its one line,
+    all within the caller's capacity, no Buffer limit below two tiles) and a generic one for everything else.  Files that
+    mix both kinds of groups, a capacity that ends inside a tile, and a small Buffer limit must give the oracle's
+    offsets, counts, maximum record length and error either way."""
+    rng = np.random.default_rng(4242)
+    dev = torch.device("cuda:0")
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+
+    def upload(data):
+        d = torch.empty(len(data) + 16, dtype=torch.uint8, device=dev)
+        d[: len(data)].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()))
+        return d
+
+    long_part = fuzzgen.valid_file(rng, 9000, seqlen=150)       # ~50 records per tile: the streamlined loop
+    short_part = fuzzgen.valid_file(rng, 30000, seqlen=40)      # ~130 per tile: second line and list area
+    mid_part = fuzzgen.valid_file(rng, 20000, seqlen=100)       # ~65 per tile: second line
+    for name, data in (("long", long_part * 3), ("long+short", long_part * 2 + short_part + long_part * 2),
+                       ("mid+long", mid_part + long_part * 3), ("short+mid+long", short_part + mid_part + long_part)):
+        res, idx = fqref.index(data)
+        assert res.status == fqref.OK
+        starts = idx[:, 0]
+        maxlen = int(np.max(np.diff(np.concatenate([starts, [len(data)]]).astype(np.int64))))
+        d = upload(data)
+        for cap_kind in ("full", "exact", "short"):
+            cap = {"full": res.n_records + 64, "exact": res.n_records + 1, "short": res.n_records // 2 + 7}[cap_kind]
+            rs = torch.full((cap + 8,), -1, dtype=torch.int64, device=dev)
+            ctx.set_spec(True)
+            ctx.set_bufsize(pkg.BUFSIZE)
+            s, c, st = ctx.scan(d.data_ptr(), len(data), True, None, rs.data_ptr(), cap)
+            assert (s.parse_status, s.n_records) == (fqref.OK, res.n_records), (name, cap_kind)
+            assert st == (pkg.E_CAPACITY if cap_kind == "short" else pkg.OK), (name, cap_kind, st)
+            got = rs.cpu().numpy()
+            nchk = min(cap, res.n_records)
+            assert np.array_equal(got[:nchk].astype(np.uint64), starts[:nchk]), (name, cap_kind)
+            assert np.all(got[cap:] == -1), (name, cap_kind)        # nothing behind the capacity
+            if cap_kind != "short":
+                assert s.max_record_len == maxlen, (name, cap_kind)
+                assert ctx.last_scan_fast(), (name, cap_kind)
+        # a Buffer limit below two tiles: the generic loop keeps the per-record "too long" test
+        lim = (maxlen + 15) // 16 * 16   # (a multiple of 16) the longest record trips the limit (src/lib.rs:276-283)
+        ctx.set_spec(True)
+        ctx.set_bufsize(lim)
+        s, c, st = ctx.scan(d.data_ptr(), len(data), True, None, None, 0)
+        r = fqref.count(data, bufsize=lim)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records), (name, lim)
+        ctx.set_bufsize(lim + 4096)
+        ctx.set_spec(True)
+        s, c, st = ctx.scan(d.data_ptr(), len(data), True, None, None, 0)
+        r = fqref.count(data, bufsize=lim + 4096)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (fqref.OK, res.n_records)
+    ctx.set_bufsize(pkg.BUFSIZE)
+    ctx.close()

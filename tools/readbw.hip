@@ -56,6 +56,50 @@ __global__ __launch_bounds__(BLK) void k_blockrow(const uint8_t* buf, uint64_t l
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
+
+// LDS-DMA pattern (global_load_lds_dwordx4, gfx950): a wave owns TILE contiguous bytes and streams them into its own LDS
+// ring, U KiB per round, two rounds in flight; one ds_read_b128 per lane and round keeps the data "used".  Inline asm: the
+// compiler brackets its own LDS-DMA builtin with vmcnt(0) in front of every LDS read, which would serialise the rounds.
+template <int U, bool NT, int TILE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_dma(const uint8_t* buf, uint64_t len, unsigned long long* out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t base = (uint32_t)(uintptr_t)lds + w * (2 * U * 1024);
+    const uint64_t n_tiles = len / TILE;
+    const uint64_t nw = (uint64_t)gridDim.x * WAVES;
+    uint32_t acc = 0;
+    constexpr int ROUNDS = TILE / 1024 / U;
+    auto issue = [&](const uint8_t* p, uint32_t ldsb) {
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane(ldsb);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint8_t* q = p + j * 1024;
+            if (NT) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" :: "s"(m0v + j * 1024), "v"(q) : "memory", "m0");
+            else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v + j * 1024), "v"(q) : "memory", "m0");
+        }
+    };
+    uint64_t t = (uint64_t)blockIdx.x * WAVES + w;
+    if (t >= n_tiles) return;
+    issue(buf + t * TILE + lane * 16, base);
+    uint32_t par = 0;
+    for (; t < n_tiles; t += nw) {
+        const uint64_t tn = t + nw < n_tiles ? t + nw : t;
+#pragma unroll 1
+        for (int g = 0; g < ROUNDS; ++g) {
+            const uint8_t* nx = (g + 1 < ROUNDS) ? buf + t * TILE + (g + 1) * U * 1024 + lane * 16 : buf + tn * TILE + lane * 16;
+            issue(nx, base + (par ^ 1) * U * 1024);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U) : "memory");
+            const uint4 v = *reinterpret_cast<const uint4*>(lds + (base - (uint32_t)(uintptr_t)lds) + par * U * 1024 + lane * 16);
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+            par ^= 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long a = acc;
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if (lane == 0 && a == 0x123456789ull) atomicAdd(out, a);
+}
+
 template <typename F> float timeit(F f, int reps = 7) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e9;
@@ -74,6 +118,15 @@ int main(int argc, char** argv) {
     auto rep = [&](const char* name, float ms) { printf("%-44s %8.3f ms %8.1f GB/s %5.1f%%\n", name, ms, len / 1e6 / ms, len / 1e6 / ms / 80.0); fflush(stdout); };
 #define WT(U, NT, TILE, GRID) rep("wavetile U=" #U " nt=" #NT " tile=" #TILE " grid=" #GRID, timeit([&] { hipLaunchKernelGGL((k_wavetile<U, NT, TILE>), dim3(GRID), dim3(256), 0, 0, buf, len, out); }))
 #define BR(U, NT, BLK, GRID) rep("blockrow U=" #U " nt=" #NT " blk=" #BLK " grid=" #GRID, timeit([&] { hipLaunchKernelGGL((k_blockrow<U, NT, BLK>), dim3(GRID), dim3(BLK), 0, 0, buf, len, out); }))
+#define DM(U, NT, TILE, WAVES, BPC) rep("lds-dma U=" #U " nt=" #NT " tile=" #TILE " waves/blk=" #WAVES " blk/cu=" #BPC, timeit([&] { hipLaunchKernelGGL((k_dma<U, NT, TILE, WAVES>), dim3(256 * BPC), dim3(WAVES * 64), WAVES * 2 * U * 1024, 0, buf, len, out); }))
+    DM(4, true, 16384, 4, 4);
+    DM(4, false, 16384, 4, 4);
+    DM(4, true, 16384, 4, 3);
+    DM(4, true, 16384, 4, 2);
+    DM(8, true, 16384, 4, 2);
+    DM(2, true, 16384, 4, 4);
+    DM(4, true, 65536, 4, 4);
+    DM(4, true, 16384, 16, 1);
     WT(4, false, 16384, 2048);
     WT(4, false, 16384, 4096);
     WT(4, false, 16384, 262144);

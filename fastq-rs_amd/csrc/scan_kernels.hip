@@ -10,6 +10,7 @@
 //   k_finalize  EOF rule (src/lib.rs:264-294), carry-out, summary.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -862,14 +863,15 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
 // the waits name exactly the operations that may stay in flight (the next group's four pieces, the byte before the next
 // tile, the tile's line store).  Operations the compiler issues on its own (the line store, rare second-line / list stores)
 // are older than anything these waits leave outstanding, so they can only make a wait longer, never too short.
-constexpr uint32_t DMA_IMG = 8192;  // two 4 KiB halves
+constexpr uint32_t DMA_SLOTS = 3;                 // 4 KiB groups in the ring: one being scanned, two in flight
+constexpr uint32_t DMA_IMG = DMA_SLOTS * 4096;
 #ifndef FQH_DMA_ENTRIES
-#define FQH_DMA_ENTRIES 1016
+#define FQH_DMA_ENTRIES 496
 #endif
 #ifndef FQH_DMA_WPE
-#define FQH_DMA_WPE 4
+#define FQH_DMA_WPE 3
 #endif
-constexpr uint32_t DMA_ENTRIES = FQH_DMA_ENTRIES;  // line starts per tile that can be staged: with 1016, image + list are 10 KiB per wavefront, 16 wavefronts per CU
+constexpr uint32_t DMA_ENTRIES = FQH_DMA_ENTRIES;  // line starts per tile that can be staged: ring + 16 + list + 16 = 13 KiB per wavefront, 12 per CU
 // (the instruction's immediate offset moves the global address AND the LDS address: one M0 for the four pieces)
 #define FQH_DMA4(p_, m0_)                                                                                 \
     asm volatile("s_mov_b32 m0, %0\n\t"                                                                   \
@@ -877,15 +879,23 @@ constexpr uint32_t DMA_ENTRIES = FQH_DMA_ENTRIES;  // line starts per tile that 
                  "global_load_lds_dwordx4 %1, off offset:1024 nt\n\t"                                     \
                  "global_load_lds_dwordx4 %1, off offset:2048 nt\n\t"                                     \
                  "global_load_lds_dwordx4 %1, off offset:3072 nt" ::"s"((m0_)), "v"((p_)) : "memory")
+// one 16-byte piece through lane 0 alone (the code around it runs with all 64 lanes: the mask is put back inside the statement)
+#define FQH_DMA1(p_, m0_)                                                                              \
+    do {                                                                                               \
+        const uint8_t *pv_ = (p_);                                                                     \
+        asm volatile("" : "+v"(pv_)); /* (a wave-uniform address would be handed over in scalar registers) */ \
+        asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, 1\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b64 exec, -1" \
+                     ::"s"((m0_)), "v"(pv_) : "memory");                                               \
+    } while (0)
 __global__ __launch_bounds__(256, FQH_DMA_WPE) void k_index_dma(const uint8_t *__restrict__ buf, uint64_t len,
                                                    uint16_t *__restrict__ list, uint32_t list_cap,
                                                    uint16_t *__restrict__ fast_rs,
                                                    uint64_t n_tiles, DevOut *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][DMA_IMG + DMA_ENTRIES * 2 + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][DMA_IMG + 16 + DMA_ENTRIES * 2 + 16];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint8_t *const lds = lds_all[wv];
-    uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + DMA_IMG);
+    uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + DMA_IMG + 16);  // (lds + DMA_IMG: the 16 bytes before the tile)
     const uint32_t lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
     const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + wv;
@@ -945,34 +955,49 @@ __global__ __launch_bounds__(256, FQH_DMA_WPE) void k_index_dma(const uint8_t *_
 
     uint64_t tile = wave0;
     if (tile < n_full) {
+        // prologue: the tile's first two groups and the 16 bytes in front of it (lane 0; tile 0 has none: any 16 bytes, to keep
+        // the count of operations in flight the same)
         const uint8_t *p = buf + (tile << WT_SHIFT) + lo;
         FQH_DMA4(p, lds_addr);
-        uint32_t pb = tile ? buf[(tile << WT_SHIFT) - 1] : 0u;  // the byte before the tile
+        FQH_DMA1(buf + (tile ? (tile << WT_SHIFT) - 16 : 0), lds_addr + DMA_IMG);
+        p += 4 * PIECE_BYTES;
+        FQH_DMA4(p, lds_addr + 4096u);
         bool pending = false;          // the previous tile's line is still in a register
         uint64_t ptile = 0;
         uint32_t prv = 0;
-        uint32_t half = 0;             // which 4 KiB half holds the group about to be scanned
+        uint32_t slot = 0;             // which 4 KiB slot of the ring holds the group about to be scanned
         for (; tile < n_full; tile += nwaves) {
             const uint64_t nxt = tile + nwaves < n_full ? tile + nwaves : tile;  // clamped: the prefetch is unconditional
             uint32_t run = 0, nstaged = 0;
-            uint32_t prev = (tile && pb == '\n') ? 1u : 0u;   // (the compiler's wait for pb: everything issued so far, i.e. this group's pieces too)
+            uint32_t prev = 0;
 #pragma unroll 1
             for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
-                const bool last = g + 1 == WT_PIECES / 4;
                 __builtin_amdgcn_wave_barrier();
-                // the next group of this tile, or the first group of the wave's next tile, into the other half
-                p = last ? buf + (nxt << WT_SHIFT) + lo : p + 4 * PIECE_BYTES;
-                FQH_DMA4(p, lds_addr + ((half ^ 1u) << 12));
-                if (last) {
-                    pb = buf[(nxt << WT_SHIFT) - (nxt ? 1 : 0)];
-                    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                } else if (g == 0 && pending) {
-                    __builtin_nontemporal_store((uint16_t)prv, fast_rs + ptile * FR_STRIDE + lane);  // a whole group before anything waits for it
-                    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                // two groups ahead: group g + 2 of this tile, or group g - 2 of the wave's next tile, into the slot group g - 1 left
+                const uint32_t s2 = slot >= 1 ? slot - 1 : DMA_SLOTS - 1;
+                p = g == 2 ? buf + (nxt << WT_SHIFT) + lo : p + 4 * PIECE_BYTES;
+                FQH_DMA4(p, lds_addr + (s2 << 12));
+                // what may stay in flight: the two groups ahead (8), the 16 bytes in front of the next tile (issued with its
+                // first group), the line store just issued; everything older has landed when the wait returns
+                if (g == 0) {
+                    if (pending) {
+                        __builtin_nontemporal_store((uint16_t)prv, fast_rs + ptile * FR_STRIDE + lane);
+                        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    prev = (tile && lds[DMA_IMG + 15] == '\n') ? 1u : 0u;
+                } else if (g == 1) {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else if (g == 2) {
+                    FQH_DMA1(buf + (nxt ? (nxt << WT_SHIFT) - 16 : 0), lds_addr + DMA_IMG);
+                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 } else {
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 }
                 __builtin_amdgcn_wave_barrier();
+                const uint32_t half = slot;  // (the slot's 4 KiB at lds + (slot << 12))
                 const uint8_t *const rptr = lds + (half << 12) + lane * 64;
                 uint32_t m_lo, m_hi;
                 {
@@ -1006,23 +1031,32 @@ __global__ __launch_bounds__(256, FQH_DMA_WPE) void k_index_dma(const uint8_t *_
                 }
                 const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
                 if (run == nstaged && run + tot <= DMA_ENTRIES) {  // uniform: stage in LDS
+                    // offsets first (no LDS read, hence no round trip, inside the serial per-lane loops) ...
                     uint16_t *dst = lst + run + pre;
                     while (ls_lo) {
                         const uint32_t q = __ffs(ls_lo) - 1;
                         ls_lo &= ls_lo - 1;
-                        const uint32_t b = rptr[q];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                        *dst++ = (uint16_t)(ebase + q);
                     }
                     while (ls_hi) {
                         const uint32_t q = __ffs(ls_hi) + 31;
                         ls_hi &= ls_hi - 1;
-                        const uint32_t b = rptr[q];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                        *dst++ = (uint16_t)(ebase + q);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // ... then one lane per entry reads the first byte of its line ('@' / '+': src/records.rs:141,155) out of
+                    // the group's image: one round trip for the whole group
+                    const uint8_t *const img = lds + (half << 12);
+                    for (uint32_t pp = lane; pp < tot; pp += 64) {
+                        const uint32_t e = lst[run + pp];
+                        const uint32_t b = img[e & 0xFFFu];
+                        lst[run + pp] = (uint16_t)(e | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
                     }
                     nstaged = run + tot;
                 }  // else: more than DMA_ENTRIES line starts in a tile: left to the exact path
                 run += tot;
-                half ^= 1u;
+                slot = slot + 1 == DMA_SLOTS ? 0u : slot + 1;
             }
             finish_tile(tile, run, nstaged, prv, false);
             ptile = tile;
@@ -1521,8 +1555,10 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
         const hipError_t e = fast ? (FQH_INDEX_DMA ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_dma, 256, 0)
                                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast, 256, 0))
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_t, 256, 0);
+        if (getenv("FQH_DEBUG_OCC")) fprintf(stderr, "launch_index fast=%d dma=%d occupancy query: %d (err %d)\n", (int)fast, (int)FQH_INDEX_DMA, o, (int)e);
         if (e != hipSuccess || o < 1) o = 4;
         occ[fast] = o > 8 ? 8 : o;
+        if (const char *f = getenv("FQH_INDEX_BPC")) occ[fast] = atoi(f);
     }
     uint64_t blocks = (n_tiles + 3) / 4;
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ[fast];

@@ -10,7 +10,6 @@
 //   k_finalize  EOF rule (src/lib.rs:264-294), carry-out, summary.
 #include <hip/hip_runtime.h>
 
-#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -852,239 +851,6 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
     if (lane == 0 && n_over) atomicAdd(&out->spec_fail, (unsigned long long)n_over);
 }
 
-// k_index_dma: k_index_fast with the input streamed into LDS by LDS-DMA (global_load_lds_dwordx4 ... nt, gfx950) instead of
-// through vector registers.  tools/readbw.hip: on MI355X a stream of 16-byte non-temporal register loads tops out at
-// 6.5 TB/s, the same stream as non-temporal LDS-DMA reaches 7.1 TB/s (and needs only 8-12 wavefronts per CU to get there).
-// The image is LINEAR (the DMA writes lane l's 16 bytes at 16 l of each 1 KiB piece; no per-lane swizzle is possible) and
-// double-buffered: while group g is scanned out of one 4 KiB half, group g+1 lands in the other.  The lane-contiguous
-// read-back of a linear image is conflict-free when lane l reads its four 16-byte chunks in the order (i + l / 4) % 4 and
-// rotates its 64-bit newline mask back (as in k_scan_stats).  The DMA and its waits are inline asm: the compiler puts a
-// vmcnt(0) in front of every LDS read that follows its own LDS-DMA builtin, which would serialise load and scan; here
-// the waits name exactly the operations that may stay in flight (the next group's four pieces, the byte before the next
-// tile, the tile's line store).  Operations the compiler issues on its own (the line store, rare second-line / list stores)
-// are older than anything these waits leave outstanding, so they can only make a wait longer, never too short.
-constexpr uint32_t DMA_SLOTS = 3;                 // 4 KiB groups in the ring: one being scanned, two in flight
-constexpr uint32_t DMA_IMG = DMA_SLOTS * 4096;
-#ifndef FQH_DMA_ENTRIES
-#define FQH_DMA_ENTRIES 496
-#endif
-#ifndef FQH_DMA_WPE
-#define FQH_DMA_WPE 3
-#endif
-constexpr uint32_t DMA_ENTRIES = FQH_DMA_ENTRIES;  // line starts per tile that can be staged: ring + 16 + list + 16 = 13 KiB per wavefront, 12 per CU
-// (the instruction's immediate offset moves the global address AND the LDS address: one M0 for the four pieces)
-#define FQH_DMA4(p_, m0_)                                                                                 \
-    asm volatile("s_mov_b32 m0, %0\n\t"                                                                   \
-                 "global_load_lds_dwordx4 %1, off nt\n\t"                                                 \
-                 "global_load_lds_dwordx4 %1, off offset:1024 nt\n\t"                                     \
-                 "global_load_lds_dwordx4 %1, off offset:2048 nt\n\t"                                     \
-                 "global_load_lds_dwordx4 %1, off offset:3072 nt" ::"s"((m0_)), "v"((p_)) : "memory")
-// one 16-byte piece through lane 0 alone (the code around it runs with all 64 lanes: the mask is put back inside the statement)
-#define FQH_DMA1(p_, m0_)                                                                              \
-    do {                                                                                               \
-        const uint8_t *pv_ = (p_);                                                                     \
-        asm volatile("" : "+v"(pv_)); /* (a wave-uniform address would be handed over in scalar registers) */ \
-        asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, 1\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b64 exec, -1" \
-                     ::"s"((m0_)), "v"(pv_) : "memory");                                               \
-    } while (0)
-__global__ __launch_bounds__(256, FQH_DMA_WPE) void k_index_dma(const uint8_t *__restrict__ buf, uint64_t len,
-                                                   uint16_t *__restrict__ list, uint32_t list_cap,
-                                                   uint16_t *__restrict__ fast_rs,
-                                                   uint64_t n_tiles, DevOut *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4][DMA_IMG + 16 + DMA_ENTRIES * 2 + 16];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint8_t *const lds = lds_all[wv];
-    uint16_t *const lst = reinterpret_cast<uint16_t *>(lds + DMA_IMG + 16);  // (lds + DMA_IMG: the 16 bytes before the tile)
-    const uint32_t lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds);
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    const uint64_t wave0 = (uint64_t)blockIdx.x * 4 + wv;
-    const uint64_t n_full = len >> WT_SHIFT;  // whole tiles
-    uint32_t n_over = 0;
-    const uint32_t rot = (lane >> 2) & 3u;                 // read-back: instruction i reads chunk (i + rot) % 4 of the lane
-    const uint32_t kro = (4u - rot) & 3u;                  // rotate the 64-bit mask right by 16 kro bits
-    const bool swp = (kro & 2u) != 0;
-    const uint32_t s16 = (kro & 1u) * 16u;
-    const uint32_t lo = lane * 16;
-
-    auto finish_tile = [&](uint64_t tile, uint32_t run, uint32_t nstaged, uint32_t &rv, bool tail) {
-        uint32_t hyp = 7;
-        if (tail && nstaged == run && run < 8) {  // the short tile at the end of the buffer: left to k_finalize_fast
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            rv = (lane >= FR_EDGE && lane < FR_EDGE + run) ? (uint32_t)lst[lane - FR_EDGE] : 0u;
-            rv = lane == FR_CNT ? run : lane == FR_HYP ? (FR_SMALL | 4u) : rv;
-            return;
-        }
-        if (nstaged == run && run >= 8) {  // uniform
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            uint32_t bad = 0, have = 0;  // bit r: some / some failing complete group starting at i == r (mod 4)
-            for (uint32_t i = lane; i + 4 < run; i += 64) {
-                const uint32_t e0 = lst[i], e1 = lst[i + 1], e2 = lst[i + 2], e3 = lst[i + 3], e4 = lst[i + 4];
-                const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
-                                ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
-                have |= 1u << (i & 3u);
-                bad |= ok ? 0u : 1u << (i & 3u);
-            }
-            uint32_t cons = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < 4; ++r)
-                if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
-            if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
-        }
-        rv = 0;
-        if (hyp < 4) {
-            if (lane < FR_N) rv = hyp + 4 * lane < run ? (uint32_t)(lst[hyp + 4 * lane] & 0x3FFFu) : 0u;
-            else if (lane < FR_EDGE + 4) rv = lst[lane - FR_EDGE];
-            else if (lane < FR_EDGE + 8) rv = lst[run - 8 + (lane - FR_EDGE)];
-            if (hyp + 4 * FR_N < run) {  // more record starts than the line holds: a second whole line ...
-                const uint32_t j2 = FR_N + lane;
-                __builtin_nontemporal_store(hyp + 4 * j2 < run ? (uint16_t)(lst[hyp + 4 * j2] & 0x3FFFu) : (uint16_t)0,
-                                            fast_rs + fr2_off(n_tiles) + tile * FR2_N + lane);
-                if (hyp + 4 * (FR_N + FR2_N) < run) {  // ... and the list area for the rest (reads shorter than ~25 bp)
-                    uint16_t *__restrict__ tl = list + tile * list_cap;
-                    for (uint32_t j = FR_N + FR2_N + lane; hyp + 4 * j < run; j += 64) tl[8 + j] = lst[hyp + 4 * j] & 0x3FFFu;
-                }
-            }
-        } else {
-            ++n_over;  // counted into spec_fail below
-        }
-        rv = lane == FR_CNT ? (run & 0xFFFFu) : lane == FR_CNT + 1 ? (run >> 16) : lane == FR_HYP ? hyp : rv;
-    };
-
-    uint64_t tile = wave0;
-    if (tile < n_full) {
-        // prologue: the tile's first two groups and the 16 bytes in front of it (lane 0; tile 0 has none: any 16 bytes, to keep
-        // the count of operations in flight the same)
-        const uint8_t *p = buf + (tile << WT_SHIFT) + lo;
-        FQH_DMA4(p, lds_addr);
-        FQH_DMA1(buf + (tile ? (tile << WT_SHIFT) - 16 : 0), lds_addr + DMA_IMG);
-        p += 4 * PIECE_BYTES;
-        FQH_DMA4(p, lds_addr + 4096u);
-        bool pending = false;          // the previous tile's line is still in a register
-        uint64_t ptile = 0;
-        uint32_t prv = 0;
-        uint32_t slot = 0;             // which 4 KiB slot of the ring holds the group about to be scanned
-        for (; tile < n_full; tile += nwaves) {
-            const uint64_t nxt = tile + nwaves < n_full ? tile + nwaves : tile;  // clamped: the prefetch is unconditional
-            uint32_t run = 0, nstaged = 0;
-            uint32_t prev = 0;
-#pragma unroll 1
-            for (uint32_t g = 0; g < WT_PIECES / 4; ++g) {
-                __builtin_amdgcn_wave_barrier();
-                // two groups ahead: group g + 2 of this tile, or group g - 2 of the wave's next tile, into the slot group g - 1 left
-                const uint32_t s2 = slot >= 1 ? slot - 1 : DMA_SLOTS - 1;
-                p = g == 2 ? buf + (nxt << WT_SHIFT) + lo : p + 4 * PIECE_BYTES;
-                FQH_DMA4(p, lds_addr + (s2 << 12));
-                // what may stay in flight: the two groups ahead (8), the 16 bytes in front of the next tile (issued with its
-                // first group), the line store just issued; everything older has landed when the wait returns
-                if (g == 0) {
-                    if (pending) {
-                        __builtin_nontemporal_store((uint16_t)prv, fast_rs + ptile * FR_STRIDE + lane);
-                        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    prev = (tile && lds[DMA_IMG + 15] == '\n') ? 1u : 0u;
-                } else if (g == 1) {
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                } else if (g == 2) {
-                    FQH_DMA1(buf + (nxt ? (nxt << WT_SHIFT) - 16 : 0), lds_addr + DMA_IMG);
-                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                }
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t half = slot;  // (the slot's 4 KiB at lds + (slot << 12))
-                const uint8_t *const rptr = lds + (half << 12) + lane * 64;
-                uint32_t m_lo, m_hi;
-                {
-                    const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u) & 48u));
-                    const uint4 d1 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 16u) & 48u));
-                    const uint4 d2 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 32u) & 48u));
-                    const uint4 d3 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 48u) & 48u));
-                    const uint32_t r_lo = eqmask16<1>(d0, 0x0A0A0A0Au) | (eqmask16<1>(d1, 0x0A0A0A0Au) << 16);
-                    const uint32_t r_hi = eqmask16<1>(d2, 0x0A0A0A0Au) | (eqmask16<1>(d3, 0x0A0A0A0Au) << 16);
-                    const uint32_t a_lo = swp ? r_hi : r_lo, a_hi = swp ? r_lo : r_hi;
-                    m_lo = __builtin_amdgcn_alignbit(a_hi, a_lo, s16);
-                    m_hi = __builtin_amdgcn_alignbit(a_lo, a_hi, s16);
-                }
-                // line starts: the byte after a newline
-                uint32_t ls_lo = (m_lo << 1) | wave_shr1(m_hi >> 31, prev);
-                uint32_t ls_hi = __builtin_amdgcn_alignbit(m_hi, m_lo, 31);
-                prev = ((uint32_t)__builtin_amdgcn_readlane((int)m_hi, 63)) >> 31;
-                const uint32_t c = __popc(ls_lo) + __popc(ls_hi);
-                const unsigned long long b1 = __ballot(c >= 1), b2 = __ballot(c >= 2), b3 = __ballot(c >= 3);
-                uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
-                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
-                pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, pre));
-                uint32_t tot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2) + (uint32_t)__popcll(b3);
-                if (__ballot(c >= 4)) {
-                    for (uint32_t k = 4;; ++k) {
-                        const unsigned long long b = __ballot(c >= k);
-                        if (!b) break;
-                        pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
-                        tot += (uint32_t)__popcll(b);
-                    }
-                }
-                const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
-                if (run == nstaged && run + tot <= DMA_ENTRIES) {  // uniform: stage in LDS
-                    // offsets first (no LDS read, hence no round trip, inside the serial per-lane loops) ...
-                    uint16_t *dst = lst + run + pre;
-                    while (ls_lo) {
-                        const uint32_t q = __ffs(ls_lo) - 1;
-                        ls_lo &= ls_lo - 1;
-                        *dst++ = (uint16_t)(ebase + q);
-                    }
-                    while (ls_hi) {
-                        const uint32_t q = __ffs(ls_hi) + 31;
-                        ls_hi &= ls_hi - 1;
-                        *dst++ = (uint16_t)(ebase + q);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    // ... then one lane per entry reads the first byte of its line ('@' / '+': src/records.rs:141,155) out of
-                    // the group's image: one round trip for the whole group
-                    const uint8_t *const img = lds + (half << 12);
-                    for (uint32_t pp = lane; pp < tot; pp += 64) {
-                        const uint32_t e = lst[run + pp];
-                        const uint32_t b = img[e & 0xFFFu];
-                        lst[run + pp] = (uint16_t)(e | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
-                    }
-                    nstaged = run + tot;
-                }  // else: more than DMA_ENTRIES line starts in a tile: left to the exact path
-                run += tot;
-                slot = slot + 1 == DMA_SLOTS ? 0u : slot + 1;
-            }
-            finish_tile(tile, run, nstaged, prv, false);
-            ptile = tile;
-            pending = true;
-            __builtin_amdgcn_wave_barrier();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped prefetch: no DMA may land after the wave has gone
-        if (pending) __builtin_nontemporal_store((uint16_t)prv, fast_rs + ptile * FR_STRIDE + lane);
-    }
-    // the partial tile at the end of the buffer
-    if (wave0 == 0 && n_full < n_tiles) {
-        const uint64_t t = n_full, tbase = t << WT_SHIFT;
-        uint32_t run = 0;
-        uint32_t prev = (t && buf[tbase - 1] == '\n') ? 1u : 0u;
-#pragma unroll 1
-        for (uint32_t j = 0; j < WT_PIECES; ++j) {
-            const uint64_t off = tbase + (uint64_t)j * PIECE_BYTES + lo;
-            if (tbase + (uint64_t)j * PIECE_BYTES >= len) break;  // uniform
-            const uint4 v = load16(buf, off, len);
-            index_piece<false, 1>(v, off, len, j * PIECE_BYTES + lo, lane, prev, run, lst, DMA_ENTRIES);
-        }
-        uint32_t rv;
-        finish_tile(t, run, run <= DMA_ENTRIES ? run : 0u, rv, true);
-        __builtin_nontemporal_store((uint16_t)rv, fast_rs + t * FR_STRIDE + lane);
-    }
-    if (lane == 0 && n_over) atomicAdd(&out->spec_fail, (unsigned long long)n_over);
-}
-
 // k_emit_fast: the fast path's emit.  Per tile: verify the tile's alignment against the true line
 // index, store the record starts, and validate the one record that straddles into the tile from
 // the previous one (its five line starts are in the two tiles' edge entries).  Any doubt sets
@@ -1546,27 +1312,18 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
     if (!n_tiles) return;
     // persistent grid = exactly the blocks that are resident at once: a static round-robin of tiles over
     // a grid with one non-resident block per CU would run that block as a tail
-#ifndef FQH_INDEX_DMA
-#define FQH_INDEX_DMA 1
-#endif
     static int occ[2] = {0, 0};
     if (!occ[fast]) {
         int o = 0;
-        const hipError_t e = fast ? (FQH_INDEX_DMA ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_dma, 256, 0)
-                                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast, 256, 0))
+        const hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast, 256, 0)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_t, 256, 0);
-        if (getenv("FQH_DEBUG_OCC")) fprintf(stderr, "launch_index fast=%d dma=%d occupancy query: %d (err %d)\n", (int)fast, (int)FQH_INDEX_DMA, o, (int)e);
         if (e != hipSuccess || o < 1) o = 4;
         occ[fast] = o > 8 ? 8 : o;
-        if (const char *f = getenv("FQH_INDEX_BPC")) occ[fast] = atoi(f);
     }
     uint64_t blocks = (n_tiles + 3) / 4;
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ[fast];
     if (blocks > maxb) blocks = maxb;
-    if (fast && FQH_INDEX_DMA)  // (the entry count travels in the tile's line: the prefix scan leaves the dense copy)
-        hipLaunchKernelGGL(k_index_dma, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
-                           fast_rs, n_tiles, out);
-    else if (fast)
+    if (fast)  // (the entry count travels in the tile's line: the prefix scan leaves the dense copy)
         hipLaunchKernelGGL(k_index_fast, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
                            fast_rs, n_tiles, out);
     else

@@ -158,8 +158,8 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_lis
         const size_t nb = (n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_count, n_tiles * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_prefix, n_tiles * sizeof(uint32_t)));
-        // first lines (+ 64 tiles: k_emit_fast loads whole rounds of tiles without clamping), then the second lines
-        HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, (2 * n_tiles + 64) * 64 * sizeof(uint16_t)));
+        // first lines (+ 64 tiles: k_emit_fast loads whole rounds of tiles without clamping), then the second lines (+ 64 again)
+        HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, (2 * n_tiles + 128) * 64 * sizeof(uint16_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
         ctx->tiles_cap = n_tiles;
     }

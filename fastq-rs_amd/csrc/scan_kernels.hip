@@ -954,47 +954,73 @@ __global__ __launch_bounds__(256) void k_emit_fast(ScanArgs a_in, DevOut *__rest
         // phase is bound by instruction issue (vector and scalar unit each ~55 % busy with the generic loop below), not
         // by its 550 MB of traffic.
         const bool no_long = bufsize32 == 0 || bufsize32 > 2 * WT_BYTES + 15;
-        if (no_long && __ballot(n_emit > FR_N || (n_emit != 0 && a.rec_start != nullptr && rbase + n_emit > a.cap)) == 0) {
+        if (no_long && __ballot(n_emit > FR_N + FR2_N || (n_emit != 0 && a.rec_start != nullptr && rbase + n_emit > a.cap)) == 0) {
             const uint64_t p0 = (uint64_t)(uintptr_t)(a.rec_start + rbase);   // lane = tile here: where its records go
             const uint32_t plo = (uint32_t)p0, phi = (uint32_t)(p0 >> 32);
             const unsigned long long vbase0 = carry_base + (t0 << WT_SHIFT);
-            auto phase_b = [&](auto store_tag) {
-                constexpr bool STORE = decltype(store_tag)::value;
-                uint32_t qa[EMIT_ROUND], qb[EMIT_ROUND];
-                auto body = [&](uint32_t i, uint32_t o) {
+            // (an explicit global pointer: rebuilt from integers it would be a flat one, and flat stores count on lgkmcnt too)
+            typedef __attribute__((address_space(1))) uint64_t g_u64;
+            // TWO: some tile of the group has record starts in its second line (reads shorter than ~140 bp) — that line is
+            // loaded and stored for every tile of the group then, with 8 tiles per round for the registers' sake
+            auto phase_b = [&](auto store_tag, auto two_tag) {
+                constexpr bool STORE = decltype(store_tag)::value, TWO = decltype(two_tag)::value;
+                constexpr uint32_t R = TWO ? EMIT_ROUND / 2 : EMIT_ROUND;
+                uint32_t qa[R], qb[R], ra[TWO ? R : 1], rb[TWO ? R : 1];
+                const uint16_t *const rs2 = a.fast_rs + fr2_off(a.n_tiles) + t0 * FR2_N + lane;
+                auto body = [&](uint32_t i, uint32_t o, uint32_t o2) {
                     const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_emit, (int)i);
-                    if (lane < n) {
-                        if (STORE) {
-                            const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)plo, (int)i);
-                            const uint32_t ph = (uint32_t)__builtin_amdgcn_readlane((int)phi, (int)i);
-                            const unsigned long long vb = vbase0 + ((unsigned long long)i << WT_SHIFT);
-                            // (an explicit global pointer: rebuilt from integers it would be a flat one, and flat stores count on lgkmcnt too)
-                            typedef __attribute__((address_space(1))) uint64_t g_u64;
-                            g_u64 *dst = reinterpret_cast<g_u64 *>(((uint64_t)ph << 32) | pl) + lane;
-                            __builtin_nontemporal_store((uint64_t)(vb + o), dst);
-                        }
+                    if (n == 0) return;  // (wave-uniform)
+                    const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)plo, (int)i);
+                    const uint32_t ph = (uint32_t)__builtin_amdgcn_readlane((int)phi, (int)i);
+                    const unsigned long long vb = vbase0 + ((unsigned long long)i << WT_SHIFT);
+                    g_u64 *const dst = reinterpret_cast<g_u64 *>(((uint64_t)ph << 32) | pl);
+                    if (lane < n && lane < FR_N) {
+                        if (STORE) __builtin_nontemporal_store((uint64_t)(vb + o), dst + lane);
                         const uint32_t reclen = o - wave_shr1(o, o);  // lane 0: 0 (the record that ends there was measured in phase A)
                         maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
                     }
+                    if (TWO && n > FR_N) {  // (wave-uniform) record starts FR_N .. n - 1 out of the second line
+                        const uint32_t last1 = (uint32_t)__builtin_amdgcn_readlane((int)o, (int)(FR_N - 1));
+                        if (lane < n - FR_N) {
+                            if (STORE) __builtin_nontemporal_store((uint64_t)(vb + o2), dst + FR_N + lane);
+                            const uint32_t reclen = o2 - wave_shr1(o2, last1);
+                            maxlen32 = reclen > maxlen32 ? reclen : maxlen32;
+                        }
+                    }
                 };
 #pragma unroll
-                for (uint32_t j = 0; j < EMIT_ROUND; ++j) qa[j] = rs0[j * FR_STRIDE];  // (the array has 64 tiles of slack)
+                for (uint32_t j = 0; j < R; ++j) {
+                    qa[j] = rs0[j * FR_STRIDE];  // (the arrays have 64 tiles of slack)
+                    if (TWO) ra[j] = rs2[j * FR2_N];
+                }
 #pragma unroll 1
-                for (uint32_t ib = 0; ib < 64; ib += 2 * EMIT_ROUND) {
+                for (uint32_t ib = 0; ib < 64; ib += 2 * R) {
 #pragma unroll
-                    for (uint32_t j = 0; j < EMIT_ROUND; ++j) qb[j] = rs0[(ib + EMIT_ROUND + j) * FR_STRIDE];
-#pragma unroll
-                    for (uint32_t j = 0; j < EMIT_ROUND; ++j) body(ib + j, qa[j]);
-                    if (ib + 2 * EMIT_ROUND < 64) {
-#pragma unroll
-                        for (uint32_t j = 0; j < EMIT_ROUND; ++j) qa[j] = rs0[(ib + 2 * EMIT_ROUND + j) * FR_STRIDE];
+                    for (uint32_t j = 0; j < R; ++j) {
+                        qb[j] = rs0[(ib + R + j) * FR_STRIDE];
+                        if (TWO) rb[j] = rs2[(ib + R + j) * FR2_N];
                     }
 #pragma unroll
-                    for (uint32_t j = 0; j < EMIT_ROUND; ++j) body(ib + EMIT_ROUND + j, qb[j]);
+                    for (uint32_t j = 0; j < R; ++j) body(ib + j, qa[j], TWO ? ra[j] : 0u);
+                    if (ib + 2 * R < 64) {
+#pragma unroll
+                        for (uint32_t j = 0; j < R; ++j) {
+                            qa[j] = rs0[(ib + 2 * R + j) * FR_STRIDE];
+                            if (TWO) ra[j] = rs2[(ib + 2 * R + j) * FR2_N];
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < R; ++j) body(ib + R + j, qb[j], TWO ? rb[j] : 0u);
                 }
             };
-            if (a.rec_start) phase_b(std::true_type{});
-            else phase_b(std::false_type{});
+            const bool two = __ballot(n_emit > FR_N) != 0;
+            if (a.rec_start) {
+                if (two) phase_b(std::true_type{}, std::true_type{});
+                else phase_b(std::true_type{}, std::false_type{});
+            } else {
+                if (two) phase_b(std::false_type{}, std::true_type{});
+                else phase_b(std::false_type{}, std::false_type{});
+            }
             continue;
         }
         for (uint32_t ib = 0; ib < ntl; ib += EMIT_ROUND) {

@@ -513,6 +513,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         const uint32_t p = c0 + lane;
                         const uint32_t ti = run + p;
                         uint32_t Pent = 0;      // the line entry p closes
+                        bool toolong = false;
                         uint32_t e4 = 0, bcr = 0;
                         uint32_t l = 0;
                         int yc = 0;
@@ -552,8 +553,10 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                     span_bad = true;  // began before the kept tail (longer than ~500 bytes)
                                 } else {
                                     if (l && bcr == '\r') --l;  // trim_winline, src/records.rs:66-73
-                                    if (l > lc) span_bad = true;  // longer than the histogram's rows
-                                    else Pent = l | FZ_P_ACT | ((uint32_t)ys << 16);
+                                    // (longer than the histogram's rows: the span is bad if this turns out to be a sequence or a
+                                    // quality line, below; header and separator lines are never read and may be longer)
+                                    toolong = l > lc;
+                                    Pent = (toolong ? 0u : l) | FZ_P_ACT | ((uint32_t)ys << 16);
                                 }
                             }
                         }
@@ -572,6 +575,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             // entry p closes line srun + p - 1.  (Runs whatever span_bad says: nothing of a bad span is used, and
                             // a region that is skipped conditionally costs a wait for the loads in flight, see DESIGN.md.)
                             const uint32_t kd = (srun + p - 1u - hyp) & 3u;
+                            if (__ballot(toolong && (kd & 1u)) != 0) span_bad = true;  // a sequence / quality line beyond the rows
                             if (Pent) {
                                 if (kd == 1u) { ++acc_rec; acc_bases += l; }
                                 if (kd == 3u) acc_qual += l;

@@ -91,7 +91,7 @@ def test_sizes_around_tiles_and_spans(env, fqref, nrec):
 
 
 @pytest.mark.parametrize("shape", ["fixed150", "fixed100", "fixed36", "fixed250", "ragged", "ragged4", "crlf", "plusid",
-                                   "qual_at_plus", "empty_reads"])
+                                   "qual_at_plus", "empty_reads", "long_headers36", "long_headers50", "long_plusid"])
 def test_single_pass_shapes(env, fqref, shape):
     rng = np.random.default_rng(zlib.crc32(shape.encode()))
     lmaxes = (150,)
@@ -112,6 +112,15 @@ def test_single_pass_shapes(env, fqref, shape):
         seqlen, nrec, kw = 150, 5000, {"crlf": 0.3}       # trim_winline in the kernel (src/records.rs:66-73)
     elif shape == "plusid":
         seqlen, nrec, kw = 150, 5000, {"plus_id": True}
+    elif shape == "long_headers36":   # header lines longer than lmax (only sequence / quality lines must fit the rows)
+        seqlen, nrec, lmaxes = 36, 20000, (36, 40)
+        kw = {"hdr": lambda i: b"A00123:45:HXXXXXXXX:1:%04d:%05d:%05d 1:N:0:ATCACG" % (1101 + i % 400, 1000 + 7 * i % 30000, 2000 + 3 * i % 30000)}
+    elif shape == "long_headers50":
+        seqlen, nrec, lmaxes = 50, 12000, (50,)
+        kw = {"hdr": lambda i: b"x" * 100 + b"%d" % i}
+    elif shape == "long_plusid":      # ... and separator lines that repeat a long id
+        seqlen, nrec, lmaxes = 50, 12000, (50, 64)
+        kw = {"hdr": lambda i: b"SRR000001.%d length=50 some text" % i, "plus_id": True}
     elif shape == "qual_at_plus":
         seqlen, nrec, kw = 150, 5000, {"qlo": 43, "qhi": 65}   # quality lines full of '+' and '@'
     else:

@@ -21,7 +21,7 @@ OPT_FAST_PATH, OPT_SINGLE_PASS = 1, 2
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
     "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
-    "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
+    "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_len_hist", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
@@ -125,6 +125,7 @@ def lib():
         L.fqh_stream_set_stats.argtypes = [vp, u32, vp, vp, vp]
         L.fqh_last_timing.argtypes = [vp, C.POINTER(Timing)]
         L.fqh_record_flags.argtypes = [vp, vp, u64, u64, vp, u64, vp]
+        L.fqh_len_hist.argtypes = [vp, vp, vp, C.c_uint32, vp]
         L.fqh_gather_records.argtypes = [vp, vp, u64, u64, vp, u64, vp, C.c_uint8, C.c_uint8, vp, u64,
                                          C.POINTER(u64), C.POINTER(u64)]
         L.fqh_last_scan_fast.argtypes = [vp]
@@ -265,6 +266,10 @@ class Ctx:
                                     C.byref(carry) if carry is not None else None, lmax,
                                     d_qual, d_base, d_scalars, C.byref(s), C.byref(c)))
         return s, c
+
+    def len_hist(self, d_base_hist, d_scalars, lmax, d_len_hist):
+        """d_len_hist[L] += reads with len(seq()) == L (L < lmax), d_len_hist[lmax] += reads of lmax bases or more."""
+        self._chk(self._L.fqh_len_hist(self._h, d_base_hist, d_scalars, lmax, d_len_hist))
 
     def record_flags(self, d_buf, length, d_index, n, d_flags, base_offset=0):
         self._chk(self._L.fqh_record_flags(self._h, d_buf, length, base_offset, d_index, n, d_flags))

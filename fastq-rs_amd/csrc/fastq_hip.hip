@@ -985,6 +985,18 @@ fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_fi
     return fqh_stats_finish(ctx, out, carry_out);
 }
 
+fqh_status fqh_len_hist(fqh_ctx *ctx, const uint64_t *d_base_hist, const uint64_t *d_scalars, uint32_t lmax,
+                        uint64_t *d_len_hist) {
+    if (!ctx || !d_base_hist || !d_scalars || !d_len_hist || lmax == 0) return FQH_E_ARG;
+    if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is pending");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_len_hist(ctx->stream, (const unsigned long long *)d_base_hist, (const unsigned long long *)d_scalars, lmax,
+                    (unsigned long long *)d_len_hist);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FQH_OK;
+}
+
 fqh_status fqh_record_flags(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t base_offset,
                             const fqh_idx_record *d_index, uint64_t n, uint8_t *d_flags) {
     if (!ctx || (n && (!d_buf || !d_index || !d_flags))) return FQH_E_ARG;

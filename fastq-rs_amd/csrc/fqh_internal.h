@@ -137,4 +137,6 @@ struct FusedArgs {
     uint32_t dbg;         // knock-out flags for timing experiments (FQH_FZ_DBG; results are wrong by design)
 };
 
+void launch_len_hist(hipStream_t s, const unsigned long long *base_hist, const unsigned long long *scalars, uint32_t lmax,
+                     unsigned long long *len_hist);
 }  // namespace fqh

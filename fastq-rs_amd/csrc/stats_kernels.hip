@@ -645,4 +645,24 @@ void launch_read_ceiling(hipStream_t s, const uint8_t *buf, uint64_t len, uint64
                        (unsigned long long *)sum);
 }
 
+// k_len_hist: the read-length histogram out of the base histogram (fqh_len_hist): reads longer than p = the counts of column p.
+__global__ __launch_bounds__(256) void k_len_hist(const unsigned long long *__restrict__ base_hist,
+                                                  const unsigned long long *__restrict__ scalars, uint32_t lmax,
+                                                  unsigned long long *__restrict__ len_hist) {
+    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L > lmax) return;
+    auto longer_than = [&](uint32_t p) {  // reads with more than p bases
+        unsigned long long c = 0;
+        for (uint32_t k = 0; k < 8; ++k) c += base_hist[(uint64_t)p * 8 + k];
+        return c;
+    };
+    const unsigned long long at_least = L == 0 ? scalars[0] : longer_than(L - 1);   // reads with at least L bases
+    const unsigned long long v = L == lmax ? at_least : at_least - longer_than(L);
+    if (v) atomicAdd(&len_hist[L], v);
+}
+void launch_len_hist(hipStream_t s, const unsigned long long *base_hist, const unsigned long long *scalars, uint32_t lmax,
+                     unsigned long long *len_hist) {
+    hipLaunchKernelGGL(k_len_hist, dim3((lmax + 1 + 255) / 256), dim3(256), 0, s, base_hist, scalars, lmax, len_hist);
+}
+
 }  // namespace fqh

@@ -117,6 +117,7 @@ extern "C" {
     // not needed by Parser itself, bound for consumers that want them
     pub fn fqh_stream_set_stats(st: *mut fqh_stream, lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64,
                                 d_scalars: *mut u64) -> c_int;
+    pub fn fqh_len_hist(ctx: *mut fqh_ctx, d_base_hist: *const u64, d_scalars: *const u64, lmax: u32, d_len_hist: *mut u64) -> c_int;
     pub fn fqh_record_flags(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, base_offset: u64,
                             d_index: *const fqh_idx_record, n: u64, d_flags: *mut u8) -> c_int;
     pub fn fqh_gather_records(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, base_offset: u64,

@@ -16,6 +16,7 @@
  *                                                                 fqh_index_records
  *   loop over Record::seq()/qual()  src/records.rs:75-90 (a8)     fqh_stats, fqh_scan_stats (one read)
  *   validate_dna / validate_dnan    src/records.rs:19-33          fqh_stats (scalars 3,4), fqh_record_flags
+ *   read lengths (sum of seq().len()) fuzz/fuzz_targets/fuzz_target_1.rs:16  fqh_len_hist
  *   Record::write (filter loops)    src/records.rs:93-96          fqh_gather_records
  *   Buffer                          src/buffer.rs:1-112           fqh_stream_* (pinned ring)
  *   thread_reader                   src/thread_reader.rs:182-200  fqh_stream_* (copy stream)
@@ -233,6 +234,14 @@ fqh_status fqh_scan_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
 fqh_status fqh_stats_launch_lead(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t lead_len,
                                  int is_final, const fqh_carry *in, uint32_t lmax,
                                  uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars);
+
+/* Read-length histogram (the optional len_hist[len(seq())] of the statistics contract; the consumer it
+ * stands in for sums rec.seq().len(), fuzz/fuzz_targets/fuzz_target_1.rs:16).  Derived on the device from what fqh_stats /
+ * fqh_scan_stats left in d_base_hist and d_scalars over the SAME records: column p of the base histogram holds one count
+ * per read longer than p, so d_len_hist[L] = reads with len(seq()) == L for L < lmax, and d_len_hist[lmax] = reads of
+ * lmax bases or more.  d_len_hist (lmax + 1 u64) is ADDED to, like the other arrays. */
+fqh_status fqh_len_hist(fqh_ctx *ctx, const uint64_t *d_base_hist, const uint64_t *d_scalars, uint32_t lmax,
+                        uint64_t *d_len_hist);
 
 /* ---- Filter and rewrite: scan -> select -> gather -> write ----------------------
  * Per-record alphabet flags of the sequence lines: bit 0 = Record::validate_dna (all of ACGT), bit 1 =

@@ -776,3 +776,37 @@ def test_fast_emit_routes(fqref, torch, pkg):
         assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (fqref.OK, res.n_records)
     ctx.set_bufsize(pkg.BUFSIZE)
     ctx.close()
+
+
+def test_read_length_histogram(fqref, gpu, torch, ctx):
+    """fqh_len_hist: the read-length histogram (optional len_hist[len(seq())]) out of the base histogram the
+    statistics call left behind, against the lengths of the oracle's records: ragged reads, empty reads, CRLF, reads longer
+    than lmax (lumped in the last slot), and a file with a parse error (records before the error only)."""
+    rng = np.random.default_rng(808)
+    dev = torch.device("cuda:0")
+    good = b"".join(fuzzgen.valid_record(rng, i, seqlen=int(rng.choice([0, 1, 7, 36, 100, 149, 150, 151, 200])),
+                                         crlf=bool(i % 11 == 0)) for i in range(6000))
+    bad = fuzzgen.mutate(rng, good, 1)
+    while fqref.count(bad).status == fqref.OK:
+        bad = fuzzgen.mutate(rng, good, 1)
+    for data in (good, bad, good[:0]):
+        for lmax in (150, 152, 256, 64):
+            d, n = gpu.upload(data)
+            qh = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+            bh = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+            sc = torch.zeros(8, dtype=torch.int64, device=dev)
+            lh = torch.full((lmax + 1,), 5, dtype=torch.int64, device=dev)   # ADDED to
+            ctx.set_spec(True)
+            s, c = ctx.stats(d.data_ptr(), n, lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+            ctx.len_hist(bh.data_ptr(), sc.data_ptr(), lmax, lh.data_ptr())
+            res, idx = fqref.index(data)
+            a = np.frombuffer(data, dtype=np.uint8)
+            want = np.zeros(lmax + 1, dtype=np.int64)
+            for k in range(res.n_records):
+                start, head, seq = int(idx[k, 0]), int(idx[k, 1]), int(idx[k, 2])   # newline offsets relative to the record
+                ln = seq - head - 1
+                if ln and a[start + seq - 1] == 13:
+                    ln -= 1                                                          # trim_winline, src/records.rs:66-73
+                want[min(ln, lmax)] += 1
+            assert s.n_records == res.n_records
+            assert np.array_equal(lh.cpu().numpy() - 5, want), (len(data), lmax)

@@ -45,6 +45,11 @@ namespace fqh {
 #ifndef FQH_FZ_W5
 #define FQH_FZ_W5 16
 #endif
+#ifdef FQH_TUNING
+#define FZ_DBG(bit) ((z.dbg & (bit)) != 0)
+#else
+#define FZ_DBG(bit) false
+#endif
 constexpr uint32_t FZ_WAVES_MAX = 16;              // wavefronts per block: 16 with up to 160 rows, 12 with 256 (LDS)
 #ifndef FQH_FZ_SPAN
 #define FQH_FZ_SPAN 4
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                     // ---- the span's last group: its last line ends in another wavefront's span (or with the buffer); the
                     // 512 bytes after the span close it, as one more (virtual) entry behind the group's
                     uint32_t totv = tot;
-                    if (last_g && last_t && !(z.dbg & 16u)) {
+                    if (last_g && last_t && !FZ_DBG(16u)) {
                         const int yend = (int)FZ_TAIL + (int)(tile_bytes - g * FZ_GROUP);  // y of the first byte after the span
                         const bool last_nl = full ? prev != 0 : buf[len - 1] == '\n';
                         int yclose = -1;
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         // phase B: the window of five entries that ends here, and the line entry p closes
                         if (p < totv) {
                             const uint32_t e3 = lst[(int)p - 1];
-                            if (p < tot && !(z.dbg & 8u)) {
+                            if (p < tot && !FZ_DBG(8u)) {
                                 if (ti < 4) {
                                     tedge[ti] = (uint16_t)e4;  // the tile's first four entries
                                 } else {
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             }
                             const uint32_t nls = cnt_c > ps ? (cnt_c - ps + 3) >> 2 : 0u, nlq = cnt_c > pq0 ? (cnt_c - pq0 + 3) >> 2 : 0u;
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
-                            const bool cnt = !(z.dbg & 2u);
+                            const bool cnt = !FZ_DBG(2u);
                             FZ_T(5);
                             fz_lines2<NSL>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, cnt);
                             FZ_T(4);  // lines: lookups, reads, counts
@@ -759,7 +764,11 @@ static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t block
 // array of FQH_NSCALARS u64 (not the caller's: see k_stats_commit)
 hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
     z.lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
+#ifdef FQH_TUNING  // knock-out flags of the timing experiments (tools/exp_fzdbg.py); not part of the product library
     z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
+#else
+    z.dbg = 0;
+#endif
     const uint32_t blocks = scan_stats_blocks(z.n_tiles, n_cu);
     const uint32_t nsl = (z.lc + 31) / 32;
     hipError_t e = nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks) : launch_scan_stats_n<8, 12>(s, z, blocks);

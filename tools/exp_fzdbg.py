@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Knock-out timing of k_scan_stats (FQH_FZ_DBG flags; results are wrong by design). usage: exp_fzdbg.py flags..."""
+"""Knock-out timing of k_scan_stats (FQH_FZ_DBG flags; results are wrong by design; needs a library built with -DFQH_TUNING:
+make -C fastq-rs_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC -DFQH_TUNING").  usage: exp_fzdbg.py flags..."""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''

@@ -9,13 +9,13 @@ LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.s
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
-           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "EXPORTS"]
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "EXPORTS"]
 
 OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY, E_AGAIN = range(11)
 SHARD_WORDS = 8
 BUFSIZE = 68 * 1024
 NSCALARS = 8
-OPT_FAST_PATH, OPT_SINGLE_PASS = 1, 2
+OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES = 1, 2, 3
 
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -326,6 +326,10 @@ class Ctx:
     def set_single_pass(self, on):
         """Whole-file statistics in the scan's own pass over the input (default) or as a second pass."""
         self._chk(self._L.fqh_set_option(self._h, OPT_SINGLE_PASS, 1 if on else 0))
+
+    def set_place_tries(self, n):
+        """Candidates of the fast path's per-tile line buffer the first big scan allocates and times (0 / 1: none)."""
+        self._chk(self._L.fqh_set_option(self._h, OPT_PLACE_TRIES, int(n)))
 
     def timing(self):
         t = Timing()

@@ -810,3 +810,31 @@ def test_read_length_histogram(fqref, gpu, torch, ctx):
                 want[min(ln, lmax)] += 1
             assert s.n_records == res.n_records
             assert np.array_equal(lh.cpu().numpy() - 5, want), (len(data), lmax)
+
+
+def test_workspace_placement_is_invisible(fqref, torch, pkg):
+    """FQH_OPT_PLACE_TRIES: the first scan of 1 GiB or more on a context allocates several candidates of the per-tile line
+    buffer, times the index kernel with each on the head of the caller's input and keeps the fastest.  Nothing but speed may
+    depend on it: the same 1.25 GiB input through a context that places (4 tries), one that does not (0), and a second call
+    on each, must give identical offsets, and the oracle's on a sample."""
+    dev = torch.device("cuda:0")
+    n = (5 << 28) // 330 * 330
+    buf = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    outs = []
+    for tries in (4, 0):
+        ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+        ctx.set_place_tries(tries)
+        if not outs:
+            ctx.synth_fill(buf.data_ptr(), 0, n)
+        for rep in range(2):
+            rs = torch.zeros(n // 330 + 2, dtype=torch.int64, device=dev)
+            s, c, st = ctx.scan(buf.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())
+            assert (st, s.parse_status, s.n_records) == (pkg.OK, pkg.OK, n // 330) and ctx.last_scan_fast()
+            outs.append(rs)
+        ctx.close()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert torch.equal(outs[0][: n // 330], torch.arange(n // 330, dtype=torch.int64, device=dev) * 330)
+    head = buf[: 330 * 4000].cpu().numpy()
+    r, off = fqref.offsets(head)
+    assert np.array_equal(outs[0][:4000].cpu().numpy().astype(np.uint64), off)

@@ -42,6 +42,7 @@ pub struct fqh_summary {
 pub const FQH_COMM_ID_BYTES: usize = 128;
 pub const FQH_OPT_FAST_PATH: c_int = 1;
 pub const FQH_OPT_SINGLE_PASS: c_int = 2;
+pub const FQH_OPT_PLACE_TRIES: c_int = 3;
 pub const FQH_SHARD_WORDS: usize = 8;
 pub const FQH_E_AGAIN: c_int = 10;
 

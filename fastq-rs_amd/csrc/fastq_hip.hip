@@ -232,7 +232,8 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_lis
         HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, (2 * n_tiles + 128) * 64 * sizeof(uint16_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
         ctx->tiles_cap = n_tiles;
-        place_fast_rs(ctx, (2 * n_tiles + 128) * 64 * sizeof(uint16_t));
+        if (!with_list || ctx->fast_needs_list)  // (a scan on the fast path allocates: the exact path does not write the lines)
+            place_fast_rs(ctx, (2 * n_tiles + 128) * 64 * sizeof(uint16_t));
         if (getenv("FQH_DEBUG_WS")) fprintf(stderr, "workspace ctx %p: fast_rs %p tile_count %p tile_prefix %p block_prefix %p\n", (void *)ctx, (void *)ctx->fast_rs, (void *)ctx->tile_count, (void *)ctx->tile_prefix, (void *)ctx->block_prefix);
     }
     return FQH_OK;

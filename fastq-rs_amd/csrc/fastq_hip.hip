@@ -232,8 +232,7 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_lis
         HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, (2 * n_tiles + 128) * 64 * sizeof(uint16_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
         ctx->tiles_cap = n_tiles;
-        if (!with_list || ctx->fast_needs_list)  // (a scan on the fast path allocates: the exact path does not write the lines)
-            place_fast_rs(ctx, (2 * n_tiles + 128) * 64 * sizeof(uint16_t));
+        ctx->placed = false;  // (the first scan on the fast path tries placements of the new line buffer: place_fast_rs)
         if (getenv("FQH_DEBUG_WS")) fprintf(stderr, "workspace ctx %p: fast_rs %p tile_count %p tile_prefix %p block_prefix %p\n", (void *)ctx, (void *)ctx->fast_rs, (void *)ctx->tile_count, (void *)ctx->tile_prefix, (void *)ctx->block_prefix);
     }
     return FQH_OK;
@@ -246,6 +245,10 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     const bool with_list = !fast || ctx->fast_needs_list;
     fqh_status st = ensure_workspace(ctx, a.n_tiles, with_list);
     if (st != FQH_OK) return st;
+    if (fast && !ctx->placed) {
+        place_fast_rs(ctx, (2 * ctx->tiles_cap + 128) * 64 * sizeof(uint16_t));
+        ctx->placed = true;
+    }
     a.list = with_list ? ctx->list : nullptr;
     a.list_cap = ctx->list_cap;
     a.tile_count = ctx->tile_count;

@@ -59,8 +59,8 @@ struct fqh_ctx {
     DevOut *h_init = nullptr;     // pinned reset image
     uint64_t *d_misc = nullptr;   // 8 u64 of scratch
     bool placed = false;             // the line buffer in use has been through place_fast_rs
-    int place_tries = 4;             // candidates of the fast path's per-tile lines the first big scan may allocate and time (FQH_OPT_PLACE_TRIES)
-    float place_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // what the candidates measured (0: not tried); [7] = the chosen one's
+    int place_tries = 8;             // candidates of the fast path's per-tile lines the first big scan may allocate and time (FQH_OPT_PLACE_TRIES)
+    float place_ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // what the candidates measured (0: not tried); [8] = the chosen one's
     uint16_t *list_dummy = nullptr;  // 1 KiB: where k_index_fast's list-area writes go while the context has no line lists
     DevCarry *d_carry = nullptr;  // device-side shard protocol: the folded carry, and its pinned twin the host reads at finish
     DevCarry *h_carry = nullptr;

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
             if (lane < FR_N) rv = hyp + 4 * lane < run ? (uint32_t)(lst[hyp + 4 * lane] & 0x3FFFu) : 0u;
             else if (lane < FR_EDGE + 4) rv = lst[lane - FR_EDGE];
             else if (lane < FR_EDGE + 8) rv = lst[run - 8 + (lane - FR_EDGE)];
-            if (hyp + 4 * FR_N < run) {  // more record starts than the line holds: a second whole line ...
+            if (hyp + 4 * FR_N < run && fast_rs) {  // more record starts than the line holds: a second whole line ...
                 const uint32_t j2 = FR_N + lane;
                 __builtin_nontemporal_store(hyp + 4 * j2 < run ? (uint16_t)(lst[hyp + 4 * j2] & 0x3FFFu) : (uint16_t)0,
                                             fast_rs + fr2_off(n_tiles) + tile * FR2_N + lane);
@@ -747,7 +747,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         // one whole 128-byte line, non-temporal: written once, read once by k_emit_fast.  On the boxes where
         // a plain store costs the kernel 0.45 ms, this one costs 0.2.  (No plain/nt switch here: the
         // optimizer merges two stores to one address and drops the hint.)
-        __builtin_nontemporal_store((uint16_t)rv, fast_rs + tile * FR_STRIDE + lane);
+        // (fast_rs == nullptr: the yardstick launch of place_fast_rs, fastq_hip.hip — the same scan without its stores)
+        if (fast_rs) __builtin_nontemporal_store((uint16_t)rv, fast_rs + tile * FR_STRIDE + lane);
         (void)run;
     };
 

@@ -104,12 +104,14 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           also clears the back-off the context keeps after failed attempts.
  *   FQH_OPT_SINGLE_PASS [1] whole-file fqh_stats / fqh_scan_stats count in the scan's own pass over the input
  *                           (k_scan_stats); 0 = always the exact scan followed by the histogram kernel.
- *   FQH_OPT_PLACE_TRIES [4] where the fast path's per-tile lines (1.6 % of the input size) land in device memory decides
+ *   FQH_OPT_PLACE_TRIES [8] where the fast path's per-tile lines (1.6 % of the input size) land in device memory decides
  *                           whether the byte scan runs at 2.65-2.70 or at 2.85-2.95 ms per 16 GiB: the same allocation call
  *                           gives either kind, at random, and the kind stays with the allocation.  The first
- *                           scan of 1 GiB or more on a context therefore allocates up to this many candidates, times the index
- *                           kernel on the first GiBs of the caller's input with each (about 1 ms per candidate, once per
- *                           context), keeps the fastest and frees the rest; 0 or 1 = take the first allocation as it comes.
+ *                           scan of 1 GiB or more on a context's fast path therefore times the index kernel on the first
+ *                           GiBs of the caller's input, once without its line stores and then with candidate line buffers
+ *                           (at most this many, about 1 ms each, once per context) until one costs no more than 3.5 % on
+ *                           top of the store-less run; the fastest is kept, the rest freed.
+ *                           0 or 1 = take the first allocation as it comes.
  * fqh_last_scan_fast: did the last finished scan (or single-pass statistics call) keep the fast path's result (1), or
  * was it rerun on the exact path (0)?  Results are identical either way; this is for benchmarks and tests. */
 #define FQH_OPT_FAST_PATH 1

@@ -170,6 +170,10 @@ static void place_fast_rs(fqh_ctx *ctx, size_t bytes) {
         }
         return m;
     };
+    // (the first handful of launches that store lines run 3-5 % slower than later ones, whatever memory they store to — seen
+    // with candidates at different offsets of ONE allocation — so warm up before anything is compared)
+    for (int w = 0; w < 6; ++w)
+        launch_index(ctx->stream, a.buf, st << WT_SHIFT, ctx->list_dummy, 0u, ctx->tile_count, ctx->fast_rs, st, tmp_out, ctx->n_cu, true);
     // the yardstick: the same kernel over the same bytes without its line stores (no line buffer at all); with a line buffer of
     // the fast kind the stores cost 1-3 % on top of that, with one of the slow kind 7-11 %
     const float ceil_ms = timed([&] {
@@ -180,6 +184,22 @@ static void place_fast_rs(fqh_ctx *ctx, size_t bytes) {
     float ms[MAXC] = {0, 0, 0, 0, 0, 0, 0, 0};
     int n = 0, best = 0;
     const int tries = ctx->place_tries < MAXC ? ctx->place_tries : MAXC;
+#ifdef FQH_TUNING  // experiment: candidates at different offsets of ONE allocation (is it the allocation or the address?)
+    if (const char *e = getenv("FQH_WS_ARENA")) {
+        const size_t step = (size_t)atoll(e) << 20;  // MiB between candidates
+        uint8_t *arena = nullptr;
+        if (hipMalloc((void **)&arena, bytes + 16 * step) == hipSuccess) {
+            fprintf(stderr, "arena %p (input %p), without stores %.3f ms:", (void *)arena, (const void *)a.buf, ceil_ms);
+            for (int k = 0; k < 16; ++k) {
+                uint16_t *c = (uint16_t *)(arena + k * step);
+                const float m = timed([&] { launch_index(ctx->stream, a.buf, st << WT_SHIFT, ctx->list_dummy, 0u, ctx->tile_count, c, st, tmp_out, ctx->n_cu, true); });
+                fprintf(stderr, " +%zuM:%.3f", k * (step >> 20), m);
+            }
+            fprintf(stderr, "\n");
+            (void)hipFree(arena);
+        }
+    }
+#endif
     for (int k = 0; k < tries; ++k) {
         if (k > 0 && hipMalloc((void **)&cand[k], bytes) != hipSuccess) {
             cand[k] = nullptr;

@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 pad_mb = int(sys.argv[1]); order = sys.argv[2] if len(sys.argv) > 2 else "input_first"
 n = (16 << 30) // 330 * 330
 cap = n // 300 + 16
-L = C.CDLL(os.path.abspath("fastq-rs_amd/libfastq_hip.so"))
+L = C.CDLL(os.path.abspath(os.environ.get("FQH_LIB_PATH", "fastq-rs_amd/libfastq_hip.so")))
 L.fqh_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
 L.fqh_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
 L.fqh_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]

@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--slot-mib", type=int, default=256, help="ring slot size of the streamed modes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: be the launcher (one rank per GPU, the contract's command line)
+        sys.exit(self_launch(args.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -71,9 +75,20 @@ def main():
                                     device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == n_gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world != n_gpus:  # a line that says n_gpus != --gpus would be a wrong record without any error
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (plain `python bench.py --gpus N` "
+                         "does it by itself)" % (n_gpus, world))
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    # who takes part: world size as the process group sees it, the backend, and the UUID of every rank's device
+    my_uuid = str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", "cuda:%d" % dev_index))
+    if world > 1:
+        uuids = [None] * world
+        dist.all_gather_object(uuids, my_uuid)
+        rccl = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "device_uuids": uuids,
+                "distinct_devices": len(set(uuids))}
+    else:
+        rccl = {"ranks": 1, "backend": None, "device_uuids": [my_uuid], "distinct_devices": 1}
 
     if args.stream_gib > 0 and world > 1:
         sharded_stream(args, pkg, torch, dist, dev, rank, world, backend)
@@ -93,6 +108,12 @@ def main():
     # stream alone; torch's default stream is the null stream, which the library would replace by a stream of its own)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     ctx = pkg.Ctx(dev.index, stream=torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("FQH_BENCH_PLACE_TRIES"):
+        ctx.set_place_tries(int(os.environ["FQH_BENCH_PLACE_TRIES"]))
+    # the harness blocks on every step anyway: it opts in to polling the stream at the end of a step (FQH_OPT_SPIN_WAIT; the
+    # library's default is to sleep, which wakes up ~15 us late); FQH_BENCH_SPIN_US=0 measures the default
+    spin_us = int(os.environ.get("FQH_BENCH_SPIN_US", "20000"))
+    ctx.set_spin_wait(spin_us)
     LEAD = 2 * pkg.BUFSIZE  # room in front of the shard for the tail of the previous rank's shard (--shard-stats)
     store = torch.empty(LEAD + nbytes + 16, dtype=torch.uint8, device=dev)
     buf = store[LEAD:]
@@ -130,10 +151,13 @@ def main():
         index_ms.append(ctx.timing().index_ms)
         h_in[0], h_in[1], h_in[2] = nbytes, nn, ns
         h_in[3], h_in[4], h_in[5], h_in[6] = back0
-        gather_in.copy_(h_in, non_blocking=True)
-        dist.all_gather_into_tensor(gather_all, gather_in)
-        h_all.copy_(gather_all, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        if backend == "nccl":
+            gather_in.copy_(h_in, non_blocking=True)
+            dist.all_gather_into_tensor(gather_all, gather_in)
+            h_all.copy_(gather_all, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            dist.all_gather_into_tensor(h_all, h_in)
         rows = h_all.numpy().reshape(world, 7)
         carry = None
         for r in range(rank):
@@ -155,7 +179,13 @@ def main():
         if os.environ.get("FQH_BENCH_HOST_PROTOCOL") == "1":
             return step_host()
         ctx.shard_prescan_launch(buf.data_ptr(), nbytes, words.data_ptr())
-        dist.all_gather_into_tensor(all_words, words)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(all_words, words)   # RCCL, enqueued on the step's stream
+        else:  # gloo (the one-GPU functional mode) gathers host tensors only: two host hops, never a timed configuration
+            hw = words.cpu()
+            ha = torch.empty(world * W, dtype=torch.int64)
+            dist.all_gather_into_tensor(ha, hw)
+            all_words.copy_(ha)
         ctx.shard_rescan_launch(is_last, all_words.data_ptr(), world, rank, rec_start.data_ptr(), cap, counts.data_ptr())
         dist.all_reduce(counts)
         try:
@@ -264,10 +294,12 @@ def main():
         "config": {"workload": "configs[1]: %d x %.3f GiB synthetic 150 bp FASTQ resident in HBM, "
                                "record-offset scan + count + validation" % (world, nbytes / 2**30),
                    "bytes_per_gpu": nbytes, "records_total": total_records,
+                   "host_wait": "FQH_OPT_SPIN_WAIT %d us (opt-in of this harness; library default 0)" % spin_us,
                    "sharding": "byte-range, cuts at multiples of %d" % shard if world > 1 else "none",
                    "exchange": ("on the device: all_gather of 8 words per rank, fold + emit, all_reduce of the counts, one "
                                 "host wait per step (%d of %d timed+warmup steps fell back to the host recipe)"
                                 % (host_steps[0], args.steps + args.warmup)) if world > 1 else "none"},
+        "rccl": rccl,
         "records_per_s": round(total_records / (dt / args.steps), 1),
         "hbm_roofline_frac_whole_step": round(gbs / world / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": "k_index_fast", "achieved": round(achieved, 1),
@@ -282,6 +314,7 @@ def main():
                      "algorithmic_bytes_per_launch": nbytes},
     }
 
+    out["placement"] = ctx.placement()   # FQH_OPT_PLACE_TRIES (FQH_BENCH_PLACE_TRIES here; default 0 = no search)
     if rank == 0 and world == 1:
         t = ctx.timing()
         out["stage_ms"] = {"index": round(t.index_ms, 4), "prefix": round(t.prefix_ms, 4),
@@ -418,6 +451,32 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run (the driver's own command line)
+    and hand its exit code back.  Refuses when the node has fewer than N GPUs, unless FQH_BENCH_ONE_GPU=1 asks for the
+    functional mode (every rank on cuda:0, gloo instead of RCCL: RCCL does not put two ranks on one device)."""
+    import socket
+    import subprocess
+    import torch
+    one_gpu = os.environ.get("FQH_BENCH_ONE_GPU", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_gpu:
+        print("bench.py: --gpus %d but this node has %d GPU(s); set FQH_BENCH_ONE_GPU=1 for the functional one-GPU mode (gloo)"
+              % (n, have), file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if one_gpu:
+        env.setdefault("FQH_BENCH_BACKEND", "gloo")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def numa_pin(torch, dev_index):

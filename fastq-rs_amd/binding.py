@@ -9,18 +9,18 @@ LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.s
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
-           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "EXPORTS"]
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "EXPORTS"]
 
 OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY, E_AGAIN = range(11)
 SHARD_WORDS = 8
 BUFSIZE = 68 * 1024
 NSCALARS = 8
-OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES = 1, 2, 3
+OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT = 1, 2, 3, 4
 
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
-    "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
+    "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_placement", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
     "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_len_hist", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
@@ -130,6 +130,7 @@ def lib():
                                          C.POINTER(u64), C.POINTER(u64)]
         L.fqh_last_scan_fast.argtypes = [vp]
         L.fqh_set_option.argtypes = [vp, i32, i32]
+        L.fqh_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float * 10)]
         L.fqh_stream_create.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
         L.fqh_stream_destroy.argtypes = [vp]
         L.fqh_stream_destroy.restype = None
@@ -330,6 +331,17 @@ class Ctx:
     def set_place_tries(self, n):
         """Candidates of the fast path's per-tile line buffer the first big scan allocates and times (0 / 1: none)."""
         self._chk(self._L.fqh_set_option(self._h, OPT_PLACE_TRIES, int(n)))
+
+    def set_spin_wait(self, usec):
+        """Microseconds *_finish polls the stream before sleeping on it (default 0: sleeps at once)."""
+        self._chk(self._L.fqh_set_option(self._h, OPT_SPIN_WAIT, int(usec)))
+
+    def placement(self):
+        """What the placement search of this context measured -> dict (engaged False: no search ran)."""
+        n, ms = C.c_int(0), (C.c_float * 10)()
+        self._chk(self._L.fqh_placement(self._h, C.byref(n), C.byref(ms)))
+        return {"engaged": n.value > 0, "candidates": n.value, "candidate_ms": [round(float(ms[i]), 4) for i in range(n.value)],
+                "no_store_ms": round(float(ms[9]), 4), "best_ms": round(float(ms[8]), 4)}
 
     def timing(self):
         t = Timing()

@@ -59,8 +59,10 @@ struct fqh_ctx {
     DevOut *h_init = nullptr;     // pinned reset image
     uint64_t *d_misc = nullptr;   // 8 u64 of scratch
     bool placed = false;             // the line buffer in use has been through place_fast_rs
-    int place_tries = 8;             // candidates of the fast path's per-tile lines the first big scan may allocate and time (FQH_OPT_PLACE_TRIES)
-    float place_ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // what the candidates measured (0: not tried); [8] = the chosen one's
+    int place_tries = 0;             // candidates of the fast path's per-tile lines the first big scan may allocate and time (FQH_OPT_PLACE_TRIES)
+    int spin_wait_us = 0;            // FQH_OPT_SPIN_WAIT: poll the stream this long in fqh_*_finish before sleeping on it
+    float place_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // what the candidates measured (0: not tried); [8] = the chosen one's, [9] = without stores
+    int place_n = 0;                 // candidates the search tried (0: no search ran)
     uint16_t *list_dummy = nullptr;  // 1 KiB: where k_index_fast's list-area writes go while the context has no line lists
     DevCarry *d_carry = nullptr;  // device-side shard protocol: the folded carry, and its pinned twin the host reads at finish
     DevCarry *h_carry = nullptr;
@@ -85,6 +87,7 @@ struct fqh_ctx {
     bool head_unchecked = false;  // fqh_shard_align: the record in progress at the chunk start is not validated
     // fast path: prove validity with a quarter of the list traffic; any doubt -> exact rerun
     bool spec_enabled = true;   // false: exact path only (callers that need full line lists, FQH_SPEC=0)
+    uint32_t exact_holds = 0;   // live fqh_streams that need complete line lists for every chunk: no fast path while > 0
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...
     uint32_t spec_backoff = 0;  // ... 1, 2, 4 .. 64 of them, doubling with every failure in a row
     bool index_full = true;     // the tile index in the workspace holds complete line lists
@@ -95,6 +98,7 @@ struct fqh_ctx {
     fqh_carry last_carry_out = {};
     // stats in flight
     bool stats_pending = false;
+    fqh_status stats_cap_st = FQH_OK;  // two-pass fqh_scan_stats: the scan's FQH_E_CAPACITY, reported by the finish
     // single-pass scan + histograms (k_scan_stats): the request of the launch in flight, and the side arrays the
     // kernel's 64-bit counters go to until k_stats_commit adds them to the caller's
     bool fused = false;           // the scan being enqueued / in flight counts as well

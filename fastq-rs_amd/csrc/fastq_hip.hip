@@ -200,7 +200,8 @@ static void place_fast_rs(fqh_ctx *ctx, size_t bytes) {
         }
     }
 #endif
-    for (int k = 0; k < tries; ++k) {
+    bool launch_err = hipGetLastError() != hipSuccess || ceil_ms > 1e29f;
+    for (int k = 0; k < tries && !launch_err; ++k) {
         if (k > 0 && hipMalloc((void **)&cand[k], bytes) != hipSuccess) {
             cand[k] = nullptr;
             (void)hipGetLastError();
@@ -209,22 +210,33 @@ static void place_fast_rs(fqh_ctx *ctx, size_t bytes) {
         ms[k] = timed([&] {
             launch_index(ctx->stream, a.buf, st << WT_SHIFT, ctx->list_dummy, 0u, ctx->tile_count, cand[k], st, tmp_out, ctx->n_cu, true);
         });
+        if (hipGetLastError() != hipSuccess || ms[k] > 1e29f) {  // a probe that did not run says nothing: keep what there was
+            launch_err = true;
+            if (k > 0) {
+                (void)hipFree(cand[k]);
+                cand[k] = nullptr;
+            }
+            break;
+        }
         n = k + 1;
-        if (ms[k] < ms[best]) best = k;
-        if (ms[best] <= 1.035f * ceil_ms) break;  // of the fast kind: no need to go on
-    }
 #ifdef FQH_TUNING  // validation of the criterion (tools/exp_ctx_placement.py): keep the SLOWEST candidate instead
-    if (const char *e = getenv("FQH_PLACE_PICK")) {
-        if (e[0] == 'w')
-            for (int k = 0; k < n; ++k)
-                if (ms[k] > ms[best]) best = k;
-    }
+        const bool worst = getenv("FQH_PLACE_PICK") && getenv("FQH_PLACE_PICK")[0] == 'w';
+#else
+        const bool worst = false;
 #endif
-    for (int k = 0; k < n; ++k) {
-        ctx->place_ms[k] = ms[k];
-        if (k != best && cand[k]) (void)hipFree(cand[k]);
+        if (k > 0) {  // the loser of (best so far, this one) is freed at once: two line buffers at most are alive
+            const bool better = worst ? ms[k] > ms[best] : ms[k] < ms[best];
+            const int lose = better ? best : k;
+            (void)hipFree(cand[lose]);
+            cand[lose] = nullptr;
+            if (better) best = k;
+        }
+        if (!worst && ms[best] <= 1.035f * ceil_ms) break;  // of the fast kind: no need to go on
     }
+    for (int k = 0; k < n; ++k) ctx->place_ms[k] = ms[k];
+    ctx->place_n = n;
     ctx->place_ms[8] = ms[best];
+    ctx->place_ms[9] = ceil_ms;
     ctx->fast_rs = cand[best];
     if (getenv("FQH_DEBUG_WS")) {
         fprintf(stderr, "place_fast_rs: %d candidates over %.2f GiB (without stores %.3f ms):", n, (double)(st << WT_SHIFT) / (1 << 30), ceil_ms);
@@ -441,13 +453,6 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
             }
         }
     }
-    // (whatever the parse status: the emit kernels clamp their writes to cap, so a caller that walks
-    // d_rec_start[0 .. n_records] of a chunk with an error AND more records than cap would read past it)
-    if (a.rec_start && s.n_records + 1 > a.cap) {
-        ctx->last_summary = s;
-        if (out) *out = s;
-        return fail(ctx, FQH_E_CAPACITY, "d_rec_start capacity < n_records + 1");
-    }
     fqh_carry c = {};
     c.base_offset = a.base_offset + a.len;
     c.nl_count = a.nl_count + d.n_newlines;
@@ -460,6 +465,10 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
     ctx->last_carry_out = c;
     if (out) *out = s;
     if (carry_out) *carry_out = c;
+    // (whatever the parse status: the emit kernels clamp their writes to cap, so a caller that walks
+    // d_rec_start[0 .. n_records] of a chunk with an error AND more records than cap would read past it;
+    // summary and carry are exact all the same)
+    if (a.rec_start && s.n_records + 1 > a.cap) return fail(ctx, FQH_E_CAPACITY, "d_rec_start capacity < n_records + 1");
     return FQH_OK;
 }
 
@@ -500,7 +509,7 @@ static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     a.idx_cap = 0;
     // fast path: when the caller does not need full line lists and no earlier input needed the exact
     // path; a rescan on a retained index uses whichever kind of index is there
-    bool fast = reuse_index ? !ctx->index_full : (ctx->spec_enabled && ctx->list_cap >= LIST_CAP_DEFAULT);
+    bool fast = reuse_index ? !ctx->index_full : (ctx->spec_enabled && !ctx->exact_holds && ctx->list_cap >= LIST_CAP_DEFAULT);
     if (fast && !reuse_index && ctx->spec_skip) {  // backing off after a failed attempt
         --ctx->spec_skip;
         fast = false;
@@ -516,14 +525,18 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     if (!ctx->pending) return fail(ctx, FQH_E_ARG, "no scan pending");
     ctx->pending = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    {   // A scan takes milliseconds and its caller is blocked anyway: poll the stream for the first 20 ms instead of sleeping on
-        // it (hipStreamSynchronize wakes up ~15 us after the last kernel: 0.5 % of a 16 GiB step), then sleep.
+    if (ctx->spin_wait_us > 0) {
+        // FQH_OPT_SPIN_WAIT (off by default: a host core spinning inside a library call is the caller's decision): poll the
+        // stream for up to that many microseconds before sleeping on it — hipStreamSynchronize wakes up ~15 us after the
+        // last kernel, 0.5 % of a 16 GiB step.
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t q;
         while ((q = hipStreamQuery(ctx->stream)) == hipErrorNotReady &&
-               std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20)) {}
+               std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(ctx->spin_wait_us)) {}
         (void)hipGetLastError();
         if (q != hipSuccess) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->dout_clean = true;  // the finalize kernel has run
     if (ctx->dev_carry) {  // the carry was folded on the device (fqh_shard_rescan_launch): the host learns it here
@@ -704,7 +717,8 @@ fqh_status fqh_shard_prescan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t
 fqh_status fqh_shard_rescan_launch(fqh_ctx *ctx, int is_final, const uint64_t *d_all_words, int n_ranks, int rank,
                                    uint64_t *d_rec_start, uint64_t cap, uint64_t *d_counts) {
     if (!ctx || !d_all_words || n_ranks < 1 || rank < 0 || rank >= n_ranks) return FQH_E_ARG;
-    if (!ctx->pending || ctx->dev_carry) return fail(ctx, FQH_E_ARG, "fqh_shard_rescan_launch continues a fqh_shard_prescan_launch");
+    if (!ctx->pending || ctx->dev_carry || !ctx->args.prescan)
+        return fail(ctx, FQH_E_ARG, "fqh_shard_rescan_launch continues a fqh_shard_prescan_launch");
     if (d_rec_start && cap == 0) return fail(ctx, FQH_E_ARG, "cap is 0");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_carry) HIPCHK(ctx, hipMalloc((void **)&ctx->d_carry, sizeof(DevCarry)));
@@ -823,8 +837,17 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
     case FQH_OPT_PLACE_TRIES:
         ctx->place_tries = value < 0 ? 0 : value > 8 ? 8 : value;
         return FQH_OK;
+    case FQH_OPT_SPIN_WAIT:
+        ctx->spin_wait_us = value < 0 ? 0 : value > 1000000 ? 1000000 : value;
+        return FQH_OK;
     }
     return fail(ctx, FQH_E_ARG, "unknown option");
+}
+fqh_status fqh_placement(fqh_ctx *ctx, int *n_candidates, float ms[10]) {
+    if (!ctx || !n_candidates || !ms) return FQH_E_ARG;
+    *n_candidates = ctx->place_n;
+    for (int i = 0; i < 10; ++i) ms[i] = ctx->place_ms[i];
+    return FQH_OK;
 }
 fqh_status fqh_invalidate(fqh_ctx *ctx) {
     if (!ctx) return FQH_E_ARG;
@@ -877,7 +900,7 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 // takes the two-pass route (exact index + k_stats_oct), which knows about chunk edges and error limits.
 static bool fused_eligible(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                            uint32_t lmax, uint64_t lead_len, uint64_t n_limit) {
-    if (!ctx->fused_enabled || !ctx->spec_enabled || ctx->spec_skip || ctx->list_cap != LIST_CAP_DEFAULT) return false;
+    if (!ctx->fused_enabled || !ctx->spec_enabled || ctx->exact_holds || ctx->spec_skip || ctx->list_cap != LIST_CAP_DEFAULT) return false;
     if (!is_final || lead_len || n_limit != UINT64_MAX || !scan_stats_supports(lmax) || !len) return false;
     if (in && !carry_is_zero(*in)) return false;
     if (same_scan(ctx, d_buf, len, is_final, in) && ctx->index_full) return false;  // a full index is there: second pass only
@@ -1034,6 +1057,8 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
     if (!ctx->stats_pending) return fail(ctx, FQH_E_ARG, "no stats pending");
     ctx->stats_pending = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    fqh_status cap_st = ctx->stats_cap_st;  // the scan in front of the histograms found d_rec_start too short
+    ctx->stats_cap_st = FQH_OK;
     if (ctx->fused) {
         const uint8_t *buf = ctx->args.buf;
         const uint64_t len = ctx->args.len;
@@ -1042,13 +1067,16 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
         const uint32_t lmax = ctx->f_lmax;
         uint64_t *qh = ctx->f_qual, *bh = ctx->f_base, *sc = ctx->f_scalars;
         bool two_pass = false;
-        fqh_status st = fused_finish(ctx, out, carry_out, &two_pass);
-        if (st != FQH_OK && st != FQH_E_CAPACITY) return st;
-        if (!two_pass) return FQH_OK;
+        const fqh_status scan_st = fused_finish(ctx, out, carry_out, &two_pass);
+        if (scan_st != FQH_OK && scan_st != FQH_E_CAPACITY) return scan_st;
+        // (FQH_E_CAPACITY: the histograms are complete and the summary exact, d_rec_start was too short — both routes
+        // report it, like fqh_scan)
+        if (!two_pass) return scan_st;
         // the exact path has rerun the scan (same buffer, full index): count over it
-        st = fqh_internal_stats_launch(ctx, buf, len, is_final, &cin, lmax, qh, bh, sc, 0, UINT64_MAX);
+        fqh_status st = fqh_internal_stats_launch(ctx, buf, len, is_final, &cin, lmax, qh, bh, sc, 0, UINT64_MAX);
         if (st != FQH_OK) return st;
         ctx->stats_pending = false;
+        cap_st = scan_st;
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;
@@ -1057,6 +1085,7 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
     if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[6]) == hipSuccess) ctx->timing.total_ms = ms;
     if (out) *out = ctx->last_summary;
     if (carry_out) *carry_out = ctx->last_carry_out;
+    if (cap_st != FQH_OK) return fail(ctx, cap_st, "d_rec_start capacity < n_records + 1");
     return FQH_OK;
 }
 
@@ -1079,8 +1108,13 @@ fqh_status fqh_scan_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     fqh_status st = do_scan_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap);
     if (st == FQH_OK) st = do_scan_finish(ctx, nullptr, nullptr);
     ctx->spec_enabled = spec;
-    if (st != FQH_OK) return st;  // (FQH_E_CAPACITY included: the summary of fqh_scan_stats_finish is not available then)
-    return fqh_internal_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars, 0, UINT64_MAX);
+    if (st != FQH_OK && st != FQH_E_CAPACITY) return st;
+    // (FQH_E_CAPACITY: d_rec_start is too short; the histograms are counted all the same and fqh_scan_stats_finish reports it
+    // with the exact summary, as the single-pass route does)
+    const fqh_status cap_st = st;
+    st = fqh_internal_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars, 0, UINT64_MAX);
+    if (st == FQH_OK) ctx->stats_cap_st = cap_st;
+    return st;
 }
 fqh_status fqh_scan_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) {
     return fqh_stats_finish(ctx, out, carry_out);

@@ -31,7 +31,7 @@ struct fqh_stream {
     fqh_carry carry = {};
     uint64_t records_done = 0;
     bool ended = false;
-    bool saved_spec = true;  // the context's fast-path setting at creation (restored by fqh_stream_destroy)
+    bool holds_exact = false;  // this stream keeps the context on the exact path (counted in fqh_ctx::exact_holds)
     fqh::BufferReplay replay;
     // FQH_STREAM_STATS
     uint32_t lmax = 0;
@@ -78,7 +78,7 @@ void fqh_stream_destroy(fqh_stream *st) {
         if (s.copied) (void)hipEventDestroy(s.copied);
     }
     if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
-    st->ctx->spec_enabled = st->saved_spec;
+    if (st->holds_exact && st->ctx->exact_holds) --st->ctx->exact_holds;
     delete st;
 }
 
@@ -100,8 +100,10 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
     st->reserve = ((want > two ? want : two) + 15) & ~(uint64_t)15;
     st->slots.resize(n_slots);
     st->replay.reset(ctx->bufsize);
-    st->saved_spec = ctx->spec_enabled;
-    if (flags & (FQH_STREAM_INDEX | FQH_STREAM_STATS)) ctx->spec_enabled = false;  // every chunk needs complete line lists
+    if (flags & (FQH_STREAM_INDEX | FQH_STREAM_STATS)) {  // every chunk needs complete line lists: the context stays on the
+        st->holds_exact = true;                             // exact path while any such stream lives (a count, not a saved flag:
+        ++ctx->exact_holds;                                 // streams may be destroyed in any order)
+    }
     fqh_status rc = FQH_OK;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = FQH_E_DEVICE; break; }

@@ -47,7 +47,7 @@ typedef enum {
     FQH_E_DEVICE = 7,       /* HIP runtime error; fqh_last_error() has the text */
     FQH_E_ARG = 8,
     FQH_E_CAPACITY = 9,     /* rec_start / index capacity too small; summary.n_records is exact */
-    FQH_E_AGAIN = 10        /* fqh_shard_rescan_launch: some shard left the fast path; take the host recipe */
+    FQH_E_AGAIN = 10        /* fqh_scan_finish after fqh_shard_rescan_launch: some shard left the fast path; take the host recipe */
 } fqh_status;
 
 /* Parser state at a byte boundary of the input: everything a scan of the NEXT chunk needs to be
@@ -104,21 +104,29 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           also clears the back-off the context keeps after failed attempts.
  *   FQH_OPT_SINGLE_PASS [1] whole-file fqh_stats / fqh_scan_stats count in the scan's own pass over the input
  *                           (k_scan_stats); 0 = always the exact scan followed by the histogram kernel.
- *   FQH_OPT_PLACE_TRIES [8] where the fast path's per-tile lines (1.6 % of the input size) land in device memory decides
+ *   FQH_OPT_PLACE_TRIES [0] where the fast path's per-tile lines (1.6 % of the input size) land in device memory can decide
  *                           whether the byte scan runs at 2.65-2.70 or at 2.85-2.95 ms per 16 GiB: the same allocation call
- *                           gives either kind, at random, and the kind stays with the allocation.  The first
- *                           scan of 1 GiB or more on a context's fast path therefore times the index kernel on the first
+ *                           gives either kind, and the kind stays with the allocation.  With a value of 2..8
+ *                           the first scan of 1 GiB or more on a context's fast path times the index kernel on the first
  *                           GiBs of the caller's input, once without its line stores and then with candidate line buffers
- *                           (at most this many, about 1 ms each, once per context) until one costs no more than 3.5 % on
- *                           top of the store-less run; the fastest is kept, the rest freed.
- *                           0 or 1 = take the first allocation as it comes.
+ *                           (at most this many, about 1 ms each, once per context; that first *_launch call blocks while it
+ *                           does) until one costs no more than 3.5 % on top of the store-less run; the fastest is kept, each
+ *                           loser is freed as soon as it has lost.  Off by default: on some boxes every allocation is of one
+ *                           kind and the search buys nothing.  fqh_placement reports what a search found.
+ *   FQH_OPT_SPIN_WAIT [0]   microseconds fqh_*_finish polls the stream before it sleeps on it (hipStreamSynchronize wakes up
+ *                           ~15 us after the last kernel); a host core spinning inside a library call is the caller's choice.
  * fqh_last_scan_fast: did the last finished scan (or single-pass statistics call) keep the fast path's result (1), or
  * was it rerun on the exact path (0)?  Results are identical either way; this is for benchmarks and tests. */
 #define FQH_OPT_FAST_PATH 1
 #define FQH_OPT_SINGLE_PASS 2
 #define FQH_OPT_PLACE_TRIES 3
+#define FQH_OPT_SPIN_WAIT 4
 fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
 int fqh_last_scan_fast(fqh_ctx *ctx);
+/* What the placement search of this context (FQH_OPT_PLACE_TRIES) measured: *n_candidates line buffers tried (0: no search
+ * ran), ms[0 .. n-1] the index kernel's time on the sample with each, ms[8] the kept one's, ms[9] the same kernel without
+ * its line stores (the yardstick).  For benchmarks: says whether the search engaged and what it bought. */
+fqh_status fqh_placement(fqh_ctx *ctx, int *n_candidates, float ms[10]);
 
 /* Record scan.  d_buf[0..len) are device-resident bytes; `in` (NULL = start of file) describes
  * where in the file they sit.  Writes d_rec_start[0..n_records]: [0] = file offset of the record in
@@ -160,8 +168,9 @@ fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, ui
  * stream); fqh_shard_rescan_launch enqueues the fold of the rows in front of `rank` (fqh_carry_combine, on the device),
  * the emit / validate step under the carry it gives, and — if d_counts is not NULL — writes (records, 1 if this
  * shard has a parse error or the recipe cannot be used) there for the sum over the ranks; fqh_scan_finish ends the
- * launch as usual (summary, carry-out).  It returns FQH_E_AGAIN on EVERY rank when some rank's byte scan could not
- * keep the fast path (its words are not to be used): the ranks then run the host recipe above.  A parse error inside
+ * launch as usual (summary, carry-out).  fqh_scan_finish — not the launch calls, which only enqueue — returns FQH_E_AGAIN
+ * on EVERY rank when some rank's byte scan could not keep the fast path (its words are not to be used): the ranks then run
+ * the host recipe above.  fqh_shard_rescan_launch only continues a fqh_shard_prescan_launch (FQH_E_ARG otherwise).  A parse error inside
  * a shard is reported by that shard's fqh_scan_finish as usual; the word d_counts[1] tells the other ranks. */
 #define FQH_SHARD_WORDS 8
 fqh_status fqh_shard_prescan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint64_t *d_words);
@@ -225,7 +234,9 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
  * fqh_scan (d_rec_start may be NULL) plus fqh_stats.  fqh_stats on its own takes the same single-pass route.
  * Other shapes of call (chunks with a carry, non-final chunks, lmax > 256) and inputs the fast path cannot
  * prove valid (any parse error, reads longer than ~500 bp) run the exact scan followed by the histogram kernel;
- * results are identical either way. */
+ * results are identical either way.  FQH_E_CAPACITY (d_rec_start shorter than n_records + 1) is reported by the blocking
+ * call / the finish on either route, with the summary, the carry-out and the histograms complete, exactly as fqh_scan
+ * reports it. */
 fqh_status fqh_scan_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                           uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
                           uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out,

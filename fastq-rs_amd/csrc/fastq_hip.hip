@@ -330,6 +330,14 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.scratch = ctx->stats_scratch;
         fz.scalars = ctx->side;
         if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fz, ctx->n_cu));
+#ifdef FQH_TUNING
+        if (getenv("FQH_FZ_WHY")) {
+            unsigned long long w = 0;
+            (void)hipMemcpyAsync(&w, ctx->side + 15, sizeof w, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "FZ_WHY %llu\n", w);
+        }
+#endif
 #ifdef FQH_FZ_TIMING  // tuning builds only: cycles a wave spends per phase of a group (tools/exp_fztime.sh)
         {
             unsigned long long t[8];

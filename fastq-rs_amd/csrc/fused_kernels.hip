@@ -701,548 +701,6 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
     }
 }
 
-
-// =====================================================================================================================
-// k_scan_stats2 — the same single pass, restructured around RECORDS (round 3).
-//
-// What the first version spent its time on was not the counting but the bookkeeping around it: every entry checked a
-// window of five entries under all four alignments, the lines of a kind were handed to their batch with ds_bpermute, and
-// two independent batch pipelines (sequence, quality) each carried their own fill level, shape and loop.  Here
-//   * the alignment is settled ONCE per span, by the windows over the entries of its first group (the only place where
-//     all four alignments are looked at); from then on an entry's role follows from its index, and validation is the
-//     reference's own three checks per record (src/records.rs:141,155,233): '@' / '+' on the line's first byte by the lane
-//     that owns the entry, equal raw lengths when the record's two lines meet in a batch;
-//   * one lane per entry works out the line the entry closes in ONE LDS round trip (the entry, its predecessor, the line's
-//     first byte and the byte in front of its '\n') and drops a one-word descriptor into the RECORD's slot of a ring
-//     (64 records, one ring per kind): record number = (line index - alignment) / 4, no compaction, no permute;
-//   * a batch is eight RECORDS: the 8 lanes of a slot read the record's two descriptors, check the length rule, fetch both
-//     lines (ds_read2_b32 + v_alignbyte per dword) and count them with the bank schedule of stats_dev.h; records that do
-//     not fill a batch at the end of a group stay in registers;
-//   * the alphabet / window check of the counted bytes is accumulated per lane and looked at once per group, not in front
-//     of every batch's atomics: nothing of a span with a bad byte is used, so its atomics may land anywhere inside the
-//     block's LDS allocation (asserted by the launcher).
-// Everything else — spans of four tiles, the linear LDS image with the rotated read-back, the tile lines in k_index_fast's
-// format, commit by k_stats_commit if and only if k_finalize_fast keeps the fast path — is unchanged.
-constexpr uint32_t FY_RING = 64;                   // records per descriptor ring
-constexpr uint32_t FY_GLIST = 224;                 // line starts per group that can be staged: 56 records + 7 waiting < FY_RING
-constexpr uint32_t FY_RS = 224;                    // record starts of a tile staged in LDS
-constexpr uint32_t FY_LST = 4 + FY_GLIST + 4;      // [-4..-1] the last four before the group, the group's, the virtual entry
-constexpr uint32_t FY_WAVE_BYTES = FZ_DATA + 16 + FY_RS * 2 + FY_LST * 2 + 2 * FY_RING * 4;  // 6560
-static_assert(FY_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesses");
-constexpr uint32_t FY_D_VALID = 0x80000000u;       // descriptor: bit 31 valid, bits 0-16 position in the span, 17-25 length, 26 '\r'
-
-template <bool IS_SEQ, uint32_t NSL>
-__device__ __forceinline__ void fy_count(FzBatch<NSL> &B, FzShape<NSL> &S, const FzLane &L, SoTotals &T, uint32_t &chk_acc) {
-    const SoLane &c = L.c;
-    if (__ballot((B.P & 0xFFFFu) != S.key) != 0) fz_shape<NSL>(S, B.P, L.m);
-    constexpr uint32_t RB = IS_SEQ ? 2048u : 16384u;
-    constexpr uint32_t REGION = IS_SEQ ? 0u : SO_SBYTES;
-    const uint32_t mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.mode);
-    const uint32_t tus = mode & 0xFFu;
-    const bool ragged_tails = tus == 0xFFu;
-    uint32_t chk = 0, orw = 0, pt = 0;
-    if (ragged_tails) {  // lines of different lengths in one batch: each lane picks the step of its line's partial dword
-        uint32_t x = B.w[0];
-#pragma unroll
-        for (uint32_t u = 1; u < NSL; ++u) x = S.tu == u ? B.w[u] : x;
-        if (IS_SEQ) {
-            pt = x & 0x07070707u;
-            chk |= (x ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pt)) & S.tb;
-            orw |= x & S.tb;
-        } else {
-            pt = x - 0x21212121u;
-            chk |= pt & S.tb & 0xC0C0C0C0u;
-        }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) {
-        const uint32_t w = B.w[u], f = S.cm[u];
-        constexpr uint32_t OFFS[8] = {REGION, REGION + 128u, REGION + RB, REGION + RB + 128u, REGION + 2 * RB, REGION + 2 * RB + 128u,
-                                      REGION + 3 * RB, REGION + 3 * RB + 128u};
-        uint32_t pb;
-        if (IS_SEQ) {
-            pb = w & 0x07070707u;
-            chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pb)) & f;
-            orw |= w & f;
-        } else {
-            pb = w - 0x21212121u;  // byte - 33 < 64 for all four bytes <=> bits 6-7 clear (stats_dev.h)
-            chk |= pb & f & 0xC0C0C0C0u;
-        }
-        if (u == tus) {  // (wave-uniform) the step that also holds the partial last dwords: per-byte values (ADDs of 0 / 1)
-            const uint32_t o = OFFS[u < 8 ? u : 7];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + o), S.tv[k],
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            fz_sub4_at<IS_SEQ>(OFFS[u < 8 ? u : 7], c, pb, f, f, f, f);
-        }
-    }
-    if (ragged_tails) {
-        const uint32_t off = REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off), S.tv[k],
-                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    chk_acc |= chk;
-    if (IS_SEQ) {  // sequence lines with an 'N' (bit 3 is set in 'N' only): the 8 lanes of a line OR their flags
-        const unsigned long long bn = __ballot((orw & 0x08080808u) != 0);
-        if (bn) T.not_dna += so_groups(bn);
-    }
-}
-
-template <uint32_t NSL, uint32_t FZ_WAVES>
-__global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats2(FusedArgs z) {
-    constexpr uint32_t FZ_THREADS = FZ_WAVES * 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    const uint32_t lc = z.lc;
-    const uint32_t wb0 = z.wave_base;  // bytes of histogram in front of the waves' areas
-    for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) hist[i] = 0;
-    __syncthreads();
-    if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();  // the address registers assume the histogram starts at LDS address 0
-    uint8_t *const lds8 = reinterpret_cast<uint8_t *>(hist);
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t wbase = wb0 + wv * FY_WAVE_BYTES;  // LDS address of y = 0 of the wave's data area
-    FzLane L;
-    L.m = lane & 7u;
-    L.wm4 = wbase + L.m * 4u;
-    L.g8 = lane >> 3;
-    L.g16 = L.g8 * 16u;
-    L.c.slots = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        const uint32_t j = k ^ (L.g8 & 3u);
-        L.c.sel[k] = 0x0C0C0004u + k + (j << 8);
-        L.c.slots |= ((L.m + 8u * j) * 4u) << (8u * k);
-    }
-    uint8_t *const wptr = lds8 + wbase + FZ_TAIL + 16u * lane;      // chunk 64 j + lane of the group: + 1024 j
-    const uint8_t *const rptr = lds8 + wbase + FZ_TAIL + 64u * lane; // this lane's 64 contiguous bytes
-    const uint32_t rot = (lane >> 2) & 3u;                           // conflict-free read-back: instruction i reads chunk (i + rot) % 4
-    const uint32_t kro = (4u - rot) & 3u;
-    const bool swp = (kro & 2u) != 0;
-    const uint32_t s16 = (kro & 1u) * 16u;
-    uint16_t *const tedge = reinterpret_cast<uint16_t *>(lds8 + wbase + FZ_DATA);  // the tile's first four entries
-    uint16_t *const trs = tedge + 8;          // the tile's record starts (FY_RS of them)
-    uint16_t *const lst = trs + FY_RS + 4;    // the group's entries; lst[-4 .. -1]: the last four before the group
-    uint32_t *const ringS = reinterpret_cast<uint32_t *>(trs + FY_RS + FY_LST);
-    uint32_t *const ringQ = ringS + FY_RING;
-
-    uint32_t acc_rec = 0, acc_bases = 0, acc_qual = 0;  // per lane (a wave never reads 4 GiB)
-    SoTotals T = {0, 0};
-    FzShape<NSL> S = {};
-    S.key = 0xFFFFFFFFu;
-
-    const uint8_t *__restrict__ const buf = z.buf;
-    const uint64_t len = z.len;
-    const uint32_t n_tiles = (uint32_t)z.n_tiles;
-    const uint32_t n_full = (uint32_t)(len >> WT_SHIFT);
-    const uint32_t n_spans = fz_spans(n_tiles, len);
-    const uint32_t nw = gridDim.x * FZ_WAVES;
-    const uint32_t lo = lane * 16u;
-    uint32_t n_over = 0;
-
-    auto fetch_group = [&](uint32_t t, uint32_t g, uint4 &n0, uint4 &n1, uint4 &n2, uint4 &n3) {
-        const uint64_t off = ((uint64_t)t << WT_SHIFT) + g * FZ_GROUP + lo;
-        if (t < n_full) {
-            const uint8_t *p = buf + off;
-            n0 = load16_nt(p); n1 = load16_nt(p + PIECE_BYTES);
-            n2 = load16_nt(p + 2 * PIECE_BYTES); n3 = load16_nt(p + 3 * PIECE_BYTES);
-        } else {  // the partial tile at the end of the buffer
-            n0 = fz_load16_tail(buf, off, len); n1 = fz_load16_tail(buf, off + PIECE_BYTES, len);
-            n2 = fz_load16_tail(buf, off + 2 * PIECE_BYTES, len); n3 = fz_load16_tail(buf, off + 3 * PIECE_BYTES, len);
-        }
-    };
-
-#ifdef FQH_FZ_TIMING
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = 0;
-#define FY_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tph[i] += t_ - tk; tk = t_; } while (0)
-#else
-#define FY_T(i) do { } while (0)
-#endif
-    uint32_t span = blockIdx.x * FZ_WAVES + wv;
-    if (span < n_spans) {
-        uint4 n0, n1, n2, n3;
-        fetch_group(span * FZ_SPAN, 0, n0, n1, n2, n3);
-        uint32_t pbv = span ? buf[((uint64_t)(span * FZ_SPAN) << WT_SHIFT) - 1] : 0u;  // the byte before the span
-        bool pending = false;  // the previous tile's line is still in a register
-        uint32_t ptile = 0, prv = 0;
-        for (; span < n_spans; span += nw) {
-            const uint32_t nspan = span + nw < n_spans ? span + nw : span;  // clamped: the prefetch is unconditional
-            const uint32_t t0 = span * FZ_SPAN;
-            const uint32_t t1 = span + 1 == n_spans ? n_tiles : t0 + FZ_SPAN;
-            uint32_t srun = 0;       // entries of the span before the current group
-            uint32_t tot = 0;        // entries of the current group
-            uint32_t prev;           // the byte before the group is a newline
-            {
-                uint32_t x = pbv;
-                asm volatile("v_mov_b32 %0, %0" : "+v"(x));  // (opaque: keeps the compiler from moving the value to a scalar at the load)
-                prev = (t0 && (uint32_t)__builtin_amdgcn_readfirstlane((int)x) == '\n') ? 1u : 0u;
-            }
-            uint32_t hyp = 7;        // the span's alignment: entries hyp, hyp + 4, .. (counted from the span's first) start records
-            bool span_bad = false;
-            bool lane_bad = false;   // per lane: something this lane saw condemns the span (looked at once per group)
-            uint32_t chk = 0;        // per lane: the alphabet / window checks of what it counted
-            FzBatch<NSL> PBs, PBq;   // the batch in progress: slot g8 holds one record's sequence and quality line
-            PBs.P = 0;
-            PBq.P = 0;
-#pragma unroll
-            for (uint32_t u = 0; u < NSL; ++u) PBs.w[u] = PBq.w[u] = 0;
-            uint32_t nfill = 0;      // records in the batch in progress
-            uint32_t nC = 0;         // records of the span that have been fetched into batches
-            uint2 post = make_uint2(0, 0);
-            __builtin_amdgcn_wave_barrier();
-            ringS[lane] = 0;
-            ringQ[lane] = 0;
-            for (uint32_t tile = t0; tile < t1; ++tile) {
-                const uint64_t tb = (uint64_t)tile << WT_SHIFT;
-                const bool full = tile < n_full;
-                const uint32_t tile_bytes = full ? WT_BYTES : (uint32_t)(len - tb);
-                const uint32_t ng = full ? WT_BYTES / FZ_GROUP : (tile_bytes + FZ_GROUP - 1) / FZ_GROUP;
-                const bool last_t = tile + 1 == t1;
-                uint32_t run = 0;            // entries of the tile before the current group
-                const uint32_t srun_t = srun + tot;  // entries of the span in front of the tile
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (uint32_t k = 0; k < FY_RS; k += 64)
-                    if (k + lane < FY_RS) trs[k + lane] = 0;  // (unused slots of the tile's lines are 0)
-#pragma unroll 1
-                for (uint32_t g = 0; g < ng; ++g) {
-                    const bool last_g = g + 1 == ng;
-#ifdef FQH_FZ_TIMING
-                    tk = __builtin_readcyclecounter();
-#endif
-                    __builtin_amdgcn_wave_barrier();
-                    *reinterpret_cast<uint4 *>(wptr) = n0;
-                    FY_T(0);  // wait for the group's loads
-                    *reinterpret_cast<uint4 *>(wptr + 1024) = n1;
-                    *reinterpret_cast<uint4 *>(wptr + 2048) = n2;
-                    *reinterpret_cast<uint4 *>(wptr + 3072) = n3;
-                    int ppos = -1;  // position of the first newline in the bytes after the span
-                    if (last_g && last_t && full) {  // those bytes (loaded three groups ago) go behind the group
-                        *reinterpret_cast<uint2 *>(lds8 + wbase + FZ_TAIL + FZ_GROUP + 8u * lane) = post;
-                        const uint32_t f0 = eq_flags(post.x, 0x0A0A0A0Au), f1 = eq_flags(post.y, 0x0A0A0A0Au);
-                        const unsigned long long bm = __ballot((f0 | f1) != 0);
-                        if (bm) {
-                            const uint32_t first = (uint32_t)__ffsll((long long)bm) - 1u;
-                            const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)f0, (int)first);
-                            const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane((int)f1, (int)first);
-                            const uint32_t byte = g0 ? ((uint32_t)__ffs(g0) - 1u) / 8u : 4u + ((uint32_t)__ffs(g1) - 1u) / 8u;
-                            ppos = (int)(8u * first + byte);
-                        }
-                    }
-                    // the next group: of this tile, of the span's next tile, or of the wave's next span
-                    if (last_t && g == 0) {  // (early: the bytes after the span are needed in the span's last group)
-                        const uint64_t pe = tb + tile_bytes + 8u * lane;
-                        if (pe + 8 <= len) post = *reinterpret_cast<const uint2 *>(buf + pe);
-                    }
-                    if (last_g && last_t) pbv = buf[((uint64_t)(nspan * FZ_SPAN) << WT_SHIFT) - (nspan ? 1 : 0)];
-                    fetch_group(last_g ? (last_t ? nspan * FZ_SPAN : tile + 1) : tile, last_g ? 0u : g + 1, n0, n1, n2, n3);
-                    if (g == 0 && pending)  // a whole group before the next wait on vmcnt
-                        __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    FY_T(1);  // LDS write, prefetch issue
-                    uint32_t m_lo, m_hi;
-                    {
-                        const uint4 d0 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u) & 48u));
-                        const uint4 d1 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 16u) & 48u));
-                        const uint4 d2 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 32u) & 48u));
-                        const uint4 d3 = *reinterpret_cast<const uint4 *>(rptr + ((rot * 16u + 48u) & 48u));
-                        const uint32_t r_lo = eqmask16<1>(d0, 0x0A0A0A0Au) | (eqmask16<1>(d1, 0x0A0A0A0Au) << 16);
-                        const uint32_t r_hi = eqmask16<1>(d2, 0x0A0A0A0Au) | (eqmask16<1>(d3, 0x0A0A0A0Au) << 16);
-                        const uint32_t a_lo = swp ? r_hi : r_lo, a_hi = swp ? r_lo : r_hi;
-                        m_lo = __builtin_amdgcn_alignbit(a_hi, a_lo, s16);
-                        m_hi = __builtin_amdgcn_alignbit(a_lo, a_hi, s16);
-                    }
-                    // line starts: the byte after a newline
-                    uint32_t ls_lo = (m_lo << 1) | wave_shr1(m_hi >> 31, prev);
-                    uint32_t ls_hi = __builtin_amdgcn_alignbit(m_hi, m_lo, 31);
-                    prev = ((uint32_t)__builtin_amdgcn_readlane((int)m_hi, 63)) >> 31;
-                    if (!full) {  // a line start must be an existing byte
-                        const int nv = (int)tile_bytes - (int)(g * FZ_GROUP + lane * 64u);
-                        const uint32_t nvalid = nv < 0 ? 0u : nv > 64 ? 64u : (uint32_t)nv;
-                        const unsigned long long keep = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-                        ls_lo &= (uint32_t)keep;
-                        ls_hi &= (uint32_t)(keep >> 32);
-                    }
-                    const uint32_t cl = __popc(ls_lo) + __popc(ls_hi);
-                    const unsigned long long b1 = __ballot(cl >= 1), b2 = __ballot(cl >= 2), b3 = __ballot(cl >= 3);
-                    uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
-                    pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, pre));
-                    pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, pre));
-                    uint32_t gtot = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2) + (uint32_t)__popcll(b3);
-                    if (__ballot(cl >= 4)) {
-                        for (uint32_t k = 4;; ++k) {
-                            const unsigned long long b = __ballot(cl >= k);
-                            if (!b) break;
-                            pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, pre));
-                            gtot += (uint32_t)__popcll(b);
-                        }
-                    }
-                    FY_T(2);  // read-back, masks, prefix
-                    run += tot;   // the previous group's entries are behind us now
-                    srun += tot;
-                    if (g == 0) run = 0;  // (they belonged to the previous tile)
-                    if (gtot > FY_GLIST) span_bad = true;  // lines shorter than ~18 bytes on average: left to the exact path
-                    tot = gtot < FY_GLIST ? gtot : FY_GLIST;
-                    const uint32_t ebase = g * FZ_GROUP + lane * 64u;
-                    if (FZ_DBG(8u)) { tot = 0; }
-                    if (pre + cl <= FY_GLIST && !FZ_DBG(8u)) {  // (a lane whose entries would leave the list writes none: the span is bad anyway)
-                        uint16_t *dst = lst + pre;
-                        while (ls_lo) {
-                            const uint32_t q = __ffs(ls_lo) - 1;
-                            ls_lo &= ls_lo - 1;
-                            *dst++ = (uint16_t)(ebase + q);
-                        }
-                        while (ls_hi) {
-                            const uint32_t q = __ffs(ls_hi) + 31;
-                            ls_hi &= ls_hi - 1;
-                            *dst++ = (uint16_t)(ebase + q);
-                        }
-                    }
-                    const int gofs = (int)FZ_TAIL - (int)(g * FZ_GROUP);  // tile offset -> y (position in the wave's data area)
-                    // span-relative position of y = 0: P = y + wofs
-                    const int wofs = (int)((tile - t0) * WT_BYTES + g * FZ_GROUP) - (int)FZ_TAIL;
-                    // ---- the span's last group: its last line ends in another wavefront's span (or with the buffer); the
-                    // 512 bytes after the span close it, as one more (virtual) entry behind the group's
-                    uint32_t totv = tot;
-                    if (last_g && last_t) {
-                        const int yend = (int)FZ_TAIL + (int)(tile_bytes - g * FZ_GROUP);  // y of the first byte after the span
-                        const bool last_nl = full ? prev != 0 : buf[len - 1] == '\n';
-                        int yclose = -1;
-                        if (last_nl) {
-                            yclose = yend;
-                        } else if (full) {
-                            if (ppos >= 0) yclose = yend + ppos + 1;
-                            else if (tb + tile_bytes + FZ_POST <= len) span_bad = true;  // a line that goes on for more than 512 bytes after the span
-                            // (else: no '\n' before the end of the buffer: not a line the parser delivers)
-                        }
-                        if (yclose >= 0) {
-                            if (lane == 0) lst[tot] = (uint16_t)((uint32_t)(yclose - gofs) & 0x3FFFu);
-                            totv = tot + 1;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    FY_T(3);  // staging
-                    // ---- the span's first group settles the alignment: class bits of its entries, windows of five under all four
-                    if (tile == t0 && g == 0) {
-                        for (uint32_t i = lane; i < tot; i += 64) {
-                            const uint32_t e = lst[i];
-                            const uint32_t b0 = lds8[wbase + (uint32_t)((int)(e & 0x3FFFu) + gofs)];
-                            lst[i] = (uint16_t)(e | (b0 == '@' ? 0x4000u : 0u) | (b0 == '+' ? 0x8000u : 0u));
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        uint32_t have = 0, wbad = 0;
-                        for (uint32_t i = lane; i + 4 < tot; i += 64) {
-                            const uint32_t e0 = lst[i], e1 = lst[i + 1], e2 = lst[i + 2], e3 = lst[i + 3], e4 = lst[i + 4];
-                            const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
-                                            ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
-                            have |= 1u << (i & 3u);
-                            wbad |= ok ? 0u : 1u << (i & 3u);
-                        }
-                        uint32_t cons = 0;
-#pragma unroll
-                        for (uint32_t r = 0; r < 4; ++r)
-                            if (__ballot((have >> r) & 1u) && !__ballot((wbad >> r) & 1u)) cons |= 1u << r;
-                        if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
-                        else span_bad = true;
-                    }
-                    FY_T(4);  // alignment (first group of a span)
-                    const uint32_t hyp_t = hyp < 4 ? (hyp - srun_t) & 3u : 7u;  // the same alignment counted from the tile's first entry
-                    // ---- one lane per entry, 64 entries at a time: the line the entry starts must begin as its role says
-                    // (src/records.rs:141,155); the line it closes goes to its record's slot
-#pragma unroll 1
-                    for (uint32_t c0 = 0; c0 < totv && !FZ_DBG(4u); c0 += 64) {
-                        const uint32_t p = c0 + lane;
-                        if (p < totv) {
-                            const uint32_t e4 = lst[p], e3 = lst[(int)p - 1];
-                            int yc = (int)(e4 & 0x3FFFu) + gofs;
-                            if (p >= tot && yc < (int)FZ_TAIL) yc += (int)WT_BYTES;  // (the virtual entry's offset may have wrapped)
-                            const uint8_t *at = lds8 + wbase + (uint32_t)yc;
-                            const uint32_t b0 = at[0];
-                            const uint32_t bcr = *(at - 2);
-                            const uint32_t G = srun + p;               // the entry's index in the span
-                            const uint32_t kn = (G - hyp) & 3u;        // role of the line it starts: 0 header, 1 sequence, 2 separator, 3 quality
-                            const uint32_t ti = run + p;
-                            if (p < tot) {
-                                const uint32_t cls = (b0 == '@' ? 0x4000u : 0u) | (b0 == '+' ? 0x8000u : 0u);
-                                if ((kn == 0 && b0 != '@') || (kn == 2 && b0 != '+')) lane_bad = true;
-                                const uint32_t ec = (e4 & 0x3FFFu) | cls;
-                                if (ti < 4) tedge[ti] = (uint16_t)ec;  // the tile's first four entries
-                                if (tot >= 4 && p + 4 >= tot) lst[(int)p - (int)tot] = (uint16_t)ec;  // the last four go in front of the next group's
-                                if (kn == 0 && ti >= hyp_t) {  // a record starts here: record start k of the tile
-                                    const uint32_t k = (ti - hyp_t) >> 2;
-                                    if (k < FY_RS) trs[k] = (uint16_t)(e4 & 0x3FFFu);
-                                    else lane_bad = true;
-                                }
-                            }
-                            if ((kn & 1u) == 0 && G != 0) {  // it closes a sequence (kn == 2) or quality (kn == 0) line of this span
-                                uint32_t l = ((e4 - e3) & 0x3FFFu) - 1u;  // raw line, without its '\n'
-                                const int ys = yc - 1 - (int)l;
-                                const uint32_t cr = (l && bcr == '\r') ? 1u : 0u;  // trim_winline, src/records.rs:66-73
-                                l -= cr;
-                                if (ys < 0 || l > lc) {
-                                    lane_bad = true;  // began before the kept tail (longer than ~500 bytes), or longer than the histogram's rows
-                                } else {
-                                    // the record of line G - 1: (G - 1 - hyp - role) / 4, counted from -1 (the record in progress at the span's start)
-                                    const uint32_t rr = (uint32_t)(((int)G - (int)hyp + (kn == 0 ? 0 : 2)) >> 2);
-                                    const uint32_t d = FY_D_VALID | (uint32_t)(ys + wofs) | (l << 17) | (cr << 26);
-                                    if (kn == 2) { ringS[rr & (FY_RING - 1)] = d; ++acc_rec; acc_bases += l; }
-                                    else { ringQ[rr & (FY_RING - 1)] = d; acc_qual += l; }
-                                }
-                            }
-                        }
-                    }
-                    if (tot < 4) {  // (rare: the four entries in front of the next group are partly the old ones)
-                        __builtin_amdgcn_wave_barrier();
-                        const uint32_t hv = lane < 4 ? (uint32_t)lst[(int)tot - 4 + (int)lane] : 0u;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < 4 && (int)lane < 4 - (int)tot) lst[(int)lane - 4] = (uint16_t)hv;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    FY_T(5);  // per-entry pass
-                    // ---- records: those whose quality line has closed join the batch in progress, eight make a batch
-                    {
-                        const uint32_t Gn = srun + totv;  // entries of the span so far
-                        const bool flush = last_g && last_t;
-                        uint32_t nEnd = (hyp < 4 && Gn > hyp) ? (Gn - hyp + 3) >> 2 : 0u;  // records 0 .. nEnd - 1: their quality line has closed
-                        if (flush && hyp < 4) {  // ... and the one whose sequence line is all this span holds (its quality line is the next span's)
-                            const uint32_t g2 = (hyp + 2) & 3u;   // the first entry that closes a sequence line
-                            const uint32_t nS = Gn > g2 ? (Gn - g2 + 3) >> 2 : 0u;
-                            const uint32_t eS = (hyp <= 1 ? 1u : 0u) + nS;
-                            nEnd = eS > nEnd ? eS : nEnd;
-                        }
-                        uint32_t avail = nEnd > nC ? nEnd - nC : 0u;
-                        if (FZ_DBG(2u)) { nC += avail; avail = 0; nfill = 0; }
-                        while (avail != 0 || (flush && nfill != 0)) {
-                            const uint32_t take = 8 - nfill < avail ? 8 - nfill : avail;
-                            const uint32_t si = L.g8 - nfill;              // (wraps for slots that keep their record)
-                            const bool newl = si < take;
-                            if (newl) {
-                                const uint32_t slot = (nC + si) & (FY_RING - 1);
-                                const uint32_t dS = ringS[slot], dQ = ringQ[slot];
-                                if (L.m == 0) {
-                                    ringS[slot] = 0;
-                                    ringQ[slot] = 0;
-                                }
-                                const uint32_t lS = (dS >> 17) & 0x1FFu, lQ = (dQ >> 17) & 0x1FFu;
-                                // the length rule, src/records.rs:233 (raw lengths: a '\r' counts)
-                                if ((dS & dQ & FY_D_VALID) && lS + ((dS >> 26) & 1u) != lQ + ((dQ >> 26) & 1u)) lane_bad = true;
-                                const int yS = (int)(dS & 0x1FFFFu) - wofs, yQ = (int)(dQ & 0x1FFFFu) - wofs;
-                                if (((dS & FY_D_VALID) && yS < 0) || ((dQ & FY_D_VALID) && yQ < 0)) lane_bad = true;  // left the window
-                                PBs.P = (dS & FY_D_VALID) && yS >= 0 ? lS | FZ_P_ACT | ((uint32_t)yS << 16) : 0u;
-                                PBq.P = (dQ & FY_D_VALID) && yQ >= 0 ? lQ | FZ_P_ACT | ((uint32_t)yQ << 16) : 0u;
-                                {
-                                    FzRaw<NSL> R;
-                                    fz_issue<NSL>(PBs, R, L, lds8);
-                                    fz_align<NSL>(PBs, R);
-                                }
-                                {
-                                    FzRaw<NSL> R;
-                                    fz_issue<NSL>(PBq, R, L, lds8);
-                                    fz_align<NSL>(PBq, R);
-                                }
-                            }
-                            nfill += take;
-                            nC += take;
-                            avail -= take;
-                            if (nfill == 8 || (flush && avail == 0)) {
-                                if (!FZ_DBG(1u)) {
-                                    fy_count<true, NSL>(PBs, S, L, T, chk);
-                                    fy_count<false, NSL>(PBq, S, L, T, chk);
-                                }
-                                nfill = 0;
-                                PBs.P = 0;
-                                PBq.P = 0;
-                            }
-                        }
-                    }
-                    FY_T(6);  // records: fetch, count
-                    if (__ballot(lane_bad || chk != 0) != 0) span_bad = true;
-                    // ---- the next group finds this one's last 512 bytes (and, above, its last four entries) in front of its own
-                    __builtin_amdgcn_wave_barrier();
-                    {
-                        const uint2 tailv = *reinterpret_cast<const uint2 *>(lds8 + wbase + FZ_GROUP + 8u * lane);
-                        __builtin_amdgcn_wave_barrier();
-                        *reinterpret_cast<uint2 *>(lds8 + wbase + 8u * lane) = tailv;
-                    }
-                    FY_T(7);  // tail copy
-                }
-                const uint32_t trun = run + tot;  // entries of the whole tile
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // ---- the tile's line in k_index_fast's format: every record that lies in this span has been validated under the
-                // span's alignment; k_emit_fast checks that alignment against the true line index and the record that straddles
-                // into the tile.  (The short tile at the end of the buffer is marked FR_SMALL: k_finalize_fast validates its records.)
-                const bool small_t = !full && trun < 8;
-                const uint32_t hyp_t = hyp < 4 ? (hyp - srun_t) & 3u : 7u;
-                if (!small_t && (trun < 8 || hyp_t > 3)) span_bad = true;
-                if (small_t && hyp_t > 3) span_bad = true;
-                {
-                    uint32_t rv = lane < FR_N ? (uint32_t)trs[lane] : 0u;
-                    if (lane >= FR_EDGE && lane < FR_EDGE + 4) rv = tedge[lane - FR_EDGE];
-                    if (lane >= FR_EDGE + 4 && lane < FR_EDGE + 8) rv = lst[(int)lane - (int)(FR_EDGE + 8)];
-                    if (small_t) {  // entries 0 .. trun - 1 in order, no record starts
-                        const uint32_t k = lane - FR_EDGE;
-                        rv = (lane >= FR_EDGE && k < trun) ? (k < 4 ? (uint32_t)tedge[k] : (uint32_t)lst[(int)k - (int)trun]) : 0u;
-                    }
-                    const uint32_t nrs = trun > hyp_t ? (trun - hyp_t + 3) >> 2 : 0u;  // record starts of the tile
-                    if (nrs > FR_N && hyp_t < 4) {
-                        z.fast_rs[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + lane] = trs[FR_N + lane];
-                        if (nrs > FR_N + FR2_N) {
-                            if (z.list) {
-                                for (uint32_t k = FR_N + FR2_N + lane; k < nrs && k < FY_RS; k += 64) z.list[(uint64_t)tile * z.list_cap + 8 + k] = trs[k];
-                            } else {  // (no line-list workspace yet: the host reruns with it)
-                                span_bad = true;
-                                if (lane == 0) z.out->need_list = 1;
-                            }
-                        }
-                    }
-                    if (span_bad) ++n_over;
-                    prv = lane == FR_CNT ? (trun & 0xFFFFu) : lane == FR_CNT + 1 ? (trun >> 16) : lane == FR_HYP ? (span_bad ? 7u : small_t ? (FR_SMALL | hyp_t) : hyp_t) : rv;
-                }
-                ptile = tile;
-                pending = true;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (pending) __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
-    }
-    if (lane == 0 && n_over) atomicAdd(&z.out->spec_fail, (unsigned long long)n_over);
-#ifdef FQH_FZ_TIMING
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&z.scalars[8 + i], tph[i]);
-#endif
-
-    // ---- per-block partial histogram, per-wave totals
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    uint32_t *__restrict__ dst = z.scratch + (uint64_t)blockIdx.x * SO_WORDS;
-    for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) dst[i] = hist[i];
-    unsigned long long sc[5] = {acc_rec, acc_bases, acc_qual, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        unsigned long long v = sc[j];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-        sc[j] = v;
-    }
-    if (lane == 0) {
-        sc[3] = sc[0] - T.not_dna;
-        sc[4] = sc[0] - T.not_dnan;
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-            if (sc[j]) atomicAdd(&z.scalars[j], sc[j]);
-    }
-}
-
 // k_stats_commit: adds what k_scan_stats left in scratch — per-block partial histograms (bank-scheduled layout)
 // and the totals — to the caller's arrays if and only if the scan's finalize kernel kept the fast path's result
 // (DevOut::stats_commit).
@@ -1304,41 +762,8 @@ static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t block
 
 // z: buf, len, n_tiles, the fast path's outputs, lmax, scratch (scan_stats_scratch_bytes), scalars = ZEROED side
 // array of FQH_NSCALARS u64 (not the caller's: see k_stats_commit)
-template <uint32_t NSL, uint32_t FZ_WAVES>
-static hipError_t launch_scan_stats2_n(hipStream_t s, FusedArgs z, uint32_t blocks) {
-    z.wave_base = SO_SBYTES + ((NSL + 1) / 2) * 16384u;
-    const size_t lds = (size_t)z.wave_base + (size_t)FZ_WAVES * FY_WAVE_BYTES + FZ_SLACK;
-    static_assert(SO_SBYTES + ((NSL + 1) / 2) * 16384u + FZ_WAVES * FY_WAVE_BYTES + FZ_SLACK <= SO_LDS_MAX, "LDS budget");
-    // a counted byte forms the address region | row block | byte << 8 | slot: any byte value stays inside the allocation,
-    // so the atomics of a span with a byte outside the alphabet / window (whose result is never used) land somewhere harmless
-    static_assert(65536 + SO_SBYTES + 128 + ((NSL - 1) / 2) * 16384u <= SO_SBYTES + ((NSL + 1) / 2) * 16384u + FZ_WAVES * FY_WAVE_BYTES,
-                  "garbage addresses must stay inside the allocation");
-    static bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_stats2<NSL, FZ_WAVES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        set = true;
-    }
-    hipLaunchKernelGGL((k_scan_stats2<NSL, FZ_WAVES>), dim3(blocks), dim3(FZ_WAVES * 64), lds, s, z);
-    return hipSuccess;
-}
-
 hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
     z.lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
-    static const int version = getenv("FQH_FUSED_V") ? atoi(getenv("FQH_FUSED_V")) : 2;  // (temporary A/B switch of round 3)
-    if (version == 2) {
-#ifdef FQH_TUNING
-        z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
-#else
-        z.dbg = 0;
-#endif
-        const uint32_t blocks = scan_stats_blocks(z.n_tiles, n_cu);
-        const uint32_t nsl = (z.lc + 31) / 32;
-        hipError_t e = nsl <= 5 ? launch_scan_stats2_n<5, 16>(s, z, blocks) : launch_scan_stats2_n<8, 12>(s, z, blocks);
-        if (e != hipSuccess) return e;
-        return hipGetLastError();
-    }
 #ifdef FQH_TUNING  // knock-out flags of the timing experiments (tools/exp_fzdbg.py); not part of the product library
     z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
 #else

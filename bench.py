@@ -61,6 +61,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
+    if world != n_gpus:  # a line that says n_gpus != --gpus would be a wrong record without any error (checked before any rendezvous)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (plain `python bench.py --gpus N` "
+                         "does it by itself)" % (n_gpus, world))
     # FQH_BENCH_BACKEND=gloo + FQH_BENCH_ONE_GPU=1: run the N > 1 protocol with every rank on cuda:0
     # (functional check of the sharded path on a 1-GPU box; the driver's runs use RCCL, one GPU per rank)
     backend = os.environ.get("FQH_BENCH_BACKEND", "nccl")
@@ -75,9 +78,6 @@ def main():
                                     device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if world != n_gpus:  # a line that says n_gpus != --gpus would be a wrong record without any error
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (plain `python bench.py --gpus N` "
-                         "does it by itself)" % (n_gpus, world))
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     # who takes part: world size as the process group sees it, the backend, and the UUID of every rank's device
@@ -536,8 +536,6 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
 
     hist = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
     sc, qh, bh = hist[:8], hist[8: 8 + LMAX * 256], hist[8 + LMAX * 256:]
-    window = torch.empty(sharded.ALIGN_WINDOW + 16, dtype=torch.uint8, device=dev)
-    scratch = torch.empty(4 * pkg.BUFSIZE + 16, dtype=torch.uint8, device=dev)
     TAILCAP = 2 * pkg.BUFSIZE
     xdev = dev if backend == "nccl" else torch.device("cpu")
 
@@ -547,29 +545,28 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
 
     barrier()
     t0 = time.perf_counter()
-    res = sharded.stream_shard(ctx, read_into, lo, hi, file_len, blk, stats=(LMAX, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()),
-                               d_window=window.data_ptr())
+    stats = (LMAX, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    sh = sharded.stream_shard(ctx, read_into, lo, hi, file_len, blk, stats=stats)     # fqh_shard_stream_run
     t_stream = time.perf_counter() - t0
     # ---- the one exchange: 8 words + the tail bytes of every rank
     mine = np.zeros(64 + TAILCAP, dtype=np.uint8)
-    mine[:64] = np.array(res.summary_words(), dtype=np.int64).view(np.uint8)
-    assert len(res.tail) <= TAILCAP
-    mine[64: 64 + len(res.tail)] = np.frombuffer(res.tail, dtype=np.uint8)
+    mine[:64] = np.array(sh.words(), dtype=np.uint64).view(np.uint8)
+    assert len(sh.tail) <= TAILCAP
+    mine[64: 64 + len(sh.tail)] = np.frombuffer(sh.tail, dtype=np.uint8)
     t_in = torch.from_numpy(mine).to(xdev)
     t_all = torch.empty(world * mine.size, dtype=torch.uint8, device=xdev)
     dist.all_gather_into_tensor(t_all, t_in)
     rows = t_all.cpu().numpy().reshape(world, mine.size)
-    words = [[int(x) for x in rows[r, :64].view(np.int64)] for r in range(world)]
-    bad = sharded.check_phases(words)
-    st_status, st_recs = pkg.OK, 0
-    if rank:
-        prev_tail = rows[rank - 1, 64: 64 + words[rank - 1][5]].tobytes()
-        st_status, st_recs = sharded.stitch(ctx, prev_tail, res.head, LMAX, scratch.data_ptr(), qh.data_ptr(), bh.data_ptr(),
-                                            sc.data_ptr())
-    counts = torch.tensor([res.n_records + st_recs, 1 if (res.status != pkg.OK or st_status != pkg.OK) else 0], dtype=torch.int64,
-                          device=dev)
-    both = torch.cat([counts, hist]).to(xdev)
+    words = [[int(x) for x in rows[r, :64].view(np.uint64)] for r in range(world)]
+    tails = [rows[r, 64: 64 + words[r][5]].tobytes() for r in range(world)]
+    # ---- phase check + one-record stitch + this rank's first-error key (fqh_shard_stream_finish), then SUM and MIN
+    rec, key = sharded.finish(ctx, words, tails, rank, sh.head, stats=stats)
+    both = torch.cat([torch.tensor([rec], dtype=torch.int64, device=dev), hist]).to(xdev)
     dist.all_reduce(both)
+    kt = torch.tensor([key - (1 << 63)], dtype=torch.int64, device=xdev)   # (order-preserving map of the u64 key into torch's i64)
+    dist.all_reduce(kt, op=dist.ReduceOp.MIN)
+    gkey = int(kt.item()) + (1 << 63)
+    g_status, g_err_record = pkg.error_key_unpack(gkey)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt, t_stream], dtype=torch.float64, device=xdev)
@@ -578,6 +575,7 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     rates = torch.zeros(world, dtype=torch.float64, device=xdev)
     rates[rank] = (hi - lo) / 1e9 / t_stream
     dist.all_reduce(rates)
+    bad = [] if g_status == pkg.OK else [(g_status, g_err_record)]
     tot = both.cpu().numpy()
     # ---- what the totals must be: the block's own histograms, times the repetitions, plus the last partial block
     reps, rem = divmod(file_len, blk)
@@ -588,7 +586,7 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     if rem:
         ctx.stats(d_blk.data_ptr(), rem, LMAX, exp[8: 8 + LMAX * 256].data_ptr(), exp[8 + LMAX * 256:].data_ptr(), exp[:8].data_ptr())
     exp = exp.cpu().numpy()
-    ok_hist = bool((tot[2:] == exp).all())
+    ok_hist = bool((tot[1:] == exp).all())
     if rank == 0:
         print(json.dumps({
             "mode": "sharded-stream",
@@ -600,10 +598,10 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
             "gbs_pcie_inclusive_aggregate": round(file_len / 1e9 / dt, 2),
             "gbs_per_rank_streaming": [round(float(x), 2) for x in rates.cpu().numpy()],
             "records": int(tot[0]), "records_per_s": round(int(tot[0]) / dt, 1), "numa_node_rank0": node,
-            "check": {"records_expected": file_len // RECLEN, "errors": int(tot[1]), "phases_ok": not bad,
-                      "histograms_ok": ok_hist}}), flush=True)
+            "check": {"records_expected": file_len // RECLEN, "first_error_key": None if g_status == pkg.OK else gkey,
+                      "phases_ok": not bad, "histograms_ok": ok_hist}}), flush=True)
     assert not bad, bad
-    assert int(tot[1]) == 0 and int(tot[0]) == file_len // RECLEN, (tot[:2], file_len // RECLEN)
+    assert int(tot[0]) == file_len // RECLEN, (tot[:1], file_len // RECLEN)
     assert ok_hist
     ctx.close()
 

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (FQH_LIB_PATH: a tuning build of the same library, tools/exp_fztime.sh; never a fallback)
 LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.so")
 
-__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
+__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "error_key_unpack", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
            "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "EXPORTS"]
 
@@ -25,7 +25,8 @@ EXPORTS = [
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
-    "fqh_allreduce_u64", "fqh_sync", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
+    "fqh_allreduce_u64", "fqh_allreduce_min_u64", "fqh_sync", "fqh_shard_stream_run", "fqh_shard_result_words",
+    "fqh_shard_stream_finish", "fqh_error_key_unpack", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
 ]
 
@@ -60,6 +61,15 @@ class Chunk(C.Structure):
                 ("err_record", C.c_uint64), ("err_offset", C.c_uint64), ("err_need", C.c_uint64)]
 
 
+class ShardResult(C.Structure):
+    """fqh_shard_result: what one rank of the sharded, host-streamed mode found in its byte range."""
+    _fields_ = [("status", C.c_int32), ("phase", C.c_uint32), ("n_records", C.c_uint64), ("n_newlines", C.c_uint64),
+                ("err_record", C.c_uint64), ("err_offset", C.c_uint64), ("head_len", C.c_uint64), ("tail_len", C.c_uint64)]
+
+
+READ_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64)   # fqh_read_fn
+SHARD_STREAM_WORDS = 8
+NO_ERROR_KEY = (1 << 64) - 1
 STREAM_INDEX = 1
 STREAM_STATS = 2
 
@@ -144,6 +154,13 @@ def lib():
         L.fqh_comm_destroy.restype = None
         L.fqh_allgather.argtypes = [vp, vp, vp, vp, u64]
         L.fqh_allreduce_u64.argtypes = [vp, vp, vp, u64]
+        L.fqh_allreduce_min_u64.argtypes = [vp, vp, vp, u64]
+        L.fqh_shard_stream_run.argtypes = [vp, READ_FN, vp, u64, u64, u64, u64, u32, u32, vp, vp, vp, C.POINTER(ShardResult),
+                                           vp, u64, vp, u64]
+        L.fqh_shard_result_words.argtypes = [C.POINTER(ShardResult), C.POINTER(u64 * 8)]
+        L.fqh_shard_result_words.restype = None
+        L.fqh_shard_stream_finish.argtypes = [vp, vp, vp, u64, i32, i32, vp, u32, vp, vp, vp, C.POINTER(u64 * 2)]
+        L.fqh_error_key_unpack.argtypes = [u64, C.POINTER(C.c_int32), C.POINTER(u64)]
         L.fqh_sync.argtypes = [vp]
         L.fqh_synth_fill.argtypes = [vp, vp, u64, u64, u64]
         L.fqh_read_ceiling.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(C.c_float)]
@@ -158,6 +175,13 @@ def lib():
 
 def strerror(status):
     return lib().fqh_strerror(status).decode()
+
+
+def error_key_unpack(key):
+    """-> (status, global record index) of a packed first-error key (fqh_shard_stream_finish); (OK, 0) for NO_ERROR_KEY."""
+    st, rec = C.c_int32(), C.c_uint64()
+    lib().fqh_error_key_unpack(key, C.byref(st), C.byref(rec))
+    return st.value, rec.value
 
 
 def carry_combine(prev, length, n_newlines, n_line_starts, back_zero_carry):

@@ -14,7 +14,7 @@
 namespace {
 typedef struct ncclComm *comm_t;
 typedef struct { char internal[128]; } unique_id;   // NCCL_UNIQUE_ID_BYTES
-enum { kUint8 = 1, kUint64 = 5, kSum = 0 };          // ncclDataType_t / ncclRedOp_t values of rccl.h
+enum { kUint8 = 1, kUint64 = 5, kSum = 0, kMin = 3 };  // ncclDataType_t / ncclRedOp_t values of rccl.h
 struct Rccl {
     void *h = nullptr;
     int (*GetUniqueId)(unique_id *) = nullptr;
@@ -97,6 +97,14 @@ fqh_status fqh_allreduce_u64(fqh_ctx *ctx, fqh_comm *comm, uint64_t *d_buf, uint
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int rc = g_rccl.AllReduce(d_buf, d_buf, n, kUint64, kSum, (comm_t)comm, ctx->stream);
     if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
+    return FQH_OK;
+}
+
+fqh_status fqh_allreduce_min_u64(fqh_ctx *ctx, fqh_comm *comm, uint64_t *d_buf, uint64_t n) {
+    if (!ctx || !comm || (n && !d_buf)) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = g_rccl.AllReduce(d_buf, d_buf, n, kUint64, kMin, (comm_t)comm, ctx->stream);
+    if (rc != 0) return rccl_fail(ctx, "ncclAllReduce(min)", rc);
     return FQH_OK;
 }
 

@@ -14,6 +14,7 @@
 //   each_zipped(p1, p2, callback)                                   fastq::each_zipped
 //   parse_path(Option<path>, FnOnce(Parser))                        fastq::parse_path (plain input only)
 //   thread_reader(bufsize, queuelen, reader, f)                     fastq::thread_reader
+//   parallel_each over byte-range shards, one process per GPU        fastq::each_sharded (no counterpart in the crate)
 //   io::Error(InvalidData, msg)                                     fastq::Error{kind(), what()}
 //
 // What runs where: bytes go reader -> pinned ring slot -> (hipMemcpyAsync on a side stream) -> HBM;
@@ -437,6 +438,86 @@ class RecordRefIter {
     bool opened_ = false, have_ = false, done_ = false;
     uint64_t i_ = (uint64_t)-1;
 };
+
+// each_sharded — the byte-range sharded, host-streamed mode (BASELINE configs[4]): one process per GPU, every rank calls this
+// with the same arguments but its own rank.  The analogue of Parser::parallel_each with a histogram closure
+// (src/lib.rs:509-565): the ranks' results are gathered at the end (src/lib.rs:553-559) and a parse error — the FIRST one in
+// file order, as Parser::each meets it — is what every rank throws (src/lib.rs:544-547, 561-564).  read_at(dst, file_offset, n)
+// fills host memory (a pread, a memcpy).  d_hist: device array of 1 + 8 + lmax * 264 u64, ADDED to and summed over the ranks:
+// [records | the 8 scalars of fqh_stats | quality histogram lmax x 256 | base histogram lmax x 8].  Returns the number of
+// records of the whole file.  comm may be NULL when n_ranks == 1.  The driver itself is the library's (fqh_shard_stream_run /
+// fqh_shard_stream_finish); this is the exchange around it: one all-gather, one SUM, one MIN.
+template <class ReadAt>
+uint64_t each_sharded(fqh_ctx *ctx, fqh_comm *comm, int n_ranks, int rank, ReadAt read_at, uint64_t file_len, uint32_t lmax,
+                      uint64_t *d_hist, Options opt = Options()) {
+    auto chk = [&](fqh_status st, const char *what) {
+        if (st != FQH_OK) throw Error(ErrorKind::Other, std::string(what) + ": " + fqh_last_error(ctx));
+    };
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !comm)) throw Error(ErrorKind::Other, "each_sharded: bad rank / communicator");
+    const uint64_t lo = file_len / (uint64_t)n_ranks * (uint64_t)rank;
+    const uint64_t hi = rank + 1 == n_ranks ? file_len : file_len / (uint64_t)n_ranks * (uint64_t)(rank + 1);
+    struct Cb {
+        ReadAt *f;
+        static int call(void *user, uint8_t *dst, uint64_t off, uint64_t n) {
+            try {
+                (*static_cast<Cb *>(user)->f)(dst, off, n);
+                return 0;
+            } catch (...) {
+                return 1;  // (an exception must not cross the C frames: reported as FQH_E_IO)
+            }
+        }
+    } cb{&read_at};
+    constexpr uint64_t EDGE = 2 * FQH_BUFSIZE, ROW = FQH_SHARD_STREAM_WORDS * 8 + EDGE;
+    std::vector<uint8_t> head(EDGE), mine(ROW, 0), all((size_t)n_ranks * ROW, 0);
+    uint64_t *d_sc = d_hist + 1, *d_q = d_hist + 9, *d_b = d_hist + 9 + (uint64_t)lmax * 256;
+    fqh_shard_result res;
+    chk(fqh_shard_stream_run(ctx, &Cb::call, &cb, lo, hi, file_len, opt.slot_bytes, opt.n_slots, lmax, d_q, d_b, d_sc, &res,
+                             head.data(), EDGE, mine.data() + FQH_SHARD_STREAM_WORDS * 8, EDGE), "fqh_shard_stream_run");
+    fqh_shard_result_words(&res, reinterpret_cast<uint64_t *>(mine.data()));
+    // ---- the one exchange: 8 words + the tail bytes of every rank
+    if (n_ranks > 1) {
+        void *d_x = nullptr;
+        chk(fqh_dev_alloc(ctx, (uint64_t)(n_ranks + 1) * ROW, &d_x), "fqh_dev_alloc");
+        uint8_t *d_mine = static_cast<uint8_t *>(d_x), *d_all = d_mine + ROW;
+        fqh_status st = fqh_memcpy_h2d(ctx, d_mine, mine.data(), ROW);
+        if (st == FQH_OK) st = fqh_allgather(ctx, comm, d_mine, d_all, ROW);
+        if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, all.data(), d_all, (uint64_t)n_ranks * ROW);
+        (void)fqh_dev_free(ctx, d_x);
+        chk(st, "each_sharded: all-gather");
+    } else {
+        all = mine;
+    }
+    std::vector<uint64_t> words((size_t)n_ranks * FQH_SHARD_STREAM_WORDS);
+    std::vector<uint8_t> tails((size_t)n_ranks * EDGE);
+    for (int r = 0; r < n_ranks; ++r) {
+        memcpy(&words[(size_t)r * FQH_SHARD_STREAM_WORDS], &all[(size_t)r * ROW], FQH_SHARD_STREAM_WORDS * 8);
+        memcpy(&tails[(size_t)r * EDGE], &all[(size_t)r * ROW + FQH_SHARD_STREAM_WORDS * 8], EDGE);
+    }
+    // ---- phase check, one-record stitch, this rank's first-error key; then SUM and MIN over the ranks
+    uint64_t out[2];
+    chk(fqh_shard_stream_finish(ctx, words.data(), tails.data(), EDGE, n_ranks, rank, head.data(), lmax, d_q, d_b, d_sc, out),
+        "fqh_shard_stream_finish");
+    void *d_k = nullptr;
+    chk(fqh_dev_alloc(ctx, 16, &d_k), "fqh_dev_alloc");
+    uint64_t h[2] = {out[1], 0};
+    fqh_status st = fqh_memcpy_h2d(ctx, d_k, h, 8);
+    uint64_t rec0 = 0;
+    if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, &rec0, d_hist, 8);
+    rec0 += out[0];
+    if (st == FQH_OK) st = fqh_memcpy_h2d(ctx, d_hist, &rec0, 8);
+    if (st == FQH_OK && n_ranks > 1) st = fqh_allreduce_u64(ctx, comm, d_hist, 9 + (uint64_t)lmax * 264);
+    if (st == FQH_OK && n_ranks > 1) st = fqh_allreduce_min_u64(ctx, comm, static_cast<uint64_t *>(d_k), 1);
+    if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, h, d_k, 8);
+    uint64_t total = 0;
+    if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, &total, d_hist, 8);
+    (void)fqh_dev_free(ctx, d_k);
+    chk(st, "each_sharded: all-reduce");
+    int32_t status = FQH_OK;
+    uint64_t err_record = 0;
+    fqh_error_key_unpack(h[0], &status, &err_record);
+    if (status != FQH_OK) throw Error(ErrorKind::InvalidData, detail::message(status, false));
+    return total;
+}
 
 // each_zipped (src/lib.rs:577-609)
 template <class R1, class R2, class F>

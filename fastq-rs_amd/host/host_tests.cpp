@@ -10,6 +10,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "fastq.hpp"
 
@@ -259,6 +260,34 @@ static int plain(const char *file) {
 int main(int argc, char **argv) {
     if (argc >= 3 && !strcmp(argv[1], "--plain")) return plain(argv[2]);
     if (argc >= 7 && !strcmp(argv[1], "--zip")) return zip(argv[2], argv[3], argv[4], strtoull(argv[5], 0, 0), strtoull(argv[6], 0, 0));
+    if (argc >= 4 && !strcmp(argv[1], "--sharded")) {  // each_sharded as the only rank: the C++ mirror over fqh_shard_stream_*
+        std::ifstream in(argv[2], std::ios::binary);
+        std::string d((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        const uint32_t lmax = (uint32_t)atoi(argv[3]);
+        fqh_ctx *ctx = nullptr;
+        if (fqh_create(0, &ctx) != FQH_OK) return 2;
+        const uint64_t nw = 9 + (uint64_t)lmax * 264;
+        void *dh = nullptr;
+        if (fqh_dev_alloc(ctx, nw * 8, &dh) != FQH_OK || fqh_memset(ctx, dh, 0, nw * 8) != FQH_OK) return 2;
+        Options o;
+        o.slot_bytes = 1 << 20;
+        try {
+            const uint64_t n = each_sharded(ctx, nullptr, 1, 0, [&](uint8_t *dst, uint64_t off, uint64_t k) { memcpy(dst, d.data() + off, k); },
+                                            d.size(), lmax, (uint64_t *)dh, o);
+            std::vector<uint64_t> h(nw);
+            if (fqh_memcpy_d2h(ctx, h.data(), dh, nw * 8) != FQH_OK) return 2;
+            uint64_t sq = 0, sb = 0;
+            for (uint64_t i = 0; i < (uint64_t)lmax * 256; ++i) sq += h[9 + i] * (i % 251 + 1);
+            for (uint64_t i = 0; i < (uint64_t)lmax * 8; ++i) sb += h[9 + (uint64_t)lmax * 256 + i] * (i % 13 + 1);
+            printf("ok %llu %llu %llu %llu %llu\n", (unsigned long long)n, (unsigned long long)h[1], (unsigned long long)h[2],
+                   (unsigned long long)sq, (unsigned long long)sb);
+        } catch (const Error &e) {
+            printf("err %s\n", e.what());
+        }
+        fqh_dev_free(ctx, dh);
+        fqh_destroy(ctx);
+        return 0;
+    }
     if (argc >= 5 && !strcmp(argv[1], "--dump"))
         return dump(argv[2], atoi(argv[3]), strtoull(argv[4], 0, 0), argc > 5 ? strtoull(argv[5], 0, 0) : (1 << 20));
 #define RUN(t) do { t(); printf("ok %s\n", #t); fflush(stdout); } while (0)

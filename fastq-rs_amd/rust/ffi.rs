@@ -14,6 +14,10 @@
 use std::io::{Error, ErrorKind, Read, Result};
 use std::os::raw::{c_char, c_int, c_void};
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct fqh_shard_result { pub status: i32, pub phase: u32, pub n_records: u64, pub n_newlines: u64, pub err_record: u64,
+                              pub err_offset: u64, pub head_len: u64, pub tail_len: u64 }
 #[repr(C)] pub struct fqh_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct fqh_stream { _p: [u8; 0] }
 
@@ -103,7 +107,19 @@ extern "C" {
     pub fn fqh_allgather(ctx: *mut fqh_ctx, comm: *mut fqh_comm, d_send: *const c_void, d_recv: *mut c_void,
                          bytes_per_rank: u64) -> c_int;
     pub fn fqh_allreduce_u64(ctx: *mut fqh_ctx, comm: *mut fqh_comm, d_buf: *mut u64, n: u64) -> c_int;
+    pub fn fqh_allreduce_min_u64(ctx: *mut fqh_ctx, comm: *mut fqh_comm, d_buf: *mut u64, n: u64) -> c_int;
     pub fn fqh_sync(ctx: *mut fqh_ctx) -> c_int;
+    // ---- the sharded, host-streamed mode (one process per GPU): the gather + error return of Parser::parallel_each,
+    // src/lib.rs:544-564, over byte-range shards
+    pub fn fqh_shard_stream_run(ctx: *mut fqh_ctx, read: extern "C" fn(*mut c_void, *mut u8, u64, u64) -> c_int, user: *mut c_void,
+                                lo: u64, hi: u64, file_len: u64, slot_bytes: u64, n_slots: u32, lmax: u32,
+                                d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64, res: *mut fqh_shard_result,
+                                h_head: *mut u8, head_cap: u64, h_tail: *mut u8, tail_cap: u64) -> c_int;
+    pub fn fqh_shard_result_words(res: *const fqh_shard_result, words: *mut u64);
+    pub fn fqh_shard_stream_finish(ctx: *mut fqh_ctx, h_all_words: *const u64, h_all_tails: *const u8, tail_stride: u64,
+                                   n_ranks: c_int, rank: c_int, h_head: *const u8, lmax: u32, d_qual_hist: *mut u64,
+                                   d_base_hist: *mut u64, d_scalars: *mut u64, out: *mut u64) -> c_int;
+    pub fn fqh_error_key_unpack(key: u64, status: *mut i32, record: *mut u64) -> c_int;
 
     // ---- Buffer + thread_reader (src/buffer.rs, src/thread_reader.rs:182-200): the pinned ring
     pub fn fqh_stream_create(ctx: *mut fqh_ctx, slot_bytes: u64, n_slots: u32, flags: u32,
@@ -236,4 +252,21 @@ impl<R: Read> Drop for GpuScanner<R> {
 //                                           qual: r.qual as usize, data: (at, at + r.qual as usize + 1) });
 //           Ok(())
 //       }
+//   }
+
+// The sharded mode in the crate's terms (sketch; the C++ mirror fastq::each_sharded in host/fastq.hpp is the tested form):
+//
+//   pub fn each_sharded(ctx, comm, n_ranks, rank, file: &File, lmax, d_hist) -> io::Result<u64> {
+//       extern "C" fn read_at(user: *mut c_void, dst: *mut u8, off: u64, n: u64) -> c_int {
+//           let f = unsafe { &*(user as *const File) };
+//           let buf = unsafe { std::slice::from_raw_parts_mut(dst, n as usize) };
+//           f.read_exact_at(buf, off).map(|_| 0).unwrap_or(1)                 // std::os::unix::fs::FileExt
+//       }
+//       let (lo, hi) = (len / n * rank, if rank + 1 == n { len } else { len / n * (rank + 1) });
+//       fqh_shard_stream_run(ctx, read_at, file as *const _ as *mut c_void, lo, hi, len, 32 << 20, 3, lmax, d_q, d_b, d_sc,
+//                            &mut res, head.as_mut_ptr(), EDGE, tail.as_mut_ptr(), EDGE);
+//       // one fqh_allgather of [fqh_shard_result_words | tail], then
+//       fqh_shard_stream_finish(ctx, words.as_ptr(), tails.as_ptr(), EDGE, n, rank, head.as_ptr(), lmax, d_q, d_b, d_sc, out.as_mut_ptr());
+//       // fqh_allreduce_u64 over [records | scalars | histograms], fqh_allreduce_min_u64 over the key, fqh_error_key_unpack:
+//       // Err(InvalidData, fqh_strerror(status)) — what parallel_each returns when the parse fails (src/lib.rs:561-564) — or Ok(total)
 //   }

@@ -203,7 +203,56 @@ fqh_status fqh_comm_create(fqh_ctx *ctx, int n_ranks, int rank, const uint8_t id
 void fqh_comm_destroy(fqh_comm *comm);
 fqh_status fqh_allgather(fqh_ctx *ctx, fqh_comm *comm, const void *d_send, void *d_recv, uint64_t bytes_per_rank);
 fqh_status fqh_allreduce_u64(fqh_ctx *ctx, fqh_comm *comm, uint64_t *d_buf, uint64_t n);
+/* Element-wise MINIMUM in place (ncclMin): the global first error of a sharded parse is the minimum over the ranks' packed
+ * (record, kind) keys — what Parser::parallel_each returns when the parse fails, src/lib.rs:544-547, 561-564. */
+fqh_status fqh_allreduce_min_u64(fqh_ctx *ctx, fqh_comm *comm, uint64_t *d_buf, uint64_t n);
 fqh_status fqh_sync(fqh_ctx *ctx);
+
+/* ---- The sharded, host-streamed mode (BASELINE configs[4]) -----------------------------------------------------------
+ * One rank = one GPU = one pinned ring; the file is cut at arbitrary byte offsets and every rank streams its own range
+ * [lo, hi) PHASE-FREE (it cannot wait for the ranks in front of it); the ranks talk once, at the end.  The reference's
+ * analogue is Parser::parallel_each over a thread_reader pipeline: per-worker results gathered at the end
+ * (src/lib.rs:553-559), a parse error returned for the whole call (src/lib.rs:544-547, 561-564).
+ *
+ * fqh_shard_stream_run: rank r > 0 first settles its line phase and the offset R of its first record on a 4 MiB window
+ * (fqh_shard_align), then streams [lo + R, hi) through a ring of n_slots x slot_bytes like a file of its own, calling
+ * `read(user, h_dst, file_offset, nbytes)` (0 = ok) to fill pinned memory — a pread, a memcpy, a decompressor.  lmax != 0:
+ * every record the rank delivers is added to the histograms (as fqh_stats).  *res: the rank's summary; h_head receives the
+ * bytes [lo, lo + R) (the end of the record the previous rank began), h_tail what is left behind the rank's last complete
+ * record; both at most 2 * FQH_BUFSIZE bytes for input the reference accepts (FQH_E_CAPACITY otherwise).  A parse error
+ * inside the rank's records is res->status, not the return value.
+ *
+ * Then ONE exchange: fqh_shard_result_words(res) (FQH_SHARD_STREAM_WORDS words) and the tail bytes of every rank, all-gathered
+ * in rank order (fqh_allgather or the host's own collective; tail_stride bytes per rank).
+ *
+ * fqh_shard_stream_finish: checks this rank's phase against the TRUE newline count of the ranks in front of it, parses the
+ * STITCH (tail of rank - 1 + own head: a file of exactly one record, added to the histograms), and writes out[0] = records
+ * this rank contributes (stitch + streamed), out[1] = its first error as a packed key (global record index << 3 | kind), or
+ * FQH_NO_ERROR_KEY.  One SUM of [out[0], scalars, histograms] (fqh_allreduce_u64) and one MIN of out[1]
+ * (fqh_allreduce_min_u64) give every rank the totals, or — fqh_error_key_unpack — the status and record index of the first
+ * error in FILE order: the error Parser::each returns for the same bytes (an error inside a rank's 4 MiB alignment window
+ * that leaves no phase standing out is reported at that shard's start). */
+typedef int (*fqh_read_fn)(void *user, uint8_t *h_dst, uint64_t file_offset, uint64_t nbytes);
+typedef struct {
+    int32_t status;      /* first parse error among the rank's own records (FQH_OK: none)        */
+    uint32_t phase;      /* newlines in front of the shard, mod 4, as settled on its first window */
+    uint64_t n_records;  /* records delivered (before the first error)                            */
+    uint64_t n_newlines; /* '\n' in [lo, hi) seen by the rank (head included)                     */
+    uint64_t err_record; /* rank-local index / file offset of the failing record                  */
+    uint64_t err_offset;
+    uint64_t head_len, tail_len;
+} fqh_shard_result;
+#define FQH_SHARD_STREAM_WORDS 8
+#define FQH_NO_ERROR_KEY UINT64_MAX
+fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t lo, uint64_t hi, uint64_t file_len,
+                                uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist,
+                                uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res, uint8_t *h_head,
+                                uint64_t head_cap, uint8_t *h_tail, uint64_t tail_cap);
+void fqh_shard_result_words(const fqh_shard_result *res, uint64_t words[FQH_SHARD_STREAM_WORDS]);
+fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, const uint8_t *h_all_tails, uint64_t tail_stride,
+                                   int n_ranks, int rank, const uint8_t *h_head, uint32_t lmax, uint64_t *d_qual_hist,
+                                   uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t out[2]);
+fqh_status fqh_error_key_unpack(uint64_t key, int32_t *status, uint64_t *record);
 
 /* Forget the cached tile index.  The index describes the BYTES of the last scanned buffer; fqh_memcpy_h2d, fqh_memset and
  * fqh_synth_fill drop it themselves when they write into that buffer, writes the library cannot see (the caller's

@@ -191,3 +191,28 @@ def test_fastq_count_on_gzip_input(gpu_ok, fqref, tmp_path):
     out = subprocess.run([os.path.join(BIN, "fastq_count"), str(tmp_path / "bad.fq.gz")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 101 and fqref.strerror(fqref.count(bad).status) in out.stderr
+
+
+@pytest.mark.parametrize("kind", ["valid", "crlf", "mismatch"])
+def test_each_sharded_cpp_mirror_equals_oracle(gpu_ok, fqref, tmp_path, kind):
+    """fastq::each_sharded (host/fastq.hpp) over fqh_shard_stream_run / fqh_shard_stream_finish as the only rank: record count,
+    totals and histogram checksums equal the oracle's Parser::each + histogram loop; a parse error is thrown with the
+    reference's message (src/lib.rs:561-564: parallel_each returns the parse error)."""
+    rng = np.random.default_rng(91)
+    data = bytearray(fuzzgen.valid_file(rng, 9000, maxlen=120, crlf=(kind == "crlf")))
+    if kind == "mismatch":
+        k = data.index(b"\n+", len(data) // 2)
+        del data[k - 1]
+    path = tmp_path / "f.fastq"
+    path.write_bytes(bytes(data))
+    lmax = 120
+    out = subprocess.run([os.path.join(BIN, "host_tests"), "--sharded", str(path), str(lmax)], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r, oq, ob, osc = fqref.stats(np.frombuffer(bytes(data), dtype=np.uint8), lmax)
+    if kind == "mismatch":
+        assert out.stdout.strip() == "err Sequence and quality length mismatch" and r.status == 3
+        return
+    sq = int((oq.reshape(-1).astype(object) * [(i % 251 + 1) for i in range(lmax * 256)]).sum()) % (1 << 64)
+    sb = int((ob.reshape(-1).astype(object) * [(i % 13 + 1) for i in range(lmax * 8)]).sum()) % (1 << 64)
+    assert out.stdout.split() == ["ok", str(r.n_records), str(int(osc[0])), str(int(osc[1])), str(sq), str(sb)], out.stdout

@@ -32,6 +32,9 @@ def env():
 
 
 def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16):
+    """Every "rank" streams its byte range (fqh_shard_stream_run), the exchange is a list, every rank finishes
+    (fqh_shard_stream_finish: phase check, stitch, packed first-error key); the sum of the records and the MINIMUM of the keys
+    are what the two all-reduces deliver.  -> (status, n_records, histograms, shards)"""
     torch, pkg, sharded = env
     dev = torch.device("cuda:0")
     n = len(data)
@@ -43,37 +46,25 @@ def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16):
     bounds = [0] + list(cuts) + [n]
     hist = torch.zeros(8 + lmax * 264, dtype=torch.int64, device=dev)
     sc, qh, bh = hist[:8], hist[8: 8 + lmax * 256], hist[8 + lmax * 256:]
-    window = torch.empty(sharded.ALIGN_WINDOW + 16, dtype=torch.uint8, device=dev)
-    scratch = torch.empty(4 * pkg.BUFSIZE + 16, dtype=torch.uint8, device=dev)
-    results = []
+    stats = (lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    shards = []
     for r in range(len(bounds) - 1):  # every "rank" has a context (a GPU) of its own; they share the histograms here
         ctx = pkg.Ctx(0)
-        res = sharded.stream_shard(ctx, read_into, bounds[r], bounds[r + 1], n, slot_bytes,
-                                   stats=(lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()), d_window=window.data_ptr())
-        results.append(res)
+        shards.append(sharded.stream_shard(ctx, read_into, bounds[r], bounds[r + 1], n, slot_bytes, stats=stats))
         ctx.close()
-    # ---- the exchange (lists instead of an all_gather), the phase check, the stitches
-    words = [res.summary_words() for res in results]
-    status, n_records, err_rank = pkg.OK, 0, None
-    bad_phase = sharded.check_phases(words)
-    ctx = pkg.Ctx(0)
-    for r, res in enumerate(results):
-        if r:
-            st, k = sharded.stitch(ctx, results[r - 1].tail, res.head, lmax, scratch.data_ptr(), qh.data_ptr(), bh.data_ptr(),
-                                   sc.data_ptr())
-            if st != pkg.OK:
-                status, err_rank = st, r
-                break
-            n_records += k
-        if any(b[0] == r for b in bad_phase):
-            status, err_rank = pkg.E_HEADER, r
-            break
-        n_records += res.n_records
-        if res.status != pkg.OK:
-            status, err_rank = res.status, r
-            break
-    ctx.close()
-    return status, n_records, hist.cpu().numpy().astype(np.uint64), results
+    # ---- the exchange (lists instead of an all_gather), then every rank's finish; sum and minimum instead of all_reduces
+    words = [sh.words() for sh in shards]
+    tails = [sh.tail for sh in shards]
+    total, key = 0, pkg.NO_ERROR_KEY
+    for r, sh in enumerate(shards):
+        ctx = pkg.Ctx(0)
+        rec, k = sharded.finish(ctx, words, tails, r, sh.head, stats=stats)
+        ctx.close()
+        total += rec
+        key = min(key, k)
+    status, err_record = pkg.error_key_unpack(key)
+    n_records = total if status == pkg.OK else err_record
+    return status, n_records, hist.cpu().numpy().astype(np.uint64), shards
 
 
 def cut_points(rng, data, k):
@@ -111,9 +102,10 @@ def test_sharded_streamed_equals_whole_file_oracle(env, fqref, seed):
     # the ranks' pieces tile the file: head + streamed records + tail of every rank
     assert sum(len(x.head) + len(x.tail) for x in results) == sum(
         len(results[i].tail) + len(results[i + 1].head) for i in range(len(results) - 1))
+    assert results[0].res.head_len == 0 and results[-1].res.tail_len == 0
 
 
-@pytest.mark.parametrize("kind", ["truncated", "mismatch", "header"])
+@pytest.mark.parametrize("kind", ["truncated", "mismatch", "header", "sep_first_shard"])
 def test_sharded_streamed_reports_the_first_error(env, fqref, kind):
     torch, pkg, sharded = env
     rng = np.random.default_rng(31)
@@ -123,6 +115,9 @@ def test_sharded_streamed_reports_the_first_error(env, fqref, kind):
     elif kind == "mismatch":
         k = data.index(b"\n+", len(data) * 2 // 3)
         del data[k - 1]          # one base less in a sequence line of the last shard
+    elif kind == "sep_first_shard":
+        k = data.index(b"\n+\n", len(data) // 8)
+        data[k + 1] = ord("-")   # a separator line without its '+', in the FIRST shard: the later ranks' records must not count
     else:
         k = data.index(b"\n@", len(data) // 2)
         data[k + 1] = ord("x")   # a header that does not start with '@', in a middle shard
@@ -132,8 +127,8 @@ def test_sharded_streamed_reports_the_first_error(env, fqref, kind):
     r = fqref.count(data)
     assert r.status != pkg.OK
     assert status != pkg.OK
-    if kind != "header":  # (an error in a shard's alignment window is reported at the shard's start: see sharded.py)
-        assert (status, n_records) == (r.status, r.n_records)
+    if kind != "header":  # (an error in a shard's alignment window is reported at the shard's start: include/fastq_hip.h)
+        assert (status, n_records) == (r.status, r.n_records)   # the MINIMUM over the ranks' keys is the error in file order
 
 
 def test_bench_sharded_streamed_three_ranks_one_gpu():

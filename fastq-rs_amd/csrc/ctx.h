@@ -26,6 +26,8 @@ hipError_t launch_scan_stats(hipStream_t, FusedArgs, int);
 void launch_stats_commit(hipStream_t, const DevOut *, const FusedArgs &, uint32_t, unsigned long long *, unsigned long long *,
                          unsigned long long *);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
+void launch_stats_edge(hipStream_t, const DevOut *, const uint8_t *, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
+                       unsigned long long *, unsigned long long *);
 void launch_record_flags(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_idx_record *, uint64_t, uint8_t *);
 uint64_t gather_blocks(uint64_t n);
 void launch_gather(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_idx_record *, uint64_t, const uint8_t *, uint32_t,
@@ -104,6 +106,10 @@ struct fqh_ctx {
     bool fused = false;           // the scan being enqueued / in flight counts as well
     uint32_t f_lmax = 0;
     uint64_t *f_qual = nullptr, *f_base = nullptr, *f_scalars = nullptr;
+    uint64_t f_lead = 0;          // bytes of valid device memory in front of the buffer (the record in progress at the chunk start)
+    bool f_defer_commit = false;  // the stream's: the commit kernels wait until the host has replayed the reference's Buffer
+    bool f_commit_owed = false;   // a deferred commit of the last finished single-pass launch has not been enqueued yet
+    FusedArgs f_args = {};        // the launch's kernel arguments (for the deferred commit)
     unsigned long long *side = nullptr;   // FQH_NSCALARS totals of the launch in flight
     bool fused_enabled = true;    // FQH_FUSED=0: histograms always as a second pass over a full index
 };
@@ -126,5 +132,11 @@ fqh_status fqh_internal_emit_index(fqh_ctx *ctx, fqh_idx_record *dst, uint64_t c
 fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                                      uint32_t lmax, uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars,
                                      uint64_t lead_len, uint64_t n_limit);
+fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                                     uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
+                                     uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t lead_len, bool *fused);
+bool fqh_internal_fused_owed(const fqh_ctx *ctx);
+void fqh_internal_fused_commit(fqh_ctx *ctx);
+void fqh_internal_fused_drop(fqh_ctx *ctx);
 // error visibility of the failing record of the last finished scan (BufferReplay::step's `need`)
 uint64_t fqh_internal_last_need(const fqh_ctx *ctx);

@@ -280,6 +280,21 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_lis
     return FQH_OK;
 }
 
+// What turns the single pass's scratch into the caller's counts, all three conditional on DevOut::stats_commit (written by
+// k_finalize_fast): the block partials and totals (k_stats_commit), the record in progress at the chunk start if the caller's
+// buffer holds its beginning (+1), and the sequence line of the partial record behind the last complete one of a chunk that
+// is not the file's last (-1): k_stats_edge.
+static void enqueue_fused_commit(fqh_ctx *ctx) {
+    const ScanArgs &a = ctx->args;
+    hipStream_t s = ctx->stream;
+    unsigned long long *q = (unsigned long long *)ctx->f_qual, *b = (unsigned long long *)ctx->f_base, *sc = (unsigned long long *)ctx->f_scalars;
+    launch_stats_commit(s, &ctx->d_out[0], ctx->f_args, scan_stats_blocks(a.n_tiles, ctx->n_cu), q, b, sc);
+    const uint64_t back0 = a.back[a.nl_count & 3];
+    if (back0 != 0 && ctx->f_lead >= back0) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, back0, +1, ctx->f_lmax, q, b, sc);
+    if (!a.is_final) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, 0, -1, ctx->f_lmax, q, b, sc);
+    ctx->f_commit_owed = false;
+}
+
 // fast == true: the speculative path (k_index_fast + k_emit_fast + k_finalize_fast)
 static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     ScanArgs &a = ctx->args;
@@ -329,6 +344,8 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.lmax = ctx->f_lmax;
         fz.scratch = ctx->stats_scratch;
         fz.scalars = ctx->side;
+        fz.skip_head = a.back[a.nl_count & 3] != 0 ? 1u : 0u;  // the chunk begins inside a record: that one is k_stats_edge's
+        ctx->f_args = fz;
         if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fz, ctx->n_cu));
 #ifdef FQH_TUNING
         if (getenv("FQH_FZ_WHY")) {
@@ -366,9 +383,10 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     if (fast) {
         if (!ctx->skip_emit) launch_emit_fast(s, a, &ctx->d_out[0], ctx->n_cu);
         launch_finalize_fast(s, a, &ctx->d_out[0]);  // a prescan still needs the newline count and the carry
-        if (fused && a.n_tiles)
-            launch_stats_commit(s, &ctx->d_out[0], fz, scan_stats_blocks(a.n_tiles, ctx->n_cu), (unsigned long long *)ctx->f_qual,
-                                (unsigned long long *)ctx->f_base, (unsigned long long *)ctx->f_scalars);
+        if (fused && a.n_tiles) {
+            ctx->f_commit_owed = ctx->f_defer_commit;
+            if (!ctx->f_defer_commit) enqueue_fused_commit(ctx);
+        }
     } else {
         if (!ctx->skip_emit) launch_emit(s, a, &ctx->d_out[0], ctx->n_cu);
         launch_finalize(s, a, &ctx->d_out[0]);
@@ -614,6 +632,8 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) ctx->timing.total_ms = ms;
     fqh_status st = resolve(ctx, out, carry_out);
     ctx->last_valid = (st == FQH_OK || st == FQH_E_CAPACITY);
+    ctx->fused = false;  // (the launch is over; a deferred commit, f_commit_owed, stays owed if the fast path stood)
+    if (!ctx->used_spec) ctx->f_commit_owed = false;
     return st;
 }
 
@@ -909,22 +929,29 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 
 }  // extern "C"
 
-// The single-pass route (k_scan_stats) counts every sequence / quality line of the buffer: it applies when all
-// records of the buffer count — a whole file from its first byte (no carry, no lead bytes, no record limit) — the
-// histogram fits the kernel's LDS rows, and the context is not backing off from the fast path.  Anything else
-// takes the two-pass route (exact index + k_stats_oct), which knows about chunk edges and error limits.
+// The single-pass route (k_scan_stats) counts every sequence / quality line that closes inside the buffer, minus the lines of
+// the record in progress at its start; k_stats_edge adds that record (if the caller's buffer holds its beginning) and takes
+// out the sequence line of the partial record at the end of a chunk that is not the file's last.  So whole files AND chunks
+// take it, as long as the histogram fits the kernel's LDS rows and the context is not backing off from the fast path.  Anything
+// else takes the two-pass route (exact index + k_stats_oct), which knows about record limits.
 static bool fused_eligible(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                            uint32_t lmax, uint64_t lead_len, uint64_t n_limit) {
     if (!ctx->fused_enabled || !ctx->spec_enabled || ctx->exact_holds || ctx->spec_skip || ctx->list_cap != LIST_CAP_DEFAULT) return false;
-    if (!is_final || lead_len || n_limit != UINT64_MAX || !scan_stats_supports(lmax) || !len) return false;
-    if (in && !carry_is_zero(*in)) return false;
+    // (chunks with a carry, chunks that are not the file's last and lead bytes are fine: k_stats_edge settles the records at
+    // the chunk's two ends; a record LIMIT is not — the kernel counts every line it meets — except for the streaming ring,
+    // which commits only after it knows that the limit does not bite: f_defer_commit)
+    if ((n_limit != UINT64_MAX && !ctx->f_defer_commit) || !scan_stats_supports(lmax) || !len) return false;
+    if (in && in->back[in->nl_count & 3] > in->base_offset) return false;
+    (void)lead_len;
+    (void)is_final;
     if (same_scan(ctx, d_buf, len, is_final, in) && ctx->index_full) return false;  // a full index is there: second pass only
     return true;
 }
 static fqh_status fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                                uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
-                               uint64_t *d_base_hist, uint64_t *d_scalars) {
+                               uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t lead_len = 0) {
     ctx->fused = true;
+    ctx->f_lead = lead_len;
     ctx->f_lmax = lmax;
     ctx->f_qual = d_qual_hist;
     ctx->f_base = d_base_hist;
@@ -943,6 +970,34 @@ static fqh_status fused_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_
     return st;
 }
 
+// The streaming ring's entry to the single pass: scan + histograms of one slot, the commit kernels held back until the ring
+// has replayed the reference's Buffer over the slot's boundaries (a "record too long" in the middle of a slot ends the stream
+// there: the records behind it must not count).  *fused = false: not eligible, nothing was launched.
+fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
+                                     uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
+                                     uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t lead_len, bool *fused) {
+    *fused = false;
+    if (!ctx || ctx->pending || ctx->stats_pending) return FQH_E_ARG;
+    ctx->f_defer_commit = true;
+    const bool ok = fused_eligible(ctx, d_buf, len, is_final, in, lmax, lead_len, 0);
+    if (!ok) {
+        ctx->f_defer_commit = false;
+        return FQH_OK;
+    }
+    ctx->last_valid = false;
+    fqh_status st = fused_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap, lmax, d_qual_hist, d_base_hist, d_scalars, lead_len);
+    ctx->f_defer_commit = false;
+    if (st == FQH_OK) *fused = true;
+    return st;
+}
+// after fqh_internal_scan_finish of such a launch: did the single pass stand (a commit is owed), and enqueue it
+bool fqh_internal_fused_owed(const fqh_ctx *ctx) { return ctx->f_commit_owed && ctx->used_spec; }
+void fqh_internal_fused_commit(fqh_ctx *ctx) {
+    if (ctx->f_commit_owed && ctx->used_spec) enqueue_fused_commit(ctx);
+    ctx->f_commit_owed = false;
+}
+void fqh_internal_fused_drop(fqh_ctx *ctx) { ctx->f_commit_owed = false; }
+
 // lead_len: bytes in front of d_buf that are valid device memory and hold the beginning of the
 // record in progress at the chunk start; n_limit: count at most this many records of the chunk.
 fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
@@ -957,7 +1012,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         // one read of the input: scan + histograms in k_scan_stats (src/lib.rs:226-237 hands each record to the
         // closure that reads seq()/qual(): one pass).  fqh_stats_finish falls back to the two-pass route if
         // the fast path's proof fails.
-        st = fused_launch(ctx, d_buf, len, is_final, in, nullptr, 0, lmax, d_qual_hist, d_base_hist, d_scalars);
+        st = fused_launch(ctx, d_buf, len, is_final, in, nullptr, 0, lmax, d_qual_hist, d_base_hist, d_scalars, lead_len);
         if (st != FQH_OK) return st;
         ctx->stats_pending = true;
         return FQH_OK;
@@ -1080,6 +1135,7 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
         const int is_final = ctx->args.is_final;
         const fqh_carry cin = ctx->carry_in;
         const uint32_t lmax = ctx->f_lmax;
+        const uint64_t lead = ctx->f_lead;
         uint64_t *qh = ctx->f_qual, *bh = ctx->f_base, *sc = ctx->f_scalars;
         bool two_pass = false;
         const fqh_status scan_st = fused_finish(ctx, out, carry_out, &two_pass);
@@ -1088,7 +1144,7 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
         // report it, like fqh_scan)
         if (!two_pass) return scan_st;
         // the exact path has rerun the scan (same buffer, full index): count over it
-        fqh_status st = fqh_internal_stats_launch(ctx, buf, len, is_final, &cin, lmax, qh, bh, sc, 0, UINT64_MAX);
+        fqh_status st = fqh_internal_stats_launch(ctx, buf, len, is_final, &cin, lmax, qh, bh, sc, lead, UINT64_MAX);
         if (st != FQH_OK) return st;
         ctx->stats_pending = false;
         cap_st = scan_st;

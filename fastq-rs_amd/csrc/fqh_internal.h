@@ -133,6 +133,7 @@ struct FusedArgs {
     uint32_t lmax, lc;    // the caller's lmax; lc = rows of the LDS histogram in use (set by the launcher)
     uint32_t *scratch;    // [gridDim.x][SO_WORDS] per-block partial histograms
     unsigned long long *scalars;  // FQH_NSCALARS totals (a zeroed side array: k_stats_commit adds them to the caller's)
+    uint32_t skip_head;   // the chunk begins inside a record (carry-in): the lines of that record are k_stats_edge's, not this kernel's
     uint32_t wave_base;   // set by the launcher: bytes of histogram in front of the wavefronts' LDS areas
     uint32_t dbg;         // knock-out flags for timing experiments (FQH_FZ_DBG; results are wrong by design)
 };

@@ -567,6 +567,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         }
                         FZ_T(3);  // per-entry pass
                         span_bad = __ballot(span_bad) != 0;
+                        const bool head_chunk = z.skip_head && span == 0 && (srun | c0) == 0;  // (wave-uniform) the chunk's very first entries
                         if (tile == t0 && g == 0 && c0 == 0) {  // the span's first entries must single out the alignment it is counted under
                             uint32_t cons = 0;
 #pragma unroll
@@ -581,6 +582,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             // a region that is skipped conditionally costs a wait for the loads in flight, see DESIGN.md.)
                             const uint32_t kd = (srun + p - 1u - hyp) & 3u;
                             if (__ballot(toolong && (kd & 1u)) != 0) span_bad = true;  // a sequence / quality line beyond the rows
+                            // a chunk that begins inside a record (carry-in): the lines up to the chunk's first record start belong to
+                            // the record in progress, which is counted as a whole by k_stats_edge (it began in front of the chunk)
+                            if (head_chunk && hyp < 4 && p <= hyp) Pent = 0;
                             if (Pent) {
                                 if (kd == 1u) { ++acc_rec; acc_bases += l; }
                                 if (kd == 3u) acc_qual += l;
@@ -596,6 +600,10 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             if ((srun | c0) == 0) {  // (the span's very first entry closes nothing of ours)
                                 if (ps == 0) ps = 4;
                                 if (pq0 == 0) pq0 = 4;
+                            }
+                            if (head_chunk && hyp < 4) {  // (nor do the entries up to the chunk's first record start)
+                                if (ps <= hyp) ps += 4;
+                                if (pq0 <= hyp) pq0 += 4;
                             }
                             const uint32_t nls = cnt_c > ps ? (cnt_c - ps + 3) >> 2 : 0u, nlq = cnt_c > pq0 ? (cnt_c - pq0 + 3) >> 2 : 0u;
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
@@ -727,6 +735,88 @@ __global__ __launch_bounds__(256) void k_stats_commit(const DevOut *__restrict__
     if (!s) return;
     if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
     else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+}
+
+// k_stats_edge — the two records at the edges of a CHUNK that the single pass cannot count by itself (one wavefront, runs
+// only if k_finalize_fast kept the fast path's result, like k_stats_commit):
+//   * sign +1, the record in progress at the chunk start: it began `back0` bytes in front of the chunk (the caller's buffer
+//     holds them: fqh_stats_launch_lead, the streaming ring) and is delivered with the chunk it ends in (src/lib.rs:255-303:
+//     the reference keeps the partial record at the front of its Buffer and parses it again with the next read).
+//     k_scan_stats skipped its lines (FusedArgs::skip_head); here all of it is counted, if it ends inside the chunk;
+//   * sign -1, the partial record behind the last complete one of a chunk that is not the file's last: k_scan_stats counts
+//     every sequence line that closes inside the buffer, also the one of a record whose quality line has not arrived yet —
+//     that record is the NEXT chunk's (as its record in progress), so its sequence line is taken out again.
+// The record is walked from its first byte: newlines by ballot over 64 bytes at a time, then the plain per-byte statement
+// on the caller's u64 arrays.
+__global__ __launch_bounds__(64) void k_stats_edge(const DevOut *__restrict__ out, const uint8_t *__restrict__ buf, uint64_t len,
+                                                   uint64_t back0, int sign, uint32_t lmax,
+                                                   unsigned long long *__restrict__ qual_hist,
+                                                   unsigned long long *__restrict__ base_hist,
+                                                   unsigned long long *__restrict__ scalars) {
+    if (!out->stats_commit) return;
+    const uint32_t lane = threadIdx.x;
+    long long start, end = (long long)len;
+    if (sign > 0) {
+        if (out->n_records == 0) return;       // the record in progress does not end in this chunk: the next one counts it
+        start = -(long long)back0;
+    } else {
+        start = out->end_off;                   // behind the last complete record
+        if (start < 0 || start >= end) return;
+    }
+    long long nl[4];
+    int found = 0;
+    for (long long b = start; b < end && found < 4; b += 64) {
+        const long long i = b + lane;
+        unsigned long long m = __ballot(i < end && buf[i] == '\n');
+        while (m && found < 4) {
+            nl[found++] = b + (long long)__ffsll((long long)m) - 1;
+            m &= m - 1;
+        }
+    }
+    const int need = sign > 0 ? 4 : 2;
+    if (found < need) return;
+    if (sign < 0 && found >= 4) return;         // (cannot be: the record would have been complete)
+    const unsigned long long one = sign > 0 ? 1ull : ~0ull;
+    unsigned long long n_bases = 0, n_qual = 0, oseq = 0, oqual = 0;
+    uint32_t any_n = 0, any_inv = 0;
+    for (int kind = 0; kind < (sign > 0 ? 2 : 1); ++kind) {
+        const long long s = (kind ? nl[2] : nl[0]) + 1;
+        long long l = (kind ? nl[3] : nl[1]) - s;                 // raw line, without its '\n'
+        if (l > 0 && buf[s + l - 1] == '\r') --l;                 // trim_winline, src/records.rs:66-73
+        if (kind) n_qual = (unsigned long long)l; else n_bases = (unsigned long long)l;
+        for (long long col = lane; col < l; col += 64) {
+            const uint32_t b = buf[s + col];
+            if (kind == 0) {
+                const uint32_t c = base_class(b);
+                any_inv |= c == 5 ? 1u : 0u;
+                any_n |= c == 4 ? 1u : 0u;
+                if (col < (long long)lmax) atomicAdd(&base_hist[(uint64_t)col * 8 + c], one);
+                else ++oseq;
+            } else {
+                if (col < (long long)lmax) atomicAdd(&qual_hist[(uint64_t)col * 256 + b], one);
+                else ++oqual;
+            }
+        }
+    }
+    const bool gi = __ballot(any_inv != 0) != 0, gn = __ballot(any_n != 0) != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        oseq += __shfl_xor(oseq, d);
+        oqual += __shfl_xor(oqual, d);
+    }
+    if (lane == 0) {
+        atomicAdd(&scalars[0], one);
+        if (n_bases) atomicAdd(&scalars[1], one * n_bases);
+        if (n_qual) atomicAdd(&scalars[2], one * n_qual);
+        if (!gi && !gn) atomicAdd(&scalars[3], one);
+        if (!gi) atomicAdd(&scalars[4], one);
+        if (oseq) atomicAdd(&scalars[5], one * oseq);
+        if (oqual) atomicAdd(&scalars[6], one * oqual);
+    }
+}
+void launch_stats_edge(hipStream_t s, const DevOut *out, const uint8_t *buf, uint64_t len, uint64_t back0, int sign, uint32_t lmax,
+                       unsigned long long *qual_hist, unsigned long long *base_hist, unsigned long long *scalars) {
+    hipLaunchKernelGGL(k_stats_edge, dim3(1), dim3(64), 0, s, out, buf, len, back0, sign, lmax, qual_hist, base_hist, scalars);
 }
 
 uint32_t stats_blocks(int n_cu);

@@ -24,6 +24,9 @@ struct fqh_stream {
         hipEvent_t copied = nullptr;
         uint64_t n_new = 0, lead = 0;
         int is_final = 0;
+        bool launched = false;  // its scan is already enqueued (by the collect of the slot in front of it)
+        bool fused = false;     // ... as a single pass (scan + histograms), commit held back
+        hipEvent_t got = nullptr;  // its boundaries have arrived on the host
         int state = 0;  // 0 free, 1 acquired, 2 submitted, 3 collected (held by the caller)
     };
     std::vector<Slot> slots;
@@ -67,6 +70,12 @@ void fqh_stream_destroy(fqh_stream *st) {
     if (!st) return;
     (void)hipSetDevice(st->ctx->device);
     if (st->copy_stream) (void)hipStreamSynchronize(st->copy_stream);
+    for (auto &s : st->slots)
+        if (s.launched) {  // a scan enqueued ahead of its collect: end it, the context must not stay "pending"
+            (void)fqh_internal_scan_finish(st->ctx, nullptr, nullptr);
+            fqh_internal_fused_drop(st->ctx);
+            s.launched = false;
+        }
     (void)hipStreamSynchronize(st->ctx->stream);
     for (auto &s : st->slots) {
         if (s.h) (void)hipHostFree(s.h);
@@ -76,6 +85,7 @@ void fqh_stream_destroy(fqh_stream *st) {
         (void)hipFree(s.d_idx);
         if (s.h_idx) (void)hipHostFree(s.h_idx);
         if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.got) (void)hipEventDestroy(s.got);
     }
     if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
     if (st->holds_exact && st->ctx->exact_holds) --st->ctx->exact_holds;
@@ -100,9 +110,9 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
     st->reserve = ((want > two ? want : two) + 15) & ~(uint64_t)15;
     st->slots.resize(n_slots);
     st->replay.reset(ctx->bufsize);
-    if (flags & (FQH_STREAM_INDEX | FQH_STREAM_STATS)) {  // every chunk needs complete line lists: the context stays on the
-        st->holds_exact = true;                             // exact path while any such stream lives (a count, not a saved flag:
-        ++ctx->exact_holds;                                 // streams may be destroyed in any order)
+    if (flags & FQH_STREAM_INDEX) {  // every chunk needs complete line lists: the context stays on the exact path while any
+        st->holds_exact = true;      // such stream lives (a count, not a saved flag: streams may be destroyed in any order).
+        ++ctx->exact_holds;          // (FQH_STREAM_STATS alone does not: its chunks take the single pass, k_scan_stats)
     }
     fqh_status rc = FQH_OK;
     do {
@@ -111,7 +121,8 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
         for (auto &s : st->slots) {
             if (hipHostMalloc((void **)&s.h, st->reserve + st->slot_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipMalloc((void **)&s.d_base, st->reserve + st->slot_bytes + 16) != hipSuccess ||
-                hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+                hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s.got, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
             s.d = s.d_base + st->reserve;  // reserve is a multiple of 16
             if (grow_rec(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
             if ((flags & FQH_STREAM_INDEX) && grow_idx(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
@@ -163,6 +174,28 @@ fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final) {
     return FQH_OK;
 }
 
+// Enqueues the scan of slot s under the carry `cy` (reuse: on the tile index of the attempt before, after its arrays grew).
+// FQH_STREAM_STATS without FQH_STREAM_INDEX: as a single pass, scan + histograms in one read of the slot (k_scan_stats), with
+// the commit held back until the host knows that every record of the slot is delivered.
+static fqh_status launch_slot(fqh_stream *st, fqh_stream::Slot &s, const fqh_carry &cy, bool reuse) {
+    fqh_ctx *ctx = st->ctx;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    s.fused = false;
+    if (!reuse && (st->flags & FQH_STREAM_STATS) && !(st->flags & FQH_STREAM_INDEX) && st->lmax) {
+        bool fused = false;
+        fqh_status rc = fqh_internal_fused_launch(ctx, s.d, s.n_new, s.is_final, &cy, s.d_rec, s.rec_cap, st->lmax, st->d_qual_hist,
+                                                  st->d_base_hist, st->d_scalars, s.lead, &fused);
+        if (rc != FQH_OK) return rc;
+        s.fused = fused;
+    }
+    if (!s.fused) {
+        fqh_status rc = fqh_internal_scan_launch(ctx, s.d, s.n_new, s.is_final, &cy, s.d_rec, s.rec_cap, reuse);
+        if (rc != FQH_OK) return rc;
+    }
+    s.launched = true;
+    return FQH_OK;
+}
+
 fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     if (!st || !out) return FQH_E_ARG;
     if (st->col >= st->sub) return FQH_E_ARG;  // nothing submitted
@@ -171,15 +204,20 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     if (s.state != 2) return FQH_E_ARG;
     fqh_ctx *ctx = st->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    const bool want_stats = (st->flags & FQH_STREAM_STATS) && st->lmax;
     fqh_summary sum = {};
     fqh_carry cout = {};
     fqh_status rc;
     for (int attempt = 0;; ++attempt) {
-        rc = fqh_internal_scan_launch(ctx, s.d, s.n_new, s.is_final, &st->carry, s.d_rec, s.rec_cap, attempt > 0);
-        if (rc != FQH_OK) return rc;
+        if (!s.launched) {
+            rc = launch_slot(st, s, st->carry, attempt > 0);
+            if (rc != FQH_OK) return rc;
+        }
+        s.launched = false;
         rc = fqh_internal_scan_finish(ctx, &sum, &cout);
         if (rc == FQH_E_CAPACITY && attempt == 0) {
+            fqh_internal_fused_drop(ctx);  // (the histograms of this attempt are not committed: the rerun below counts them in two passes)
+            s.fused = false;
             rc = grow_rec(st, s, sum.n_records + 16);
             if (rc != FQH_OK) return rc;
             continue;
@@ -199,13 +237,48 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         if (rc != FQH_OK) return rc;
         HIPCHK(ctx, hipMemcpyAsync(s.h_idx, s.d_idx, n * sizeof(fqh_idx_record), hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipEventRecord(s.got, ctx->stream));
+    const uint64_t base_offset = st->carry.base_offset;
+    const uint64_t known_end = base_offset + s.n_new;
+    const uint64_t need0 = sum.parse_status != FQH_OK ? fqh_internal_last_need(ctx) : UINT64_MAX;
+    // ---- before the host waits for the boundaries: what can already go to the GPU.  The reference's "record too long"
+    // (src/lib.rs:278-283) can only bite a record of BUFSIZE - 15 bytes or more: if the slot holds none (and its partial
+    // trailing record is shorter too), every record the scan found is delivered, and
+    //   * the single pass's histograms are committed now,
+    //   * the partial trailing record goes in front of the next slot's device data,
+    //   * the NEXT slot's scan is enqueued under this one's carry-out: it runs while the host walks this slot.
+    const bool single = s.fused && fqh_internal_fused_owed(ctx);
+    const bool no_long = !ctx->bufsize || (sum.max_record_len + 15 < ctx->bufsize && sum.tail_len + 15 < ctx->bufsize);
+    const bool clean = sum.parse_status == FQH_OK && no_long && sum.tail_len <= st->reserve;
+    bool stats_done = !want_stats;
+    if (n == 0 && !stats_done) {  // nothing is delivered with this slot: nothing to count
+        fqh_internal_fused_drop(ctx);
+        stats_done = true;
+    }
+    bool dev_tail_done = false;
+    if (clean) {
+        if (single) {
+            fqh_internal_fused_commit(ctx);
+            stats_done = true;
+        }
+        fqh_stream::Slot &nx = st->slots[(st->col + 1) % st->n_slots];
+        if (!s.is_final && sum.tail_len && want_stats) {  // device twin of the tail move (may reach into s's own lead)
+            HIPCHK(ctx, hipMemcpyAsync(nx.d - sum.tail_len, s.d + s.n_new - sum.tail_len, sum.tail_len, hipMemcpyDeviceToDevice, ctx->stream));
+            dev_tail_done = true;
+        }
+        if (stats_done && !s.is_final && st->col + 1 < st->sub && nx.state == 2 && !nx.launched) {
+            nx.lead = sum.tail_len;
+            rc = launch_slot(st, nx, cout, false);
+            if (rc != FQH_OK) return rc;
+        }
+    }
+    HIPCHK(ctx, hipEventSynchronize(s.got));
 
     fqh_chunk c = {};
     c.parse_status = sum.parse_status;
     c.is_final = s.is_final;
     c.n_records = n;
-    c.base_offset = st->carry.base_offset;
+    c.base_offset = base_offset;
     c.data_len = s.n_new;
     c.lead_len = s.lead;
     c.h_data = s.h + st->reserve;
@@ -215,13 +288,12 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     c.d_rec_start = s.d_rec;
     c.err_record = sum.err_record;
     c.err_offset = sum.err_offset;
-    c.err_need = sum.parse_status != FQH_OK ? fqh_internal_last_need(ctx) : UINT64_MAX;
+    c.err_need = need0;
 
     // "Fastq record is too long": replay the reference's buffer over the boundaries seen so far
-    const uint64_t known_end = c.base_offset + s.n_new;
     uint64_t which = 0;
     const bool bad_here = sum.parse_status != FQH_OK;
-    const uint64_t need = bad_here ? fqh_internal_last_need(ctx) : fqh::BufferReplay::NO_BAD;
+    const uint64_t need = bad_here ? need0 : fqh::BufferReplay::NO_BAD;
     if (ctx->bufsize &&
         st->replay.step(s.h_rec, st->records_done, n, known_end, s.is_final || bad_here, need, &which)) {
         c.parse_status = FQH_E_TOO_LONG;
@@ -231,12 +303,19 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     }
     // histograms of the records this chunk delivers (the one in progress at its start included: its
     // beginning sits in front of the slot's device data)
-    if ((st->flags & FQH_STREAM_STATS) && st->lmax && c.n_records) {
-        rc = fqh_internal_stats_launch(ctx, s.d, s.n_new, s.is_final, &st->carry, st->lmax, st->d_qual_hist,
-                                       st->d_base_hist, st->d_scalars, s.lead, c.n_records);
-        if (rc != FQH_OK) return rc;
-        rc = fqh_stats_finish(ctx, nullptr, nullptr);
-        if (rc != FQH_OK) return rc;
+    if (!stats_done && c.n_records) {
+        if (single && c.n_records == n) {
+            fqh_internal_fused_commit(ctx);   // (no scan of a later slot is in flight: the context still describes this one)
+        } else {
+            fqh_internal_fused_drop(ctx);
+            rc = fqh_internal_stats_launch(ctx, s.d, s.n_new, s.is_final, &st->carry, st->lmax, st->d_qual_hist,
+                                           st->d_base_hist, st->d_scalars, s.lead, c.n_records);
+            if (rc != FQH_OK) return rc;
+            rc = fqh_stats_finish(ctx, nullptr, nullptr);
+            if (rc != FQH_OK) return rc;
+        }
+    } else if (!stats_done) {
+        fqh_internal_fused_drop(ctx);
     }
     // the partial trailing record goes in front of the next slot's data
     const uint64_t tail = known_end - s.h_rec[n];
@@ -253,7 +332,7 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         } else {
             fqh_stream::Slot &nx = st->slots[(st->col + 1) % st->n_slots];
             if (tail) memcpy(nx.h + st->reserve - tail, s.h + st->reserve + s.n_new - tail, tail);
-            if (tail && (st->flags & FQH_STREAM_STATS)) {  // device twin of the same move (may reach into s's own lead)
+            if (tail && want_stats && !dev_tail_done) {  // device twin of the same move (may reach into s's own lead)
                 HIPCHK(ctx, hipMemcpyAsync(nx.d - tail, s.d + s.n_new - tail, tail, hipMemcpyDeviceToDevice, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             }
@@ -281,6 +360,7 @@ fqh_status fqh_stream_release(fqh_stream *st) {
     if (s.state != 3) return FQH_E_ARG;
     s.state = 0;
     s.lead = 0;
+    s.launched = false;
     return FQH_OK;
 }
 

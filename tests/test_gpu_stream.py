@@ -145,7 +145,7 @@ def test_stream_fuzzing_bufsize(fqref, env):
         assert (status, len(recs)) == (res.status, res.n_records), data
 
 
-def stream_stats(torch, pkg, data, slot_bytes, lmax, n_slots=3, read_sizes=None, seed=0):
+def stream_stats(torch, pkg, data, slot_bytes, lmax, n_slots=3, read_sizes=None, seed=0, routes=None):
     """Feeds `data` through a FQH_STREAM_STATS stream; returns (status, n_records, qual, base, scalars)."""
     dev = torch.device("cuda:0")
     ctx = pkg.Ctx(0)
@@ -178,6 +178,8 @@ def stream_stats(torch, pkg, data, slot_bytes, lmax, n_slots=3, read_sizes=None,
         c = st.collect()
         collected += 1
         nrec += c.n_records
+        if routes is not None:
+            routes.append((c.data_len, bool(ctx.last_scan_fast())))
         st.release()
         if c.parse_status != pkg.OK:
             status = c.parse_status
@@ -261,3 +263,70 @@ def test_stats_lead_chunks_add_up(fqref, env):
         else:
             assert got[0] == sc[0] - lost and lost > 0
         ctx.close()
+
+
+def _clean_reads(rng, nrec, L, crlf=False):
+    alph = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    e = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(nrec):
+        n = L if isinstance(L, int) else int(rng.integers(L[0], L[1] + 1))
+        seq = rng.choice(alph, n, p=[.2475, .2475, .2475, .2475, .01]).tobytes()
+        qual = rng.integers(33, 75, n).astype(np.uint8).tobytes()
+        out.append(b"@read%d 1:N:0" % i + e + seq + e + b"+" + e + qual + e)
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("shape", ["fixed150", "ragged", "crlf"])
+def test_streamed_stats_take_the_single_pass(fqref, env, shape):
+    """FQH_STREAM_STATS on ordinary reads: every slot is scanned AND counted in one read of its bytes (k_scan_stats with the
+    slot's carry; k_stats_edge for the record that straddles into the slot and for the partial one at its end), the way the
+    reference touches a record once whatever the buffer (src/lib.rs:226-237, src/records.rs:83-90).  Values == oracle; the
+    route is pinned: the fast path stood for every slot but (possibly) the short last one."""
+    torch, pkg = env
+    rng = np.random.default_rng(4242)
+    data = _clean_reads(rng, 30000, 150 if shape == "fixed150" else (20, 150), crlf=(shape == "crlf"))
+    lmax = 150
+    r, qh, bh, sc = fqref.stats(data, lmax)
+    for slot in (1 << 20, 300000 // 16 * 16):
+        routes = []
+        status, nrec, gq, gb, gs = stream_stats(torch, pkg, data, slot, lmax, routes=routes)
+        assert (status, nrec) == (r.status, r.n_records) == (pkg.OK, 30000)
+        assert np.array_equal(gs, sc), (gs, sc)
+        assert np.array_equal(gq, qh) and np.array_equal(gb, bh)
+        full = [fast for n, fast in routes if n == slot]
+        assert len(full) >= 3 and all(full), routes
+
+
+def test_chunked_stats_take_the_single_pass(fqref, env):
+    """fqh_stats_launch_lead over consecutive chunks of one device buffer, cut anywhere (16-byte aligned): each chunk is ONE
+    read of its bytes (single pass kept) and the chunked calls add up to the whole-file oracle."""
+    torch, pkg = env
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(515)
+    data = _clean_reads(rng, 40000, (100, 150))
+    n = len(data)
+    d = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    d[:n].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()))
+    lmax = 150
+    r, qh, bh, sc = fqref.stats(data, lmax)
+    cuts = [0] + sorted(int(x) // 16 * 16 for x in rng.integers(1 << 20, n - (1 << 20), 5)) + [n]
+    ctx = pkg.Ctx(0)
+    gq = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+    gb = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+    gs = torch.zeros(8, dtype=torch.int64, device=dev)
+    carry, total = None, 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a == b:
+            continue
+        ctx.stats_launch_lead(d.data_ptr() + a, b - a, a, lmax, gq.data_ptr(), gb.data_ptr(), gs.data_ptr(), is_final=(b == n), carry=carry)
+        s, c = ctx.stats_finish()
+        assert s.parse_status == pkg.OK, (a, b)
+        assert ctx.last_scan_fast() or b - a < (1 << 18), (a, b)   # (a chunk of a few tiles may not settle an alignment)
+        total += s.n_records
+        carry = c
+    ctx.close()
+    assert total == r.n_records
+    assert np.array_equal(gs.cpu().numpy().astype(np.uint64), sc)
+    assert np.array_equal(gq.cpu().numpy().astype(np.uint64).reshape(lmax, 256), qh)
+    assert np.array_equal(gb.cpu().numpy().astype(np.uint64).reshape(lmax, 8), bh)

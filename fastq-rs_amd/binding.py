@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (FQH_LIB_PATH: a tuning build of the same library, tools/exp_fztime.sh; never a fallback)
 LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.so")
 
-__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "error_key_unpack", "STREAM_INDEX", "STREAM_STATS", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
+__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "error_key_unpack", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
            "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "EXPORTS"]
 
@@ -24,7 +24,7 @@ EXPORTS = [
     "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_len_hist", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
-    "fqh_stream_collect", "fqh_stream_release", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
+    "fqh_stream_collect", "fqh_stream_release", "fqh_stream_timing", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
     "fqh_allreduce_u64", "fqh_allreduce_min_u64", "fqh_sync", "fqh_shard_stream_run", "fqh_shard_result_words",
     "fqh_shard_stream_finish", "fqh_error_key_unpack", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
@@ -72,6 +72,12 @@ SHARD_STREAM_WORDS = 8
 NO_ERROR_KEY = (1 << 64) - 1
 STREAM_INDEX = 1
 STREAM_STATS = 2
+STREAM_TIMING = 4
+
+
+class StreamTimes(C.Structure):
+    _fields_ = [("wall_ms", C.c_double), ("copy_busy_ms", C.c_double), ("scan_busy_ms", C.c_double), ("both_busy_ms", C.c_double),
+                ("n_slots", C.c_uint64)]
 
 
 class FqhError(RuntimeError):
@@ -148,6 +154,7 @@ def lib():
         L.fqh_stream_submit.argtypes = [vp, u64, i32]
         L.fqh_stream_collect.argtypes = [vp, C.POINTER(Chunk)]
         L.fqh_stream_release.argtypes = [vp]
+        L.fqh_stream_timing.argtypes = [vp, C.POINTER(StreamTimes)]
         L.fqh_comm_unique_id.argtypes = [C.c_char_p]
         L.fqh_comm_create.argtypes = [vp, i32, i32, C.c_char_p, C.POINTER(vp)]
         L.fqh_comm_destroy.argtypes = [vp]
@@ -423,3 +430,9 @@ class Stream:
         c = Carry()
         self.ctx._chk(self._L.fqh_stream_carry(self._h, C.byref(c)))
         return c
+
+    def timing(self):
+        """STREAM_TIMING: copy / scan busy times and their overlap over the slots collected so far."""
+        t = StreamTimes()
+        self.ctx._chk(self._L.fqh_stream_timing(self._h, C.byref(t)))
+        return t

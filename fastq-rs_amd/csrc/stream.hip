@@ -3,6 +3,7 @@
 // GPU path: ingest of slot c+1 overlaps the scan of slot c and the caller's walk over slot c-1.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -27,6 +28,7 @@ struct fqh_stream {
         bool launched = false;  // its scan is already enqueued (by the collect of the slot in front of it)
         bool fused = false;     // ... as a single pass (scan + histograms), commit held back
         hipEvent_t got = nullptr;  // its boundaries have arrived on the host
+        hipEvent_t tc0 = nullptr, tc1 = nullptr, ts0 = nullptr, ts1 = nullptr;  // FQH_STREAM_TIMING: its copy and its scan, begin / end
         int state = 0;  // 0 free, 1 acquired, 2 submitted, 3 collected (held by the caller)
     };
     std::vector<Slot> slots;
@@ -36,6 +38,9 @@ struct fqh_stream {
     bool ended = false;
     bool holds_exact = false;  // this stream keeps the context on the exact path (counted in fqh_ctx::exact_holds)
     fqh::BufferReplay replay;
+    // FQH_STREAM_TIMING: when each slot's copy (side stream) and scan (the context's stream) ran, in ms since t_base
+    hipEvent_t t_base = nullptr;
+    std::vector<float> iv_copy, iv_scan;  // begin, end, begin, end, ..
     // FQH_STREAM_STATS
     uint32_t lmax = 0;
     uint64_t *d_qual_hist = nullptr, *d_base_hist = nullptr, *d_scalars = nullptr;
@@ -86,7 +91,10 @@ void fqh_stream_destroy(fqh_stream *st) {
         if (s.h_idx) (void)hipHostFree(s.h_idx);
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.got) (void)hipEventDestroy(s.got);
+        for (hipEvent_t e : {s.tc0, s.tc1, s.ts0, s.ts1})
+            if (e) (void)hipEventDestroy(e);
     }
+    if (st->t_base) (void)hipEventDestroy(st->t_base);
     if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
     if (st->holds_exact && st->ctx->exact_holds) --st->ctx->exact_holds;
     delete st;
@@ -118,11 +126,14 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = FQH_E_DEVICE; break; }
         if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+        if ((flags & FQH_STREAM_TIMING) && (hipEventCreate(&st->t_base) != hipSuccess || hipEventRecord(st->t_base, ctx->stream) != hipSuccess)) { rc = FQH_E_DEVICE; break; }
         for (auto &s : st->slots) {
             if (hipHostMalloc((void **)&s.h, st->reserve + st->slot_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipMalloc((void **)&s.d_base, st->reserve + st->slot_bytes + 16) != hipSuccess ||
                 hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s.got, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+            if ((flags & FQH_STREAM_TIMING) && (hipEventCreate(&s.tc0) != hipSuccess || hipEventCreate(&s.tc1) != hipSuccess ||
+                                                 hipEventCreate(&s.ts0) != hipSuccess || hipEventCreate(&s.ts1) != hipSuccess)) { rc = FQH_E_DEVICE; break; }
             s.d = s.d_base + st->reserve;  // reserve is a multiple of 16
             if (grow_rec(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
             if ((flags & FQH_STREAM_INDEX) && grow_idx(st, s, st->slot_bytes / 64 + 16) != FQH_OK) { rc = FQH_E_DEVICE; break; }
@@ -167,7 +178,9 @@ fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     s.n_new = nbytes;
     s.is_final = is_final ? 1 : 0;
+    if (s.tc0) HIPCHK(ctx, hipEventRecord(s.tc0, st->copy_stream));
     if (nbytes) HIPCHK(ctx, hipMemcpyAsync(s.d, s.h + st->reserve, nbytes, hipMemcpyHostToDevice, st->copy_stream));
+    if (s.tc1) HIPCHK(ctx, hipEventRecord(s.tc1, st->copy_stream));
     HIPCHK(ctx, hipEventRecord(s.copied, st->copy_stream));
     s.state = 2;
     ++st->sub;
@@ -180,6 +193,7 @@ fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final) {
 static fqh_status launch_slot(fqh_stream *st, fqh_stream::Slot &s, const fqh_carry &cy, bool reuse) {
     fqh_ctx *ctx = st->ctx;
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    if (s.ts0) HIPCHK(ctx, hipEventRecord(s.ts0, ctx->stream));
     s.fused = false;
     if (!reuse && (st->flags & FQH_STREAM_STATS) && !(st->flags & FQH_STREAM_INDEX) && st->lmax) {
         bool fused = false;
@@ -192,6 +206,7 @@ static fqh_status launch_slot(fqh_stream *st, fqh_stream::Slot &s, const fqh_car
         fqh_status rc = fqh_internal_scan_launch(ctx, s.d, s.n_new, s.is_final, &cy, s.d_rec, s.rec_cap, reuse);
         if (rc != FQH_OK) return rc;
     }
+    if (s.ts1) HIPCHK(ctx, hipEventRecord(s.ts1, ctx->stream));
     s.launched = true;
     return FQH_OK;
 }
@@ -273,6 +288,17 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         }
     }
     HIPCHK(ctx, hipEventSynchronize(s.got));
+    if (s.tc0 && st->iv_copy.size() < (1u << 22)) {  // (all four events lie behind: the scan was finished above)
+        float a = 0, b = 0, c0 = 0, c1 = 0;
+        if (hipEventElapsedTime(&a, st->t_base, s.tc0) == hipSuccess && hipEventElapsedTime(&b, st->t_base, s.tc1) == hipSuccess &&
+            hipEventElapsedTime(&c0, st->t_base, s.ts0) == hipSuccess && hipEventElapsedTime(&c1, st->t_base, s.ts1) == hipSuccess) {
+            st->iv_copy.push_back(a);
+            st->iv_copy.push_back(b);
+            st->iv_scan.push_back(c0);
+            st->iv_scan.push_back(c1);
+        }
+        (void)hipGetLastError();
+    }
 
     fqh_chunk c = {};
     c.parse_status = sum.parse_status;
@@ -345,6 +371,28 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     s.state = 3;
     ++st->col;
     *out = c;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_timing(fqh_stream *st, fqh_stream_times *out) {
+    if (!st || !out) return FQH_E_ARG;
+    *out = fqh_stream_times{};
+    const std::vector<float> &c = st->iv_copy, &k = st->iv_scan;
+    out->n_slots = c.size() / 2;
+    if (c.empty()) return FQH_OK;
+    // both lists are in time order and their intervals do not overlap among themselves (one stream each)
+    double busy_c = 0, busy_k = 0, both = 0;
+    for (size_t i = 0; i + 1 < c.size(); i += 2) busy_c += c[i + 1] - c[i];
+    for (size_t i = 0; i + 1 < k.size(); i += 2) busy_k += k[i + 1] - k[i];
+    for (size_t i = 0, j = 0; i + 1 < c.size() && j + 1 < k.size();) {
+        const float lo = std::max(c[i], k[j]), hi = std::min(c[i + 1], k[j + 1]);
+        if (hi > lo) both += hi - lo;
+        if (c[i + 1] < k[j + 1]) i += 2; else j += 2;
+    }
+    out->wall_ms = std::max(c.back(), k.back()) - std::min(c.front(), k.front());
+    out->copy_busy_ms = busy_c;
+    out->scan_busy_ms = busy_k;
+    out->both_busy_ms = both;
     return FQH_OK;
 }
 

@@ -16,6 +16,9 @@ use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct fqh_stream_times { pub wall_ms: f64, pub copy_busy_ms: f64, pub scan_busy_ms: f64, pub both_busy_ms: f64, pub n_slots: u64 }
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct fqh_shard_result { pub status: i32, pub phase: u32, pub n_records: u64, pub n_newlines: u64, pub err_record: u64,
                               pub err_offset: u64, pub head_len: u64, pub tail_len: u64 }
 #[repr(C)] pub struct fqh_ctx { _p: [u8; 0] }
@@ -130,6 +133,7 @@ extern "C" {
     pub fn fqh_stream_collect(st: *mut fqh_stream, out: *mut fqh_chunk) -> c_int;
     pub fn fqh_stream_release(st: *mut fqh_stream) -> c_int;
     pub fn fqh_stream_carry(st: *mut fqh_stream, out: *mut fqh_carry) -> c_int;
+    pub fn fqh_stream_timing(st: *mut fqh_stream, out: *mut fqh_stream_times) -> c_int;
     // histograms per delivered record (FQH_STREAM_STATS) and the device-side filter (flags + gather);
     // not needed by Parser itself, bound for consumers that want them
     pub fn fqh_stream_set_stats(st: *mut fqh_stream, lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64,

@@ -358,6 +358,7 @@ typedef struct {
 } fqh_chunk;
 #define FQH_STREAM_INDEX 1u /* also build + download the IdxRecord-style index per chunk */
 #define FQH_STREAM_STATS 2u /* also add every delivered record to the histograms of fqh_stream_set_stats */
+#define FQH_STREAM_TIMING 4u /* HIP events around every slot's copy and scan: fqh_stream_timing */
 fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots, uint32_t flags,
                              fqh_stream **out);
 void fqh_stream_destroy(fqh_stream *st);
@@ -372,6 +373,15 @@ fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap);
 fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final);
 fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out);
 fqh_status fqh_stream_release(fqh_stream *st); /* done with the chunk of the last collect */
+/* FQH_STREAM_TIMING: how the ingest overlapped the scan, measured with HIP events on the two streams over the slots collected
+ * so far — the point of src/thread_reader.rs:131-139 (the producer's read() runs while the consumer parses).  copy_busy_ms /
+ * scan_busy_ms: time the side stream spent in host-to-device copies / the context's stream in the slots' kernels;
+ * both_busy_ms: time both were busy at once; wall_ms: first begin to last end. */
+typedef struct {
+    double wall_ms, copy_busy_ms, scan_busy_ms, both_busy_ms;
+    uint64_t n_slots;
+} fqh_stream_times;
+fqh_status fqh_stream_timing(fqh_stream *st, fqh_stream_times *out);
 /* Parser state behind the last collected chunk (nl_count = newlines the stream has seen: what the next shard's phase is
  * checked against in the sharded mode). */
 fqh_status fqh_stream_carry(fqh_stream *st, fqh_carry *out);

@@ -448,6 +448,206 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_stats_long — reads longer than the 256 bank-scheduled LDS rows (kilobase reads), counted in ONE walk over the record
+// index instead of one pass of k_stats_oct per 256 columns (each of which walks every tile for the few lines it holds: 5 kbp
+// reads took 20 passes, 557 GB/s).  The reference treats every record up to BUFSIZE alike (src/lib.rs:276-283,
+// src/records.rs:75-90); so does this: the work item is (record, block of 256 columns), found by plain arithmetic on the
+// IdxRecord-style index (fqh_idx_record: start + the four newline offsets) — no tile lists, no line-start search.
+//   * a block of 1024 threads owns one column block cb = blockIdx.x % n_cb and a slice of the records; its LDS holds the
+//     bank-scheduled histogram of those 256 columns (stats_dev.h: 8 KiB sequence + 64 KiB quality);
+//   * eight lanes walk a line's 256 columns, one dword each and step, eight records per wavefront and round — the same
+//     lane -> bank schedule as k_stats_oct: whole dwords of bytes inside the alphabet / window cost one v_perm_b32 and one
+//     ds_sub_u32 per byte; a dword with a byte outside, or with fewer than four bytes of the line, takes the per-byte
+//     statement (so_exact_step: window bytes to LDS, the rest to the caller's arrays);
+//   * per-record facts: lengths and the columns beyond lmax are arithmetic, done by column block 0; "has an N / a byte
+//     outside ACGTN" is ORed over a line's column blocks through one bit per record and flag in scratch (atomicOr: the
+//     block that sets a bit first counts the record), sequence columns beyond lmax included;
+//   * every input byte of a sequence / quality line is read once; algorithmic bytes: the buffer's length.
+struct LongArgs {
+    const uint8_t *buf;            // chunk-relative: the byte at file offset o is buf[o - base_offset]
+    uint64_t len, base_offset;
+    const fqh_idx_record *idx;     // the records that count: idx[0 .. n)
+    uint64_t n;
+    uint32_t lmax, n_cb, n_slices;
+    uint32_t *flagmap;             // 2 x flag_words words, zeroed: [has N or worse | has a byte outside ACGTN]
+    uint64_t flag_words;
+    unsigned long long *qual_hist, *base_hist, *scalars;
+};
+__global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) hist[i] = 0;
+    __syncthreads();
+    if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();  // the address registers assume the histogram starts at LDS address 0
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t m = lane & 7u, m4 = m * 4u, g8 = lane >> 3;
+    SoLane c;
+    c.slots = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t j = k ^ (g8 & 3u);
+        c.sel[k] = 0x0C0C0004u + k + (j << 8);
+        c.slots |= ((m + 8u * j) * 4u) << (8u * k);
+    }
+    const uint32_t cb = blockIdx.x % a.n_cb, slice = blockIdx.x / a.n_cb;
+    const uint32_t col0 = cb * SO_LC_MAX;
+    const uint32_t lc = a.lmax > col0 ? (a.lmax - col0 < SO_LC_MAX ? a.lmax - col0 : SO_LC_MAX) : 0u;  // rows of this block that the caller has
+    StatsArgs sa = {};           // what so_exact_step wants to know
+    sa.lc = lc;
+    sa.col0 = col0;
+    sa.qual_hist = a.qual_hist;
+    sa.base_hist = a.base_hist;
+    const uint64_t per = (a.n + a.n_slices - 1) / a.n_slices;
+    const uint64_t r_lo = (uint64_t)slice * per, r_hi = r_lo + per < a.n ? r_lo + per : a.n;
+    unsigned long long recs = 0, bases = 0, quals = 0, over_s = 0, over_q = 0;   // per lane (lane m == 0 of a record's group adds)
+    uint32_t newn = 0, newi = 0;
+    const uint8_t *const bend = a.buf + a.len;
+    for (uint64_t r0 = r_lo + (uint64_t)wv * 8; r0 < r_hi; r0 += (uint64_t)SO_WAVES * 8) {
+        const uint64_t r = r0 + g8;
+        const bool has = r < r_hi;
+        fqh_idx_record ir = {};
+        if (has) ir = a.idx[r];
+        uint32_t any_n = 0, any_inv = 0;
+        // both lines' words first (sixteen loads in flight per lane), then the counting
+        uint32_t segs[2], ws[2][8];
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+            const uint8_t *line = a.buf + (ir.start - a.base_offset) + (kind ? ir.sep : ir.head) + 1;
+            uint32_t len = has ? (kind ? ir.qual - ir.sep : ir.seq - ir.head) - 1u : 0u;   // raw line, without its '\n'
+            if (len && line[len - 1] == '\r') --len;                                        // trim_winline, src/records.rs:66-73
+            if (cb == 0 && m == 0 && has) {
+                if (kind) { quals += len; over_q += len > a.lmax ? len - a.lmax : 0u; }
+                else { ++recs; bases += len; over_s += len > a.lmax ? len - a.lmax : 0u; }
+            }
+            // this block's columns of the line: [col0, col0 + 256); sequence lines are LOOKED AT to their end (the alphabet
+            // flags cover every base), counted up to the caller's rows
+            const uint32_t seg = len > col0 ? (len - col0 < SO_LC_MAX ? len - col0 : SO_LC_MAX) : 0u;  // columns of the line in this block
+            segs[kind] = seg;
+            const uint8_t *p = line + col0 + m4;
+            if (__ballot(seg != 0 && p + 256 > bend) == 0) {   // (wave-uniform) every load of the round lies inside the buffer
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) ws[kind][u] = 32u * u + m4 < seg ? load4_fast(p + 32u * u) : 0u;
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) ws[kind][u] = 32u * u + m4 < seg ? load4_any(p + 32u * u, bend) : 0u;
+            }
+        }
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+            const uint32_t seg = segs[kind];
+            if (__ballot(seg != 0) == 0) continue;
+            constexpr uint32_t RB = 16384u;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t wu = ws[kind][u];
+                const uint32_t pos = 32u * u + m4;                      // column of the dword's first byte, relative to col0
+                const bool whole = pos + 4 <= seg && pos + 4 <= lc;    // four bytes of the line, all inside the caller's rows
+                uint32_t pb, chk;
+                if (kind == 0) {
+                    pb = wu & 0x07070707u;
+                    chk = wu ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pb);   // != 0: a byte outside ACGTN
+                    if (whole && !chk) any_n |= wu & 0x08080808u;                      // (bit 3 is set in 'N' only)
+                } else {
+                    pb = wu - 0x21212121u;
+                    chk = pb & 0xC0C0C0C0u;                                             // != 0: a byte outside '!'..'`'
+                }
+                const uint32_t f = (whole && !chk) ? 0xFFFFFFFFu : 0u;
+                const uint32_t off = (kind ? SO_SBYTES : 0u) + 128u * (u & 1u) + (kind ? RB : 2048u) * (u >> 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off), f,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__ballot(pos < seg && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
+                    if (pos < seg && !f) {
+                        uint32_t an = 0, ai = 0;
+                        if (kind == 0) so_exact_step<true>(sa, wu, pos, seg, lc, hist, an, ai);
+                        else so_exact_step<false>(sa, wu, pos, seg, lc, hist, an, ai);
+                        any_n |= an;
+                        any_inv |= ai;
+                    }
+                }
+            }
+        }
+        // a record's alphabet flags: ORed over the 8 lanes of its group here, over its column blocks through the flag maps
+        const unsigned long long bi = __ballot(any_inv != 0), bn = __ballot(any_n != 0) | bi;
+        if (bn) {
+            const uint32_t sh = lane & 56u;
+            const bool gn = ((bn >> sh) & 0xFFull) != 0, gi = ((bi >> sh) & 0xFFull) != 0;
+            if (m == 0 && gn && has) {
+                const uint32_t bit = 1u << (r & 31u);
+                if (!(atomicOr(&a.flagmap[r >> 5], bit) & bit)) ++newn;
+                if (gi && !(atomicOr(&a.flagmap[a.flag_words + (r >> 5)], bit) & bit)) ++newi;
+            }
+        }
+    }
+    // ---- the block's rows -> the caller's arrays (u64), totals
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (uint32_t id = threadIdx.x; id < SO_WORDS; id += SO_THREADS) {
+        const uint32_t v = hist[id];
+        if (!v) continue;
+        const bool isq = id >= SO_SBYTES / 4;
+        const uint32_t q = isq ? id - SO_SBYTES / 4 : id;
+        const uint32_t rb = isq ? q >> 12 : q >> 9;
+        const uint32_t bin = isq ? (q >> 6) & 63u : (q >> 6) & 7u;
+        const uint32_t row = rb * 64 + so_row6(q & 63u);
+        if (row >= lc) continue;
+        if (isq) atomicAdd(&a.qual_hist[(uint64_t)(col0 + row) * 256 + 33 + bin], (unsigned long long)v);
+        else atomicAdd(&a.base_hist[(uint64_t)(col0 + row) * 8 + bin_to_class(bin)], (unsigned long long)v);
+    }
+    unsigned long long t[7] = {recs, bases, quals, over_s, over_q, newn, newi};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        unsigned long long v = t[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        t[j] = v;
+    }
+    if (lane == 0) {
+        if (t[0]) atomicAdd(&a.scalars[0], t[0]);
+        if (t[1]) atomicAdd(&a.scalars[1], t[1]);
+        if (t[2]) atomicAdd(&a.scalars[2], t[2]);
+        if (t[0] || t[5]) atomicAdd(&a.scalars[3], t[0] - t[5]);   // valid_dna = records - (records with an N or worse), summed over the blocks
+        if (t[0] || t[6]) atomicAdd(&a.scalars[4], t[0] - t[6]);
+        if (t[3]) atomicAdd(&a.scalars[5], t[3]);
+        if (t[4]) atomicAdd(&a.scalars[6], t[4]);
+    }
+}
+// records [0, n) of idx; max_line: no sequence / quality line is longer (bounds the column blocks); flagmap: 2 * flag_words zeroed words
+hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, uint64_t base_offset, const fqh_idx_record *idx, uint64_t n,
+                             uint32_t lmax, uint32_t max_line, uint32_t *flagmap, uint64_t flag_words, unsigned long long *qual_hist,
+                             unsigned long long *base_hist, unsigned long long *scalars, int n_cu) {
+    if (!n) return hipSuccess;
+    LongArgs a = {};
+    a.buf = buf;
+    a.len = len;
+    a.base_offset = base_offset;
+    a.idx = idx;
+    a.n = n;
+    a.lmax = lmax;
+    a.n_cb = (max_line + SO_LC_MAX - 1) / SO_LC_MAX;
+    if (a.n_cb == 0) a.n_cb = 1;
+    const uint32_t cus = stats_blocks(n_cu);
+    a.n_slices = (4 * cus + a.n_cb - 1) / a.n_cb;                       // ~4 blocks per CU over the launch (one resident at a time: LDS)
+    const uint64_t max_slices = (n + 8 * SO_WAVES - 1) / (8 * SO_WAVES);
+    if (a.n_slices > max_slices) a.n_slices = (uint32_t)max_slices;
+    if (a.n_slices == 0) a.n_slices = 1;
+    a.flagmap = flagmap;
+    a.flag_words = flag_words;
+    a.qual_hist = qual_hist;
+    a.base_hist = base_hist;
+    a.scalars = scalars;
+    const size_t lds = SO_ADDR_SPAN;   // (a lane without a whole dword subtracts 0 wherever its bytes point: all of that is allocated)
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        set = true;
+    }
+    hipLaunchKernelGGL(k_stats_long, dim3(a.n_cb * a.n_slices), dim3(SO_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_stats_head — the record in progress at the chunk start, for callers whose buffer also holds its
 // beginning in front of the chunk (fqh_stats_launch_lead; the streaming ring).  One wavefront.  The
 // record's line starts before the chunk come from the carry (distances back[]), those inside from

@@ -4,5 +4,5 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/tuning
-(cd fastq-rs_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFQH_FZ_TIMING ${FQH_EXTRA_DEFS:-} -shared -o ../../gpurun_out/tuning/libfastq_hip.so fastq_hip.hip scan_kernels.hip stats_kernels.hip fused_kernels.hip filter_kernels.hip stream.hip comm.hip -ldl 2>&1 | grep -E "error")
+(cd fastq-rs_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFQH_FZ_TIMING ${FQH_EXTRA_DEFS:-} -shared -o ../../gpurun_out/tuning/libfastq_hip.so *.hip -ldl 2>&1 | grep -E "error")
 FQH_LIB_PATH=$PWD/gpurun_out/tuning/libfastq_hip.so python tools/exp_fzone.py 4 3 2>&1 | grep "FZ_TIMING\|kernel ms" | tail -4

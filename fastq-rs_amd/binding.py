@@ -9,13 +9,13 @@ LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.s
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "error_key_unpack", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
-           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "EXPORTS"]
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "OPT_REUSE_INDEX", "EXPORTS"]
 
 OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY, E_AGAIN = range(11)
 SHARD_WORDS = 8
 BUFSIZE = 68 * 1024
 NSCALARS = 8
-OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT = 1, 2, 3, 4
+OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT, OPT_REUSE_INDEX = 1, 2, 3, 4, 5
 
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -362,6 +362,10 @@ class Ctx:
     def set_place_tries(self, n):
         """Candidates of the fast path's per-tile line buffer the first big scan allocates and times (0 / 1: none)."""
         self._chk(self._L.fqh_set_option(self._h, OPT_PLACE_TRIES, int(n)))
+
+    def set_reuse_index(self, on):
+        """Let fqh_stats* count over the last scan's tile index when buffer, length and carry match (the caller vouches for the bytes)."""
+        self._chk(self._L.fqh_set_option(self._h, OPT_REUSE_INDEX, 1 if on else 0))
 
     def set_spin_wait(self, usec):
         """Microseconds *_finish polls the stream before sleeping on it (default 0: sleeps at once)."""

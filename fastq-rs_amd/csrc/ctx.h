@@ -94,6 +94,8 @@ struct fqh_ctx {
     uint32_t exact_holds = 0;   // live fqh_streams that need complete line lists for every chunk: no fast path while > 0
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...
     uint32_t spec_backoff = 0;  // ... 1, 2, 4 .. 64 of them, doubling with every failure in a row
+    bool reuse_index = false;   // FQH_OPT_REUSE_INDEX: fqh_stats* may count over the last scan's tile index (the caller vouches for the bytes)
+    bool trust_index = false;   // ... the library's own scan-then-count sequence (the ring) is running
     bool index_full = true;     // the tile index in the workspace holds complete line lists
     bool fast_needs_list = false;  // an input of this context had tiles denser than the fast path's two lines: keep the line lists allocated
     bool dout_clean = false;    // d_out[0]'s accumulators were reset by the last finalize kernel (no init copy needed)

@@ -637,8 +637,11 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     return st;
 }
 
+// May a statistics call count over the tile index of the last finished scan instead of scanning again?  Only when the
+// caller has said that the bytes are what they were (FQH_OPT_REUSE_INDEX, or the library's own scan-then-count sequences:
+// the ring): matching pointer, length and carry do not prove it — the caller's own kernels may have rewritten the buffer.
 static bool same_scan(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in) {
-    if (!ctx->last_valid) return false;
+    if (!ctx->last_valid || !(ctx->reuse_index || ctx->trust_index)) return false;
     fqh_carry c = {};
     if (in) c = *in;
     return ctx->args.buf == d_buf && ctx->args.len == len && ctx->args.is_final == (is_final ? 1 : 0) &&
@@ -871,6 +874,9 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
         return FQH_OK;
     case FQH_OPT_PLACE_TRIES:
         ctx->place_tries = value < 0 ? 0 : value > 8 ? 8 : value;
+        return FQH_OK;
+    case FQH_OPT_REUSE_INDEX:
+        ctx->reuse_index = value != 0;
         return FQH_OK;
     case FQH_OPT_SPIN_WAIT:
         ctx->spin_wait_us = value < 0 ? 0 : value > 1000000 ? 1000000 : value;
@@ -1160,7 +1166,9 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
         // report it, like fqh_scan)
         if (!two_pass) return scan_st;
         // the exact path has rerun the scan (same buffer, full index): count over it
+        ctx->trust_index = true;   // (the exact scan of these very bytes has just finished inside this call)
         fqh_status st = fqh_internal_stats_launch(ctx, buf, len, is_final, &cin, lmax, qh, bh, sc, lead, UINT64_MAX);
+        ctx->trust_index = false;
         if (st != FQH_OK) return st;
         ctx->stats_pending = false;
         cap_st = scan_st;
@@ -1199,7 +1207,9 @@ fqh_status fqh_scan_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     // (FQH_E_CAPACITY: d_rec_start is too short; the histograms are counted all the same and fqh_scan_stats_finish reports it
     // with the exact summary, as the single-pass route does)
     const fqh_status cap_st = st;
+    ctx->trust_index = true;   // (scan and count of one call)
     st = fqh_internal_stats_launch(ctx, d_buf, len, is_final, in, lmax, d_qual_hist, d_base_hist, d_scalars, 0, UINT64_MAX);
+    ctx->trust_index = false;
     if (st == FQH_OK) ctx->stats_cap_st = cap_st;
     return st;
 }

@@ -334,8 +334,10 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
             fqh_internal_fused_commit(ctx);   // (no scan of a later slot is in flight: the context still describes this one)
         } else {
             fqh_internal_fused_drop(ctx);
+            ctx->trust_index = true;   // (the slot's bytes are the ring's own: nobody has written them since the scan above)
             rc = fqh_internal_stats_launch(ctx, s.d, s.n_new, s.is_final, &st->carry, st->lmax, st->d_qual_hist,
                                            st->d_base_hist, st->d_scalars, s.lead, c.n_records);
+            ctx->trust_index = false;
             if (rc != FQH_OK) return rc;
             rc = fqh_stats_finish(ctx, nullptr, nullptr);
             if (rc != FQH_OK) return rc;

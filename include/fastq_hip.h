@@ -113,6 +113,10 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           does) until one costs no more than 3.5 % on top of the store-less run; the fastest is kept, each
  *                           loser is freed as soon as it has lost.  Off by default: on some boxes every allocation is of one
  *                           kind and the search buys nothing.  fqh_placement reports what a search found.
+ *   FQH_OPT_REUSE_INDEX [0] 1: a fqh_stats* call on the buffer, length and carry of the last finished fqh_scan counts over that scan's
+ *                           tile index instead of scanning again (two-pass route only).  The caller thereby VOUCHES that the bytes
+ *                           have not changed since the scan: pointer identity proves nothing about a buffer the caller's own
+ *                           kernels may have rewritten.  Off: every statistics call reads its input itself.
  *   FQH_OPT_SPIN_WAIT [0]   microseconds fqh_*_finish polls the stream before it sleeps on it (hipStreamSynchronize wakes up
  *                           ~15 us after the last kernel); a host core spinning inside a library call is the caller's choice.
  * fqh_last_scan_fast: did the last finished scan (or single-pass statistics call) keep the fast path's result (1), or
@@ -121,6 +125,7 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
 #define FQH_OPT_SINGLE_PASS 2
 #define FQH_OPT_PLACE_TRIES 3
 #define FQH_OPT_SPIN_WAIT 4
+#define FQH_OPT_REUSE_INDEX 5
 fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
 int fqh_last_scan_fast(fqh_ctx *ctx);
 /* What the placement search of this context (FQH_OPT_PLACE_TRIES) measured: *n_candidates line buffers tried (0: no search

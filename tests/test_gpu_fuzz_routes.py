@@ -30,10 +30,16 @@ def fuzz_routes(torch, pkg, fqref, seed, budget_s, max_cases=None):
             out.append(b"@" + h + e + seq + e + b"+" + (h if plus_id else b"") + e + qual + e)
         return b"".join(out)
 
-    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
     t_end = time.time() + budget_s
     cases = fast = fused = 0
+    ctx = None
     while time.time() < t_end and (max_cases is None or cases < max_cases):
+        if ctx is None or cases % 4 == 0:
+            # (list sizes and back-offs stick to a context — one file of very short lines keeps it off the fast path for good:
+            # a fresh one every few files, so that both kinds of history are seen)
+            if ctx is not None:
+                ctx.close()
+            ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
         segs = []
         for _ in range(int(rng.integers(1, 5))):
             L = int(rng.choice([0, 1, 20, 36, 50, 75, 100, 125, 150, 151, 200, 250, 400]))

@@ -786,8 +786,12 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                 const uint4 d1 = *reinterpret_cast<const uint4 *>(rptr + (16u ^ s4));
                 const uint4 d2 = *reinterpret_cast<const uint4 *>(rptr + (32u ^ s4));
                 const uint4 d3 = *reinterpret_cast<const uint4 *>(rptr + (48u ^ s4));
+#ifdef FQH_IDX_NOMASK   // tuning knock-out: no newline search (one cheap use of every loaded dword keeps the LDS reads alive)
+                const uint32_t m_lo = (d0.x ^ d1.y ^ d2.z ^ d3.w) == 0x12345678u ? 1u : 0u, m_hi = (d0.y ^ d1.z ^ d2.w ^ d3.x ^ d0.z ^ d0.w ^ d1.x ^ d1.w ^ d2.x ^ d2.y ^ d3.y ^ d3.z) == 0x12345678u ? 1u : 0u;
+#else
                 const uint32_t m_lo = eqmask16<1>(d0, 0x0A0A0A0Au) | (eqmask16<1>(d1, 0x0A0A0A0Au) << 16);
                 const uint32_t m_hi = eqmask16<1>(d2, 0x0A0A0A0Au) | (eqmask16<1>(d3, 0x0A0A0A0Au) << 16);
+#endif
                 // line starts: the byte after a newline
                 uint32_t ls_lo = (m_lo << 1) | wave_shr1(m_hi >> 31, prev);
                 uint32_t ls_hi = __builtin_amdgcn_alignbit(m_hi, m_lo, 31);
@@ -807,25 +811,44 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                     }
                 }
                 const uint32_t ebase = g * 4 * PIECE_BYTES + lane * 64;
+#ifdef FQH_IDX_NOSTAGE
+                if (false) {
+#else
                 if (run == nstaged && run + tot <= FAST_ENTRIES) {  // uniform: stage in LDS
+#endif
+                    // the lane's first three line starts without a loop: positions by find-first-set, the three class bytes read in
+                    // ONE LDS round trip, then the entries (ordinary reads have two to three line starts in a lane's 64 bytes;
+                    // a fourth and later ones take the loop)
                     uint16_t *dst = lst + run + pre;
-                    while (ls_lo) {
-                        const uint32_t q = __ffs(ls_lo) - 1;
-                        ls_lo &= ls_lo - 1;
-                        const uint32_t b = rptr[q ^ s4];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
-                    }
-                    while (ls_hi) {
-                        const uint32_t q = __ffs(ls_hi) + 31;
-                        ls_hi &= ls_hi - 1;
-                        const uint32_t b = rptr[q ^ s4];
-                        *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                    unsigned long long lsm = ((unsigned long long)ls_hi << 32) | ls_lo;
+                    const uint32_t q0 = lsm ? (uint32_t)__ffsll((long long)lsm) - 1u : 0u;
+                    lsm &= lsm - 1ull;
+                    const uint32_t q1 = lsm ? (uint32_t)__ffsll((long long)lsm) - 1u : 0u;
+                    lsm &= lsm - 1ull;
+                    const uint32_t q2 = lsm ? (uint32_t)__ffsll((long long)lsm) - 1u : 0u;
+                    lsm &= lsm - 1ull;
+                    const uint32_t b0 = rptr[q0 ^ s4], b1 = rptr[q1 ^ s4], b2 = rptr[q2 ^ s4];
+                    if (c > 0) dst[0] = (uint16_t)((ebase + q0) | ((b0 == '@') ? 0x4000u : 0u) | ((b0 == '+') ? 0x8000u : 0u));
+                    if (c > 1) dst[1] = (uint16_t)((ebase + q1) | ((b1 == '@') ? 0x4000u : 0u) | ((b1 == '+') ? 0x8000u : 0u));
+                    if (c > 2) dst[2] = (uint16_t)((ebase + q2) | ((b2 == '@') ? 0x4000u : 0u) | ((b2 == '+') ? 0x8000u : 0u));
+                    if (__ballot(c > 3) != 0) {
+                        dst += 3;
+                        while (lsm) {
+                            const uint32_t q = (uint32_t)__ffsll((long long)lsm) - 1u;
+                            lsm &= lsm - 1ull;
+                            const uint32_t b = rptr[q ^ s4];
+                            *dst++ = (uint16_t)((ebase + q) | ((b == '@') ? 0x4000u : 0u) | ((b == '+') ? 0x8000u : 0u));
+                        }
                     }
                     nstaged = run + tot;
                 }  // else: more than FAST_ENTRIES line starts in a tile: left to the exact path
                 run += tot;
             }
+#ifdef FQH_IDX_NOFINISH
+            prv = run;
+#else
             finish_tile(tile, run, nstaged, prv, false);
+#endif
             prun = run;
             ptile = tile;
             pending = true;

@@ -232,12 +232,12 @@ def main():
     k_ms = float(np.mean(index_ms))
     achieved = nbytes / 1e9 / (k_ms / 1e3)
 
-    # From the committed rocprofv3 passes of the same command (tools/prof.sh -> profiles/round2_rocprof.json; only valid
+    # From the committed rocprofv3 passes of the same command (tools/prof.sh -> profiles/round3_rocprof.json; only valid
     # for the workload they were measured on): HBM bytes per launch of the dominant kernel (PMC), and its duration as
     # rocprofv3 --kernel-trace saw it, next to the HIP-event figure of THIS run.
     traffic = rp = None
     try:
-        with open(os.path.join(ROOT, "profiles", "round2_rocprof.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round3_rocprof.json")) as f:
             pj = json.load(f)
         if pj.get("workload_bytes") == nbytes:
             rp = pj["k_index_fast"]
@@ -270,7 +270,7 @@ def main():
         "hbm_roofline_frac_whole_step": round(gbs / world / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": "k_index_fast", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "traffic_source": "profiles/round2_rocprof.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                     "traffic": traffic, "traffic_source": "profiles/round3_rocprof.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, a committed run of the "
                                                            "same command)" if traffic else None,
                      "kernel_ms": round(k_ms, 4), "kernel_ms_source": "HIP events on the launch stream, this run, mean of the timed steps",
                      "kernel_ms_min": round(float(np.min(index_ms)), 4), "kernel_ms_max": round(float(np.max(index_ms)), 4),

@@ -15,4 +15,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -o pmc -- $CMD > $OUT/pmc_$tag.log 2>&1
 done
-python3 tools/prof_summary.py $OUT ${1:-round2}
+# configs[3]: the streamed leg on its own, kernels AND memory copies (no counters in this pass)
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/stream -o stream -- python bench.py --stream-gib 32 --producer-threads 8 > $OUT/stream.log 2>&1
+python3 tools/prof_summary.py $OUT ${1:-round3}

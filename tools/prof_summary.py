@@ -12,11 +12,11 @@ import shutil
 import sys
 from collections import defaultdict
 
-out, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "round2")
+out, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "round3")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
-HOT = ("k_index_fast", "k_scan_stats", "k_emit_fast", "k_prefix", "k_finalize", "k_stats_commit", "k_index_t", "k_stats_oct",
+HOT = ("k_index_fast", "k_scan_stats", "k_emit_fast", "k_prefix", "k_finalize", "k_stats_commit", "k_stats_edge", "k_stats_long", "k_index_t", "k_stats_oct",
        "k_emit(", "k_read_ceiling", "k_stats_reduce")
 txt = []
 
@@ -97,6 +97,44 @@ if bench:
     if "stats" in bench and "k_scan_stats" in res:
         txt.append("== k_scan_stats rocprofv3 avg %.4f ms vs bench.py stats.kernel_ms %.4f ms" % (res["k_scan_stats"]["avg_ms"],
                                                                                          bench["stats"]["kernel_ms"]))
+# the streamed leg: kernels and copies of `bench.py --stream-gib 32 --producer-threads 8` (rocprofv3 --kernel-trace --memory-copy-trace)
+sd = os.path.join(out, "stream")
+if os.path.isdir(sd):
+    st = {}
+    for f in glob.glob(os.path.join(sd, "**", "*memory_copy_trace.csv"), recursive=True):
+        n = 0
+        tot = 0.0
+        nbytes = 0
+        t0 = t1 = None
+        for r in csv.DictReader(open(f)):
+            if "HOST_TO_DEVICE" not in r.get("Direction", "").upper().replace(" ", "_"):
+                continue
+            b, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            if e - b < 1000000:   # the ring's slot copies take milliseconds; the rest (words, tails) does not count here
+                continue
+            n += 1
+            tot += (e - b) / 1e6
+            t0 = b if t0 is None else min(t0, b)
+            t1 = e if t1 is None else max(t1, e)
+        if n:
+            st["h2d_slot_copies"] = n
+            st["h2d_busy_ms"] = round(tot, 2)
+            st["h2d_first_to_last_ms"] = round((t1 - t0) / 1e6, 2)
+            st["h2d_busy_frac"] = round(tot / ((t1 - t0) / 1e6), 4)
+    for f in glob.glob(os.path.join(sd, "**", "*kernel_trace.csv"), recursive=True):
+        kt = defaultdict(float)
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k:
+                kt[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        st["kernel_busy_ms"] = {k: round(v, 2) for k, v in sorted(kt.items())}
+    sl = os.path.join(out, "stream.log")
+    if os.path.exists(sl):
+        lines = [l for l in open(sl) if l.startswith("{")]
+        if lines:
+            st["bench_line"] = json.loads(lines[-1])
+    res["stream_trace"] = st
+    txt.append("== configs[3] streamed leg under rocprofv3 (--kernel-trace --memory-copy-trace): " + json.dumps({k: v for k, v in st.items() if k != "bench_line"}))
 with open(os.path.join(PROF, tag + "_rocprof.json"), "w") as f:
     json.dump(res, f, indent=1, sort_keys=True)
 with open(os.path.join(PROF, tag + "_rocprofv3_summary.txt"), "w") as f:

@@ -786,7 +786,10 @@ struct Bz2 {  // bzlib.h 1.0: bz_stream, BZ2_bzDecompress{Init,,End}; BZ_OK 0, B
     static const char *name() { return "bzip2"; }
     bool load() {
         void *h = open_lib("libbz2.so.1", "libbz2.so.1.0");
-        return h && sym(h, "BZ2_bzDecompressInit", init) && sym(h, "BZ2_bzDecompress", run) && sym(h, "BZ2_bzDecompressEnd", end);
+        // (the struct above is bzlib 1.0's: a library that does not say "1.0.x" is not used)
+        const char *(*ver)() = nullptr;
+        if (!h || !sym(h, "BZ2_bzlibVersion", ver) || strncmp(ver(), "1.0.", 4) != 0) return false;
+        return sym(h, "BZ2_bzDecompressInit", init) && sym(h, "BZ2_bzDecompress", run) && sym(h, "BZ2_bzDecompressEnd", end);
     }
     bool start() { memset(&z, 0, sizeof z); live = init(&z, 0, 0) == 0; return live; }
     void stop() { if (live) end(&z); live = false; }
@@ -819,7 +822,10 @@ struct Xz {  // lzma/base.h 5.2: lzma_stream (136 bytes on LP64), lzma_stream_de
     static const char *name() { return "xz"; }
     bool load() {
         void *h = open_lib("liblzma.so.5", nullptr);
-        return h && sym(h, "lzma_stream_decoder", init) && sym(h, "lzma_code", run) && sym(h, "lzma_end", end);
+        // (lzma_stream as declared above: liblzma 5.x — 5.0 .. 5.8 kept the layout; anything else is not used)
+        uint32_t (*ver)() = nullptr;
+        if (!h || !sym(h, "lzma_version_number", ver) || ver() / 10000000u != 5u) return false;
+        return sym(h, "lzma_stream_decoder", init) && sym(h, "lzma_code", run) && sym(h, "lzma_end", end);
     }
     bool start() { memset(&z, 0, sizeof z); live = init(&z, UINT64_MAX, 0) == 0; return live; }  // one .xz stream per start
     void stop() { if (live) end(&z); live = false; }
@@ -842,7 +848,10 @@ struct Zstd {  // zstd.h 1.4: ZSTD_DStream, ZSTD_inBuffer / ZSTD_outBuffer, ZSTD
     static const char *name() { return "zstd"; }
     bool load() {
         void *h = open_lib("libzstd.so.1", nullptr);
-        return h && sym(h, "ZSTD_createDStream", create) && sym(h, "ZSTD_freeDStream", destroy) && sym(h, "ZSTD_initDStream", init) &&
+        // (the streaming API and ZSTD_inBuffer / ZSTD_outBuffer as above are stable since zstd 1.3; 1.x only)
+        unsigned (*ver)() = nullptr;
+        if (!h || !sym(h, "ZSTD_versionNumber", ver) || ver() < 10300u || ver() >= 20000u) return false;
+        return sym(h, "ZSTD_createDStream", create) && sym(h, "ZSTD_freeDStream", destroy) && sym(h, "ZSTD_initDStream", init) &&
                sym(h, "ZSTD_decompressStream", run) && sym(h, "ZSTD_isError", is_error);
     }
     bool start() {
@@ -886,12 +895,17 @@ class CodecReader {
                 if (!c_.start()) throw Error(ErrorKind::Other, std::string(Codec::name()) + " decoder init failed");
                 in_stream_ = true;
             }
-            if (avail_ == 0) throw Error(ErrorKind::InvalidData, std::string("unexpected end of ") + Codec::name() + " stream");
+            // (input exhausted inside a stream: the decoder may still hold output and the stream's end — the step before may have
+            // consumed the last input bytes with its output buffer full — so it is stepped once more with no input; only a step
+            // that then yields nothing and no end is a truncated stream)
+            const bool drained = avail_ == 0;
+            const size_t left0 = left;
             const uint8_t *ip = pos_;
             const int rc = c_.step(ip, avail_, out, left);
             pos_ = ip;
             if (rc < 0) throw Error(ErrorKind::InvalidData, std::string("corrupt ") + Codec::name() + " stream");
             if (rc == 1) { c_.stop(); in_stream_ = false; }
+            else if (drained && left == left0) throw Error(ErrorKind::InvalidData, std::string("unexpected end of ") + Codec::name() + " stream");
         }
         return n - left;
     }
@@ -956,8 +970,12 @@ class Lz4Reader {
                 if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame
                     uint8_t sz[4];
                     fill(sz, 4);
-                    std::vector<uint8_t> skip(le32(sz));
-                    if (!skip.empty()) fill(skip.data(), skip.size());
+                    uint8_t skip[4096];  // (the size is untrusted, up to 4 GiB: skipped in pieces, never allocated)
+                    for (uint64_t left = le32(sz); left;) {
+                        const size_t k = (size_t)std::min<uint64_t>(left, sizeof skip);
+                        fill(skip, k);
+                        left -= k;
+                    }
                     continue;
                 }
                 if (magic != 0x184D2204u) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: bad frame magic");
@@ -965,6 +983,11 @@ class Lz4Reader {
                 fill(fb, 2);
                 if ((fb[0] >> 6) != 1) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: unsupported frame version");
                 independent_ = (fb[0] >> 5) & 1;
+                {   // block maximum size (BD byte, bits 4-6): 4 = 64 KiB .. 7 = 4 MiB; a block's OUTPUT may not exceed it
+                    const uint32_t bd = (fb[1] >> 4) & 7u;
+                    if (bd < 4) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: block maximum size");
+                    block_max_ = (size_t)1 << (8 + 2 * bd);
+                }
                 block_checksum_ = (fb[0] >> 4) & 1;
                 const bool content_size = (fb[0] >> 3) & 1;
                 content_checksum_ = (fb[0] >> 2) & 1;
@@ -984,7 +1007,7 @@ class Lz4Reader {
             }
             const bool stored = (word >> 31) != 0;
             const uint32_t size = word & 0x7FFFFFFFu;
-            if (size > (4u << 20)) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: block size");
+            if (size > block_max_) throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: block size");
             blk_.resize(size);
             if (size) fill(blk_.data(), size);
             if (block_checksum_) { uint8_t c[4]; fill(c, 4); }
@@ -1004,7 +1027,6 @@ class Lz4Reader {
     void decode_block(size_t base) {  // LZ4 block format: token, literals, 2-byte offset, match length
         const uint8_t *p = blk_.data(), *end = p + blk_.size();
         auto bad = [] { throw Error(ErrorKind::InvalidData, "corrupt lz4 stream: block data"); };
-        (void)base;
         while (p < end) {
             const uint32_t tok = *p++;
             size_t lit = tok >> 4;
@@ -1012,7 +1034,7 @@ class Lz4Reader {
                 uint8_t b;
                 do { if (p >= end) bad(); b = *p++; lit += b; } while (b == 255);
             }
-            if ((size_t)(end - p) < lit) bad();
+            if ((size_t)(end - p) < lit || out_.size() - base + lit > block_max_) bad();
             out_.insert(out_.end(), p, p + lit);
             p += lit;
             if (p >= end) break;  // the last sequence is literals only
@@ -1025,6 +1047,7 @@ class Lz4Reader {
                 do { if (p >= end) bad(); b = *p++; len += b; } while (b == 255);
             }
             if (off == 0 || off > out_.size()) bad();
+            if (out_.size() - base + len > block_max_) bad();   // (a match may not expand a block beyond the frame's block maximum)
             const size_t from = out_.size() - off;
             out_.reserve(out_.size() + len);
             for (size_t i = 0; i < len; ++i) out_.push_back(out_[from + i]);  // (may overlap its own output)
@@ -1032,15 +1055,17 @@ class Lz4Reader {
     }
     Reader r_;
     std::vector<uint8_t> in_, blk_, out_, window_;
-    size_t in_pos_ = 0, in_len_ = 0, out_pos_ = 0;
+    size_t in_pos_ = 0, in_len_ = 0, out_pos_ = 0, block_max_ = 4u << 20;
     bool in_frame_ = false, done_ = false, independent_ = true, block_checksum_ = false, content_checksum_ = false;
 };
 
 // parse_path (src/lib.rs:167-196): open the file (nullopt / "-" = stdin), sniff the compression
 // format, hand the closure a Parser over plain bytes.  Plain input goes straight to the parser;
 // compressed input is decoded on a thread_reader thread with the reference's parameters (4 MiB
-// buffers, queue of 2; src/lib.rs:191).  Gzip is decoded with zlib, lz4 frames with the decoder above; bzip2 / xz /
-// zstd are detected but no decoder library is present in this build.
+// buffers, queue of 2; src/lib.rs:191).  Gzip is decoded with zlib; bzip2 / xz / zstd with the system's run-time libraries
+// (codec::*, bound with dlopen; an input in a format whose library is missing fails like niffler built without that feature).
+// lz4 frames are an EXTENSION of the mirror: the crate's docs name lz4 (src/lib.rs:137-141), but niffler >= 2.4 has no lz4
+// format, so the reference as built today would read an .lz4 file as plain bytes and fail on its header.
 template <class F>
 auto with_plain_reader(const std::optional<std::string> &path, F use) {  // use(DynReader &) sees plain bytes
     FILE *f = stdin;

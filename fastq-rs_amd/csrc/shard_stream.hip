@@ -188,7 +188,9 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
 fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, const uint8_t *h_all_tails, uint64_t tail_stride,
                                    int n_ranks, int rank, const uint8_t *h_head, uint32_t lmax, uint64_t *d_qual_hist,
                                    uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t out[2]) {
-    if (!ctx || !h_all_words || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return FQH_E_ARG;
+    // (ctx may be NULL when this rank has no stitch to parse — both the previous rank's tail and its own head are empty: the
+    // phase check and the key are host arithmetic on the gathered words)
+    if (!h_all_words || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return FQH_E_ARG;
     const uint64_t *mine = h_all_words + (size_t)rank * FQH_SHARD_STREAM_WORDS;
     // ---- what lies in front of this rank: true newline count, records (the streamed ones and one per non-empty stitch)
     uint64_t nl_before = 0, rec_before = 0;
@@ -207,7 +209,7 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, co
     if (rank > 0) {
         const uint64_t tl = h_all_words[(size_t)(rank - 1) * FQH_SHARD_STREAM_WORDS + 5], hl = mine[4];
         if (tl + hl) {
-            if ((tl && !h_all_tails) || (hl && !h_head) || tl > tail_stride) return FQH_E_ARG;
+            if (!ctx || (tl && !h_all_tails) || (hl && !h_head) || tl > tail_stride) return FQH_E_ARG;
             std::vector<uint8_t> file(tl + hl);
             if (tl) memcpy(file.data(), h_all_tails + (size_t)(rank - 1) * tail_stride, tl);
             if (hl) memcpy(file.data() + tl, h_head, hl);

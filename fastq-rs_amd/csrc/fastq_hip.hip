@@ -633,6 +633,7 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     fqh_status st = resolve(ctx, out, carry_out);
     ctx->last_valid = (st == FQH_OK || st == FQH_E_CAPACITY);
     ctx->fused = false;  // (the launch is over; a deferred commit, f_commit_owed, stays owed if the fast path stood)
+    ctx->f_defer_commit = false;
     if (!ctx->used_spec) ctx->f_commit_owed = false;
     return st;
 }
@@ -992,8 +993,11 @@ fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     }
     ctx->last_valid = false;
     fqh_status st = fused_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap, lmax, d_qual_hist, d_base_hist, d_scalars, lead_len);
-    ctx->f_defer_commit = false;
+    // (f_defer_commit stays set until the launch's finish: the finish may run the fast path a second time — a context that
+    // meets its first tile with more record starts than two lines hold allocates the list area and reruns — and that run's
+    // commit must be held back as well)
     if (st == FQH_OK) *fused = true;
+    else ctx->f_defer_commit = false;
     return st;
 }
 // after fqh_internal_scan_finish of such a launch: did the single pass stand (a commit is owed), and enqueue it

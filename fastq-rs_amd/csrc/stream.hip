@@ -28,6 +28,8 @@ struct fqh_stream {
         bool launched = false;  // its scan is already enqueued (by the collect of the slot in front of it)
         bool fused = false;     // ... as a single pass (scan + histograms), commit held back
         hipEvent_t got = nullptr;  // its boundaries have arrived on the host
+        hipEvent_t idle = nullptr; // everything the context's stream was given to do on the slot's device data has run
+        bool idle_set = false;
         hipEvent_t tc0 = nullptr, tc1 = nullptr, ts0 = nullptr, ts1 = nullptr;  // FQH_STREAM_TIMING: its copy and its scan, begin / end
         int state = 0;  // 0 free, 1 acquired, 2 submitted, 3 collected (held by the caller)
     };
@@ -91,6 +93,7 @@ void fqh_stream_destroy(fqh_stream *st) {
         if (s.h_idx) (void)hipHostFree(s.h_idx);
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.got) (void)hipEventDestroy(s.got);
+        if (s.idle) (void)hipEventDestroy(s.idle);
         for (hipEvent_t e : {s.tc0, s.tc1, s.ts0, s.ts1})
             if (e) (void)hipEventDestroy(e);
     }
@@ -131,7 +134,8 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
             if (hipHostMalloc((void **)&s.h, st->reserve + st->slot_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipMalloc((void **)&s.d_base, st->reserve + st->slot_bytes + 16) != hipSuccess ||
                 hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&s.got, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+                hipEventCreateWithFlags(&s.got, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s.idle, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
             if ((flags & FQH_STREAM_TIMING) && (hipEventCreate(&s.tc0) != hipSuccess || hipEventCreate(&s.tc1) != hipSuccess ||
                                                  hipEventCreate(&s.ts0) != hipSuccess || hipEventCreate(&s.ts1) != hipSuccess)) { rc = FQH_E_DEVICE; break; }
             s.d = s.d_base + st->reserve;  // reserve is a multiple of 16
@@ -178,6 +182,9 @@ fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     s.n_new = nbytes;
     s.is_final = is_final ? 1 : 0;
+    // (the copy may not overtake what the context's stream still has to do on this slot's previous contents: commit kernels
+    // that read its bytes, the move of its partial trailing record — enqueued by the collect that handed the slot back)
+    if (s.idle_set) HIPCHK(ctx, hipStreamWaitEvent(st->copy_stream, s.idle, 0));
     if (s.tc0) HIPCHK(ctx, hipEventRecord(s.tc0, st->copy_stream));
     if (nbytes) HIPCHK(ctx, hipMemcpyAsync(s.d, s.h + st->reserve, nbytes, hipMemcpyHostToDevice, st->copy_stream));
     if (s.tc1) HIPCHK(ctx, hipEventRecord(s.tc1, st->copy_stream));
@@ -367,6 +374,8 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
             nx.lead = tail;
         }
     }
+    HIPCHK(ctx, hipEventRecord(s.idle, ctx->stream));
+    s.idle_set = true;
     if (c.parse_status != FQH_OK || s.is_final) st->ended = true;
     st->records_done += n;
     st->carry = cout;

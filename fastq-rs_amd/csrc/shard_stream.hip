@@ -82,6 +82,10 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
     if (stats && (!d_qual_hist || !d_base_hist || !d_scalars)) return FQH_E_ARG;
     *res = fqh_shard_result{};
     res->status = FQH_OK;
+    if (hi == lo) {  // an empty range: the rank takes part in the exchange and contributes nothing (its neighbours stitch across it)
+        res->phase = FQH_SHARD_EMPTY;
+        return FQH_OK;
+    }
     uint64_t R = 0;
     if (lo > 0 && hi > lo) {
         // ---- where does this shard's first record begin, and at which line phase does the shard start?
@@ -99,8 +103,16 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
         if (st != FQH_OK) return st;
         uint32_t phase = 0;
         st = fqh_shard_align(ctx, (const uint8_t *)win.p, w, prev_nl ? 1 : 0, &phase, &R);
-        if (st == FQH_E_HEADER || st == FQH_E_ARG) {
-            // the window holds a parse error (or cannot settle the phase): reported as this shard's error at its start
+        if (st == FQH_E_ARG || (st == FQH_E_HEADER && hi - lo < FQH_BUFSIZE)) {
+            // several line phases validate, or none does in a range that need not even hold one record start (the reference
+            // accepts records of up to BUFSIZE bytes): too few lines to tell, and a parse error could not be told from "too
+            // little to see".  Not a property of the file: the caller has cut it too finely (merge the range with a neighbour;
+            // an EMPTY range is fine)
+            ctx->err = "fqh_shard_stream_run: the byte range is too small to settle its line phase (it must hold a few records)";
+            return FQH_E_ARG;
+        }
+        if (st == FQH_E_HEADER) {
+            // the window holds a parse error: reported as this shard's error at its start
             res->status = FQH_E_HEADER;
             res->err_offset = lo;
             return FQH_OK;
@@ -192,26 +204,41 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, co
     // phase check and the key are host arithmetic on the gathered words)
     if (!h_all_words || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return FQH_E_ARG;
     const uint64_t *mine = h_all_words + (size_t)rank * FQH_SHARD_STREAM_WORDS;
+    auto W = [&](int j) { return h_all_words + (size_t)j * FQH_SHARD_STREAM_WORDS; };
+    auto empty = [&](int j) { return W(j)[3] == FQH_SHARD_EMPTY; };
+    auto prev_of = [&](int j) {  // the nearest rank in front of j that holds bytes (-1: none): the cut between the two is ONE cut
+        int p = j - 1;
+        while (p >= 0 && empty(p)) --p;
+        return p;
+    };
     // ---- what lies in front of this rank: true newline count, records (the streamed ones and one per non-empty stitch)
     uint64_t nl_before = 0, rec_before = 0;
     bool earlier_error = false;  // a rank in front of this one stopped at an error of its own (or parsed under a wrong phase): its
                                  // key is the smaller one in file order, and what this rank derives from its counts is not to be used
     for (int j = 0; j < rank; ++j) {
-        const uint64_t *w = h_all_words + (size_t)j * FQH_SHARD_STREAM_WORDS;
-        if (j && (h_all_words[(size_t)(j - 1) * FQH_SHARD_STREAM_WORDS + 5] + w[4]) != 0) ++rec_before;  // rank j's stitch
-        if ((int32_t)w[0] != FQH_OK || (j && (nl_before & 3) != w[3])) earlier_error = true;
+        if (empty(j)) continue;
+        const uint64_t *w = W(j);
+        const int p = prev_of(j);
+        if (p >= 0 && (W(p)[5] + w[4]) != 0) ++rec_before;  // rank j's stitch
+        if ((int32_t)w[0] != FQH_OK || (p >= 0 && (nl_before & 3) != w[3])) earlier_error = true;
         nl_before += w[2];
         rec_before += w[1];
     }
     uint64_t records = 0;
     uint64_t key = FQH_NO_ERROR_KEY;
-    // ---- the record that straddles the cut in front of this rank: tail of rank - 1 + own head, a file of its own
-    if (rank > 0) {
-        const uint64_t tl = h_all_words[(size_t)(rank - 1) * FQH_SHARD_STREAM_WORDS + 5], hl = mine[4];
+    if (empty(rank)) {
+        out[0] = 0;
+        out[1] = FQH_NO_ERROR_KEY;
+        return FQH_OK;
+    }
+    const int prev = prev_of(rank);
+    // ---- the record that straddles the cut in front of this rank: tail of the rank before it + own head, a file of its own
+    if (prev >= 0) {
+        const uint64_t tl = W(prev)[5], hl = mine[4];
         if (tl + hl) {
             if (!ctx || (tl && !h_all_tails) || (hl && !h_head) || tl > tail_stride) return FQH_E_ARG;
             std::vector<uint8_t> file(tl + hl);
-            if (tl) memcpy(file.data(), h_all_tails + (size_t)(rank - 1) * tail_stride, tl);
+            if (tl) memcpy(file.data(), h_all_tails + (size_t)prev * tail_stride, tl);
             if (hl) memcpy(file.data() + tl, h_head, hl);
             DevBuf d(ctx);
             fqh_status st = d.alloc(tl + hl + 16);
@@ -228,7 +255,7 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, co
         }
     }
     // ---- the phase this rank parsed under against the true one
-    if (key == FQH_NO_ERROR_KEY && rank > 0 && (int32_t)mine[0] == FQH_OK && (nl_before & 3) != mine[3])
+    if (key == FQH_NO_ERROR_KEY && prev >= 0 && (int32_t)mine[0] == FQH_OK && (nl_before & 3) != mine[3])
         key = pack_key(rec_before + records, FQH_E_HEADER);
     // ---- the rank's own records and its own first error
     if (key == FQH_NO_ERROR_KEY) {

@@ -454,8 +454,11 @@ uint64_t each_sharded(fqh_ctx *ctx, fqh_comm *comm, int n_ranks, int rank, ReadA
         if (st != FQH_OK) throw Error(ErrorKind::Other, std::string(what) + ": " + fqh_last_error(ctx));
     };
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !comm)) throw Error(ErrorKind::Other, "each_sharded: bad rank / communicator");
-    const uint64_t lo = file_len / (uint64_t)n_ranks * (uint64_t)rank;
-    const uint64_t hi = rank + 1 == n_ranks ? file_len : file_len / (uint64_t)n_ranks * (uint64_t)(rank + 1);
+    // byte ranges of equal size; a file too small to give every rank a megabyte goes to rank 0 as a whole (a range must hold
+    // enough lines to settle its line phase; the other ranks take part in the exchange with empty ranges)
+    const bool tiny = file_len / (uint64_t)n_ranks < (1u << 20);
+    const uint64_t lo = tiny ? (rank ? file_len : 0) : file_len / (uint64_t)n_ranks * (uint64_t)rank;
+    const uint64_t hi = tiny ? file_len : (rank + 1 == n_ranks ? file_len : file_len / (uint64_t)n_ranks * (uint64_t)(rank + 1));
     struct Cb {
         ReadAt *f;
         static int call(void *user, uint8_t *dst, uint64_t off, uint64_t n) {

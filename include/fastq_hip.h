@@ -225,7 +225,9 @@ fqh_status fqh_sync(fqh_ctx *ctx);
  * every record the rank delivers is added to the histograms (as fqh_stats).  *res: the rank's summary; h_head receives the
  * bytes [lo, lo + R) (the end of the record the previous rank began), h_tail what is left behind the rank's last complete
  * record; both at most 2 * FQH_BUFSIZE bytes for input the reference accepts (FQH_E_CAPACITY otherwise).  A parse error
- * inside the rank's records is res->status, not the return value.
+ * inside the rank's records is res->status, not the return value.  FQH_E_ARG: the byte range holds too few lines to settle its line
+ * phase — several phases validate, or none does in a range shorter than FQH_BUFSIZE (it need not hold a single record start, and
+ * a parse error could not be told from "too little to see"): cut less finely; an EMPTY range (lo == hi) is fine.
  *
  * Then ONE exchange: fqh_shard_result_words(res) (FQH_SHARD_STREAM_WORDS words) and the tail bytes of every rank, all-gathered
  * in rank order (fqh_allgather or the host's own collective; tail_stride bytes per rank).
@@ -249,6 +251,7 @@ typedef struct {
 } fqh_shard_result;
 #define FQH_SHARD_STREAM_WORDS 8
 #define FQH_NO_ERROR_KEY UINT64_MAX
+#define FQH_SHARD_EMPTY 0xFFFFFFFFu /* fqh_shard_result.phase of an empty byte range (lo == hi): its neighbours stitch across it */
 fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t lo, uint64_t hi, uint64_t file_len,
                                 uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist,
                                 uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res, uint8_t *h_head,

@@ -144,3 +144,63 @@ def test_bench_sharded_streamed_three_ranks_one_gpu():
     j = json.loads(lines[-1])
     assert j["mode"] == "sharded-stream" and j["n_gpus"] == 3 and j["check"]["phases_ok"] and j["check"]["histograms_ok"]
     assert j["records"] == j["check"]["records_expected"]
+
+
+def test_a_byte_range_too_small_to_settle_its_phase_is_refused(env):
+    """A shard of a few bytes inside one record gives the alignment step nothing to tell the line phases apart: the call is
+    refused (FQH_E_ARG), the file is not mis-parsed; an EMPTY range is fine."""
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(5)
+    data = fuzzgen.valid_file(rng, 4000, maxlen=100, seqlen=100, crlf=False)
+    k = data.index(b"\n+\n", len(data) // 2) + 10          # well inside a quality line: no newline within [k, k + 4)
+    with pytest.raises(pkg.FqhError) as ei:
+        run_sharded(env, data, [k, k + 4], 100)
+    assert ei.value.status == pkg.E_ARG
+    r = __import__("oracle.fqref", fromlist=["x"]).count(data)
+    status, n_records, hist, shards = run_sharded(env, data, [k, k], 100)   # (an empty range between two shards)
+    assert (status, n_records) == (r.status, r.n_records)
+
+
+def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
+    """Random files (valid, damaged, truncated) cut into random byte-range shards -> (files checked, files with a parse error):
+    status and record count must be the oracle's sequential Parser::each over the whole file; histograms too when it is valid."""
+    import time
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    cases = errs = 0
+    while time.time() < t_end and (max_cases is None or cases < max_cases):
+        L = int(rng.choice([20, 75, 150, 300]))
+        data = fuzzgen.valid_file(rng, int(rng.integers(300, 12000)), maxlen=L, crlf=bool(rng.random() < 0.15))
+        kind = rng.random()
+        if kind < 0.25:
+            data = fuzzgen.mutate(rng, data, 1)
+        elif kind < 0.35:
+            data = data[: len(data) - int(rng.integers(1, 300))]
+        n = len(data)
+        k = int(rng.integers(1, 5))
+        cuts = sorted(set(int(x) for x in rng.integers(1, n, k)))
+        lmax = 150
+        try:
+            status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=int(rng.choice([1 << 16, 1 << 18, 1 << 20])))
+        except pkg.FqhError as e:
+            assert e.status == pkg.E_ARG and min(b - a for a, b in zip(cuts, cuts[1:] + [n])) < pkg.BUFSIZE, (seed, cases, cuts, e)
+            continue   # a byte range too small to settle its line phase: refused, not mis-parsed
+        r, oq, ob, osc = fqref.stats(data, lmax)
+        window_error = any(sh.res.status == pkg.E_HEADER and sh.res.n_records == 0 and sh.lo > 0 for sh in shards)
+        if r.status == pkg.OK:
+            assert (status, n_records) == (pkg.OK, r.n_records), (seed, cases, cuts, status, n_records, r.n_records)
+            assert np.array_equal(hist[:8], osc) and np.array_equal(hist[8: 8 + lmax * 256].reshape(lmax, 256), oq) and np.array_equal(hist[8 + lmax * 256:].reshape(lmax, 8), ob), (seed, cases, cuts)
+        else:
+            errs += 1
+            assert status != pkg.OK, (seed, cases, cuts)
+            if not window_error:  # (an error inside a shard's alignment window is reported at the shard's start)
+                assert (status, n_records) == (r.status, r.n_records), (seed, cases, cuts, (status, n_records), (r.status, r.n_records))
+        cases += 1
+    return cases, errs
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_sharded(env, fqref, seed):
+    cases, errs = fuzz_sharded(env, fqref, seed, 15.0, max_cases=100)
+    assert cases >= 20 and errs >= 1, (cases, errs)

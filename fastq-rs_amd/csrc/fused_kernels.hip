@@ -513,10 +513,11 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                     __builtin_amdgcn_wave_barrier();
                     // ---- one lane per entry, 64 entries at a time: the window of five entries that ends at it (src/records.rs:141,
                     // 155,233 under each alignment), and the line it closes (the one entry p - 1 starts)
-#pragma unroll 1
                     // (the span's last group runs the pass at least once, entries or not: the batches in progress are flushed there — a
                     // chunk that is not the file's last may end in a group without a single line start)
-                    for (uint32_t c0 = 0; c0 < totv || (c0 == 0 && last_g && last_t); c0 += 64) {
+                    const uint32_t nent = totv ? totv : (last_g && last_t ? 1u : 0u);
+#pragma unroll 1
+                    for (uint32_t c0 = 0; c0 < nent; c0 += 64) {
                         const uint32_t p = c0 + lane;
                         const uint32_t ti = run + p;
                         uint32_t Pent = 0;      // the line entry p closes

@@ -55,6 +55,13 @@ constexpr uint32_t SO_LISTW_REG = 512;        // ... staged per wave by the othe
 constexpr uint32_t SO_SLOT_BYTES = 2 * SO_LISTW + 256;  // a tile's slot in LDS: its list entries and 64 words of bookkeeping
 constexpr uint32_t SO_LDS_MAX = 160 * 1024;
 constexpr uint32_t SO_ADDR_SPAN = 65536 + SO_SBYTES + 128 + 3 * 16384;  // see launch_stats_oct
+// k_stats_long keeps 128 quality bins per column ('!' .. 0xA0: Q0 .. Q127 covers PacBio HiFi's '~' = Q93, which the 64-bin window
+// sent to the caller's arrays in device memory byte by byte): 4 row blocks x 128 bins x 64 slots x 4 B behind the sequence region
+constexpr uint32_t SO_LQBITS = 7;
+constexpr uint32_t SO_LRB = 64u * 4u << SO_LQBITS;                      // bytes of one quality row block (64 columns)
+constexpr uint32_t SO_LWORDS = (SO_SBYTES + 4 * SO_LRB) / 4;
+constexpr uint32_t SO_LADDR_SPAN = SO_SBYTES + 4 * SO_LRB + 128;        // bins are clamped to 7 bits before they become addresses
+static_assert(SO_LADDR_SPAN <= SO_LDS_MAX, "k_stats_long: LDS budget");
 
 __device__ __forceinline__ uint32_t so_slot(uint32_t r) {  // r = row % 64
     return ((r >> 2) & 7u) | ((r & 3u) << 3) | (r & 32u);
@@ -62,11 +69,12 @@ __device__ __forceinline__ uint32_t so_slot(uint32_t r) {  // r = row % 64
 __device__ __forceinline__ uint32_t so_row6(uint32_t slot) {
     return ((slot & 7u) << 2) | ((slot >> 3) & 3u) | (slot & 32u);
 }
-// word index of (bin, row): quality bins 0..63, sequence bins 0..7
-template <bool IS_SEQ>
+// word index of (bin, row): quality bins 0 .. 2^QBITS - 1 (6: the window '!'..'`' of every kernel but k_stats_long, 7: '!'..0xA0,
+// which holds PacBio HiFi's '~'), sequence bins 0..7
+template <bool IS_SEQ, uint32_t QBITS = 6>
 __device__ __forceinline__ uint32_t so_word(uint32_t bin, uint32_t row) {
     const uint32_t rb = row >> 6, slot = so_slot(row & 63u);
-    return IS_SEQ ? ((rb << 9) | (bin << 6) | slot) : SO_SBYTES / 4 + ((rb << 12) | (bin << 6) | slot);
+    return IS_SEQ ? ((rb << 9) | (bin << 6) | slot) : SO_SBYTES / 4 + ((rb << (6 + QBITS)) | (bin << 6) | slot);
 }
 __device__ __forceinline__ uint32_t load4_any(const uint8_t *__restrict__ p, const uint8_t *__restrict__ end) {
     uint32_t v = 0;
@@ -101,7 +109,7 @@ __device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v) {
 // to the overflow counters, which are plain arithmetic on the line's length; the alphabet flags cover every byte.
 // (lc is the tile's view of the bank-scheduled rows: 0 in tiles that take the exact path for everything; columns the
 // LDS rows do not take — and quality bytes outside '!'..'`' — go to the caller's arrays.)
-template <bool IS_SEQ>
+template <bool IS_SEQ, uint32_t QBITS = 6>
 __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, uint32_t pos, uint32_t len, uint32_t lc,
                                               uint32_t *hist, uint32_t &any_n, uint32_t &any_inv) {
     const int rem = (int)len - (int)pos;
@@ -119,7 +127,7 @@ __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, ui
             else atomicAdd(&a.base_hist[(uint64_t)(a.col0 + col) * 8 + bin_to_class(bin)], 1ull);
         } else {
             if (col >= a.lc) continue;
-            if (col < lc && b - 33u < 64u) atomicAdd(hist + so_word<false>(b - 33u, col), 1u);
+            if (col < lc && b - 33u < (1u << QBITS)) atomicAdd(hist + so_word<false, QBITS>(b - 33u, col), 1u);
             else atomicAdd(&a.qual_hist[(uint64_t)(a.col0 + col) * 256 + b], 1ull);
         }
     }

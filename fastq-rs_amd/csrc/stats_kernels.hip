@@ -454,7 +454,8 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
 // src/records.rs:75-90); so does this: the work item is (record, block of 256 columns), found by plain arithmetic on the
 // IdxRecord-style index (fqh_idx_record: start + the four newline offsets) — no tile lists, no line-start search.
 //   * a block of 1024 threads owns one column block cb = blockIdx.x % n_cb and a slice of the records; its LDS holds the
-//     bank-scheduled histogram of those 256 columns (stats_dev.h: 8 KiB sequence + 64 KiB quality);
+//     bank-scheduled histogram of those 256 columns (stats_dev.h: 8 KiB sequence + 128 KiB quality: 128 bins per column,
+//     '!' .. 0xA0 — HiFi reads are mostly '~' (Q93), and a 64-bin window sent every such byte to the caller's arrays);
 //   * eight lanes walk a line's 256 columns, one dword each and step, eight records per wavefront and round — the same
 //     lane -> bank schedule as k_stats_oct: whole dwords of bytes inside the alphabet / window cost one v_perm_b32 and one
 //     ds_sub_u32 per byte; a dword with a byte outside, or with fewer than four bytes of the line, takes the per-byte
@@ -475,7 +476,7 @@ struct LongArgs {
 };
 __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-    for (uint32_t i = threadIdx.x; i < SO_WORDS; i += SO_THREADS) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < SO_LWORDS; i += SO_THREADS) hist[i] = 0;
     __syncthreads();
     if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();  // the address registers assume the histogram starts at LDS address 0
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         for (int kind = 0; kind < 2; ++kind) {
             const uint32_t seg = segs[kind];
             if (__ballot(seg != 0) == 0) continue;
-            constexpr uint32_t RB = 16384u;
+            constexpr uint32_t RB = SO_LRB;
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
                 const uint32_t wu = ws[kind][u];
@@ -548,7 +549,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
                     if (whole && !chk) any_n |= wu & 0x08080808u;                      // (bit 3 is set in 'N' only)
                 } else {
                     pb = wu - 0x21212121u;
-                    chk = pb & 0xC0C0C0C0u;                                             // != 0: a byte outside '!'..'`'
+                    chk = pb & 0x80808080u;                                             // != 0: a byte outside '!' .. 0xA0 (128 bins)
+                    pb &= 0x7F7F7F7Fu;                                                  // (whatever the bytes are, the address stays inside the rows)
                 }
                 const uint32_t f = (whole && !chk) ? 0xFFFFFFFFu : 0u;
                 const uint32_t off = (kind ? SO_SBYTES : 0u) + 128u * (u & 1u) + (kind ? RB : 2048u) * (u >> 1);
@@ -559,8 +561,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
                 if (__ballot(pos < seg && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
                     if (pos < seg && !f) {
                         uint32_t an = 0, ai = 0;
-                        if (kind == 0) so_exact_step<true>(sa, wu, pos, seg, lc, hist, an, ai);
-                        else so_exact_step<false>(sa, wu, pos, seg, lc, hist, an, ai);
+                        if (kind == 0) so_exact_step<true, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
+                        else so_exact_step<false, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
                         any_n |= an;
                         any_inv |= ai;
                     }
@@ -582,13 +584,13 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     // ---- the block's rows -> the caller's arrays (u64), totals
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    for (uint32_t id = threadIdx.x; id < SO_WORDS; id += SO_THREADS) {
+    for (uint32_t id = threadIdx.x; id < SO_LWORDS; id += SO_THREADS) {
         const uint32_t v = hist[id];
         if (!v) continue;
         const bool isq = id >= SO_SBYTES / 4;
         const uint32_t q = isq ? id - SO_SBYTES / 4 : id;
-        const uint32_t rb = isq ? q >> 12 : q >> 9;
-        const uint32_t bin = isq ? (q >> 6) & 63u : (q >> 6) & 7u;
+        const uint32_t rb = isq ? q >> (6 + SO_LQBITS) : q >> 9;
+        const uint32_t bin = isq ? (q >> 6) & ((1u << SO_LQBITS) - 1u) : (q >> 6) & 7u;
         const uint32_t row = rb * 64 + so_row6(q & 63u);
         if (row >= lc) continue;
         if (isq) atomicAdd(&a.qual_hist[(uint64_t)(col0 + row) * 256 + 33 + bin], (unsigned long long)v);
@@ -636,7 +638,7 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
     a.qual_hist = qual_hist;
     a.base_hist = base_hist;
     a.scalars = scalars;
-    const size_t lds = SO_ADDR_SPAN;   // (a lane without a whole dword subtracts 0 wherever its bytes point: all of that is allocated)
+    const size_t lds = SO_LADDR_SPAN;  // (a lane without a whole dword subtracts 0 wherever its bytes point: all of that is allocated)
     static bool set = false;
     if (!set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -227,11 +227,11 @@ def test_stats_long_reads_and_odd_bytes(fqref, gpu):
         assert np.array_equal(gq, qh) and np.array_equal(gb, bh) and np.array_equal(gs, sc)
 
 
-@pytest.mark.parametrize("shape", ["clean", "crlf", "dirty", "hifi", "mixed"])
+@pytest.mark.parametrize("shape", ["clean", "crlf", "dirty", "hifi", "mixed", "wide"])
 def test_stats_kilobase_reads(fqref, gpu, shape):
     """Reads of 2 - 5 kbp (and a mix with short ones): k_stats_oct counts them in passes of 256 columns, every pass in
     LDS; the caller's lmax may be smaller than the reads (overflow counters), larger, or no multiple of anything."""
-    rng = np.random.default_rng({"clean": 1, "crlf": 2, "dirty": 3, "hifi": 4, "mixed": 5}[shape])
+    rng = np.random.default_rng({"clean": 1, "crlf": 2, "dirty": 3, "hifi": 4, "mixed": 5, "wide": 6}[shape])
     recs = []
     for i in range(260):
         n = int(rng.integers(2000, 5001))
@@ -240,7 +240,10 @@ def test_stats_kilobase_reads(fqref, gpu, shape):
         seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes()
         qual = rng.integers(33, 75, n).astype(np.uint8).tobytes()
         if shape == "hifi":
-            qual = rng.choice(np.frombuffer(b"~!5I", dtype=np.uint8), n).tobytes()   # '~' = Q93 lies outside the LDS window
+            qual = rng.choice(np.frombuffer(b"~!5I", dtype=np.uint8), n).tobytes()   # '~' = Q93: beyond the 64 bins, inside k_stats_long's 128
+        if shape == "wide":   # both edges of k_stats_long's 128-bin window '!' .. 0xA0, and bytes on either side of it
+            qual = rng.choice(np.array([0x21, 0x60, 0x61, 0x7E, 0x7F, 0x80, 0xA0, 0xA1, 0xFF, 0x20, 0x0B, 0x00], dtype=np.uint8), n,
+                              p=[.2, .1, .1, .3, .05, .05, .1, .04, .02, .02, .01, .01]).tobytes()
         if shape == "dirty" and i % 4 == 0 and n:
             sa = bytearray(seq)
             for k in rng.integers(0, n, 3):

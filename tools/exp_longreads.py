@@ -10,6 +10,8 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 nrec = max(256, 4096 * 300 // max(L, 300))
 seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (nrec, L))
 qual = rng.integers(35, 74, (nrec, L)).astype(np.uint8)
+if os.environ.get("EXP_HIFI"):  # PacBio HiFi-like qualities: most bytes '~' (Q93), the rest spread over '!'..'~'
+    qual = np.where(rng.random((nrec, L)) < 0.8, 126, rng.integers(33, 127, (nrec, L))).astype(np.uint8)
 recs = []
 for i in range(nrec):
     recs.append(b"@r%07d\n" % i + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n")

@@ -710,19 +710,27 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         if (nstaged == run && run >= 8) {  // uniform
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            uint32_t bad = 0, have = 0;  // bit r: some / some failing complete group starting at i == r (mod 4)
-            for (uint32_t i = lane; i + 4 < run; i += 64) {
+            auto window_ok = [&](uint32_t i) -> bool {  // entries i .. i + 4 as header, sequence, separator, quality, next header
                 const uint32_t e0 = lst[i], e1 = lst[i + 1], e2 = lst[i + 2], e3 = lst[i + 3], e4 = lst[i + 4];
-                const bool ok = (e0 & 0x4000u) && (e2 & 0x8000u) &&
-                                ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
-                have |= 1u << (i & 3u);
-                bad |= ok ? 0u : 1u << (i & 3u);
-            }
+                return (e0 & 0x4000u) && (e2 & 0x8000u) &&
+                       ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
+            };
+            // the tile's first 64 windows, one lane each, under all four alignments: they must single out ONE ...
+            const bool in0 = lane + 4 < run;
+            const bool ok0 = in0 && window_ok(lane);
             uint32_t cons = 0;
 #pragma unroll
             for (uint32_t r = 0; r < 4; ++r)
-                if (__ballot((have >> r) & 1u) && !__ballot((bad >> r) & 1u)) cons |= 1u << r;
+                if (__ballot(in0 && (lane & 3u) == r) && !__ballot(in0 && !ok0 && (lane & 3u) == r)) cons |= 1u << r;
             if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
+            // ... under which the rest of the tile is checked, one lane per RECORD (a 16 KiB tile of 150 bp reads: 34 lanes, one
+            // trip — the windows of the three other alignments, three quarters of the work, decide nothing once one is singled
+            // out: k_emit_fast holds the tile's alignment against the true line index anyway)
+            if (hyp < 4) {
+                bool bad = false;
+                for (uint32_t i = 64 + hyp + 4 * lane; i + 4 < run; i += 256) bad = bad || !window_ok(i);
+                if (__ballot(bad) != 0) hyp = 7;
+            }
         }
         rv = 0;
         if (hyp < 4) {

@@ -715,20 +715,29 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
                 return (e0 & 0x4000u) && (e2 & 0x8000u) &&
                        ((e2 & 0x3FFFu) - (e1 & 0x3FFFu)) == ((e4 & 0x3FFFu) - (e3 & 0x3FFFu));
             };
-            // the tile's first 64 windows, one lane each, under all four alignments: they must single out ONE ...
-            const bool in0 = lane + 4 < run;
-            const bool ok0 = in0 && window_ok(lane);
-            uint32_t cons = 0;
+            // the alignment: among the tile's first four entries exactly one starts with '@' and has a '+' two entries on (a
+            // header and its separator: a sequence line starts with neither, and a quality line that starts with '@' is followed
+            // two lines on by a sequence line) ...
+            const bool cand = lane < 4 && lane + 4 < run && (lst[lane] & 0x4000u) && (lst[lane + 2] & 0x8000u);
+            uint32_t cons = (uint32_t)__ballot(cand);
+            if (!cons || (cons & (cons - 1))) {
+                // (rare: none or several — a quality line that starts with '@' in front of a sequence line that starts with
+                // '+', which the parser accepts: the tile's first 64 windows under all four alignments must single out one)
+                const bool in0 = lane + 4 < run;
+                const bool ok0 = in0 && window_ok(lane);
+                cons = 0;
 #pragma unroll
-            for (uint32_t r = 0; r < 4; ++r)
-                if (__ballot(in0 && (lane & 3u) == r) && !__ballot(in0 && !ok0 && (lane & 3u) == r)) cons |= 1u << r;
+                for (uint32_t r = 0; r < 4; ++r)
+                    if (__ballot(in0 && (lane & 3u) == r) && !__ballot(in0 && !ok0 && (lane & 3u) == r)) cons |= 1u << r;
+            }
             if (cons && !(cons & (cons - 1))) hyp = (uint32_t)__ffs(cons) - 1;
-            // ... under which the rest of the tile is checked, one lane per RECORD (a 16 KiB tile of 150 bp reads: 34 lanes, one
-            // trip — the windows of the three other alignments, three quarters of the work, decide nothing once one is singled
-            // out: k_emit_fast holds the tile's alignment against the true line index anyway)
+            // ... under which the whole tile is checked, one lane per RECORD (a 16 KiB tile of 150 bp reads: 49 lanes, one trip;
+            // the windows of the three other alignments — three quarters of the work until round 3 — decide nothing: the tile's
+            // records are valid if they are valid under the TRUE alignment, and k_emit_fast holds the tile's against the true
+            // line index; a tile that guesses wrong fails there and the scan reruns on the exact path)
             if (hyp < 4) {
                 bool bad = false;
-                for (uint32_t i = 64 + hyp + 4 * lane; i + 4 < run; i += 256) bad = bad || !window_ok(i);
+                for (uint32_t i = hyp + 4 * lane; i + 4 < run; i += 256) bad = bad || !window_ok(i);
                 if (__ballot(bad) != 0) hyp = 7;
             }
         }

@@ -282,6 +282,15 @@ def main():
     }
 
     out["placement"] = ctx.placement()   # FQH_OPT_PLACE_TRIES (FQH_BENCH_PLACE_TRIES here; default 0 = no search)
+    if world == 1:
+        # what the last timed step left in the caller's array: record k of the synthetic file starts at 330 k (every record of
+        # fqh_synth_fill is RECLEN bytes), so the offsets' sum is known in closed form — a figure outside the library's own
+        # summary that says the scan wrote what it says it wrote
+        got = int(rec_start[:total_records].sum().item())
+        exp = RECLEN * total_records * (total_records - 1) // 2
+        assert got == exp, ("rec_start checksum", got, exp)
+        out["rec_start_checksum"] = {"sum_of_offsets": got, "expected": exp, "records": total_records,
+                                     "rule": "record k starts at byte %d k" % RECLEN}
     if rank == 0 and world == 1:
         t = ctx.timing()
         out["stage_ms"] = {"index": round(t.index_ms, 4), "prefix": round(t.prefix_ms, 4),

@@ -561,6 +561,37 @@ def test_sharded_histograms_with_tail_exchange(fqref, torch, pkg, seed):
     assert np.array_equal(gb.cpu().numpy().astype(np.uint64).reshape(lmax, 8), bh)
 
 
+@pytest.mark.parametrize("shape", ["plain_sep", "id_sep"])
+def test_fast_path_alignment_from_the_first_entries(fqref, torch, pkg, shape):
+    """k_index_fast takes a tile's alignment from its first four entries (the one that starts with '@' and has a '+' two
+    entries on) and checks the tile's records under it.  Every record here has a quality line that starts with '@' and a
+    sequence line that starts with '+' — the parser looks at neither (src/records.rs:141,155 test the header's and the
+    separator's first byte only) — so the first entries offer two candidates in half of the tiles: `plain_sep` must fall back
+    to the windows under all four alignments and KEEP the fast path; `id_sep` repeats the id behind the '+', which makes the
+    wrong alignment consistent as well ('@id' and '+id' have one length): the tile cannot be settled, the scan reruns on
+    the exact path.  Offsets and counts equal the oracle's either way."""
+    rng = np.random.default_rng(31)
+    recs = []
+    for i in range(6000):
+        n = int(rng.integers(60, 160))
+        seq = b"+" + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n - 1).tolist())
+        qual = b"@" + bytes(rng.integers(33, 75, n - 1).astype(np.uint8).tolist())
+        rid = b"r%d" % i
+        recs.append(b"@" + rid + b"\n" + seq + b"\n+" + (rid if shape == "id_sep" else b"") + b"\n" + qual + b"\n")
+    data = b"".join(recs)
+    dev = torch.device("cuda:0")
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    d = torch.empty(len(data) + 16, dtype=torch.uint8, device=dev)
+    d[: len(data)].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()))
+    rs = torch.zeros(len(recs) + 1, dtype=torch.int64, device=dev)
+    s, c, st = ctx.scan(d.data_ptr(), len(data), True, None, rs.data_ptr(), len(recs) + 1)
+    res, idx = fqref.index(data)
+    assert (s.parse_status, s.n_records) == (res.status, res.n_records) == (fqref.OK, len(recs))
+    assert np.array_equal(rs.cpu().numpy().astype(np.uint64)[: res.n_records], idx[:, 0])
+    assert ctx.last_scan_fast() == (shape == "plain_sep")
+    ctx.close()
+
+
 def test_fast_path_is_taken_and_falls_back_exactly(fqref, torch, pkg):
     """The fast path (record starts + tile edges only) must (a) really run on valid
     multi-tile input and (b) hand every input it cannot prove valid to the exact path: same status,

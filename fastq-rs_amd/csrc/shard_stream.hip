@@ -96,6 +96,21 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
             return FQH_E_IO;
         }
         const bool prev_nl = hostw[0] == '\n';
+        bool any_line_start = false;  // (a line starts at lo + i iff the byte in front of it is a newline)
+        for (uint64_t i = 0; i < w && !any_line_start; ++i) any_line_start = hostw[i] == '\n';
+        if (!any_line_start && w == hi - lo) {
+            // not one line starts inside the range, so no record does: it lies inside one line of one record, and there is no
+            // line phase to settle — the record in progress runs through this rank (FQH_SHARD_PASS, below)
+            if (w > tail_cap || !h_tail) {
+                ctx->err = "fqh_shard_stream_run: tail_cap is smaller than a byte range that holds no record start";
+                return FQH_E_CAPACITY;
+            }
+            memcpy(h_tail, hostw.data() + 1, w);
+            res->tail_len = w;
+            res->phase = FQH_SHARD_PASS;
+            for (uint64_t i = 0; i < w; ++i) res->n_newlines += hostw[1 + i] == '\n';
+            return FQH_OK;
+        }
         DevBuf win(ctx);
         fqh_status st = win.alloc(w + 16);
         if (st != FQH_OK) return st;
@@ -119,6 +134,22 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
         }
         if (st != FQH_OK) return st;
         res->phase = phase;
+        if (R >= hi - lo) {
+            // no record starts inside the range (it lies inside one record, or ends exactly where the next one begins): the
+            // record in progress runs THROUGH this rank.  All of its bytes are handed on as its tail; the stitch in front of the
+            // next rank that holds a record start (or the end of the file) is parsed across it.  The phase a few bytes settle on
+            // means nothing and is not looked at.
+            const uint64_t n = hi - lo;
+            if (n > tail_cap || !h_tail) {
+                ctx->err = "fqh_shard_stream_run: tail_cap is smaller than a byte range that holds no record start";
+                return FQH_E_CAPACITY;
+            }
+            memcpy(h_tail, hostw.data() + 1, n);
+            res->tail_len = n;
+            res->phase = FQH_SHARD_PASS;
+            for (uint64_t i = 0; i < n; ++i) res->n_newlines += hostw[1 + i] == '\n';
+            return FQH_OK;
+        }
         if (R > head_cap || (R && !h_head)) {
             ctx->err = "fqh_shard_stream_run: head_cap is smaller than the shard's head";
             return FQH_E_CAPACITY;
@@ -206,10 +237,17 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, co
     const uint64_t *mine = h_all_words + (size_t)rank * FQH_SHARD_STREAM_WORDS;
     auto W = [&](int j) { return h_all_words + (size_t)j * FQH_SHARD_STREAM_WORDS; };
     auto empty = [&](int j) { return W(j)[3] == FQH_SHARD_EMPTY; };
-    auto prev_of = [&](int j) {  // the nearest rank in front of j that holds bytes (-1: none): the cut between the two is ONE cut
+    auto pass = [&](int j) { return W(j)[3] == FQH_SHARD_PASS; };   // bytes, but no record start: the stitch runs across it
+    auto prev_of = [&](int j) {  // the nearest rank in front of j that holds a record start (-1: none)
         int p = j - 1;
-        while (p >= 0 && empty(p)) --p;
+        while (p >= 0 && (empty(p) || pass(p))) --p;
         return p;
+    };
+    auto carried = [&](int p, int j) {  // bytes that reach rank j from the ranks in front of it: rank p's tail + every rank passed through
+        uint64_t n = p >= 0 ? W(p)[5] : 0;
+        for (int q = p + 1; q < j; ++q)
+            if (pass(q)) n += W(q)[5];
+        return n;
     };
     // ---- what lies in front of this rank: true newline count, records (the streamed ones and one per non-empty stitch)
     uint64_t nl_before = 0, rec_before = 0;
@@ -218,8 +256,12 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, co
     for (int j = 0; j < rank; ++j) {
         if (empty(j)) continue;
         const uint64_t *w = W(j);
+        if (pass(j)) {  // (its bytes belong to the stitch of a later rank)
+            nl_before += w[2];
+            continue;
+        }
         const int p = prev_of(j);
-        if (p >= 0 && (W(p)[5] + w[4]) != 0) ++rec_before;  // rank j's stitch
+        if (p >= 0 && (carried(p, j) + w[4]) != 0) ++rec_before;  // rank j's stitch
         if ((int32_t)w[0] != FQH_OK || (p >= 0 && (nl_before & 3) != w[3])) earlier_error = true;
         nl_before += w[2];
         rec_before += w[1];
@@ -231,15 +273,34 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, co
         out[1] = FQH_NO_ERROR_KEY;
         return FQH_OK;
     }
+    bool last_bytes = true;  // no rank behind this one holds bytes
+    for (int j = rank + 1; j < n_ranks; ++j)
+        if (!empty(j)) last_bytes = false;
+    const bool through = pass(rank);
+    if (through && !last_bytes) {  // the record in progress ends in a later rank: that one parses the stitch
+        out[0] = 0;
+        out[1] = FQH_NO_ERROR_KEY;
+        return FQH_OK;
+    }
     const int prev = prev_of(rank);
-    // ---- the record that straddles the cut in front of this rank: tail of the rank before it + own head, a file of its own
+    // ---- the record that straddles the cut(s) in front of this rank: tail of the last rank with a record start + the ranks it
+    // runs through + own head, a file of its own.  (A rank WITHOUT a record start at the end of the file parses what has reached
+    // it, itself included, as the file's end: a last record without its newline, or a truncated one.)
     if (prev >= 0) {
-        const uint64_t tl = W(prev)[5], hl = mine[4];
+        const uint64_t tl = carried(prev, rank) + (through ? mine[5] : 0), hl = through ? 0 : mine[4];
         if (tl + hl) {
-            if (!ctx || (tl && !h_all_tails) || (hl && !h_head) || tl > tail_stride) return FQH_E_ARG;
+            if (!ctx || (tl && !h_all_tails) || (hl && !h_head)) return FQH_E_ARG;
             std::vector<uint8_t> file(tl + hl);
-            if (tl) memcpy(file.data(), h_all_tails + (size_t)prev * tail_stride, tl);
-            if (hl) memcpy(file.data() + tl, h_head, hl);
+            uint64_t at = 0;
+            for (int q = prev; q <= rank; ++q) {
+                if (q != prev && !pass(q)) continue;
+                if (q == rank && !through) continue;
+                const uint64_t n = W(q)[5];
+                if (n > tail_stride) return FQH_E_ARG;
+                if (n) memcpy(file.data() + at, h_all_tails + (size_t)q * tail_stride, n);
+                at += n;
+            }
+            if (hl) memcpy(file.data() + at, h_head, hl);
             DevBuf d(ctx);
             fqh_status st = d.alloc(tl + hl + 16);
             if (st != FQH_OK) return st;
@@ -253,6 +314,11 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, co
             else if (s.n_records != 1) key = pack_key(rec_before + s.n_records, FQH_E_TRUNCATED);  // (a tail + head of one record: cannot happen)
             records += s.n_records;
         }
+    }
+    if (through) {  // (nothing of its own behind the stitch)
+        out[0] = records;
+        out[1] = earlier_error ? FQH_NO_ERROR_KEY : key;
+        return FQH_OK;
     }
     // ---- the phase this rank parsed under against the true one
     if (key == FQH_NO_ERROR_KEY && prev >= 0 && (int32_t)mine[0] == FQH_OK && (nl_before & 3) != mine[3])

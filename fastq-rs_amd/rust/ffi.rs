@@ -51,6 +51,8 @@ pub const FQH_OPT_FAST_PATH: c_int = 1;
 pub const FQH_OPT_SINGLE_PASS: c_int = 2;
 pub const FQH_OPT_PLACE_TRIES: c_int = 3;
 pub const FQH_SHARD_WORDS: usize = 8;
+pub const FQH_SHARD_EMPTY: u32 = 0xFFFF_FFFF;  // fqh_shard_result.phase of an empty byte range
+pub const FQH_SHARD_PASS: u32 = 0xFFFF_FFFE;   // ... of a byte range without a record start: its bytes are its tail
 pub const FQH_E_AGAIN: c_int = 10;
 
 #[link(name = "fastq_hip")]

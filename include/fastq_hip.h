@@ -227,7 +227,8 @@ fqh_status fqh_sync(fqh_ctx *ctx);
  * record; both at most 2 * FQH_BUFSIZE bytes for input the reference accepts (FQH_E_CAPACITY otherwise).  A parse error
  * inside the rank's records is res->status, not the return value.  FQH_E_ARG: the byte range holds too few lines to settle its line
  * phase — several phases validate, or none does in a range shorter than FQH_BUFSIZE (it need not hold a single record start, and
- * a parse error could not be told from "too little to see"): cut less finely; an EMPTY range (lo == hi) is fine.
+ * a parse error could not be told from "too little to see"): cut less finely; an EMPTY range (lo == hi) is fine, and so is a range
+ * without a single record start (FQH_SHARD_PASS: the record in progress runs through it).
  *
  * Then ONE exchange: fqh_shard_result_words(res) (FQH_SHARD_STREAM_WORDS words) and the tail bytes of every rank, all-gathered
  * in rank order (fqh_allgather or the host's own collective; tail_stride bytes per rank).
@@ -252,6 +253,8 @@ typedef struct {
 #define FQH_SHARD_STREAM_WORDS 8
 #define FQH_NO_ERROR_KEY UINT64_MAX
 #define FQH_SHARD_EMPTY 0xFFFFFFFFu /* fqh_shard_result.phase of an empty byte range (lo == hi): its neighbours stitch across it */
+#define FQH_SHARD_PASS 0xFFFFFFFEu  /* ... of a byte range that holds NO record start (it lies inside one record): all of its bytes are its
+                                      tail, no head; the stitch of the next rank with a record start (or the file's end) runs across it */
 fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t lo, uint64_t hi, uint64_t file_len,
                                 uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist,
                                 uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res, uint8_t *h_head,

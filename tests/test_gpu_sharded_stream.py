@@ -147,16 +147,19 @@ def test_bench_sharded_streamed_three_ranks_one_gpu():
 
 
 def test_a_byte_range_too_small_to_settle_its_phase_is_refused(env):
-    """A shard of a few bytes inside one record gives the alignment step nothing to tell the line phases apart: the call is
-    refused (FQH_E_ARG), the file is not mis-parsed; an EMPTY range is fine."""
+    """A shard of a few LINES gives the alignment step too little to tell the line phases apart: the call is refused (FQH_E_ARG),
+    the file is not mis-parsed.  A range without a single line start needs no phase (it is stitched across, next test), and an
+    EMPTY range is fine."""
     torch, pkg, sharded = env
     rng = np.random.default_rng(5)
     data = fuzzgen.valid_file(rng, 4000, maxlen=100, seqlen=100, crlf=False)
-    k = data.index(b"\n+\n", len(data) // 2) + 10          # well inside a quality line: no newline within [k, k + 4)
-    with pytest.raises(pkg.FqhError) as ei:
-        run_sharded(env, data, [k, k + 4], 100)
+    k = data.index(b"\n+\n", len(data) // 2)                # the end of a sequence line: [k - 4, k + 8) holds the separator
+    with pytest.raises(pkg.FqhError) as ei:                 # line and the starts of two more lines, and nothing to tell a
+        run_sharded(env, data, [k - 4, k + 8], 100)         # separator from a header by
     assert ei.value.status == pkg.E_ARG
     r = __import__("oracle.fqref", fromlist=["x"]).count(data)
+    status, n_records, hist, shards = run_sharded(env, data, [k + 10, k + 14], 100)   # four bytes inside the quality line
+    assert (status, n_records) == (r.status, r.n_records)
     status, n_records, hist, shards = run_sharded(env, data, [k, k], 100)   # (an empty range between two shards)
     assert (status, n_records) == (r.status, r.n_records)
 
@@ -198,6 +201,40 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
                 assert (status, n_records) == (r.status, r.n_records), (seed, cases, cuts, (status, n_records), (r.status, r.n_records))
         cases += 1
     return cases, errs
+
+
+@pytest.mark.parametrize("shape", ["inside", "to_boundary", "two_in_a_row", "last_truncated", "last_no_newline"])
+def test_byte_ranges_without_a_record_start_are_stitched_across(env, fqref, shape):
+    """A byte range that lies inside ONE record holds no record start (FQH_SHARD_PASS): all of its bytes are its tail, and the
+    stitch of the next rank with a record start — or the end of the file — is parsed across it.  (tools/fuzz_sharded.py, seed
+    311: two cuts sixteen bytes apart gave 'truncated' for a valid file before.)  Against the oracle over the whole file."""
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(5)
+    data = fuzzgen.valid_file(rng, 3000, seqlen=150, crlf=False)
+    k = data.index(b"\n@", len(data) // 2) + 1            # a record start in the middle of the file
+    rec_end = data.index(b"\n@", k + 1) + 1                # ... and the next one
+    if shape == "inside":
+        cuts = [k + 40, k + 56]                            # sixteen bytes inside the sequence line
+    elif shape == "to_boundary":
+        cuts = [k + 40, rec_end]                           # the range ends exactly where the next record begins
+    elif shape == "two_in_a_row":
+        cuts = [k + 30, k + 50, k + 70]                    # two ranges in a row inside one line of one record
+    elif shape == "last_truncated":
+        data = data[: k + 100]                             # the file ends inside the sequence line of its last record ...
+        cuts = [k - 400, k + 40]                           # ... and the last byte range lies inside that line
+    else:
+        data = data[: rec_end - 1]                         # the file's last record lacks its '\n' ...
+        cuts = [k - 400, rec_end - 50]                     # ... and the last byte range lies inside its quality line
+    status, n_records, hist, shards = run_sharded(env, data, cuts, 150)
+    r, oq, ob, osc = fqref.stats(data, 150)
+    assert (status, n_records) == (r.status, r.n_records), (shape, status, n_records, r.status, r.n_records)
+    assert any(sh.res.phase == 0xFFFFFFFE for sh in shards), [sh.res.phase for sh in shards]
+    if r.status == pkg.OK:
+        assert np.array_equal(hist[:8], osc)
+        assert np.array_equal(hist[8: 8 + 150 * 256].reshape(150, 256), oq)
+        assert np.array_equal(hist[8 + 150 * 256:].reshape(150, 8), ob)
+    else:   # (the oracle's verdict on a last record without its newline is the reference's: src/lib.rs:264-294)
+        assert shape in ("last_truncated", "last_no_newline")
 
 
 @pytest.mark.parametrize("seed", [1, 2])

@@ -111,13 +111,32 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
             for (uint64_t i = 0; i < w; ++i) res->n_newlines += hostw[1 + i] == '\n';
             return FQH_OK;
         }
-        DevBuf win(ctx);
-        fqh_status st = win.alloc(w + 16);
-        if (st != FQH_OK) return st;
-        st = fqh_memcpy_h2d(ctx, win.p, hostw.data() + 1, w);
-        if (st != FQH_OK) return st;
         uint32_t phase = 0;
-        st = fqh_shard_align(ctx, (const uint8_t *)win.p, w, prev_nl ? 1 : 0, &phase, &R);
+        auto align_on = [&](uint64_t wn) -> fqh_status {  // line phase and first record start from the wn bytes at lo
+            DevBuf win(ctx);
+            fqh_status e = win.alloc(wn + 16);
+            if (e != FQH_OK) return e;
+            e = fqh_memcpy_h2d(ctx, win.p, hostw.data() + 1, wn);
+            if (e != FQH_OK) return e;
+            return fqh_shard_align(ctx, (const uint8_t *)win.p, wn, prev_nl ? 1 : 0, &phase, &R);
+        };
+        fqh_status st = align_on(w);
+        const bool unsettled = st == FQH_E_ARG || (st == FQH_E_HEADER && hi - lo < FQH_BUFSIZE);
+        if (unsettled && hi < file_len && std::min<uint64_t>(ALIGN_WINDOW, file_len - lo) > w) {
+            // too few lines in the range itself to tell the line phases apart: look at what FOLLOWS it in the file as well (the
+            // window only settles the phase and finds the first record start — which may lie behind the range: it then holds none,
+            // FQH_SHARD_PASS below; an error in there is the business of the rank whose range it lies in).  Only a phase that
+            // stands out is taken; anything else is refused as before.
+            const uint64_t w2 = std::min<uint64_t>(ALIGN_WINDOW, file_len - lo);
+            hostw.resize(w2 + 1);
+            if (read(user, hostw.data(), lo - 1, w2 + 1) != 0) {
+                ctx->err = "fqh_shard_stream_run: the read callback failed";
+                return FQH_E_IO;
+            }
+            const fqh_status st2 = align_on(w2);
+            if (st2 == FQH_OK) st = st2;
+            else if (st2 != FQH_E_ARG && st2 != FQH_E_HEADER) return st2;
+        }
         if (st == FQH_E_ARG || (st == FQH_E_HEADER && hi - lo < FQH_BUFSIZE)) {
             // several line phases validate, or none does in a range that need not even hold one record start (the reference
             // accepts records of up to BUFSIZE bytes): too few lines to tell, and a parse error could not be told from "too

@@ -225,10 +225,11 @@ fqh_status fqh_sync(fqh_ctx *ctx);
  * every record the rank delivers is added to the histograms (as fqh_stats).  *res: the rank's summary; h_head receives the
  * bytes [lo, lo + R) (the end of the record the previous rank began), h_tail what is left behind the rank's last complete
  * record; both at most 2 * FQH_BUFSIZE bytes for input the reference accepts (FQH_E_CAPACITY otherwise).  A parse error
- * inside the rank's records is res->status, not the return value.  FQH_E_ARG: the byte range holds too few lines to settle its line
- * phase — several phases validate, or none does in a range shorter than FQH_BUFSIZE (it need not hold a single record start, and
- * a parse error could not be told from "too little to see"): cut less finely; an EMPTY range (lo == hi) is fine, and so is a range
- * without a single record start (FQH_SHARD_PASS: the record in progress runs through it).
+ * inside the rank's records is res->status, not the return value.  A byte range of a few lines that cannot tell the line phases
+ * apart by itself is settled with the bytes that FOLLOW it in the file (the read callback is asked for up to 4 MiB from lo); an
+ * EMPTY range (lo == hi) is fine, and so is a range without a single record start (FQH_SHARD_PASS: the record in progress runs
+ * through it).  FQH_E_ARG is left for a range at the very end of the file whose few lines fit several phases, or none (a parse
+ * error could not be told from "too little to see").
  *
  * Then ONE exchange: fqh_shard_result_words(res) (FQH_SHARD_STREAM_WORDS words) and the tail bytes of every rank, all-gathered
  * in rank order (fqh_allgather or the host's own collective; tail_stride bytes per rank).

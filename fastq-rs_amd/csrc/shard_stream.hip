@@ -120,23 +120,24 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
             if (e != FQH_OK) return e;
             return fqh_shard_align(ctx, (const uint8_t *)win.p, wn, prev_nl ? 1 : 0, &phase, &R);
         };
-        fqh_status st = align_on(w);
-        const bool unsettled = st == FQH_E_ARG || (st == FQH_E_HEADER && hi - lo < FQH_BUFSIZE);
-        if (unsettled && hi < file_len && std::min<uint64_t>(ALIGN_WINDOW, file_len - lo) > w) {
-            // too few lines in the range itself to tell the line phases apart: look at what FOLLOWS it in the file as well (the
-            // window only settles the phase and finds the first record start — which may lie behind the range: it then holds none,
-            // FQH_SHARD_PASS below; an error in there is the business of the rank whose range it lies in).  Only a phase that
-            // stands out is taken; anything else is refused as before.
-            const uint64_t w2 = std::min<uint64_t>(ALIGN_WINDOW, file_len - lo);
+        // The window only settles the phase and finds the first record start, so it may reach BEHIND the range: a few lines
+        // settle nothing — worse, the phase that "gets furthest" in them can be the wrong one (a quality line that starts with
+        // '@' right behind the cut looks like a header: tools/fuzz_sharded.py with cuts close together) — while up to 4 MiB of
+        // the file behind lo do, whatever the range's own size.  The first record start may then lie behind the range: it holds
+        // none (FQH_SHARD_PASS below).  If the long window holds a parse error and no phase stands out, the error may lie in a
+        // later rank's bytes: the range's own bytes decide then, as before.
+        const uint64_t w2 = std::min<uint64_t>(ALIGN_WINDOW, file_len - lo);
+        fqh_status st = FQH_E_ARG;
+        if (w2 > w) {
             hostw.resize(w2 + 1);
             if (read(user, hostw.data(), lo - 1, w2 + 1) != 0) {
                 ctx->err = "fqh_shard_stream_run: the read callback failed";
                 return FQH_E_IO;
             }
-            const fqh_status st2 = align_on(w2);
-            if (st2 == FQH_OK) st = st2;
-            else if (st2 != FQH_E_ARG && st2 != FQH_E_HEADER) return st2;
+            st = align_on(w2);
+            if (st != FQH_OK && st != FQH_E_ARG && st != FQH_E_HEADER) return st;
         }
+        if (st != FQH_OK) st = align_on(w);
         if (st == FQH_E_ARG || (st == FQH_E_HEADER && hi - lo < FQH_BUFSIZE)) {
             // several line phases validate, or none does in a range that need not even hold one record start (the reference
             // accepts records of up to BUFSIZE bytes): too few lines to tell, and a parse error could not be told from "too

@@ -189,6 +189,13 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
         n = len(data)
         k = int(rng.integers(1, 5))
         cuts = sorted(set(int(x) for x in rng.integers(1, n, k)))
+        if rng.random() < 0.3:    # two cuts close together: a byte range of a few bytes to a few lines
+            c0 = cuts[int(rng.integers(0, len(cuts)))]
+            cuts = sorted(set(cuts + [min(n - 1, c0 + int(rng.integers(1, 400)))]))
+        if rng.random() < 0.2:    # a cut right behind a newline
+            j = data.find(b"\n", cuts[0])
+            if 0 < j + 1 < n:
+                cuts = sorted(set(cuts + [j + 1]))
         lmax = 150
         try:
             status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=int(rng.choice([1 << 16, 1 << 18, 1 << 20])))

@@ -25,6 +25,13 @@ while time.time() < t_end:
     n = len(data)
     k = int(rng.integers(1, 5))
     cuts = sorted(set(int(x) for x in rng.integers(1, n, k)))
+    if rng.random() < 0.3:    # (as fuzz_sharded: two cuts close together, a cut right behind a newline)
+        c0 = cuts[int(rng.integers(0, len(cuts)))]
+        cuts = sorted(set(cuts + [min(n - 1, c0 + int(rng.integers(1, 400)))]))
+    if rng.random() < 0.2:
+        j = data.find(b"\n", cuts[0])
+        if 0 < j + 1 < n:
+            cuts = sorted(set(cuts + [j + 1]))
     slot = int(rng.choice([1 << 16, 1 << 18, 1 << 20]))
     try:
         status, n_records, hist, shards = run_sharded(env, data, cuts, 150, slot_bytes=slot)
@@ -32,10 +39,16 @@ while time.time() < t_end:
         continue
     r, oq, ob, osc = fqref.stats(data, 150)
     bad = (r.status == pkg.OK and (status, n_records) != (pkg.OK, r.n_records))
+    window_error = any(sh.res.status == pkg.E_HEADER and sh.res.n_records == 0 and sh.lo > 0 for sh in shards)
+    bad = bad or (r.status != pkg.OK and not window_error and (status, n_records) != (r.status, r.n_records))
     if bad:
         os.makedirs("gpurun_out", exist_ok=True)
         np.savez("gpurun_out/repro_sharded_%d.npz" % seed, data=np.frombuffer(data, dtype=np.uint8), cuts=np.array(cuts), slot=slot)
         print("FAIL case %d: n=%d cuts=%s slot=%d -> status %d records %d, oracle %d %d" % (cases, n, cuts, slot, status, n_records, r.status, r.n_records))
+        bnd = [0] + cuts + [n]
+        for a_, b_ in zip(bnd[:-1], bnd[1:]):
+            if b_ - a_ < 600:
+                print("  range [%d, %d): %r" % (a_, b_, data[max(0, a_ - 40): b_ + 40]))
         for sh in shards:
             print("  shard lo=%d hi=%d: status %d records %d head %d tail %d words %s" % (sh.lo, sh.hi, sh.res.status, sh.res.n_records, len(sh.head), len(sh.tail), list(sh.words())))
         break

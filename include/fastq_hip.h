@@ -240,7 +240,9 @@ fqh_status fqh_sync(fqh_ctx *ctx);
  * FQH_NO_ERROR_KEY.  One SUM of [out[0], scalars, histograms] (fqh_allreduce_u64) and one MIN of out[1]
  * (fqh_allreduce_min_u64) give every rank the totals, or — fqh_error_key_unpack — the status and record index of the first
  * error in FILE order: the error Parser::each returns for the same bytes (an error inside a rank's 4 MiB alignment window
- * that leaves no phase standing out is reported at that shard's start). */
+ * that leaves no phase standing out is reported at that shard's start; the KIND of an error in a record that straddles a cut
+ * can be FQH_E_TRUNCATED / FQH_E_HEADER where the sequential parser, reading on into the next rank's bytes, names another —
+ * the record index is exact). */
 typedef int (*fqh_read_fn)(void *user, uint8_t *h_dst, uint64_t file_offset, uint64_t nbytes);
 typedef struct {
     int32_t status;      /* first parse error among the rank's own records (FQH_OK: none)        */

@@ -211,7 +211,13 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
             errs += 1
             assert status != pkg.OK, (seed, cases, cuts)
             if not window_error:  # (an error inside a shard's alignment window is reported at the shard's start)
-                assert (status, n_records) == (r.status, r.n_records), (seed, cases, cuts, (status, n_records), (r.status, r.n_records))
+                # the first failing record is the oracle's; so is the kind of the error, unless the record straddles a cut:
+                # the stitch holds that record's bytes only up to the next rank's first record start as THAT rank settled it, so
+                # a damaged record that swallows a line (its '\n' gone) is incomplete there (TRUNCATED), or shows as the next
+                # rank's line phase not fitting the newlines in front of it (HEADER) — where the sequential parser reads on into
+                # the next record and names another kind (tools/fuzz_sharded.py seed 341: "+\r" instead of "+\n")
+                assert n_records == r.n_records, (seed, cases, cuts, (status, n_records), (r.status, r.n_records))
+                assert status == r.status or status in (pkg.E_TRUNCATED, pkg.E_HEADER), (seed, cases, cuts, status, r.status)
         cases += 1
     return cases, errs
 

@@ -601,8 +601,9 @@ def numa_pin(torch, dev_index):
 def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     """configs[4]: byte-range sharded AND host-streamed.  The file is the endless repetition of one pinned block (a slot's
     worth of synthetic records), cut at multiples of a shard size that is NOT a multiple of the record size: every cut
-    falls inside a record.  Each rank streams its range phase-free (fastq-rs_amd/sharded.py), then: one all_gather of 8
-    words + the tail bytes per rank, the phase check, the one-record stitch, one all_reduce of counts + histograms."""
+    falls inside a record.  Each rank streams its range phase-free (fastq-rs_amd/sharded.py), then: one all_gather of ten
+    words per rank, the true-phase check, the record that straddles each cut parsed by the rank it ends in (through that rank's
+    own read callback), one all_reduce SUM of per-rank record slots + histograms and one MIN of the first-error keys."""
     import ctypes as C
     import importlib
     import numpy as np
@@ -635,7 +636,6 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
 
     hist = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
     sc, qh, bh = hist[:8], hist[8: 8 + LMAX * 256], hist[8 + LMAX * 256:]
-    TAILCAP = 2 * pkg.BUFSIZE
     xdev = dev if backend == "nccl" else torch.device("cpu")
 
     def barrier():
@@ -645,27 +645,28 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     barrier()
     t0 = time.perf_counter()
     stats = (LMAX, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
-    sh = sharded.stream_shard(ctx, read_into, lo, hi, file_len, blk, stats=stats)     # fqh_shard_stream_run
+    sh = sharded.stream_shard(ctx, read_into, lo, hi, file_len, blk, stats=stats)     # fqh_shard_stream_run (a failure goes into the words)
     t_stream = time.perf_counter() - t0
-    # ---- the one exchange: 8 words + the tail bytes of every rank
-    mine = np.zeros(64 + TAILCAP, dtype=np.uint8)
-    mine[:64] = np.array(sh.words(), dtype=np.uint64).view(np.uint8)
-    assert len(sh.tail) <= TAILCAP
-    mine[64: 64 + len(sh.tail)] = np.frombuffer(sh.tail, dtype=np.uint8)
-    t_in = torch.from_numpy(mine).to(xdev)
-    t_all = torch.empty(world * mine.size, dtype=torch.uint8, device=xdev)
+    # ---- the one exchange: FQH_SHARD_STREAM_WORDS words of every rank (bytes of another rank's range, where a rank needs
+    # them, come through its own read callback)
+    NW = pkg.SHARD_STREAM_WORDS
+    t_in = torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in sh.words()], dtype=torch.int64).to(xdev)
+    t_all = torch.empty(world * NW, dtype=torch.int64, device=xdev)
     dist.all_gather_into_tensor(t_all, t_in)
-    rows = t_all.cpu().numpy().reshape(world, mine.size)
-    words = [[int(x) for x in rows[r, :64].view(np.uint64)] for r in range(world)]
-    tails = [rows[r, 64: 64 + words[r][5]].tobytes() for r in range(world)]
-    # ---- phase check + one-record stitch + this rank's first-error key (fqh_shard_stream_finish), then SUM and MIN
-    rec, key = sharded.finish(ctx, words, tails, rank, sh.head, stats=stats)
-    both = torch.cat([torch.tensor([rec], dtype=torch.int64, device=dev), hist]).to(xdev)
+    words = [[int(x) & ((1 << 64) - 1) for x in row] for row in t_all.cpu().numpy().reshape(world, NW)]
+    # ---- true-phase check + the gap in front of this rank + its first-error key (fqh_shard_stream_finish), then SUM and MIN
+    t1 = time.perf_counter()
+    rec, key = sharded.finish(ctx, read_into, file_len, words, rank, blk, stats=stats)
+    t_finish = time.perf_counter() - t1
+    slots = torch.zeros(world, dtype=torch.int64, device=dev)
+    slots[rank] = rec
+    both = torch.cat([slots, hist]).to(xdev)
     dist.all_reduce(both)
     kt = torch.tensor([key - (1 << 63)], dtype=torch.int64, device=xdev)   # (order-preserving map of the u64 key into torch's i64)
     dist.all_reduce(kt, op=dist.ReduceOp.MIN)
     gkey = int(kt.item()) + (1 << 63)
-    g_status, g_err_record = pkg.error_key_unpack(gkey)
+    tot = both.cpu().numpy()
+    g_status, g_records, g_err_offset = sharded.outcome([int(x) for x in tot[:world]], gkey)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt, t_stream], dtype=torch.float64, device=xdev)
@@ -674,8 +675,7 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     rates = torch.zeros(world, dtype=torch.float64, device=xdev)
     rates[rank] = (hi - lo) / 1e9 / t_stream
     dist.all_reduce(rates)
-    bad = [] if g_status == pkg.OK else [(g_status, g_err_record)]
-    tot = both.cpu().numpy()
+    bad = [] if g_status == pkg.OK else [(g_status, g_records, g_err_offset)]
     # ---- what the totals must be: the block's own histograms, times the repetitions, plus the last partial block
     reps, rem = divmod(file_len, blk)
     exp = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
@@ -685,7 +685,7 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     if rem:
         ctx.stats(d_blk.data_ptr(), rem, LMAX, exp[8: 8 + LMAX * 256].data_ptr(), exp[8 + LMAX * 256:].data_ptr(), exp[:8].data_ptr())
     exp = exp.cpu().numpy()
-    ok_hist = bool((tot[1:] == exp).all())
+    ok_hist = bool((tot[world:] == exp).all())
     if rank == 0:
         print(json.dumps({
             "mode": "sharded-stream",
@@ -696,11 +696,12 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
             "n_gpus": world, "backend": backend, "bytes_per_gpu": shard, "seconds": round(dt, 4),
             "gbs_pcie_inclusive_aggregate": round(file_len / 1e9 / dt, 2),
             "gbs_per_rank_streaming": [round(float(x), 2) for x in rates.cpu().numpy()],
-            "records": int(tot[0]), "records_per_s": round(int(tot[0]) / dt, 1), "numa_node_rank0": node,
+            "records": int(g_records), "records_per_s": round(int(g_records) / dt, 1), "numa_node_rank0": node,
+            "finish_seconds_rank0": round(t_finish, 4),
             "check": {"records_expected": file_len // RECLEN, "first_error_key": None if g_status == pkg.OK else gkey,
                       "phases_ok": not bad, "histograms_ok": ok_hist}}), flush=True)
     assert not bad, bad
-    assert int(tot[0]) == file_len // RECLEN, (tot[:1], file_len // RECLEN)
+    assert int(g_records) == file_len // RECLEN, (g_records, file_len // RECLEN)
     assert ok_hist
     ctx.close()
 

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (FQH_LIB_PATH: a tuning build of the same library, tools/exp_fztime.sh; never a fallback)
 LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.so")
 
-__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "error_key_unpack", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
+__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "shard_stream_outcome", "shard_failed_words", "shard_failure_key", "SHARD_EMPTY", "SHARD_PASS", "SHARD_DEFER", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
            "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "OPT_REUSE_INDEX", "EXPORTS"]
 
@@ -26,7 +26,8 @@ EXPORTS = [
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
     "fqh_stream_collect", "fqh_stream_release", "fqh_stream_timing", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
     "fqh_allreduce_u64", "fqh_allreduce_min_u64", "fqh_sync", "fqh_shard_stream_run", "fqh_shard_result_words",
-    "fqh_shard_stream_finish", "fqh_error_key_unpack", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
+    "fqh_shard_failed_words", "fqh_shard_failure_key",
+    "fqh_shard_stream_finish", "fqh_shard_stream_outcome", "fqh_stream_set_origin", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset",
 ]
 
@@ -64,11 +65,12 @@ class Chunk(C.Structure):
 class ShardResult(C.Structure):
     """fqh_shard_result: what one rank of the sharded, host-streamed mode found in its byte range."""
     _fields_ = [("status", C.c_int32), ("phase", C.c_uint32), ("n_records", C.c_uint64), ("n_newlines", C.c_uint64),
-                ("err_record", C.c_uint64), ("err_offset", C.c_uint64), ("head_len", C.c_uint64), ("tail_len", C.c_uint64)]
+                ("err_offset", C.c_uint64), ("head_len", C.c_uint64), ("tail_len", C.c_uint64), ("flags", C.c_uint64)]
 
 
 READ_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64)   # fqh_read_fn
-SHARD_STREAM_WORDS = 8
+SHARD_STREAM_WORDS = 10
+SHARD_EMPTY, SHARD_PASS, SHARD_DEFER = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFD
 NO_ERROR_KEY = (1 << 64) - 1
 STREAM_INDEX = 1
 STREAM_STATS = 2
@@ -162,12 +164,16 @@ def lib():
         L.fqh_allgather.argtypes = [vp, vp, vp, vp, u64]
         L.fqh_allreduce_u64.argtypes = [vp, vp, vp, u64]
         L.fqh_allreduce_min_u64.argtypes = [vp, vp, vp, u64]
-        L.fqh_shard_stream_run.argtypes = [vp, READ_FN, vp, u64, u64, u64, u64, u32, u32, vp, vp, vp, C.POINTER(ShardResult),
-                                           vp, u64, vp, u64]
-        L.fqh_shard_result_words.argtypes = [C.POINTER(ShardResult), C.POINTER(u64 * 8)]
+        L.fqh_shard_stream_run.argtypes = [vp, READ_FN, vp, u64, u64, u64, u64, u32, u32, vp, vp, vp, C.POINTER(ShardResult)]
+        L.fqh_shard_result_words.argtypes = [C.POINTER(ShardResult), u64, u64, C.POINTER(u64 * SHARD_STREAM_WORDS)]
         L.fqh_shard_result_words.restype = None
-        L.fqh_shard_stream_finish.argtypes = [vp, vp, vp, u64, i32, i32, vp, u32, vp, vp, vp, C.POINTER(u64 * 2)]
-        L.fqh_error_key_unpack.argtypes = [u64, C.POINTER(C.c_int32), C.POINTER(u64)]
+        L.fqh_shard_failed_words.argtypes = [i32, u64, u64, C.POINTER(u64 * SHARD_STREAM_WORDS)]
+        L.fqh_shard_failed_words.restype = None
+        L.fqh_shard_failure_key.argtypes = [i32, u64, i32]
+        L.fqh_shard_failure_key.restype = u64
+        L.fqh_shard_stream_finish.argtypes = [vp, READ_FN, vp, u64, vp, i32, i32, u64, u32, u32, vp, vp, vp, C.POINTER(u64 * 2)]
+        L.fqh_shard_stream_outcome.argtypes = [u64, vp, i32, C.POINTER(C.c_int32), C.POINTER(u64), C.POINTER(u64)]
+        L.fqh_stream_set_origin.argtypes = [vp, u64]
         L.fqh_sync.argtypes = [vp]
         L.fqh_synth_fill.argtypes = [vp, vp, u64, u64, u64]
         L.fqh_read_ceiling.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(C.c_float)]
@@ -184,11 +190,27 @@ def strerror(status):
     return lib().fqh_strerror(status).decode()
 
 
-def error_key_unpack(key):
-    """-> (status, global record index) of a packed first-error key (fqh_shard_stream_finish); (OK, 0) for NO_ERROR_KEY."""
-    st, rec = C.c_int32(), C.c_uint64()
-    lib().fqh_error_key_unpack(key, C.byref(st), C.byref(rec))
-    return st.value, rec.value
+def shard_stream_outcome(min_key, records_per_rank):
+    """The two reductions of the sharded, host-streamed mode -> Parser::each's result (fqh_shard_stream_outcome):
+    (status, records delivered before the first error — all of them when status is OK —, file offset of the failing record)."""
+    n = len(records_per_rank)
+    arr = (C.c_uint64 * n)(*[int(x) for x in records_per_rank])
+    st, rec, off = C.c_int32(), C.c_uint64(), C.c_uint64()
+    rc = lib().fqh_shard_stream_outcome(min_key, C.addressof(arr), n, C.byref(st), C.byref(rec), C.byref(off))
+    if rc != OK:
+        raise FqhError(rc, "fqh_shard_stream_outcome")
+    return st.value, rec.value, off.value
+
+
+def shard_failed_words(status, lo, hi):
+    """The words a rank sends into the exchange when its fqh_shard_stream_run failed (it must still take part)."""
+    w = (C.c_uint64 * SHARD_STREAM_WORDS)()
+    lib().fqh_shard_failed_words(status, lo, hi, C.byref(w))
+    return [int(x) for x in w]
+
+
+def shard_failure_key(rank, offset, status):
+    return int(lib().fqh_shard_failure_key(rank, offset, status))
 
 
 def carry_combine(prev, length, n_newlines, n_line_starts, back_zero_carry):

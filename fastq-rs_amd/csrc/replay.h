@@ -123,4 +123,39 @@ struct BufferReplay {
     }
 };
 
+// ---- The same rule in closed form, for RecordRefIter::advance (Parser::each) over a reader that fills every read.
+//
+// Two invariants of src/buffer.rs make the replay above unnecessary for `each` (it stays the statement of record for
+// RecordSets, whose CUTS do depend on where the refills end):
+//   (1) every read lands at a buffer offset that is a multiple of 16 (clean() / replace_buffer() round the kept bytes up to
+//       16, src/buffer.rs:33, 57) and asks for a multiple of 16 bytes (BUFSIZE - end with both multiples of 16, or a multiple
+//       of 4096, src/buffer.rs:75-80), so the file offset rd of the buffer's end is a multiple of 16 until EOF; hence a byte
+//       at file offset p sits at a buffer offset == p (mod 16);
+//   (2) after clean() the record in progress therefore starts at buffer offset fpos & 15 — moved there, or there already
+//       (`new_start >= self.start`, src/buffer.rs:60) — and the refills that follow fill the buffer to its last byte.
+// So the parser sees the record that starts at file offset fpos through the WINDOW [fpos, fpos + BUFSIZE - (fpos & 15)) and
+// reports "too long" iff from_buffer (src/records.rs:201-247) is still Incomplete on all of it: a record of L bytes iff
+// L > BUFSIZE - (fpos & 15); a record whose own error needs `need` bytes to show iff need > BUFSIZE - (fpos & 15); the
+// incomplete record at the end of the input iff at least a window of its bytes exists.  No state, hence no history: a byte
+// range of a file can be judged by itself as long as its record boundaries are TRUE file offsets (the sharded mode), and
+// nothing waits for a refill that a stream which ends at a cut would never see.  tests/replay_fuzz.cpp holds it against the
+// oracle's streaming restatement (and against the replay) at BUFSIZE 64 and 69632.
+struct TooLong {
+    static constexpr uint64_t NO_BAD = UINT64_MAX;
+    static uint64_t window(uint64_t B, uint64_t fpos) { return B - (fpos & 15); }
+    // rs[0..n]: boundaries (true file offsets) of n complete valid records; what follows rs[n]: `avail` bytes that are not a
+    // complete valid record — an invalid one whose error needs `need` bytes (0: it is only incomplete), or NO_BAD: the bytes
+    // of a record still in progress (more may follow) or nothing.  -> true and *which = index (0..n) of the first record the
+    // reference calls too long.
+    static bool first(uint64_t B, const uint64_t *rs, uint64_t n, uint64_t avail, uint64_t need, uint64_t *which) {
+        if (!B) return false;
+        for (uint64_t i = 0; i < n; ++i)
+            if (rs[i + 1] - rs[i] > window(B, rs[i])) { *which = i; return true; }
+        const uint64_t w = window(B, rs[n]);
+        const bool t = (need == NO_BAD || need == 0) ? avail >= w : need > w;
+        if (t) *which = n;
+        return t;
+    }
+};
+
 }  // namespace fqh

@@ -39,7 +39,6 @@ struct fqh_stream {
     uint64_t records_done = 0;
     bool ended = false;
     bool holds_exact = false;  // this stream keeps the context on the exact path (counted in fqh_ctx::exact_holds)
-    fqh::BufferReplay replay;
     // FQH_STREAM_TIMING: when each slot's copy (side stream) and scan (the context's stream) ran, in ms since t_base
     hipEvent_t t_base = nullptr;
     std::vector<float> iv_copy, iv_scan;  // begin, end, begin, end, ..
@@ -120,7 +119,6 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
     const uint64_t want = ctx->bufsize ? 2 * ctx->bufsize : (st->slot_bytes < (16u << 20) ? st->slot_bytes : (uint64_t)(16u << 20));
     st->reserve = ((want > two ? want : two) + 15) & ~(uint64_t)15;
     st->slots.resize(n_slots);
-    st->replay.reset(ctx->bufsize);
     if (flags & FQH_STREAM_INDEX) {  // every chunk needs complete line lists: the context stays on the exact path while any
         st->holds_exact = true;      // such stream lives (a count, not a saved flag: streams may be destroyed in any order).
         ++ctx->exact_holds;          // (FQH_STREAM_STATS alone does not: its chunks take the single pass, k_scan_stats)
@@ -323,16 +321,18 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     c.err_offset = sum.err_offset;
     c.err_need = need0;
 
-    // "Fastq record is too long": replay the reference's buffer over the boundaries seen so far
+    // "Fastq record is too long" (src/lib.rs:278-283): the reference sees the record that starts at file offset p through a window
+    // of BUFSIZE - (p & 15) bytes, whatever came before it (csrc/replay.h, fqh::TooLong: the closed form of the Buffer's
+    // arithmetic) — the boundaries are file offsets (fqh_stream_set_origin for a stream that does not begin the file), so every
+    // slot is judged by itself, the record in progress at its end included
     uint64_t which = 0;
     const bool bad_here = sum.parse_status != FQH_OK;
-    const uint64_t need = bad_here ? need0 : fqh::BufferReplay::NO_BAD;
-    if (ctx->bufsize &&
-        st->replay.step(s.h_rec, st->records_done, n, known_end, s.is_final || bad_here, need, &which)) {
+    const uint64_t need = bad_here ? need0 : fqh::TooLong::NO_BAD;
+    if (fqh::TooLong::first(ctx->bufsize, s.h_rec, n, known_end - s.h_rec[n], need, &which)) {
         c.parse_status = FQH_E_TOO_LONG;
-        c.err_record = which;
-        c.n_records = which >= st->records_done ? which - st->records_done : 0;
-        c.err_offset = s.h_rec[c.n_records];
+        c.err_record = st->records_done + which;
+        c.n_records = which;
+        c.err_offset = s.h_rec[which];
     }
     // histograms of the records this chunk delivers (the one in progress at its start included: its
     // beginning sits in front of the slot's device data)
@@ -404,6 +404,13 @@ fqh_status fqh_stream_timing(fqh_stream *st, fqh_stream_times *out) {
     out->copy_busy_ms = busy_c;
     out->scan_busy_ms = busy_k;
     out->both_busy_ms = both;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_set_origin(fqh_stream *st, uint64_t file_offset) {
+    if (!st || st->head || st->sub || st->col) return FQH_E_ARG;  // before the first acquire
+    st->carry = fqh_carry{};
+    st->carry.base_offset = file_offset;
     return FQH_OK;
 }
 

@@ -442,23 +442,29 @@ class RecordRefIter {
 // each_sharded — the byte-range sharded, host-streamed mode (BASELINE configs[4]): one process per GPU, every rank calls this
 // with the same arguments but its own rank.  The analogue of Parser::parallel_each with a histogram closure
 // (src/lib.rs:509-565): the ranks' results are gathered at the end (src/lib.rs:553-559) and a parse error — the FIRST one in
-// file order, as Parser::each meets it — is what every rank throws (src/lib.rs:544-547, 561-564).  read_at(dst, file_offset, n)
-// fills host memory (a pread, a memcpy).  d_hist: device array of 1 + 8 + lmax * 264 u64, ADDED to and summed over the ranks:
-// [records | the 8 scalars of fqh_stats | quality histogram lmax x 256 | base histogram lmax x 8].  Returns the number of
-// records of the whole file.  comm may be NULL when n_ranks == 1.  The driver itself is the library's (fqh_shard_stream_run /
-// fqh_shard_stream_finish); this is the exchange around it: one all-gather, one SUM, one MIN.
+// file order, kind and record exactly as Parser::each meets it — is what every rank throws (src/lib.rs:544-547, 561-564).
+// read_at(dst, file_offset, n) fills host memory (a pread, a memcpy).  d_hist: device array of 1 + 8 + lmax * 264 u64, this
+// rank's own, zeroed: [records | the 8 scalars of fqh_stats | quality histogram lmax x 256 | base histogram lmax x 8]; on return
+// it holds the sums over the ranks.  Returns the number of records of the whole file; *err (if given) receives status, records
+// delivered before the error and the failing record's file offset instead of a throw.  comm may be NULL when n_ranks == 1.  The
+// driver itself is the library's (fqh_shard_stream_run / fqh_shard_stream_finish / fqh_shard_stream_outcome); this is the exchange
+// around it: one all-gather, the SUMs, one MIN.  A rank whose part fails (the callback throws, a device error) still takes part
+// in every collective — the others would wait for it forever — and every rank learns of the failure from the MIN.
+struct ShardedOutcome {
+    int32_t status = FQH_OK;
+    uint64_t n_records = 0, err_offset = 0;
+};
 template <class ReadAt>
 uint64_t each_sharded(fqh_ctx *ctx, fqh_comm *comm, int n_ranks, int rank, ReadAt read_at, uint64_t file_len, uint32_t lmax,
-                      uint64_t *d_hist, Options opt = Options()) {
+                      uint64_t *d_hist, Options opt = Options(), ShardedOutcome *err = nullptr) {
     auto chk = [&](fqh_status st, const char *what) {
         if (st != FQH_OK) throw Error(ErrorKind::Other, std::string(what) + ": " + fqh_last_error(ctx));
     };
-    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !comm)) throw Error(ErrorKind::Other, "each_sharded: bad rank / communicator");
-    // byte ranges of equal size; a file too small to give every rank a megabyte goes to rank 0 as a whole (a range must hold
-    // enough lines to settle its line phase; the other ranks take part in the exchange with empty ranges)
-    const bool tiny = file_len / (uint64_t)n_ranks < (1u << 20);
-    const uint64_t lo = tiny ? (rank ? file_len : 0) : file_len / (uint64_t)n_ranks * (uint64_t)rank;
-    const uint64_t hi = tiny ? file_len : (rank + 1 == n_ranks ? file_len : file_len / (uint64_t)n_ranks * (uint64_t)(rank + 1));
+    if (n_ranks < 1 || n_ranks > FQH_SHARD_MAX_RANKS || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !comm))
+        throw Error(ErrorKind::Other, "each_sharded: bad rank / communicator");
+    // byte ranges of equal size (any cut is fine: inside a line, a file of three lines on eight ranks)
+    const uint64_t lo = file_len / (uint64_t)n_ranks * (uint64_t)rank;
+    const uint64_t hi = rank + 1 == n_ranks ? file_len : file_len / (uint64_t)n_ranks * (uint64_t)(rank + 1);
     struct Cb {
         ReadAt *f;
         static int call(void *user, uint8_t *dst, uint64_t off, uint64_t n) {
@@ -470,56 +476,65 @@ uint64_t each_sharded(fqh_ctx *ctx, fqh_comm *comm, int n_ranks, int rank, ReadA
             }
         }
     } cb{&read_at};
-    constexpr uint64_t EDGE = 2 * FQH_BUFSIZE, ROW = FQH_SHARD_STREAM_WORDS * 8 + EDGE;
-    std::vector<uint8_t> head(EDGE), mine(ROW, 0), all((size_t)n_ranks * ROW, 0);
+    constexpr uint64_t ROW = FQH_SHARD_STREAM_WORDS;
+    std::vector<uint64_t> mine(ROW, 0), words((size_t)n_ranks * ROW, 0);
     uint64_t *d_sc = d_hist + 1, *d_q = d_hist + 9, *d_b = d_hist + 9 + (uint64_t)lmax * 256;
     fqh_shard_result res;
-    chk(fqh_shard_stream_run(ctx, &Cb::call, &cb, lo, hi, file_len, opt.slot_bytes, opt.n_slots, lmax, d_q, d_b, d_sc, &res,
-                             head.data(), EDGE, mine.data() + FQH_SHARD_STREAM_WORDS * 8, EDGE), "fqh_shard_stream_run");
-    fqh_shard_result_words(&res, reinterpret_cast<uint64_t *>(mine.data()));
-    // ---- the one exchange: 8 words + the tail bytes of every rank
+    std::string local_failure;
+    const fqh_status run_st = fqh_shard_stream_run(ctx, &Cb::call, &cb, lo, hi, file_len, opt.slot_bytes, opt.n_slots, lmax, d_q, d_b, d_sc, &res);
+    if (run_st == FQH_OK) {
+        fqh_shard_result_words(&res, lo, hi, mine.data());
+    } else {  // this rank failed: the others must not wait for it in the exchange
+        local_failure = std::string("fqh_shard_stream_run: ") + fqh_last_error(ctx);
+        fqh_shard_failed_words(run_st, lo, hi, mine.data());
+    }
+    // ---- the one exchange: FQH_SHARD_STREAM_WORDS words of every rank; device scratch: [mine | all | records per rank | key]
+    void *d_x = nullptr;
+    const uint64_t n_x = ROW + (uint64_t)n_ranks * ROW + (uint64_t)n_ranks + 1;
+    chk(fqh_dev_alloc(ctx, n_x * 8, &d_x), "fqh_dev_alloc");
+    struct Free {
+        fqh_ctx *c;
+        void *p;
+        ~Free() { (void)fqh_dev_free(c, p); }
+    } free_x{ctx, d_x};
+    uint64_t *d_mine = static_cast<uint64_t *>(d_x), *d_all = d_mine + ROW, *d_slots = d_all + (uint64_t)n_ranks * ROW, *d_key = d_slots + n_ranks;
     if (n_ranks > 1) {
-        void *d_x = nullptr;
-        chk(fqh_dev_alloc(ctx, (uint64_t)(n_ranks + 1) * ROW, &d_x), "fqh_dev_alloc");
-        uint8_t *d_mine = static_cast<uint8_t *>(d_x), *d_all = d_mine + ROW;
-        fqh_status st = fqh_memcpy_h2d(ctx, d_mine, mine.data(), ROW);
-        if (st == FQH_OK) st = fqh_allgather(ctx, comm, d_mine, d_all, ROW);
-        if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, all.data(), d_all, (uint64_t)n_ranks * ROW);
-        (void)fqh_dev_free(ctx, d_x);
+        fqh_status st = fqh_memcpy_h2d(ctx, d_mine, mine.data(), ROW * 8);
+        if (st == FQH_OK) st = fqh_allgather(ctx, comm, d_mine, d_all, ROW * 8);
+        if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, words.data(), d_all, (uint64_t)n_ranks * ROW * 8);
         chk(st, "each_sharded: all-gather");
     } else {
-        all = mine;
+        words = mine;
     }
-    std::vector<uint64_t> words((size_t)n_ranks * FQH_SHARD_STREAM_WORDS);
-    std::vector<uint8_t> tails((size_t)n_ranks * EDGE);
-    for (int r = 0; r < n_ranks; ++r) {
-        memcpy(&words[(size_t)r * FQH_SHARD_STREAM_WORDS], &all[(size_t)r * ROW], FQH_SHARD_STREAM_WORDS * 8);
-        memcpy(&tails[(size_t)r * EDGE], &all[(size_t)r * ROW + FQH_SHARD_STREAM_WORDS * 8], EDGE);
+    // ---- true-phase check, the gap in front of this rank, its first-error key; then the SUMs and the MIN over the ranks
+    uint64_t out[2] = {0, FQH_NO_ERROR_KEY};
+    const fqh_status fin_st = fqh_shard_stream_finish(ctx, &Cb::call, &cb, file_len, words.data(), n_ranks, rank, opt.slot_bytes, opt.n_slots,
+                                                      lmax, d_q, d_b, d_sc, out);
+    if (fin_st != FQH_OK) {
+        local_failure = std::string("fqh_shard_stream_finish: ") + fqh_last_error(ctx);
+        out[0] = 0;
+        out[1] = fqh_shard_failure_key(rank, lo, fin_st);
     }
-    // ---- phase check, one-record stitch, this rank's first-error key; then SUM and MIN over the ranks
-    uint64_t out[2];
-    chk(fqh_shard_stream_finish(ctx, words.data(), tails.data(), EDGE, n_ranks, rank, head.data(), lmax, d_q, d_b, d_sc, out),
-        "fqh_shard_stream_finish");
-    void *d_k = nullptr;
-    chk(fqh_dev_alloc(ctx, 16, &d_k), "fqh_dev_alloc");
-    uint64_t h[2] = {out[1], 0};
-    fqh_status st = fqh_memcpy_h2d(ctx, d_k, h, 8);
-    uint64_t rec0 = 0;
-    if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, &rec0, d_hist, 8);
-    rec0 += out[0];
-    if (st == FQH_OK) st = fqh_memcpy_h2d(ctx, d_hist, &rec0, 8);
-    if (st == FQH_OK && n_ranks > 1) st = fqh_allreduce_u64(ctx, comm, d_hist, 9 + (uint64_t)lmax * 264);
-    if (st == FQH_OK && n_ranks > 1) st = fqh_allreduce_min_u64(ctx, comm, static_cast<uint64_t *>(d_k), 1);
-    if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, h, d_k, 8);
-    uint64_t total = 0;
-    if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, &total, d_hist, 8);
-    (void)fqh_dev_free(ctx, d_k);
+    std::vector<uint64_t> slots((size_t)n_ranks + 1, 0);
+    slots[(size_t)rank] = out[0];
+    slots[(size_t)n_ranks] = out[1];
+    fqh_status st = fqh_memcpy_h2d(ctx, d_slots, slots.data(), ((uint64_t)n_ranks + 1) * 8);
+    if (st == FQH_OK && n_ranks > 1) st = fqh_allreduce_u64(ctx, comm, d_slots, (uint64_t)n_ranks);
+    if (st == FQH_OK && n_ranks > 1) st = fqh_allreduce_u64(ctx, comm, d_hist + 1, 8 + (uint64_t)lmax * 264);
+    if (st == FQH_OK && n_ranks > 1) st = fqh_allreduce_min_u64(ctx, comm, d_key, 1);
+    if (st == FQH_OK) st = fqh_memcpy_d2h(ctx, slots.data(), d_slots, ((uint64_t)n_ranks + 1) * 8);
     chk(st, "each_sharded: all-reduce");
-    int32_t status = FQH_OK;
-    uint64_t err_record = 0;
-    fqh_error_key_unpack(h[0], &status, &err_record);
-    if (status != FQH_OK) throw Error(ErrorKind::InvalidData, detail::message(status, false));
-    return total;
+    ShardedOutcome o;
+    chk(fqh_shard_stream_outcome(slots[(size_t)n_ranks], slots.data(), n_ranks, &o.status, &o.n_records, &o.err_offset), "fqh_shard_stream_outcome");
+    chk(fqh_memcpy_h2d(ctx, d_hist, &o.n_records, 8), "each_sharded: record count");
+    if (err) {
+        *err = o;
+        return o.n_records;
+    }
+    if (o.status != FQH_OK && o.status <= FQH_E_TOO_LONG) throw Error(ErrorKind::InvalidData, detail::message(o.status, false));
+    if (o.status != FQH_OK)
+        throw Error(ErrorKind::Other, local_failure.empty() ? std::string("each_sharded: a rank failed: ") + fqh_strerror((fqh_status)o.status) : local_failure);
+    return o.n_records;
 }
 
 // each_zipped (src/lib.rs:577-609)

@@ -19,8 +19,8 @@ use std::os::raw::{c_char, c_int, c_void};
 pub struct fqh_stream_times { pub wall_ms: f64, pub copy_busy_ms: f64, pub scan_busy_ms: f64, pub both_busy_ms: f64, pub n_slots: u64 }
 #[repr(C)]
 #[derive(Clone, Copy)]
-pub struct fqh_shard_result { pub status: i32, pub phase: u32, pub n_records: u64, pub n_newlines: u64, pub err_record: u64,
-                              pub err_offset: u64, pub head_len: u64, pub tail_len: u64 }
+pub struct fqh_shard_result { pub status: i32, pub phase: u32, pub n_records: u64, pub n_newlines: u64, pub err_offset: u64,
+                              pub head_len: u64, pub tail_len: u64, pub flags: u64 }
 #[repr(C)] pub struct fqh_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct fqh_stream { _p: [u8; 0] }
 
@@ -50,9 +50,15 @@ pub const FQH_COMM_ID_BYTES: usize = 128;
 pub const FQH_OPT_FAST_PATH: c_int = 1;
 pub const FQH_OPT_SINGLE_PASS: c_int = 2;
 pub const FQH_OPT_PLACE_TRIES: c_int = 3;
+pub const FQH_OPT_SPIN_WAIT: c_int = 4;
+pub const FQH_OPT_REUSE_INDEX: c_int = 5;      // default 0: fqh_stats after fqh_scan on the same buffer reads the input again
 pub const FQH_SHARD_WORDS: usize = 8;
+pub const FQH_SHARD_STREAM_WORDS: usize = 10;
+pub const FQH_SHARD_MAX_RANKS: c_int = 256;
+pub const FQH_NO_ERROR_KEY: u64 = u64::MAX;
 pub const FQH_SHARD_EMPTY: u32 = 0xFFFF_FFFF;  // fqh_shard_result.phase of an empty byte range
-pub const FQH_SHARD_PASS: u32 = 0xFFFF_FFFE;   // ... of a byte range without a record start: its bytes are its tail
+pub const FQH_SHARD_PASS: u32 = 0xFFFF_FFFE;   // ... of a byte range without a record start
+pub const FQH_SHARD_DEFER: u32 = 0xFFFF_FFFD;  // ... of a byte range whose window does not single out a line phase
 pub const FQH_E_AGAIN: c_int = 10;
 
 #[link(name = "fastq_hip")]
@@ -66,6 +72,7 @@ extern "C" {
     pub fn fqh_set_bufsize(ctx: *mut fqh_ctx, bufsize: u64) -> c_int;
     pub fn fqh_set_option(ctx: *mut fqh_ctx, option: c_int, value: c_int) -> c_int;
     pub fn fqh_last_scan_fast(ctx: *mut fqh_ctx) -> c_int;
+    pub fn fqh_placement(ctx: *mut fqh_ctx, n_candidates: *mut c_int, ms: *mut f32) -> c_int;   // ms: [f32; 10]
 
     // ---- whole buffers in HBM: IdxRecord::from_buffer over every record (src/records.rs:201-247)
     pub fn fqh_scan(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int, carry_in: *const fqh_carry,
@@ -118,13 +125,15 @@ extern "C" {
     // src/lib.rs:544-564, over byte-range shards
     pub fn fqh_shard_stream_run(ctx: *mut fqh_ctx, read: extern "C" fn(*mut c_void, *mut u8, u64, u64) -> c_int, user: *mut c_void,
                                 lo: u64, hi: u64, file_len: u64, slot_bytes: u64, n_slots: u32, lmax: u32,
-                                d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64, res: *mut fqh_shard_result,
-                                h_head: *mut u8, head_cap: u64, h_tail: *mut u8, tail_cap: u64) -> c_int;
-    pub fn fqh_shard_result_words(res: *const fqh_shard_result, words: *mut u64);
-    pub fn fqh_shard_stream_finish(ctx: *mut fqh_ctx, h_all_words: *const u64, h_all_tails: *const u8, tail_stride: u64,
-                                   n_ranks: c_int, rank: c_int, h_head: *const u8, lmax: u32, d_qual_hist: *mut u64,
-                                   d_base_hist: *mut u64, d_scalars: *mut u64, out: *mut u64) -> c_int;
-    pub fn fqh_error_key_unpack(key: u64, status: *mut i32, record: *mut u64) -> c_int;
+                                d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64, res: *mut fqh_shard_result) -> c_int;
+    pub fn fqh_shard_result_words(res: *const fqh_shard_result, lo: u64, hi: u64, words: *mut u64);
+    pub fn fqh_shard_failed_words(why: c_int, lo: u64, hi: u64, words: *mut u64);
+    pub fn fqh_shard_stream_finish(ctx: *mut fqh_ctx, read: extern "C" fn(*mut c_void, *mut u8, u64, u64) -> c_int, user: *mut c_void,
+                                   file_len: u64, h_all_words: *const u64, n_ranks: c_int, rank: c_int, slot_bytes: u64, n_slots: u32,
+                                   lmax: u32, d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64, out: *mut u64) -> c_int;
+    pub fn fqh_shard_failure_key(rank: c_int, offset: u64, why: c_int) -> u64;
+    pub fn fqh_shard_stream_outcome(min_key: u64, records_per_rank: *const u64, n_ranks: c_int, status: *mut i32,
+                                    n_records: *mut u64, err_offset: *mut u64) -> c_int;
 
     // ---- Buffer + thread_reader (src/buffer.rs, src/thread_reader.rs:182-200): the pinned ring
     pub fn fqh_stream_create(ctx: *mut fqh_ctx, slot_bytes: u64, n_slots: u32, flags: u32,
@@ -135,6 +144,7 @@ extern "C" {
     pub fn fqh_stream_collect(st: *mut fqh_stream, out: *mut fqh_chunk) -> c_int;
     pub fn fqh_stream_release(st: *mut fqh_stream) -> c_int;
     pub fn fqh_stream_carry(st: *mut fqh_stream, out: *mut fqh_carry) -> c_int;
+    pub fn fqh_stream_set_origin(st: *mut fqh_stream, file_offset: u64) -> c_int;
     pub fn fqh_stream_timing(st: *mut fqh_stream, out: *mut fqh_stream_times) -> c_int;
     // histograms per delivered record (FQH_STREAM_STATS) and the device-side filter (flags + gather);
     // not needed by Parser itself, bound for consumers that want them
@@ -160,6 +170,8 @@ const FQH_E_CAPACITY: c_int = 9;
 const FQH_STREAM_INDEX: u32 = 1;
 #[allow(dead_code)]
 const FQH_STREAM_STATS: u32 = 2;
+#[allow(dead_code)]
+const FQH_STREAM_TIMING: u32 = 4;
 
 /// What `Parser` holds instead of `buffer::Buffer`.
 pub struct GpuScanner<R: Read> {
@@ -269,10 +281,13 @@ impl<R: Read> Drop for GpuScanner<R> {
 //           f.read_exact_at(buf, off).map(|_| 0).unwrap_or(1)                 // std::os::unix::fs::FileExt
 //       }
 //       let (lo, hi) = (len / n * rank, if rank + 1 == n { len } else { len / n * (rank + 1) });
-//       fqh_shard_stream_run(ctx, read_at, file as *const _ as *mut c_void, lo, hi, len, 32 << 20, 3, lmax, d_q, d_b, d_sc,
-//                            &mut res, head.as_mut_ptr(), EDGE, tail.as_mut_ptr(), EDGE);
-//       // one fqh_allgather of [fqh_shard_result_words | tail], then
-//       fqh_shard_stream_finish(ctx, words.as_ptr(), tails.as_ptr(), EDGE, n, rank, head.as_ptr(), lmax, d_q, d_b, d_sc, out.as_mut_ptr());
-//       // fqh_allreduce_u64 over [records | scalars | histograms], fqh_allreduce_min_u64 over the key, fqh_error_key_unpack:
-//       // Err(InvalidData, fqh_strerror(status)) — what parallel_each returns when the parse fails (src/lib.rs:561-564) — or Ok(total)
+//       let st = fqh_shard_stream_run(ctx, read_at, file as *const _ as *mut c_void, lo, hi, len, 32 << 20, 3, lmax, d_q, d_b, d_sc, &mut res);
+//       // a rank that failed still takes part in the exchange (the others would wait for it forever):
+//       if st == FQH_OK { fqh_shard_result_words(&res, lo, hi, words.as_mut_ptr()) } else { fqh_shard_failed_words(st, lo, hi, words.as_mut_ptr()) }
+//       // one fqh_allgather of the FQH_SHARD_STREAM_WORDS words, then
+//       let st = fqh_shard_stream_finish(ctx, read_at, user, len, all_words.as_ptr(), n, rank, 32 << 20, 3, lmax, d_q, d_b, d_sc, out.as_mut_ptr());
+//       if st != FQH_OK { out = [0, fqh_shard_failure_key(rank, lo, st)] }
+//       // fqh_allreduce_u64 over [records_per_rank (out[0] in slot `rank`) | scalars | histograms], fqh_allreduce_min_u64 over out[1],
+//       // fqh_shard_stream_outcome(min_key, records_per_rank, n, &mut status, &mut n_records, &mut err_offset):
+//       // Err(InvalidData, fqh_strerror(status)) — what parallel_each returns when the parse fails (src/lib.rs:561-564) — or Ok(n_records)
 //   }

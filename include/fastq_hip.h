@@ -217,56 +217,69 @@ fqh_status fqh_sync(fqh_ctx *ctx);
  * One rank = one GPU = one pinned ring; the file is cut at arbitrary byte offsets and every rank streams its own range
  * [lo, hi) PHASE-FREE (it cannot wait for the ranks in front of it); the ranks talk once, at the end.  The reference's
  * analogue is Parser::parallel_each over a thread_reader pipeline: per-worker results gathered at the end
- * (src/lib.rs:553-559), a parse error returned for the whole call (src/lib.rs:544-547, 561-564).
+ * (src/lib.rs:553-559), a parse error returned for the whole call (src/lib.rs:544-547, 561-564).  The outcome — status and
+ * number of records delivered before the first error — is EXACTLY Parser::each's over the same bytes, whatever the cuts
+ * (inside lines, sixteen bytes apart, empty ranges, a file of three lines on eight ranks), and so are the histograms of a file
+ * that parses.  (Of a file that does NOT parse the summed histograms also hold records behind the error, counted by the ranks
+ * behind it: discard them, as parallel_each discards its workers' results when the parse fails, src/lib.rs:561-564.)
  *
- * fqh_shard_stream_run: rank r > 0 first settles its line phase and the offset R of its first record on a 4 MiB window
- * (fqh_shard_align), then streams [lo + R, hi) through a ring of n_slots x slot_bytes like a file of its own, calling
- * `read(user, h_dst, file_offset, nbytes)` (0 = ok) to fill pinned memory — a pread, a memcpy, a decompressor.  lmax != 0:
- * every record the rank delivers is added to the histograms (as fqh_stats).  *res: the rank's summary; h_head receives the
- * bytes [lo, lo + R) (the end of the record the previous rank began), h_tail what is left behind the rank's last complete
- * record; both at most 2 * FQH_BUFSIZE bytes for input the reference accepts (FQH_E_CAPACITY otherwise).  A parse error
- * inside the rank's records is res->status, not the return value.  A byte range of a few lines that cannot tell the line phases
- * apart by itself is settled with the bytes that FOLLOW it in the file (the read callback is asked for up to 4 MiB from lo); an
- * EMPTY range (lo == hi) is fine, and so is a range without a single record start (FQH_SHARD_PASS: the record in progress runs
- * through it).  FQH_E_ARG is left for a range at the very end of the file whose few lines fit several phases, or none (a parse
- * error could not be told from "too little to see").
+ * fqh_shard_stream_run: rank r > 0 first settles its line phase and the offset R of its first record on the 4 MiB of the file
+ * behind lo (fqh_shard_align; it may look past hi: a range of a few lines settles nothing by itself), then streams
+ * [lo + R, hi) through a ring of n_slots x slot_bytes like a file of its own that begins at file offset lo + R, calling
+ * `read(user, h_dst, file_offset, nbytes)` (0 = ok) to fill pinned memory — a pread, a memcpy, a decompressor with an index.
+ * lmax != 0: every record the rank delivers is added to the histograms (as fqh_stats); the three arrays must be this rank's
+ * own for this call (zeroed by the caller, summed over the ranks afterwards).  *res: the rank's summary.  A parse error inside
+ * the rank's records is res->status, not the return value.  A range that holds no record start (it lies inside one record:
+ * FQH_SHARD_PASS), or whose window does not single out one line phase (several fit a few lines at the end of the file; none
+ * fits a window that begins with a parse error: FQH_SHARD_DEFER), streams nothing, counts its newlines and leaves its bytes to
+ * the rank that parses the gap it lies in (below); an EMPTY range (lo == hi) is fine.  No byte range is refused.
  *
- * Then ONE exchange: fqh_shard_result_words(res) (FQH_SHARD_STREAM_WORDS words) and the tail bytes of every rank, all-gathered
- * in rank order (fqh_allgather or the host's own collective; tail_stride bytes per rank).
+ * Then ONE exchange: fqh_shard_result_words(res, lo, hi) — FQH_SHARD_STREAM_WORDS words — of every rank, all-gathered in rank
+ * order (fqh_allgather or the host's own collective).  A rank whose run FAILED (FQH_E_IO from the callback, a device error)
+ * must still take part — the others would wait for it forever: it sends fqh_shard_failed_words(status, lo, hi) and goes on.
  *
- * fqh_shard_stream_finish: checks this rank's phase against the TRUE newline count of the ranks in front of it, parses the
- * STITCH (tail of rank - 1 + own head: a file of exactly one record, added to the histograms), and writes out[0] = records
- * this rank contributes (stitch + streamed), out[1] = its first error as a packed key (global record index << 3 | kind), or
- * FQH_NO_ERROR_KEY.  One SUM of [out[0], scalars, histograms] (fqh_allreduce_u64) and one MIN of out[1]
- * (fqh_allreduce_min_u64) give every rank the totals, or — fqh_error_key_unpack — the status and record index of the first
- * error in FILE order: the error Parser::each returns for the same bytes (an error inside a rank's 4 MiB alignment window
- * that leaves no phase standing out is reported at that shard's start; the KIND of an error in a record that straddles a cut
- * can be FQH_E_TRUNCATED / FQH_E_HEADER where the sequential parser, reading on into the next rank's bytes, names another —
- * the record index is exact). */
+ * fqh_shard_stream_finish: every rank derives the same picture from the words — the TRUE newline count in front of every
+ * range, hence which ranks parsed under the true line phase.  Between the last complete record of one such rank and the first
+ * record of the next lies a GAP: the record that straddles the cut, and every PASS / DEFER / wrongly-phased range in between.
+ * The rank a gap ends at parses it through its own `read` callback — a sequential parse from a true record start over the
+ * file's bytes, on the GPU, which must land on its first record; what lies behind the last such rank is parsed to the end of
+ * the file by the last rank that holds bytes.  (A rank that parsed under a wrong phase contributes nothing; finish zeroes its
+ * histogram arrays.)  out[0] = records this rank contributes (gap + streamed), out[1] = its first error as a packed key
+ * (file offset of the failing record << 11 | rank << 3 | kind), or FQH_NO_ERROR_KEY.  ctx and read may be NULL for a rank
+ * without a gap to parse.  If finish itself fails on a rank, that rank goes on with out[1] = fqh_shard_failure_key(rank, lo, status).
+ *
+ * One SUM over [records_per_rank[n_ranks] (rank r puts out[0] into slot r), scalars, histograms] (fqh_allreduce_u64) and one
+ * MIN over out[1] (fqh_allreduce_min_u64) give every rank the totals, or the first error in FILE order;
+ * fqh_shard_stream_outcome turns the two into Parser::each's result: *status, *n_records = records delivered before the error
+ * (the slots up to the failing rank's; all of them when the parse succeeded), *err_offset = where the failing record starts. */
 typedef int (*fqh_read_fn)(void *user, uint8_t *h_dst, uint64_t file_offset, uint64_t nbytes);
 typedef struct {
-    int32_t status;      /* first parse error among the rank's own records (FQH_OK: none)        */
-    uint32_t phase;      /* newlines in front of the shard, mod 4, as settled on its first window */
-    uint64_t n_records;  /* records delivered (before the first error)                            */
-    uint64_t n_newlines; /* '\n' in [lo, hi) seen by the rank (head included)                     */
-    uint64_t err_record; /* rank-local index / file offset of the failing record                  */
-    uint64_t err_offset;
-    uint64_t head_len, tail_len;
+    int32_t status;      /* first parse error among the rank's own streamed records (FQH_OK: none)            */
+    uint32_t phase;      /* newlines in front of the range, mod 4, as settled on its window; or FQH_SHARD_*    */
+    uint64_t n_records;  /* records delivered (before the first error)                                        */
+    uint64_t n_newlines; /* '\n' in [lo, hi)                                                                  */
+    uint64_t err_offset; /* file offset of the failing record                                                 */
+    uint64_t head_len;   /* R: [lo, lo + R) ends the record the ranks in front began                           */
+    uint64_t tail_len;   /* bytes behind the rank's last complete record                                      */
+    uint64_t flags;      /* bit 0: n_newlines stops where the stream stopped (an error in a range of many MiB) */
 } fqh_shard_result;
-#define FQH_SHARD_STREAM_WORDS 8
+#define FQH_SHARD_STREAM_WORDS 10
+#define FQH_SHARD_MAX_RANKS 256
 #define FQH_NO_ERROR_KEY UINT64_MAX
-#define FQH_SHARD_EMPTY 0xFFFFFFFFu /* fqh_shard_result.phase of an empty byte range (lo == hi): its neighbours stitch across it */
-#define FQH_SHARD_PASS 0xFFFFFFFEu  /* ... of a byte range that holds NO record start (it lies inside one record): all of its bytes are its
-                                      tail, no head; the stitch of the next rank with a record start (or the file's end) runs across it */
+#define FQH_SHARD_EMPTY 0xFFFFFFFFu /* fqh_shard_result.phase of an empty byte range (lo == hi) */
+#define FQH_SHARD_PASS 0xFFFFFFFEu  /* ... of a byte range that holds NO record start (it lies inside one record) */
+#define FQH_SHARD_DEFER 0xFFFFFFFDu /* ... of a byte range whose window does not single out a line phase: parsed after the exchange */
 fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t lo, uint64_t hi, uint64_t file_len,
                                 uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist,
-                                uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res, uint8_t *h_head,
-                                uint64_t head_cap, uint8_t *h_tail, uint64_t tail_cap);
-void fqh_shard_result_words(const fqh_shard_result *res, uint64_t words[FQH_SHARD_STREAM_WORDS]);
-fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, const uint64_t *h_all_words, const uint8_t *h_all_tails, uint64_t tail_stride,
-                                   int n_ranks, int rank, const uint8_t *h_head, uint32_t lmax, uint64_t *d_qual_hist,
-                                   uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t out[2]);
-fqh_status fqh_error_key_unpack(uint64_t key, int32_t *status, uint64_t *record);
+                                uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res);
+void fqh_shard_result_words(const fqh_shard_result *res, uint64_t lo, uint64_t hi, uint64_t words[FQH_SHARD_STREAM_WORDS]);
+void fqh_shard_failed_words(fqh_status why, uint64_t lo, uint64_t hi, uint64_t words[FQH_SHARD_STREAM_WORDS]);
+fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t file_len, const uint64_t *h_all_words,
+                                   int n_ranks, int rank, uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax,
+                                   uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t out[2]);
+uint64_t fqh_shard_failure_key(int rank, uint64_t offset, fqh_status why);
+fqh_status fqh_shard_stream_outcome(uint64_t min_key, const uint64_t *records_per_rank, int n_ranks, int32_t *status,
+                                    uint64_t *n_records, uint64_t *err_offset);
 
 /* Forget the cached tile index.  The index describes the BYTES of the last scanned buffer; fqh_memcpy_h2d, fqh_memset and
  * fqh_synth_fill drop it themselves when they write into that buffer, writes the library cannot see (the caller's
@@ -281,8 +294,9 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 /* Per-position statistics over the records the scan delivers (everything before the first
  * error): d_qual_hist[p*256 + qual()[p]] and d_base_hist[p*8 + class(seq()[p])] for p < lmax
  * (classes A0 C1 G2 T3 N4 other5), d_scalars as above.  All are u64 device arrays that are ADDED
- * to (zero them first).  Runs the scan itself unless the last fqh_scan on this context was on the
- * same (d_buf, len, carry), in which case its tile index is reused. */
+ * to (zero them first).  Reads its input itself; only with FQH_OPT_REUSE_INDEX set (the caller vouches
+ * that the bytes are unchanged) does a call on the (d_buf, len, carry) of the last finished fqh_scan count over that
+ * scan's tile index. */
 fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
                      const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                      uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out,
@@ -396,6 +410,11 @@ typedef struct {
     uint64_t n_slots;
 } fqh_stream_times;
 fqh_status fqh_stream_timing(fqh_stream *st, fqh_stream_times *out);
+/* For a stream that does not begin the file (a byte range of it, from a record start): the file offset of its first byte.
+ * Boundaries and error offsets are then file offsets, and "Fastq record is too long" — which depends on a record's file
+ * offset mod 16 and on nothing else (csrc/replay.h) — is judged as the reference judges it in the whole file.  Before the
+ * first fqh_stream_acquire. */
+fqh_status fqh_stream_set_origin(fqh_stream *st, uint64_t file_offset);
 /* Parser state behind the last collected chunk (nl_count = newlines the stream has seen: what the next shard's phase is
  * checked against in the sharded mode). */
 fqh_status fqh_stream_carry(fqh_stream *st, fqh_carry *out);

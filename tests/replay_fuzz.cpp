@@ -43,9 +43,26 @@ int main(int argc, char **argv) {
             data += record(rng, len);
         }
         bool truncated = false;
+        uint64_t bad_need = 0;  // != 0: the input ends with an INVALID record whose error shows once bad_need of its bytes are visible
         if (rng() % 5 == 0 && data.size() > 3) {  // cut inside the last record: a truncated tail
             data.resize(data.size() - 1 - rng() % 3);
             truncated = true;
+        } else if (rng() % 4 == 0) {  // a broken record behind the valid ones, its error near the end of the window or beyond it
+            const uint64_t r = rng() % 10;
+            const uint64_t len = r < 7 ? B - 24 + rng() % 30 : 8 + rng() % (2 * B);
+            const uint64_t body = len > 8 ? len - 8 : 0, sq = body / 2 > 0 ? rng() % (body / 2 + 1) : 0, h = body - 2 * sq;
+            const uint64_t kind = rng() % 3;
+            if (kind == 0) {         // separator line without '+': shows with the first byte of that line
+                data += "@" + std::string(h, 'h') + "\n" + std::string(sq, 'A') + "\n-\n" + std::string(sq, 'I') + "\n";
+                bad_need = 1 + h + 1 + sq + 1 + 1;
+            } else if (kind == 1) {  // quality one byte longer than the sequence: shows with the record's last newline
+                data += "@" + std::string(h, 'h') + "\n" + std::string(sq, 'A') + "\n+\n" + std::string(sq + 1, 'I') + "\n";
+                bad_need = 1 + h + 1 + sq + 1 + 2 + sq + 1 + 1;
+            } else {                 // a header that does not start with '@': shows with its first byte
+                data += "x" + std::string(h, 'h') + "\n" + std::string(sq, 'A') + "\n+\n" + std::string(sq, 'I') + "\n";
+                bad_need = 1;
+            }
+            if (rng() % 3 == 0) data += record(rng, 6 + rng() % 40);  // (what follows a broken record is never looked at)
         }
         const uint8_t *p = (const uint8_t *)data.data();
         // what the scan delivers: all record boundaries (unlimited buffer), and the status before the too-long rule
@@ -58,6 +75,35 @@ int main(int argc, char **argv) {
         // the reference
         fqref_result want;
         fqref_count(p, data.size(), B, 0, &want);
+        // the closed form (stateless: fqh::TooLong) over the same boundaries; for the invalid record behind them the bytes it
+        // needs, for a truncated tail 0, for a clean end NO_BAD
+        {
+            uint64_t w3 = 0;
+            const uint64_t need3 = bad_need ? bad_need : (truncated ? 0 : fqh::TooLong::NO_BAD);
+            const bool t3 = fqh::TooLong::first(B, rs.data(), n, data.size() - rs[n], need3, &w3);
+            const bool want3 = want.status == FQREF_E_TOO_LONG;
+            bool ok3 = t3 == want3 && (!t3 || w3 == want.n_records);
+            if (!t3 && ok3) ok3 = want.n_records == n && want.status == big.status;
+            if (!ok3) {
+                ++fails;
+                if (fails < 5)
+                    fprintf(stderr, "CLOSED FORM MISMATCH it=%llu B=%llu n=%llu t3=%d w3=%llu want status=%d n=%llu big status=%d bad_need=%llu\n",
+                            (unsigned long long)it, (unsigned long long)B, (unsigned long long)n, t3, (unsigned long long)w3, want.status,
+                            (unsigned long long)want.n_records, big.status, (unsigned long long)bad_need);
+            }
+            // a byte range judged by itself: the records from a random boundary on (one the reference reaches), with their TRUE
+            // file offsets, give the same verdict
+            if (n > 1) {
+                const uint64_t from = rng() % (std::min<uint64_t>(n, want.n_records) + 1);
+                uint64_t w4 = 0;
+                const bool t4 = fqh::TooLong::first(B, rs.data() + from, n - from, data.size() - rs[n], need3, &w4);
+                if (t4 != want3 || (t4 && from + w4 != want.n_records)) {
+                    ++fails;
+                    if (fails < 5) fprintf(stderr, "CLOSED FORM (RANGE) MISMATCH it=%llu from=%llu\n", (unsigned long long)it, (unsigned long long)from);
+                }
+            }
+        }
+        if (bad_need) continue;  // (the replay below is fed valid records and truncated tails only, as before)
         // the replay, fed in random chunks of boundaries
         fqh::BufferReplay rp;
         rp.reset(B);

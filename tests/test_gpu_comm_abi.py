@@ -68,11 +68,12 @@ def test_shard_protocol_over_the_c_abi_with_rccl(fqref):
     assert (s2.parse_status, s2.n_records, s2.n_newlines) == (pkg.OK, 40000, 160000)
     assert cnt.cpu().tolist() == [40000, 0] and wall.cpu().tolist() == [n, nn, ns] + back0 + [0]
     assert np.array_equal(rs.cpu().numpy()[:40001], np.arange(40001) * 330)
-    # the first-error exchange of the sharded modes: element-wise MINIMUM of packed (record, kind) keys (ncclMin)
+    # the first-error exchange of the sharded modes: element-wise MINIMUM of packed (file offset, rank, kind) keys (ncclMin)
     keys = torch.tensor([pkg.NO_ERROR_KEY - (1 << 64), (12345 << 3) | 2, 7], dtype=torch.int64, device=dev)   # (u64 bit patterns)
     ctx._chk(L.fqh_allreduce_min_u64(ctx._h, comm, keys.data_ptr(), 3))
     ctx._chk(L.fqh_sync(ctx._h))
     assert keys.cpu().tolist() == [-1, (12345 << 3) | 2, 7]
-    assert pkg.error_key_unpack(pkg.NO_ERROR_KEY) == (pkg.OK, 0) and pkg.error_key_unpack((12345 << 3) | 2) == (pkg.E_LEN_MISMATCH, 12345)
+    assert pkg.shard_stream_outcome(pkg.NO_ERROR_KEY, [5, 6, 7]) == (pkg.OK, 18, 0)
+    assert pkg.shard_stream_outcome((12345 << 11) | (1 << 3) | 2, [5, 6, 7]) == (pkg.E_LEN_MISMATCH, 11, 12345)
     L.fqh_comm_destroy(comm)
     ctx.close()

@@ -1,6 +1,6 @@
 """configs[4] on one GPU: a file cut into byte-range shards at arbitrary offsets, every shard streamed through its own
-pinned ring phase-free (fastq-rs_amd/sharded.py: fqh_shard_align + fqh_stream_*), one exchange, the one-record
-stitch at every cut, one sum — must equal the oracle's sequential Parser::each + histogram loop over the whole file
+pinned ring phase-free (fastq-rs_amd/sharded.py: fqh_shard_stream_run), one exchange of ten words per rank, the gaps between
+the ranks' records parsed under the true line phase (fqh_shard_stream_finish), the sums and one minimum — must equal the oracle's sequential Parser::each + histogram loop over the whole file
 (the reference gathers per-worker results the same way, src/lib.rs:553-559).  The "ranks" run one after the other in
 this process; the multi-process form of the same protocol is bench.py --gpus N --stream-gib G
 (tests/test_gpu_sharded_stream.py::test_bench_sharded_streamed_three_ranks_one_gpu)."""
@@ -31,40 +31,55 @@ def env():
     return torch, pkg, sharded
 
 
-def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16):
-    """Every "rank" streams its byte range (fqh_shard_stream_run), the exchange is a list, every rank finishes
-    (fqh_shard_stream_finish: phase check, stitch, packed first-error key); the sum of the records and the MINIMUM of the keys
-    are what the two all-reduces deliver.  -> (status, n_records, histograms, shards)"""
+def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, bufsize=None, fail_rank=None):
+    """Every "rank" streams its byte range (fqh_shard_stream_run), the exchange is a list of words, every rank finishes
+    (fqh_shard_stream_finish: true-phase check, the parse of the gap in front of it, packed first-error key); the per-rank record
+    slots, the sum of the histograms and the MINIMUM of the keys are what the all-reduces deliver, fqh_shard_stream_outcome
+    turns them into Parser::each's result.  Every rank has histogram arrays of its own.  fail_rank: that rank's read callback
+    raises.  -> (status, n_records, histograms, shards)"""
     torch, pkg, sharded = env
     dev = torch.device("cuda:0")
     n = len(data)
-    host = (C.c_uint8 * n).from_buffer_copy(data)
+    host = (C.c_uint8 * max(1, n)).from_buffer_copy(data if n else b"\0")
 
-    def read_into(addr, off, nbytes):
-        C.memmove(addr, C.addressof(host) + off, nbytes)
+    def reader(r):
+        def read_into(addr, off, nbytes):
+            if r == fail_rank:
+                raise OSError("injected")
+            assert off + nbytes <= n
+            C.memmove(addr, C.addressof(host) + off, nbytes)
+        return read_into
 
     bounds = [0] + list(cuts) + [n]
-    hist = torch.zeros(8 + lmax * 264, dtype=torch.int64, device=dev)
-    sc, qh, bh = hist[:8], hist[8: 8 + lmax * 256], hist[8 + lmax * 256:]
-    stats = (lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    world = len(bounds) - 1
+    hists = [torch.zeros(8 + lmax * 264, dtype=torch.int64, device=dev) for _ in range(world)]
+
+    def stats_of(r):
+        h = hists[r]
+        return (lmax, h[8: 8 + lmax * 256].data_ptr(), h[8 + lmax * 256:].data_ptr(), h[:8].data_ptr())
+
+    def ctx_of():
+        ctx = pkg.Ctx(0)
+        if bufsize is not None:
+            ctx.set_bufsize(bufsize)
+        return ctx
+
     shards = []
-    for r in range(len(bounds) - 1):  # every "rank" has a context (a GPU) of its own; they share the histograms here
-        ctx = pkg.Ctx(0)
-        shards.append(sharded.stream_shard(ctx, read_into, bounds[r], bounds[r + 1], n, slot_bytes, stats=stats))
+    for r in range(world):  # every "rank" has a context (a GPU) of its own
+        ctx = ctx_of()
+        shards.append(sharded.stream_shard(ctx, reader(r), bounds[r], bounds[r + 1], n, slot_bytes, stats=stats_of(r)))
         ctx.close()
-    # ---- the exchange (lists instead of an all_gather), then every rank's finish; sum and minimum instead of all_reduces
+    # ---- the exchange (a list instead of an all_gather), then every rank's finish; sums and minimum instead of all_reduces
     words = [sh.words() for sh in shards]
-    tails = [sh.tail for sh in shards]
-    total, key = 0, pkg.NO_ERROR_KEY
-    for r, sh in enumerate(shards):
-        ctx = pkg.Ctx(0)
-        rec, k = sharded.finish(ctx, words, tails, r, sh.head, stats=stats)
+    slots, key = [0] * world, pkg.NO_ERROR_KEY
+    for r in range(world):
+        ctx = ctx_of()
+        slots[r], k = sharded.finish(ctx, reader(r), n, words, r, slot_bytes, stats=stats_of(r))
         ctx.close()
-        total += rec
         key = min(key, k)
-    status, err_record = pkg.error_key_unpack(key)
-    n_records = total if status == pkg.OK else err_record
-    return status, n_records, hist.cpu().numpy().astype(np.uint64), shards
+    status, n_records, err_offset = sharded.outcome(slots, key)
+    hist = sum(h.cpu().numpy().astype(np.uint64) for h in hists)
+    return status, n_records, hist, shards
 
 
 def cut_points(rng, data, k):
@@ -99,17 +114,20 @@ def test_sharded_streamed_equals_whole_file_oracle(env, fqref, seed):
     assert np.array_equal(hist[:8], osc), (hist[:8], osc)
     assert np.array_equal(hist[8: 8 + lmax * 256].reshape(lmax, 256), oq)
     assert np.array_equal(hist[8 + lmax * 256:].reshape(lmax, 8), ob)
-    # the ranks' pieces tile the file: head + streamed records + tail of every rank
-    assert sum(len(x.head) + len(x.tail) for x in results) == sum(
-        len(results[i].tail) + len(results[i + 1].head) for i in range(len(results) - 1))
+    # every rank parsed by itself under the phase its window settled (no rank deferred), and the pieces tile the file
+    assert all(x.res.phase <= 3 and not x.failed for x in results)
     assert results[0].res.head_len == 0 and results[-1].res.tail_len == 0
 
 
-@pytest.mark.parametrize("kind", ["truncated", "mismatch", "header", "sep_first_shard"])
+@pytest.mark.parametrize("kind", ["truncated", "mismatch", "header", "sep_first_shard", "header_at_cut", "swallowed_newline_at_cut",
+                                  "crlf_sep_at_cut"])
 def test_sharded_streamed_reports_the_first_error(env, fqref, kind):
+    """THE error of the sequential parse — kind and record — whatever rank it falls into: inside a rank's records, inside a
+    rank's alignment window, in the record that straddles a cut (src/lib.rs:544-547, 561-564)."""
     torch, pkg, sharded = env
     rng = np.random.default_rng(31)
     data = bytearray(fuzzgen.valid_file(rng, 6000, maxlen=150, crlf=False))
+    cuts = [len(data) // 4 + 3, len(data) // 2 - 40, len(data) * 3 // 4 + 11]
     if kind == "truncated":
         del data[-7:]
     elif kind == "mismatch":
@@ -118,17 +136,24 @@ def test_sharded_streamed_reports_the_first_error(env, fqref, kind):
     elif kind == "sep_first_shard":
         k = data.index(b"\n+\n", len(data) // 8)
         data[k + 1] = ord("-")   # a separator line without its '+', in the FIRST shard: the later ranks' records must not count
-    else:
+    elif kind == "header":
         k = data.index(b"\n@", len(data) // 2)
-        data[k + 1] = ord("x")   # a header that does not start with '@', in a middle shard
+        data[k + 1] = ord("x")   # a header that does not start with '@', in a middle shard (inside its alignment window)
+    elif kind == "header_at_cut":
+        k = data.index(b"\n@", cuts[1])
+        data[k + 1] = ord("x")   # ... the first record that starts behind a cut
+    elif kind == "swallowed_newline_at_cut":
+        k = data.rindex(b"\n", 0, cuts[1])
+        del data[k]              # the record that straddles a cut loses a newline in front of the cut: it swallows a line
+    else:
+        k = data.index(b"\n+\n", cuts[1] - 200)
+        data[k + 2: k + 2] = b"\r"   # "+\r\n" is fine; then break the NEXT line's end: '+' 'r' without '\n' ...
+        del data[k + 3]              # ... so the separator line runs on into the quality line (seed 341 of the round-3 fuzzer)
     data = bytes(data)
-    cuts = [len(data) // 4 + 3, len(data) // 2 - 40, len(data) * 3 // 4 + 11]
     status, n_records, hist, results = run_sharded(env, data, cuts, 150)
     r = fqref.count(data)
     assert r.status != pkg.OK
-    assert status != pkg.OK
-    if kind != "header":  # (an error in a shard's alignment window is reported at the shard's start: include/fastq_hip.h)
-        assert (status, n_records) == (r.status, r.n_records)   # the MINIMUM over the ranks' keys is the error in file order
+    assert (status, n_records) == (r.status, r.n_records)   # the MINIMUM over the ranks' keys is the error in file order
 
 
 def test_bench_sharded_streamed_three_ranks_one_gpu():
@@ -146,33 +171,100 @@ def test_bench_sharded_streamed_three_ranks_one_gpu():
     assert j["records"] == j["check"]["records_expected"]
 
 
-def test_a_byte_range_too_small_to_settle_its_phase_is_refused(env):
+def test_no_byte_range_is_refused(env, fqref):
     """A byte range of a few lines cannot tell the line phases apart by itself; the driver then looks at what FOLLOWS it in
-    the file (the window only settles the phase and finds the first record start).  Only at the very end of the file is there
-    nothing to look at: such a range is settled by its own few lines or refused (FQH_E_ARG), the file is never mis-parsed.  A range without a single line start
-    needs no phase (it is stitched across, next test), and an EMPTY range is fine."""
+    the file (the window only settles the phase and finds the first record start).  At the very end of the file there is
+    nothing to look at: such a range defers (FQH_SHARD_DEFER), and the rank that parses the gap behind the last rank with a
+    settled phase reads it under the TRUE phase after the exchange.  Any cut gives the oracle's result and histograms."""
     torch, pkg, sharded = env
     rng = np.random.default_rng(5)
     data = fuzzgen.valid_file(rng, 4000, maxlen=100, seqlen=100, crlf=False)
-    r = __import__("oracle.fqref", fromlist=["x"]).count(data)
+    r, oq, ob, osc = fqref.stats(data, 100)
+
+    def same(cuts):
+        status, n_records, hist, shards = run_sharded(env, data, cuts, 100)
+        assert (status, n_records) == (r.status, r.n_records), cuts
+        assert np.array_equal(hist[:8], osc) and np.array_equal(hist[8: 8 + 100 * 256].reshape(100, 256), oq), cuts
+        assert np.array_equal(hist[8 + 100 * 256:].reshape(100, 8), ob), cuts
+        return shards
+
     k = data.index(b"\n+\n", len(data) // 2)                # the end of a sequence line: [k - 4, k + 8) holds the separator
-    status, n_records, hist, shards = run_sharded(env, data, [k - 4, k + 8], 100)   # line and the starts of two more lines:
-    assert (status, n_records) == (r.status, r.n_records)                             # settled by the lines behind the range
-    for back in range(1, 140, 7):                           # ranges of a few bytes to two lines at the very END of the file,
-        try:                                                # where nothing follows: settled (and then right) or refused
-            status, n_records, hist, shards = run_sharded(env, data, [len(data) - back], 100)
-            assert (status, n_records) == (r.status, r.n_records), back
-        except pkg.FqhError as e:
-            assert e.status == pkg.E_ARG, back
-    status, n_records, hist, shards = run_sharded(env, data, [k + 10, k + 14], 100)   # four bytes inside the quality line
-    assert (status, n_records) == (r.status, r.n_records)
-    status, n_records, hist, shards = run_sharded(env, data, [k, k], 100)   # (an empty range between two shards)
-    assert (status, n_records) == (r.status, r.n_records)
+    same([k - 4, k + 8])                                     # line and the starts of two more lines: settled by the lines behind it
+    deferred = 0
+    for back in range(1, 140, 7):                            # ranges of a few bytes to two lines at the very END of the file
+        shards = same([len(data) - back])
+        deferred += shards[-1].res.phase == pkg.SHARD_DEFER
+    assert deferred >= 3
+    same([k + 10, k + 14])                                   # four bytes inside the quality line
+    same([k, k])                                             # an empty range between two shards
+    same([len(data) - 300, len(data) - 200, len(data) - 90, len(data) - 40, len(data) - 3])   # five ranks in the last record and a half
+    same(sorted(int(x) for x in np.random.default_rng(1).integers(1, 600, 7)))                 # seven cuts in the first two records
+
+
+def test_three_lines_on_eight_ranks(env, fqref):
+    """Files smaller than the number of ranks, empty files, a file that is one newline: every rank takes part."""
+    torch, pkg, sharded = env
+    for data in (b"", b"\n", b"@a\nAC\n+\n!!\n", b"@a\nAC\n+\n!!", b"@a\nAC\n+\n!", b"@a\nAC\n", b"x", b"@a\nAC\n+\n!!\n@b\nG\n+\n#\n"):
+        r = fqref.count(data)
+        n = len(data)
+        for cuts in ([min(n, i) for i in range(1, 8)], [n * i // 8 for i in range(1, 8)], [0, 0, n // 2, n // 2, n, n, n]):
+            status, n_records, hist, shards = run_sharded(env, data, cuts, 8)
+            assert (status, n_records) == (r.status, r.n_records), (data, cuts, status, n_records, r.status, r.n_records)
+
+
+def test_a_rank_that_fails_still_takes_part(env, fqref):
+    """A rank whose read callback fails sends its failure into the exchange and goes on (the others would wait for it forever in
+    a collective); every rank learns FQH_E_IO from the minimum — unless the sequential parser meets a parse error first."""
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(9)
+    data = bytearray(fuzzgen.valid_file(rng, 3000, maxlen=100, crlf=False))
+    cuts = [len(data) // 4, len(data) // 2, len(data) * 3 // 4]
+    status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_rank=2)
+    assert status == pkg.E_IO and shards[2].failed == pkg.E_IO
+    k = data.index(b"\n+\n", len(data) // 8)
+    data[k + 1] = ord("-")      # a parse error in rank 0 lies in front of the failure in file order
+    r = fqref.count(bytes(data))
+    status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_rank=2)
+    assert (status, n_records) == (r.status, r.n_records) == (pkg.E_SEP, r.n_records)
+
+
+@pytest.mark.parametrize("bufsize", [256, 69632])
+def test_too_long_is_judged_on_file_offsets(env, fqref, bufsize):
+    """"Fastq record is too long" (src/lib.rs:278-283) depends on the record's file offset mod 16 (csrc/replay.h): records of
+    BUFSIZE - 15 .. BUFSIZE bytes in every rank, and across a cut, are accepted or refused as the sequential parser does."""
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(bufsize)
+
+    def rec(total):
+        body = total - 6
+        sl = int(rng.integers(0, body // 2 + 1))
+        return b"@" + b"h" * (body - 2 * sl) + b"\n" + b"A" * sl + b"\n+\n" + b"I" * sl + b"\n"
+
+    hits = 0
+    for trial in range(6 if bufsize > 1000 else 24):
+        parts = []
+        for i in range(60):
+            x = rng.random()
+            L = int(rng.integers(bufsize - 17, bufsize + 1)) if x < 0.08 else int(rng.integers(6, bufsize // 2))
+            parts.append(rec(max(6, L)))
+        data = b"".join(parts)
+        n = len(data)
+        cuts = sorted(set(int(x) for x in rng.integers(1, n, 3)))
+        big = [i for i, p in enumerate(parts) if len(p) >= bufsize - 17]
+        if big:   # one cut inside a record of the band
+            at = sum(len(p) for p in parts[: big[len(big) // 2]])
+            cuts = sorted(set(cuts + [at + bufsize // 2]))
+        r = fqref.count(data, bufsize=bufsize)
+        status, n_records, hist, shards = run_sharded(env, data, cuts, 8, slot_bytes=1 << 18, bufsize=bufsize)
+        assert (status, n_records) == (r.status, r.n_records), (trial, cuts, status, n_records, r.status, r.n_records)
+        hits += r.status == pkg.E_TOO_LONG
+    assert hits >= 1
 
 
 def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
     """Random files (valid, damaged, truncated) cut into random byte-range shards -> (files checked, files with a parse error):
-    status and record count must be the oracle's sequential Parser::each over the whole file; histograms too when it is valid."""
+    status and record count must be the oracle's sequential Parser::each over the whole file, for EVERY file and cut; histograms
+    too when it is valid.  No byte range is refused."""
     import time
     torch, pkg, sharded = env
     rng = np.random.default_rng(seed)
@@ -197,27 +289,14 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
             if 0 < j + 1 < n:
                 cuts = sorted(set(cuts + [j + 1]))
         lmax = 150
-        try:
-            status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=int(rng.choice([1 << 16, 1 << 18, 1 << 20])))
-        except pkg.FqhError as e:
-            assert e.status == pkg.E_ARG and min(b - a for a, b in zip(cuts, cuts[1:] + [n])) < pkg.BUFSIZE, (seed, cases, cuts, e)
-            continue   # a byte range too small to settle its line phase: refused, not mis-parsed
+        status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=int(rng.choice([1 << 16, 1 << 18, 1 << 20])))
         r, oq, ob, osc = fqref.stats(data, lmax)
-        window_error = any(sh.res.status == pkg.E_HEADER and sh.res.n_records == 0 and sh.lo > 0 for sh in shards)
+        # status and the number of records delivered before the first error are the sequential parser's, whatever the cuts
+        assert (status, n_records) == (r.status, r.n_records), (seed, cases, cuts, (status, n_records), (r.status, r.n_records))
         if r.status == pkg.OK:
-            assert (status, n_records) == (pkg.OK, r.n_records), (seed, cases, cuts, status, n_records, r.n_records)
             assert np.array_equal(hist[:8], osc) and np.array_equal(hist[8: 8 + lmax * 256].reshape(lmax, 256), oq) and np.array_equal(hist[8 + lmax * 256:].reshape(lmax, 8), ob), (seed, cases, cuts)
         else:
             errs += 1
-            assert status != pkg.OK, (seed, cases, cuts)
-            if not window_error:  # (an error inside a shard's alignment window is reported at the shard's start)
-                # the first failing record is the oracle's; so is the kind of the error, unless the record straddles a cut:
-                # the stitch holds that record's bytes only up to the next rank's first record start as THAT rank settled it, so
-                # a damaged record that swallows a line (its '\n' gone) is incomplete there (TRUNCATED), or shows as the next
-                # rank's line phase not fitting the newlines in front of it (HEADER) — where the sequential parser reads on into
-                # the next record and names another kind (tools/fuzz_sharded.py seed 341: "+\r" instead of "+\n")
-                assert n_records == r.n_records, (seed, cases, cuts, (status, n_records), (r.status, r.n_records))
-                assert status == r.status or status in (pkg.E_TRUNCATED, pkg.E_HEADER), (seed, cases, cuts, status, r.status)
         cases += 1
     return cases, errs
 
@@ -247,7 +326,7 @@ def test_byte_ranges_without_a_record_start_are_stitched_across(env, fqref, shap
     status, n_records, hist, shards = run_sharded(env, data, cuts, 150)
     r, oq, ob, osc = fqref.stats(data, 150)
     assert (status, n_records) == (r.status, r.n_records), (shape, status, n_records, r.status, r.n_records)
-    assert any(sh.res.phase == 0xFFFFFFFE for sh in shards), [sh.res.phase for sh in shards]
+    assert any(sh.res.phase in (pkg.SHARD_PASS, pkg.SHARD_DEFER) for sh in shards), [sh.res.phase for sh in shards]
     if r.status == pkg.OK:
         assert np.array_equal(hist[:8], osc)
         assert np.array_equal(hist[8: 8 + 150 * 256].reshape(150, 256), oq)

@@ -328,6 +328,29 @@ def main():
             ctx.set_single_pass(False)
             two = timed(lambda: ctx.stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()), reps=2)
             ctx.set_single_pass(True)
+            # the same call on input with ANY bytes in seq() / qual() (src/records.rs:19-33, 75-90): one base in a million
+            # lower-cased, one quality in a million '~' (outside the kernel's window).  The single pass dumps the batches of eight
+            # lines it will not count and k_stats_declined counts them behind it; the scan's result stands, and the plain scan
+            # that follows takes the fast path (a count the kernel declines is no doubt about the parse).
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(20260930)
+            nd = max(1, int(total_records * 150 * 1e-6))
+            pos_s = torch.unique(torch.randint(0, total_records, (nd,), device=dev, generator=gen) * RECLEN + 26 +
+                                 torch.randint(0, 150, (nd,), device=dev, generator=gen))
+            pos_q = torch.unique(torch.randint(0, total_records, (nd,), device=dev, generator=gen) * RECLEN + 179 +
+                                 torch.randint(0, 150, (nd,), device=dev, generator=gen))
+            keep_s, keep_q = buf[pos_s].clone(), buf[pos_q].clone()
+            buf[pos_s] = keep_s | 0x20
+            buf[pos_q] = 126
+            dirty = timed(lambda: ctx.stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()), reps=3)
+            dirty_route = ctx.last_stats_route()
+            assert int(bh.view(150, 8)[:, 5].sum().item()) == pos_s.numel() and int(qh.view(150, 256)[:, 126].sum().item()) == pos_q.numel()
+            ds, dc, dst = ctx.scan(buf.data_ptr(), nbytes, True, None, rec_start.data_ptr(), cap)
+            dirty_scan_fast = ctx.last_scan_fast()
+            assert ds.n_records == total_records and ds.parse_status == pkg.OK
+            buf[pos_s] = keep_s
+            buf[pos_q] = keep_q
+            ctx.invalidate()
             out["stats"] = {
                 "workload": "configs[2]: per-position quality + base histograms, same buffer, cold call (fqh_stats)",
                 "route": "single pass: k_scan_stats reads the input once for offsets, validation and histograms" if one[3]
@@ -338,6 +361,12 @@ def main():
                 "frac_of_hbm_peak_end_to_end": round(nbytes / 1e6 / one[0] / HBM_PEAK_GBS, 4),
                 "scan_offsets_and_histograms_end_to_end_ms": round(both[0], 3),
                 "two_pass_route_end_to_end_ms": round(two[0], 3),
+                "dirty_input": {"what": "the same cold call with 1e-6 of the bases lower-cased and 1e-6 of the qualities '~' (%d + %d bytes)"
+                                        % (pos_s.numel(), pos_q.numel()),
+                                "end_to_end_ms": round(dirty[0], 3), "stats_route": dirty_route,
+                                "route": {2: "single pass + the declined batches counted behind it (k_stats_declined)",
+                                          1: "single pass", 0: "second pass over the input"}[dirty_route],
+                                "next_plain_scan_on_fast_path": bool(dirty_scan_fast)},
                 "bound": "vector ALU issue, then LDS atomics (DESIGN.md 5b); HBM is read once"}
         if not args.no_stats and not args.no_long_reads:
             out["long_reads"] = long_read_leg(pkg, torch, dev, ctx)

@@ -20,7 +20,7 @@ OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT, OPT_REUSE_INDEX 
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
-    "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_placement", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
+    "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_last_stats_route", "fqh_placement", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
     "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_len_hist", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
@@ -147,6 +147,7 @@ def lib():
         L.fqh_gather_records.argtypes = [vp, vp, u64, u64, vp, u64, vp, C.c_uint8, C.c_uint8, vp, u64,
                                          C.POINTER(u64), C.POINTER(u64)]
         L.fqh_last_scan_fast.argtypes = [vp]
+        L.fqh_last_stats_route.argtypes = [vp]
         L.fqh_set_option.argtypes = [vp, i32, i32]
         L.fqh_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float * 10)]
         L.fqh_stream_create.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
@@ -372,6 +373,10 @@ class Ctx:
     def last_scan_fast(self):
         """Test hook: did the last scan complete on the fast path (no exact rerun)?"""
         return bool(self._L.fqh_last_scan_fast(self._h))
+
+    def last_stats_route(self):
+        """How the last statistics call counted: 1 single pass, 2 single pass + declined lines recounted, 0 second pass."""
+        return int(self._L.fqh_last_stats_route(self._h))
 
     def set_spec(self, on):
         """Test hook: (re-)enable or disable the fast path for this context."""

@@ -27,6 +27,8 @@ size_t scan_stats_scratch_bytes(int n_cu);
 hipError_t launch_scan_stats(hipStream_t, FusedArgs, int);
 void launch_stats_commit(hipStream_t, const DevOut *, const FusedArgs &, uint32_t, unsigned long long *, unsigned long long *,
                          unsigned long long *);
+void launch_stats_declined(hipStream_t, const DevOut *, const FusedArgs &, unsigned long long *, unsigned long long *, unsigned long long *);
+uint32_t scan_stats_nsl(uint32_t lmax);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_stats_edge(hipStream_t, const DevOut *, const uint8_t *, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
                        unsigned long long *, unsigned long long *);
@@ -115,6 +117,11 @@ struct fqh_ctx {
     bool f_commit_owed = false;   // a deferred commit of the last finished single-pass launch has not been enqueued yet
     FusedArgs f_args = {};        // the launch's kernel arguments (for the deferred commit)
     unsigned long long *side = nullptr;   // FQH_NSCALARS totals of the launch in flight
+    uint32_t *decl_b = nullptr;   // the single pass's dump area (batches it would not count) and list of long lines, counted
+    uint64_t *decl_l = nullptr;   // exactly by k_stats_declined (fqh_internal.h: FusedArgs); one slot per 512 KiB of input + 1024
+    uint32_t decl_cap = 0;
+    size_t decl_b_bytes = 0;
+    int stats_route = 0;          // fqh_last_stats_route: how the last finished statistics call counted
     bool fused_enabled = true;    // FQH_FUSED=0: histograms always as a second pass over a full index
 };
 

@@ -111,6 +111,8 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->stats_scratch);
     (void)hipFree(ctx->gather_ws);
     (void)hipFree(ctx->side);
+    (void)hipFree(ctx->decl_b);
+    (void)hipFree(ctx->decl_l);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->h_init) (void)hipHostFree(ctx->h_init);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -289,6 +291,7 @@ static void enqueue_fused_commit(fqh_ctx *ctx) {
     hipStream_t s = ctx->stream;
     unsigned long long *q = (unsigned long long *)ctx->f_qual, *b = (unsigned long long *)ctx->f_base, *sc = (unsigned long long *)ctx->f_scalars;
     launch_stats_commit(s, &ctx->d_out[0], ctx->f_args, scan_stats_blocks(a.n_tiles, ctx->n_cu), q, b, sc);
+    launch_stats_declined(s, &ctx->d_out[0], ctx->f_args, q, b, sc);  // (batches with a byte outside the alphabets, lines beyond the rows)
     const uint64_t back0 = a.back[a.nl_count & 3];
     if (back0 != 0 && ctx->f_lead >= back0) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, back0, +1, ctx->f_lmax, q, b, sc);
     if (!a.is_final) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, 0, -1, ctx->f_lmax, q, b, sc);
@@ -332,6 +335,22 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
             ctx->stats_scratch_bytes = need;
         }
         if (!ctx->side) HIPCHK(ctx, hipMalloc((void **)&ctx->side, 2 * FQH_NSCALARS * sizeof(unsigned long long)));
+        {   // where the kernel puts what it will not count itself: a slot per 512 KiB of input + 1024 (1.5 KiB per slot: 0.3 % of the input)
+            const uint64_t cap = a.len / (512u << 10) + 1024;
+            const size_t bb = (size_t)cap * (1 + scan_stats_nsl(ctx->f_lmax)) * 64 * sizeof(uint32_t);
+            if (cap > ctx->decl_cap || bb > ctx->decl_b_bytes) {
+                (void)hipFree(ctx->decl_b);
+                (void)hipFree(ctx->decl_l);
+                ctx->decl_b = nullptr;
+                ctx->decl_l = nullptr;
+                ctx->decl_cap = 0;
+                ctx->decl_b_bytes = 0;
+                HIPCHK(ctx, hipMalloc((void **)&ctx->decl_b, bb));
+                HIPCHK(ctx, hipMalloc((void **)&ctx->decl_l, (size_t)cap * 2 * sizeof(uint64_t)));
+                ctx->decl_cap = (uint32_t)cap;
+                ctx->decl_b_bytes = bb;
+            }
+        }
         HIPCHK(ctx, hipMemsetAsync(ctx->side, 0, 2 * FQH_NSCALARS * sizeof(unsigned long long), s));
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));  // (after the memset: index_ms is the kernel alone)
         fz.buf = a.buf;
@@ -345,6 +364,9 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.scratch = ctx->stats_scratch;
         fz.scalars = ctx->side;
         fz.skip_head = a.back[a.nl_count & 3] != 0 ? 1u : 0u;  // the chunk begins inside a record: that one is k_stats_edge's
+        fz.decl_b = ctx->decl_b;
+        fz.decl_l = ctx->decl_l;
+        fz.decl_cap = ctx->decl_cap;
         ctx->f_args = fz;
         if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fz, ctx->n_cu));
 #ifdef FQH_TUNING
@@ -862,6 +884,7 @@ fqh_status fqh_rescan_launch(fqh_ctx *ctx, int is_final, const fqh_carry *in, ui
 }
 
 int fqh_last_scan_fast(fqh_ctx *ctx) { return ctx && ctx->used_spec ? 1 : 0; }
+int fqh_last_stats_route(fqh_ctx *ctx) { return ctx ? ctx->stats_route : 0; }
 fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
     if (!ctx) return FQH_E_ARG;
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is pending");
@@ -972,7 +995,11 @@ static fqh_status fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len,
 static fqh_status fused_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out, bool *two_pass) {
     fqh_status st = do_scan_finish(ctx, out, carry_out);
     ctx->fused = false;
-    *two_pass = !ctx->used_spec;
+    // (stats_declined: the kernel met lines it can neither count nor hand to k_stats_declined — kilobase reads, more dirty
+    // batches than the dump area holds.  The scan's result stands, on the fast path; only the histograms take a second pass,
+    // and the fast path's back-off does not hear of it: nothing was wrong with the parse)
+    *two_pass = !ctx->used_spec || ctx->h_out->stats_declined != 0;
+    ctx->stats_route = *two_pass ? 0 : (ctx->h_out->decl_batches || ctx->h_out->decl_lines) ? 2 : 1;
     if (ctx->used_spec) ctx->timing.stats_ms = ctx->timing.index_ms;  // the one kernel that read the input
     return st;
 }
@@ -1001,9 +1028,9 @@ fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     return st;
 }
 // after fqh_internal_scan_finish of such a launch: did the single pass stand (a commit is owed), and enqueue it
-bool fqh_internal_fused_owed(const fqh_ctx *ctx) { return ctx->f_commit_owed && ctx->used_spec; }
+bool fqh_internal_fused_owed(const fqh_ctx *ctx) { return ctx->f_commit_owed && ctx->used_spec && !ctx->h_out->stats_declined; }
 void fqh_internal_fused_commit(fqh_ctx *ctx) {
-    if (ctx->f_commit_owed && ctx->used_spec) enqueue_fused_commit(ctx);
+    if (ctx->f_commit_owed && ctx->used_spec && !ctx->h_out->stats_declined) enqueue_fused_commit(ctx);
     ctx->f_commit_owed = false;
 }
 void fqh_internal_fused_drop(fqh_ctx *ctx) { ctx->f_commit_owed = false; }
@@ -1155,6 +1182,7 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
     HIPCHK(ctx, hipSetDevice(ctx->device));
     fqh_status cap_st = ctx->stats_cap_st;  // the scan in front of the histograms found d_rec_start too short
     ctx->stats_cap_st = FQH_OK;
+    if (!ctx->fused) ctx->stats_route = 0;
     if (ctx->fused) {
         const uint8_t *buf = ctx->args.buf;
         const uint64_t len = ctx->args.len;
@@ -1169,9 +1197,13 @@ fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out
         // (FQH_E_CAPACITY: the histograms are complete and the summary exact, d_rec_start was too short — both routes
         // report it, like fqh_scan)
         if (!two_pass) return scan_st;
-        // the exact path has rerun the scan (same buffer, full index): count over it
-        ctx->trust_index = true;   // (the exact scan of these very bytes has just finished inside this call)
+        // the exact path has rerun the scan (same buffer, full index), or the single pass kept the scan and declined the
+        // count: the histogram kernels count over the full index of these very bytes (built now, in the second case)
+        ctx->trust_index = true;   // (the scan of these very bytes has just finished inside this call)
+        const bool fe = ctx->fused_enabled;
+        ctx->fused_enabled = false;  // (not the single pass again)
         fqh_status st = fqh_internal_stats_launch(ctx, buf, len, is_final, &cin, lmax, qh, bh, sc, lead, UINT64_MAX);
+        ctx->fused_enabled = fe;
         ctx->trust_index = false;
         if (st != FQH_OK) return st;
         ctx->stats_pending = false;

@@ -103,6 +103,12 @@ struct DevOut {
     unsigned long long max_len;     // longest complete record ending in the chunk
     unsigned long long overflow;    // tiles whose list overflowed list_cap (=> rerun)
     unsigned long long spec_fail;   // fast path: some tile could not be proven valid (=> exact rerun)
+    // the single pass (k_scan_stats): what it could not COUNT — no doubt about the parse.  Batches of eight lines with a byte
+    // outside ACGTN / '!'..'`' are dumped (registers and all) to FusedArgs::decl_b, lines longer than the histogram's rows are
+    // listed in FusedArgs::decl_l; k_stats_declined counts both exactly behind k_stats_commit.  stats_declined: something could
+    // be neither dumped nor listed (a line of more than ~500 bytes, a full dump area): nothing of the pass is committed and
+    // the host counts in a second pass — the scan's result stands, the fast path's back-off is not touched
+    unsigned long long decl_batches, decl_lines, stats_declined;
     // written by k_finalize
     unsigned long long total_entries;
     unsigned long long lastnl;
@@ -116,8 +122,10 @@ struct DevOut {
     unsigned long long tail_len;
     unsigned long long need_list;    // fast path without a line-list workspace: a tile has more record starts than its two lines hold
                                      // (reads shorter than ~50 bp): rerun the fast path with the workspace (reset by finalize)
-    unsigned long long stats_commit; // written by k_finalize_fast: 1 = the fast path's result stands (k_stats_commit may add
-                                     // what k_scan_stats counted to the caller's histograms), 0 = it is discarded
+    unsigned long long stats_commit; // written by k_finalize_fast: 1 = the fast path's result stands AND the single pass counted (or
+                                     // dumped / listed) every line (k_stats_commit may add what k_scan_stats counted to the caller's
+                                     // histograms), 0 = it is discarded
+    unsigned long long decl_b, decl_l;  // ... and how many dumped batches / listed lines k_stats_declined has to count
 };
 
 // Arguments of k_scan_stats (fused_kernels.hip): the input, the fast path's outputs of the byte scan, and where the
@@ -134,6 +142,9 @@ struct FusedArgs {
     uint32_t *scratch;    // [gridDim.x][SO_WORDS] per-block partial histograms
     unsigned long long *scalars;  // FQH_NSCALARS totals (a zeroed side array: k_stats_commit adds them to the caller's)
     uint32_t skip_head;   // the chunk begins inside a record (carry-in): the lines of that record are k_stats_edge's, not this kernel's
+    uint32_t *decl_b;     // dump area of declined batches: [decl_cap][(1 + NSL) * 64] words: the lanes' P (bit 31: quality lines), then their raw dwords per step
+    uint64_t *decl_l;     // declined lines: [decl_cap][2]: offset of the line's first byte in buf, length | kind << 32 (1: quality)
+    uint32_t decl_cap;
     uint32_t wave_base;   // set by the launcher: bytes of histogram in front of the wavefronts' LDS areas
     uint32_t dbg;         // knock-out flags for timing experiments (FQH_FZ_DBG; results are wrong by design)
 };

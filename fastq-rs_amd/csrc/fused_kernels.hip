@@ -26,9 +26,13 @@
 //     the next group's lines (batches are 97 % full instead of 77 %);
 //   * the span's last line ends in another wavefront's span: the 512 bytes after the span are read as well and
 //     the line is closed there;
-//   * no exact path in here: a byte outside ACGTN / '!'..'`', a line longer than the histogram's rows or than the
-//     kept tail, more than 251 line starts in 4 KiB — the span is marked bad, spec_fail is set, and the caller
-//     reruns on the exact two-pass route (k_index_t + k_stats_oct), which handles all of it;
+//   * no exact path in here, and a count the kernel cannot make is NOT a doubt about the parse: a batch of eight lines with
+//     a byte outside ACGTN / '!'..'`' is not counted but DUMPED — the lanes' line words and raw dwords, 1.5 KiB — and a
+//     sequence / quality line longer than the histogram's rows is LISTED (offset, length); k_stats_declined counts both with
+//     the plain per-byte statement behind k_stats_commit.  A line longer than the kept tail, or a full dump area, sets
+//     DevOut::stats_declined: nothing of the pass is committed and the caller counts in a second pass (the scan's result
+//     stands).  Only what the kernel cannot VALIDATE — more than 251 line starts in 4 KiB, an alignment that does not
+//     stand out — marks the span bad and sets spec_fail (the caller reruns the exact path);
 //   * per-block partial histograms and the totals go to scratch; k_stats_commit adds them to the caller's arrays
 //     only if the scan's finalize kernel found no reason to doubt the fast path.
 //
@@ -143,9 +147,30 @@ __device__ __forceinline__ void fz_sub4_at(const uint32_t off, const SoLane &c, 
 }
 
 // Count one batch: pass 1 checks every byte the batch counts, pass 2 adds them — one v_perm_b32 and one ds_sub_u32 per
-// byte (stats_dev.h).  No exact path: a byte outside the alphabet / window sets `bad` and nothing is counted.
+// byte (stats_dev.h).  No exact path: a batch with a byte outside the alphabet / window is dumped, not counted (fz_dump).
+// Sequence dwords stay RAW in the batch (the bins are worked out again in pass 2: one v_and per step) so that a dump holds
+// the bytes the file holds; quality dwords are rebased in place, which a dump undoes.
+// A batch that holds a byte outside the alphabet / window: its lanes' line words (bit 31: quality lines) and raw dwords go to
+// the dump area, 64 x (1 + NSL) words per batch; k_stats_declined counts them.  No room left: nothing of this pass is used.
 template <bool IS_SEQ, uint32_t NSL>
-__device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const FzLane &L, SoTotals &T, bool &bad) {
+__device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &z) {
+    uint32_t slot = 0;
+    if (__lane_id() == 0) slot = (uint32_t)atomicAdd(&z.out->decl_batches, 1ull);
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+    if (slot >= z.decl_cap) {
+        if (__lane_id() == 0) atomicAdd(&z.out->stats_declined, 1ull);
+        return;
+    }
+    uint32_t *dst = z.decl_b + (uint64_t)slot * ((1u + NSL) * 64u) + __lane_id();
+    dst[0] = (B.P & 0x7FFFFFFFu) | (IS_SEQ ? 0u : 0x80000000u);
+#pragma unroll
+    for (uint32_t u = 0; u < NSL; ++u) dst[64u * (1u + u)] = IS_SEQ ? B.w[u] : B.w[u] + 0x21212121u;  // (quality dwords were rebased in place)
+}
+
+template <bool IS_SEQ, uint32_t NSL>
+__device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const FzLane &L, SoTotals &T, bool &bad, const FusedArgs &z) {
+    (void)bad;  // (not written any more: a batch the kernel will not count is dumped.  The parameter stays: without it the register
+                // allocator spills 116 instead of 21 vector registers around the tile loop — tools/isa.sh)
     const SoLane &c = L.c;
     if (__ballot((B.P & 0xFFFFu) != S.key) != 0) fz_shape<NSL>(S, B.P, L.m);
     constexpr uint32_t RB = IS_SEQ ? 2048u : 16384u;
@@ -174,7 +199,6 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
             const uint32_t bins = w & 0x07070707u;
             chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;
             orw |= w & f;
-            B.w[u] = bins;
         } else {
             const uint32_t t = w - 0x21212121u;  // byte - 33 < 64 for all four bytes <=> bits 6-7 clear (stats_dev.h)
             chk |= t & f;
@@ -182,12 +206,12 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
         }
     }
     if (__ballot(IS_SEQ ? chk != 0 : (chk & 0xC0C0C0C0u) != 0) != 0) {
-        bad = true;
+        fz_dump<IS_SEQ, NSL>(B, z);
         return;
     }
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
-        const uint32_t pb = B.w[u], f = S.cm[u];
+        const uint32_t pb = IS_SEQ ? B.w[u] & 0x07070707u : B.w[u], f = S.cm[u];
         // (the row block and slot half go into the instruction's immediate offset)
         constexpr uint32_t OFFS[8] = {REGION, REGION + 128u, REGION + RB, REGION + RB + 128u, REGION + 2 * RB, REGION + 2 * RB + 128u,
                                       REGION + 3 * RB, REGION + 3 * RB + 128u};
@@ -244,7 +268,7 @@ struct FzKind {          // one kind's lines of the chunk
 template <uint32_t NSL>
 __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKind ks, FzBatch<NSL> &PBq, uint32_t &nfq, FzKind kq,
                                           uint32_t Pent, bool flush, const FzLane &L, const uint8_t *lds8, FzShape<NSL> &S,
-                                          SoTotals &T, bool &bad, bool do_count) {
+                                          SoTotals &T, bool &bad, const FusedArgs &z, bool do_count) {
     const uint32_t q0s = nfs, tots = q0s + ks.n, nbs = tots >> 3, rems = tots & 7u, nits = nbs + ((rems && flush) ? 1u : 0u);
     const uint32_t q0q = nfq, totq = q0q + kq.n, nbq = totq >> 3, remq = totq & 7u, nitq = nbq + ((remq && flush) ? 1u : 0u);
     const uint32_t nbm = nbs > nbq ? nbs : nbq;
@@ -263,9 +287,9 @@ __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKi
         Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)(is0 + 8) + L.g16), (int)Pent);
         Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)(iq0 + 8) + L.g16), (int)Pent);
         if (news) fz_align<NSL>(PBs, Rs);
-        if (act_s && b < nits && do_count) fz_count<true, NSL>(PBs, S, L, T, bad);
+        if (act_s && b < nits && do_count) fz_count<true, NSL>(PBs, S, L, T, bad, z);
         if (newq) fz_align<NSL>(PBq, Rq);
-        if (act_q && b < nitq && do_count) fz_count<false, NSL>(PBq, S, L, T, bad);
+        if (act_q && b < nitq && do_count) fz_count<false, NSL>(PBq, S, L, T, bad, z);
     }
     nfs = flush ? 0u : rems;
     nfq = flush ? 0u : remq;
@@ -501,7 +525,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             yclose = yend;
                         } else if (full) {
                             if (ppos >= 0) yclose = yend + ppos + 1;
-                            else if (tb + tile_bytes + FZ_POST <= len) span_bad = true;  // a line that goes on for more than 512 bytes after the span
+                            else if (tb + tile_bytes + FZ_POST <= len) {  // a line that goes on for more than 512 bytes after the span:
+                                if (lane == 0) atomicAdd(&z.out->stats_declined, 1ull);  // not counted here (no doubt about the parse)
+                            }
                             // (else: no '\n' before the end of the buffer: not a line the parser delivers)
                         }
                         if (yclose >= 0) {
@@ -558,7 +584,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                 l = ((e4 - e3) & 0x3FFFu) - 1u;  // raw line, without its '\n'
                                 const int ys = yc - 1 - (int)l;
                                 if (ys < 0) {
-                                    span_bad = true;  // began before the kept tail (longer than ~500 bytes)
+                                    atomicAdd(&z.out->stats_declined, 1ull);  // began before the kept tail (longer than ~500 bytes): not counted here
                                 } else {
                                     if (l && bcr == '\r') --l;  // trim_winline, src/records.rs:66-73
                                     // (longer than the histogram's rows: the span is bad if this turns out to be a sequence or a
@@ -584,10 +610,28 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             // entry p closes line srun + p - 1.  (Runs whatever span_bad says: nothing of a bad span is used, and
                             // a region that is skipped conditionally costs a wait for the loads in flight, see DESIGN.md.)
                             const uint32_t kd = (srun + p - 1u - hyp) & 3u;
-                            if (__ballot(toolong && (kd & 1u)) != 0) span_bad = true;  // a sequence / quality line beyond the rows
                             // a chunk that begins inside a record (carry-in): the lines up to the chunk's first record start belong to
                             // the record in progress, which is counted as a whole by k_stats_edge (it began in front of the chunk)
                             if (head_chunk && hyp < 4 && p <= hyp) Pent = 0;
+                            {   // a sequence / quality line beyond the histogram's rows joins its batch with length 0 and is LISTED
+                                // (where it starts in the buffer, its length, its kind) for k_stats_declined
+                                const bool listed = toolong && (kd & 1u) && Pent != 0;
+                                const unsigned long long lb = __ballot(listed);
+                                if (lb) {
+                                    uint32_t base = 0;
+                                    const uint32_t nl_ = (uint32_t)__popcll(lb);
+                                    if (lane == 0) base = (uint32_t)atomicAdd(&z.out->decl_lines, (unsigned long long)nl_);
+                                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                                    if (base + nl_ > z.decl_cap) {
+                                        if (lane == 0) atomicAdd(&z.out->stats_declined, 1ull);
+                                    } else if (listed) {
+                                        const uint32_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb, 0));
+                                        const long long gs = (long long)tb + ((int)(Pent >> 16) - gofs);
+                                        z.decl_l[2ull * k] = (uint64_t)gs;
+                                        z.decl_l[2ull * k + 1] = (uint64_t)l | ((uint64_t)(kd == 3u ? 1u : 0u) << 32);
+                                    }
+                                }
+                            }
                             if (Pent) {
                                 if (kd == 1u) { ++acc_rec; acc_bases += l; }
                                 if (kd == 3u) acc_qual += l;
@@ -612,7 +656,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
                             const bool cnt = !FZ_DBG(2u);
                             FZ_T(5);
-                            fz_lines2<NSL>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, cnt);
+                            fz_lines2<NSL>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, z, cnt);
                             FZ_T(4);  // lines: lookups, reads, counts
                         }
                     }
@@ -820,6 +864,91 @@ __global__ __launch_bounds__(64) void k_stats_edge(const DevOut *__restrict__ ou
 void launch_stats_edge(hipStream_t s, const DevOut *out, const uint8_t *buf, uint64_t len, uint64_t back0, int sign, uint32_t lmax,
                        unsigned long long *qual_hist, unsigned long long *base_hist, unsigned long long *scalars) {
     hipLaunchKernelGGL(k_stats_edge, dim3(1), dim3(64), 0, s, out, buf, len, back0, sign, lmax, qual_hist, base_hist, scalars);
+}
+
+// k_stats_declined — what k_scan_stats could not count itself (fz_dump, the list of long lines), counted with the plain
+// per-byte statement on the caller's u64 arrays; runs behind k_stats_commit and, like it, only if the pass is committed
+// (DevOut::stats_commit).  One wavefront per dumped batch / listed line.  The single pass has already counted these lines'
+// records and lengths (its totals come from the line starts), and has taken every sequence line for valid DNA that it did
+// not count itself: a line with an 'N' or a byte outside ACGTN is taken out of scalars[3] / [4] here
+// (validate_dna / validate_dnan, src/records.rs:19-33).
+__global__ __launch_bounds__(256) void k_stats_declined(const DevOut *__restrict__ out, const uint32_t *__restrict__ decl_b, uint32_t nsl,
+                                                        const uint64_t *__restrict__ decl_l, uint32_t cap, const uint8_t *__restrict__ buf,
+                                                        uint32_t lmax, unsigned long long *__restrict__ qual_hist,
+                                                        unsigned long long *__restrict__ base_hist, unsigned long long *__restrict__ scalars) {
+    if (!out->stats_commit) return;
+    const uint32_t nb = (uint32_t)(out->decl_b < cap ? out->decl_b : cap), nl = (uint32_t)(out->decl_l < cap ? out->decl_l : cap);
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t m = lane & 7u;
+    for (uint32_t sidx = wave; sidx < nb; sidx += nw) {
+        const uint32_t *src = decl_b + (uint64_t)sidx * ((1u + nsl) * 64u) + lane;
+        const uint32_t P = src[0];
+        const bool isq = (P >> 31) != 0, act = (P & FZ_P_ACT) != 0;
+        const uint32_t n = P & 0x1FFu;
+        uint32_t inv = 0, hasn = 0;
+        for (uint32_t u = 0; u < nsl; ++u) {
+            const uint32_t w = src[64u * (1u + u)];
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t col = 32u * u + 4u * m + j;
+                if (!act || col >= n || col >= lmax) continue;   // (n <= lmax: longer lines are listed, not batched)
+                const uint32_t b = (w >> (8u * j)) & 0xFFu;
+                if (isq) {
+                    atomicAdd(&qual_hist[(uint64_t)col * 256 + b], 1ull);
+                } else {
+                    const uint32_t c = base_class(b);
+                    inv |= c == 5 ? 1u : 0u;
+                    hasn |= c == 4 ? 1u : 0u;
+                    atomicAdd(&base_hist[(uint64_t)col * 8 + c], 1ull);
+                }
+            }
+        }
+        const unsigned long long bi = __ballot(inv != 0), bn = __ballot(hasn != 0);
+        if (m == 0 && act && !isq) {
+            const bool li = ((bi >> lane) & 0xFFull) != 0, ln = ((bn >> lane) & 0xFFull) != 0;
+            if (li || ln) atomicAdd(&scalars[3], ~0ull);
+            if (li) atomicAdd(&scalars[4], ~0ull);
+        }
+    }
+    for (uint32_t sidx = wave; sidx < nl; sidx += nw) {
+        const uint64_t gs = decl_l[2ull * sidx], lk = decl_l[2ull * sidx + 1];
+        const uint32_t n = (uint32_t)lk;
+        const bool isq = (lk >> 32) != 0;
+        unsigned long long over = 0;
+        uint32_t inv = 0, hasn = 0;
+        for (uint32_t col = lane; col < n; col += 64) {
+            const uint32_t b = buf[gs + col];
+            if (isq) {
+                if (col < lmax) atomicAdd(&qual_hist[(uint64_t)col * 256 + b], 1ull);
+                else ++over;
+            } else {
+                const uint32_t c = base_class(b);
+                inv |= c == 5 ? 1u : 0u;
+                hasn |= c == 4 ? 1u : 0u;
+                if (col < lmax) atomicAdd(&base_hist[(uint64_t)col * 8 + c], 1ull);
+                else ++over;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) over += __shfl_xor(over, d);
+        const bool li = __ballot(inv != 0) != 0, ln = __ballot(hasn != 0) != 0;
+        if (lane == 0) {
+            if (over) atomicAdd(&scalars[isq ? 6 : 5], over);
+            if (!isq && (li || ln)) atomicAdd(&scalars[3], ~0ull);
+            if (!isq && li) atomicAdd(&scalars[4], ~0ull);
+        }
+    }
+}
+void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist, unsigned long long *base_hist,
+                           unsigned long long *scalars) {
+    if (!z.decl_cap) return;
+    const uint32_t lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
+    const uint32_t nsl = (lc + 31) / 32 <= 5 ? 5u : 8u;
+    hipLaunchKernelGGL(k_stats_declined, dim3(128), dim3(256), 0, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap, z.buf, z.lmax, qual_hist,
+                       base_hist, scalars);
+}
+uint32_t scan_stats_nsl(uint32_t lmax) {
+    const uint32_t lc = lmax < SO_LC_MAX ? lmax : SO_LC_MAX;
+    return (lc + 31) / 32 <= 5 ? 5u : 8u;
 }
 
 uint32_t stats_blocks(int n_cu);

@@ -480,6 +480,9 @@ __device__ __forceinline__ void publish_and_reset(const ScanArgs &a, DevOut *out
     out->overflow = 0;
     out->spec_fail = 0;
     out->need_list = 0;
+    out->decl_batches = 0;
+    out->decl_lines = 0;
+    out->stats_declined = 0;
 }
 
 template <bool DEVC>
@@ -1290,7 +1293,9 @@ __global__ void k_finalize_fast(ScanArgs a_in, DevOut *__restrict__ out) {
         if (a.is_final && ((T & 3) != 0 || col > 0)) fail = chk;  // truncated: the exact path reports it
     }
     out->spec_fail = fail ? 1 : 0;
-    out->stats_commit = fail ? 0 : 1;
+    out->stats_commit = (fail || out->stats_declined) ? 0 : 1;
+    out->decl_b = out->decl_batches;
+    out->decl_l = out->decl_lines;
     out->min_key = NOKEY;
     out->first_long = first_long;
     out->max_len = max_len;

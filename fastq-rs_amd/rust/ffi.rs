@@ -72,6 +72,7 @@ extern "C" {
     pub fn fqh_set_bufsize(ctx: *mut fqh_ctx, bufsize: u64) -> c_int;
     pub fn fqh_set_option(ctx: *mut fqh_ctx, option: c_int, value: c_int) -> c_int;
     pub fn fqh_last_scan_fast(ctx: *mut fqh_ctx) -> c_int;
+    pub fn fqh_last_stats_route(ctx: *mut fqh_ctx) -> c_int;
     pub fn fqh_placement(ctx: *mut fqh_ctx, n_candidates: *mut c_int, ms: *mut f32) -> c_int;   // ms: [f32; 10]
 
     // ---- whole buffers in HBM: IdxRecord::from_buffer over every record (src/records.rs:201-247)

@@ -128,6 +128,13 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
 #define FQH_OPT_REUSE_INDEX 5
 fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
 int fqh_last_scan_fast(fqh_ctx *ctx);
+/* How the last finished statistics call (fqh_stats*, fqh_scan_stats*) counted: 1 = in the scan's own pass over the input
+ * (k_scan_stats); 2 = the same, and the lines that pass does not count itself — batches of eight with a byte outside ACGTN
+ * or '!'..'`', lines longer than lmax — were counted one by one behind it (a few KiB re-read); 0 = in a second pass over the
+ * input (lmax > 256, reads of more than ~500 bases, a parse error, or more such lines than one per 512 KiB).  Results are
+ * identical; for benchmarks and tests.  A count the single pass declines is no doubt about the parse: it neither reruns the
+ * scan nor touches the fast path's back-off. */
+int fqh_last_stats_route(fqh_ctx *ctx);
 /* What the placement search of this context (FQH_OPT_PLACE_TRIES) measured: *n_candidates line buffers tried (0: no search
  * ran), ms[0 .. n-1] the index kernel's time on the sample with each, ms[8] the kept one's, ms[9] the same kernel without
  * its line stores (the yardstick).  For benchmarks: says whether the search engaged and what it bought. */

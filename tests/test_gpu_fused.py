@@ -35,17 +35,17 @@ def make(rng, nrec, seqlen, crlf=0.0, plus_id=False, hdr=None, qlo=33, qhi=75):
     return b"".join(out)
 
 
-def run(env, fqref, data, lmax, want_fused, offsets=False):
+def run(env, fqref, data, lmax, want_fused, offsets=False, want_route=None):
     torch, pkg = env
     # a context of its own: list sizes and the fast path's back-off stick to a context
     ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
     try:
-        return run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets)
+        return run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets, want_route)
     finally:
         ctx.close()
 
 
-def run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets):
+def run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets, want_route=None):
     dev = torch.device("cuda:0")
     a = np.frombuffer(data, dtype=np.uint8)
     d = torch.empty(max(a.size, 16), dtype=torch.uint8, device=dev)
@@ -77,6 +77,10 @@ def run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets):
         assert np.array_equal(rs.cpu().numpy()[: r2.n_records].astype(np.uint64), off)
     if want_fused is not None:
         assert fused == want_fused, "route: single pass kept = %s, expected %s" % (fused, want_fused)
+        if want_route is None:
+            want_route = 1 if want_fused else 0
+    if want_route is not None:
+        assert ctx.last_stats_route() == want_route, "statistics route %d, expected %d" % (ctx.last_stats_route(), want_route)
     return s
 
 
@@ -131,13 +135,17 @@ def test_single_pass_shapes(env, fqref, shape):
     run(env, fqref, data, lmaxes[0], want_fused=True, offsets=True)
 
 
-@pytest.mark.parametrize("shape", ["lowercase", "qual_high", "lmax_short", "long_reads", "mismatch", "truncated", "no_final_nl"])
-def test_declined_inputs_take_the_exact_route(env, fqref, shape):
-    """Whatever the single pass cannot prove or count sends the call to the exact two-pass route; the arrays the
-    caller passed get exactly the oracle's counts (nothing of the discarded pass leaks into them)."""
+@pytest.mark.parametrize("shape", ["lowercase", "qual_high", "both_many", "few_long", "crlf_dirty", "lmax_short", "long_reads"])
+def test_declined_counts_are_no_parse_doubt(env, fqref, shape):
+    """Any byte may stand in seq() / qual() (src/records.rs:19-33, 75-90).  What the single pass does not count itself — a
+    batch of eight lines with a byte outside ACGTN / '!'..'`', a line longer than lmax — is counted one by one behind it
+    (route 2); lines of more than ~500 bytes, or more declined lines than the dump area holds, send the HISTOGRAMS to a second
+    pass (route 0).  Either way the scan's result stands on the fast path, the arrays get exactly the oracle's counts, and
+    the context's next plain scan takes the fast path: nothing was wrong with the parse."""
+    torch, pkg = env
     rng = np.random.default_rng(11)
     data = bytearray(make(rng, 4000, 150))
-    lmax = 150
+    lmax, route = 150, 2
     if shape == "lowercase":
         pos = data.index(b"\n", 700000) + 1   # some line start far into the file; flip a base of the next sequence line
         k = data.index(b"\n", pos) + 5
@@ -145,19 +153,61 @@ def test_declined_inputs_take_the_exact_route(env, fqref, shape):
     elif shape == "qual_high":
         k = len(data) - 20
         data[k] = 126                         # '~' is outside the kernel's window '!'..'`' (and a valid quality byte)
+    elif shape == "both_many":                # one byte in ~3000 of either kind, anywhere in the lines (first, last, partial dwords)
+        recs = [bytearray(make(rng, 1, 150, hdr=lambda i: b"r%d" % j)) for j in range(4000)]
+        for j in rng.choice(4000, 400, replace=False):
+            r = recs[j]
+            h = r.index(b"\n") + 1
+            col = int(rng.integers(0, 150))
+            if rng.random() < 0.5:
+                r[h + col] = int(rng.choice(np.frombuffer(b"acgtnRYKM.-*", dtype=np.uint8)))
+            else:
+                r[h + 151 + 2 + col] = int(rng.choice([97, 105, 126, 125, 200, 255, 0, 32]))   # above '`', below '!', NUL, high bit
+        data = bytearray(b"".join(bytes(r) for r in recs))
+    elif shape == "few_long":                 # a few reads longer than lmax among reads that fit: columns >= lmax go to scalars[5], [6]
+        data = bytearray(make(rng, 4000, lambda i: 190 if i % 500 == 7 else 150))
+    elif shape == "crlf_dirty":
+        data = bytearray(make(rng, 4000, 150, crlf=0.5))
+        for k in rng.integers(1000, len(data) - 1000, 40):
+            if data[k] not in (10, 13, 43, 64):   # (not a line end, and no new '+' / '@' at a line start)
+                data[k] = ord("n") if data[k] in b"ACGTN" else data[k] | 0x80
     elif shape == "lmax_short":
-        lmax = 100                            # columns 100..149 go to the overflow counters: exact route
+        lmax, route = 100, 0                  # EVERY line is longer than lmax: more than the list holds, a second pass counts
     elif shape == "long_reads":
         data = bytearray(make(rng, 600, 700))  # lines longer than the tail the kernel keeps
-        lmax = 256
-    elif shape == "mismatch":
+        lmax, route = 256, 0
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        for _ in range(2):   # (the second call: no back-off from the first)
+            r = fqref.count(bytes(data))
+            assert r.status == pkg.OK
+            run_ctx(torch, pkg, ctx, fqref, bytes(data), lmax, True, False, want_route=route)
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        d = torch.from_numpy(a.copy()).cuda()
+        s = ctx.scan(d.data_ptr(), a.size)[0]
+        assert ctx.last_scan_fast() and (s.parse_status, s.n_records) == (pkg.OK, r.n_records)
+    finally:
+        ctx.close()
+    if shape in ("lowercase", "both_many"):
+        run(env, fqref, bytes(data), lmax, want_fused=True, offsets=True, want_route=route)
+
+
+@pytest.mark.parametrize("shape", ["mismatch", "truncated", "no_final_nl", "mismatch_and_dirty"])
+def test_parse_errors_take_the_exact_route(env, fqref, shape):
+    """What the single pass cannot PROVE sends the call to the exact two-pass route; the arrays the caller passed get exactly
+    the oracle's counts (nothing of the discarded pass — not even the lines it had dumped for a recount — leaks into them)."""
+    rng = np.random.default_rng(11)
+    data = bytearray(make(rng, 4000, 150))
+    if shape in ("mismatch", "mismatch_and_dirty"):
         k = data.index(b"\n", 900000)
         del data[k - 3]                       # one quality (or sequence) byte less: length mismatch somewhere
+        if shape == "mismatch_and_dirty":
+            data[data.index(b"\n", data.index(b"\n", 300000) + 1) - 9] = ord("c")
     elif shape == "truncated":
         del data[-100:]
     elif shape == "no_final_nl":
         del data[-1:]
-    run(env, fqref, bytes(data), lmax, want_fused=False)
+    run(env, fqref, bytes(data), 150, want_fused=False)
 
 
 @pytest.mark.parametrize("crlf", [0.0, 0.3])

@@ -193,12 +193,33 @@ def test_no_byte_range_is_refused(env, fqref):
     deferred = 0
     for back in range(1, 140, 7):                            # ranges of a few bytes to two lines at the very END of the file
         shards = same([len(data) - back])
-        deferred += shards[-1].res.phase == pkg.SHARD_DEFER
+        deferred += shards[-1].res.phase in (pkg.SHARD_DEFER, pkg.SHARD_PASS)
     assert deferred >= 3
     same([k + 10, k + 14])                                   # four bytes inside the quality line
     same([k, k])                                             # an empty range between two shards
     same([len(data) - 300, len(data) - 200, len(data) - 90, len(data) - 40, len(data) - 3])   # five ranks in the last record and a half
     same(sorted(int(x) for x in np.random.default_rng(1).integers(1, 600, 7)))                 # seven cuts in the first two records
+
+
+def test_ambiguous_files_defer_to_the_exchange(env, fqref):
+    """A file whose sequence lines start with '@' and whose quality lines start with '+' parses under two line phases: no
+    window settles one (FQH_SHARD_DEFER, formerly refused), the true phase comes with the exchange, and the rank behind the
+    last one that could parse by itself reads the rest of the file under it.  Also with a real error far behind the cuts."""
+    torch, pkg, sharded = env
+    unit = b"@AB\n@CD\n+EF\n+GH\n"
+    data = unit * 6000
+    n = len(data)
+    for cuts in ([n // 4 + 1, n // 2 + 7, 3 * n // 4 + 2], [n // 3, n // 3 + 5, n // 3 + 9], [16 * 100, 16 * 200 + 4]):
+        status, n_records, hist, shards = run_sharded(env, data, cuts, 8)
+        r, oq, ob, osc = fqref.stats(data, 8)
+        assert (status, n_records) == (r.status, r.n_records) == (pkg.OK, 6000), (cuts, status, n_records)
+        assert np.array_equal(hist[:8], osc) and np.array_equal(hist[8: 8 + 8 * 256].reshape(8, 256), oq)
+        assert any(sh.res.phase == pkg.SHARD_DEFER for sh in shards[1:]), [hex(sh.res.phase) for sh in shards]
+    bad = bytearray(data)
+    bad[16 * 5000 + 8] = ord("x")      # the separator line of record 5000 loses its '+'
+    r = fqref.count(bytes(bad))
+    status, n_records, hist, shards = run_sharded(env, bytes(bad), [n // 4 + 1, n // 2 + 7, 3 * n // 4 + 2], 8)
+    assert (status, n_records) == (r.status, r.n_records) == (pkg.E_SEP, 5000)
 
 
 def test_three_lines_on_eight_ranks(env, fqref):

@@ -291,7 +291,7 @@ static void enqueue_fused_commit(fqh_ctx *ctx) {
     hipStream_t s = ctx->stream;
     unsigned long long *q = (unsigned long long *)ctx->f_qual, *b = (unsigned long long *)ctx->f_base, *sc = (unsigned long long *)ctx->f_scalars;
     launch_stats_commit(s, &ctx->d_out[0], ctx->f_args, scan_stats_blocks(a.n_tiles, ctx->n_cu), q, b, sc);
-    launch_stats_declined(s, &ctx->d_out[0], ctx->f_args, q, b, sc);  // (batches with a byte outside the alphabets, lines beyond the rows)
+    (void)launch_stats_declined(s, &ctx->d_out[0], ctx->f_args, q, b, sc);  // (batches with a byte outside the alphabets, lines beyond the rows)
     const uint64_t back0 = a.back[a.nl_count & 3];
     if (back0 != 0 && ctx->f_lead >= back0) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, back0, +1, ctx->f_lmax, q, b, sc);
     if (!a.is_final) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, 0, -1, ctx->f_lmax, q, b, sc);

@@ -143,7 +143,7 @@ struct FusedArgs {
     unsigned long long *scalars;  // FQH_NSCALARS totals (a zeroed side array: k_stats_commit adds them to the caller's)
     uint32_t skip_head;   // the chunk begins inside a record (carry-in): the lines of that record are k_stats_edge's, not this kernel's
     uint32_t *decl_b;     // dump area of declined batches: [decl_cap][(1 + NSL) * 64] words: the lanes' P (bit 31: quality lines), then their raw dwords per step
-    uint64_t *decl_l;     // declined lines: [decl_cap][2]: offset of the line's first byte in buf, length | kind << 32 (1: quality)
+    uint64_t *decl_l;     // declined lines: [decl_cap] x 4 u32: tile, place of the line's first byte in the wave's data area | group << 16, length, kind (1: quality)
     uint32_t decl_cap;
     uint32_t wave_base;   // set by the launcher: bytes of histogram in front of the wavefronts' LDS areas
     uint32_t dbg;         // knock-out flags for timing experiments (FQH_FZ_DBG; results are wrong by design)

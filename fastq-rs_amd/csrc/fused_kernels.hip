@@ -39,6 +39,7 @@
 // Algorithmic bytes: len per launch — the only read of the input for offsets, validation and histograms.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "scan_dev.h"
@@ -626,9 +627,11 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                         if (lane == 0) atomicAdd(&z.out->stats_declined, 1ull);
                                     } else if (listed) {
                                         const uint32_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb, 0));
-                                        const long long gs = (long long)tb + ((int)(Pent >> 16) - gofs);
-                                        z.decl_l[2ull * k] = (uint64_t)gs;
-                                        z.decl_l[2ull * k + 1] = (uint64_t)l | ((uint64_t)(kd == 3u ? 1u : 0u) << 32);
+                                        uint32_t *e = reinterpret_cast<uint32_t *>(z.decl_l) + 4u * k;   // (tile, y | group << 16, length, kind)
+                                        e[0] = tile;
+                                        e[1] = (Pent >> 16) | (g << 16);
+                                        e[2] = l;
+                                        e[3] = kd == 3u ? 1u : 0u;
                                     }
                                 }
                             }
@@ -867,17 +870,32 @@ void launch_stats_edge(hipStream_t s, const DevOut *out, const uint8_t *buf, uin
 }
 
 // k_stats_declined — what k_scan_stats could not count itself (fz_dump, the list of long lines), counted with the plain
-// per-byte statement on the caller's u64 arrays; runs behind k_stats_commit and, like it, only if the pass is committed
-// (DevOut::stats_commit).  One wavefront per dumped batch / listed line.  The single pass has already counted these lines'
-// records and lengths (its totals come from the line starts), and has taken every sequence line for valid DNA that it did
-// not count itself: a line with an 'N' or a byte outside ACGTN is taken out of scalars[3] / [4] here
-// (validate_dna / validate_dnan, src/records.rs:19-33).
+// per-byte statement; runs behind k_stats_commit and, like it, only if the pass is committed (DevOut::stats_commit).  One
+// wavefront per dumped batch / listed line.  A dumped batch is eight whole lines — a thousand clean bytes around the one that
+// made the kernel decline — so the counts first go to a histogram in the block's LDS (lmax rows x (8 classes + 256 quality
+// values), 16-bit counters packed in pairs: a block never sees more than DECL_LINES_PER_BLOCK lines) and only its non-zero
+// bins to the caller's u64 arrays: 18 M global atomics on the same few thousand addresses took 1.5 ms for one dirty byte in a
+// million, the flush of 128 small histograms takes a twentieth of that.  The single pass has already counted these lines'
+// records and lengths (its totals come from the line starts), and has taken every sequence line it did not count itself for
+// valid DNA: a line with an 'N' or a byte outside ACGTN is taken out of scalars[3] / [4] here (validate_dna / validate_dnan,
+// src/records.rs:19-33).
+constexpr uint32_t DECL_BINS = 264;               // per row: base classes 0..7, then quality values 0..255
+constexpr uint32_t DECL_LINES_PER_BLOCK = 60000;  // (16-bit counters)
 __global__ __launch_bounds__(256) void k_stats_declined(const DevOut *__restrict__ out, const uint32_t *__restrict__ decl_b, uint32_t nsl,
                                                         const uint64_t *__restrict__ decl_l, uint32_t cap, const uint8_t *__restrict__ buf,
-                                                        uint32_t lmax, unsigned long long *__restrict__ qual_hist,
+                                                        uint32_t lmax, uint32_t rows, unsigned long long *__restrict__ qual_hist,
                                                         unsigned long long *__restrict__ base_hist, unsigned long long *__restrict__ scalars) {
     if (!out->stats_commit) return;
     const uint32_t nb = (uint32_t)(out->decl_b < cap ? out->decl_b : cap), nl = (uint32_t)(out->decl_l < cap ? out->decl_l : cap);
+    if (!nb && !nl) return;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dh[];   // rows * DECL_BINS / 2 words
+    const uint32_t words = rows * DECL_BINS / 2;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dh[i] = 0;
+    __syncthreads();
+    auto count = [&](uint32_t row, uint32_t bin) {
+        const uint32_t i = row * DECL_BINS + bin;
+        atomicAdd(&dh[i >> 1], 1u << (16u * (i & 1u)));
+    };
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     const uint32_t m = lane & 7u;
     for (uint32_t sidx = wave; sidx < nb; sidx += nw) {
@@ -890,15 +908,15 @@ __global__ __launch_bounds__(256) void k_stats_declined(const DevOut *__restrict
             const uint32_t w = src[64u * (1u + u)];
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t col = 32u * u + 4u * m + j;
-                if (!act || col >= n || col >= lmax) continue;   // (n <= lmax: longer lines are listed, not batched)
+                if (!act || col >= n || col >= rows) continue;   // (n <= lmax: longer lines are listed, not batched)
                 const uint32_t b = (w >> (8u * j)) & 0xFFu;
                 if (isq) {
-                    atomicAdd(&qual_hist[(uint64_t)col * 256 + b], 1ull);
+                    count(col, 8u + b);
                 } else {
                     const uint32_t c = base_class(b);
                     inv |= c == 5 ? 1u : 0u;
                     hasn |= c == 4 ? 1u : 0u;
-                    atomicAdd(&base_hist[(uint64_t)col * 8 + c], 1ull);
+                    count(col, c);
                 }
             }
         }
@@ -910,23 +928,23 @@ __global__ __launch_bounds__(256) void k_stats_declined(const DevOut *__restrict
         }
     }
     for (uint32_t sidx = wave; sidx < nl; sidx += nw) {
-        const uint64_t gs = decl_l[2ull * sidx], lk = decl_l[2ull * sidx + 1];
-        const uint32_t n = (uint32_t)lk;
-        const bool isq = (lk >> 32) != 0;
+        const uint32_t *e = reinterpret_cast<const uint32_t *>(decl_l) + 4u * sidx;
+        // the line's first byte: tile, position y in the wave's data area while group g of the tile was in it (y = FZ_TAIL is the group's first byte)
+        const uint64_t gs = ((uint64_t)e[0] << WT_SHIFT) + (e[1] >> 16) * FZ_GROUP + (e[1] & 0xFFFFu) - FZ_TAIL;
+        const uint32_t n = e[2];
+        const bool isq = e[3] != 0;
         unsigned long long over = 0;
         uint32_t inv = 0, hasn = 0;
         for (uint32_t col = lane; col < n; col += 64) {
             const uint32_t b = buf[gs + col];
-            if (isq) {
-                if (col < lmax) atomicAdd(&qual_hist[(uint64_t)col * 256 + b], 1ull);
-                else ++over;
-            } else {
-                const uint32_t c = base_class(b);
-                inv |= c == 5 ? 1u : 0u;
-                hasn |= c == 4 ? 1u : 0u;
-                if (col < lmax) atomicAdd(&base_hist[(uint64_t)col * 8 + c], 1ull);
-                else ++over;
+            uint32_t bin = 8u + b;
+            if (!isq) {
+                bin = base_class(b);
+                inv |= bin == 5 ? 1u : 0u;
+                hasn |= bin == 4 ? 1u : 0u;
             }
+            if (col < rows) count(col, bin);
+            else ++over;
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) over += __shfl_xor(over, d);
@@ -937,14 +955,39 @@ __global__ __launch_bounds__(256) void k_stats_declined(const DevOut *__restrict
             if (!isq && li) atomicAdd(&scalars[4], ~0ull);
         }
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
+        const uint32_t v = dh[i];
+        if (!v) continue;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint32_t c = (v >> (16u * h)) & 0xFFFFu;
+            if (!c) continue;
+            const uint32_t k = 2u * i + h, row = k / DECL_BINS, bin = k - row * DECL_BINS;
+            if (bin < 8) atomicAdd(&base_hist[(uint64_t)row * 8 + bin], (unsigned long long)c);
+            else atomicAdd(&qual_hist[(uint64_t)row * 256 + (bin - 8)], (unsigned long long)c);
+        }
+    }
 }
-void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist, unsigned long long *base_hist,
-                           unsigned long long *scalars) {
-    if (!z.decl_cap) return;
-    const uint32_t lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
+hipError_t launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
+                                 unsigned long long *base_hist, unsigned long long *scalars) {
+    if (!z.decl_cap) return hipSuccess;
+    const uint32_t lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;   // (the rows the caller's arrays and the single pass share)
     const uint32_t nsl = (lc + 31) / 32 <= 5 ? 5u : 8u;
-    hipLaunchKernelGGL(k_stats_declined, dim3(128), dim3(256), 0, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap, z.buf, z.lmax, qual_hist,
-                       base_hist, scalars);
+    const size_t lds = (size_t)lc * DECL_BINS * 2;
+    // a block's 16-bit counters hold the lines of its share of the slots: 8 lines per dumped batch, 1 per listed line
+    const uint64_t per_block = DECL_LINES_PER_BLOCK / 9;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(512, ((uint64_t)z.decl_cap + per_block - 1) / per_block);
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_declined), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(SO_LC_MAX * DECL_BINS * 2));
+        if (e != hipSuccess) return e;
+        set = true;
+    }
+    hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(256), lds, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap, z.buf, z.lmax, lc,
+                       qual_hist, base_hist, scalars);
+    return hipSuccess;
 }
 uint32_t scan_stats_nsl(uint32_t lmax) {
     const uint32_t lc = lmax < SO_LC_MAX ? lmax : SO_LC_MAX;

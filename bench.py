@@ -48,7 +48,16 @@ def main():
                     help="threads that fill a ring slot from pageable host memory (0: 1, the reference's one reader thread, AND 8)")
     ap.add_argument("--no-stream", action="store_true", help="skip the configs[3] leg of the default run")
     ap.add_argument("--no-long-reads", action="store_true", help="skip the kilobase-read histogram leg of the default run")
-    ap.add_argument("--default-stream-gib", type=float, default=32.0)
+    ap.add_argument("--default-stream-gib", type=float, default=256.0,
+                    help="size of the configs[3] leg of the default run (its stated size: 256 GiB, ~5 s at the link's rate; the "
+                         "one-thread producer run stops at 8 GiB)")
+    ap.add_argument("--numa-pin", choices=["auto", "require", "off"], default="auto",
+                    help="streamed legs: run on (and first-touch the pinned ring from) the NUMA node of the GPU.  auto: best effort, "
+                         "the JSON line says what happened; require: fail if it did not happen")
+    ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
+                    help="roofline.traffic from this run's own rocprofv3 --pmc passes (two short child runs, FETCH_SIZE and WRITE_SIZE "
+                         "apart, calibrated on the plain read kernel) when rocprofv3 is on the box; otherwise from the committed profile")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -123,6 +132,13 @@ def main():
     store = torch.empty(LEAD + nbytes + 16, dtype=torch.uint8, device=dev)
     buf = store[LEAD:]
     ctx.synth_fill(buf.data_ptr(), lo, nbytes)
+    # FQH_BENCH_INJECT=<file offset of a separator line's '+'> (tests only): that byte becomes '-', and the run must report
+    # Parser::each's error for it — "Sequence and quality not separated by +" at record offset // RECLEN — instead of totals
+    inject = int(os.environ.get("FQH_BENCH_INJECT", "-1"))
+    if inject >= 0:
+        assert inject % RECLEN == 177, "FQH_BENCH_INJECT must point at a '+' (offset 177 of a %d-byte record)" % RECLEN
+        if lo <= inject < hi and args.stream_gib == 0:
+            buf[inject - lo] = ord("-")
     cap = nbytes // 300 + 16
     rec_start = torch.empty(cap, dtype=torch.int64, device=dev)
     is_last = rank == world - 1
@@ -225,8 +241,21 @@ def main():
     else:
         n_rec_total = int(s.n_records)
         n_err = 0 if s.parse_status == pkg.OK else 1
-    assert n_err == 0, "scan reported a parse error on valid synthetic input"
-    assert n_rec_total == total_records, (n_rec_total, total_records)
+    first_error = None
+    if inject >= 0:
+        # the first error in file order: MIN over the ranks of (failing record, kind) — what Parser::parallel_each returns
+        # (src/lib.rs:544-547, 561-564)
+        key = ((int(s.err_record) << 3) | int(s.parse_status)) if s.parse_status != pkg.OK else (1 << 62)
+        kt = torch.tensor([key], dtype=torch.int64, device=dev)
+        if world > 1:
+            kt = kt.to(dev if backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(kt, op=dist.ReduceOp.MIN)
+        gk = int(kt.item())
+        first_error = {"status": gk & 7, "n_records": gk >> 3, "expected": {"status": pkg.E_SEP, "n_records": inject // RECLEN}}
+        assert n_err >= 1 and (gk & 7, gk >> 3) == (pkg.E_SEP, inject // RECLEN), first_error
+    else:
+        assert n_err == 0, "scan reported a parse error on valid synthetic input"
+        assert n_rec_total == total_records, (n_rec_total, total_records)
 
     ms_per_step = dt / args.steps * 1e3
     gbs = file_len / 1e9 / (dt / args.steps)
@@ -237,14 +266,27 @@ def main():
     # for the workload they were measured on): HBM bytes per launch of the dominant kernel (PMC), and its duration as
     # rocprofv3 --kernel-trace saw it, next to the HIP-event figure of THIS run.
     traffic = rp = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "round3_rocprof.json")) as f:
-            pj = json.load(f)
-        if pj.get("workload_bytes") == nbytes:
-            rp = pj["k_index_fast"]
-            traffic = rp.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    traffic_source = None
+    if args.pmc_child:   # (a child of pmc_traffic below: the counters are rocprofv3's business, the line is not looked at)
+        print(json.dumps({"pmc_child": True, "kernel_ms": round(k_ms, 4)}), flush=True)
+        ctx.read_ceiling(buf.data_ptr(), nbytes)
+        return
+    if world == 1 and args.pmc_traffic == "auto":
+        live = pmc_traffic(nbytes)
+        if live:
+            traffic, traffic_source = live["hbm_bytes_per_launch"], live["source"]
+    for prof in ("round4_rocprof.json", "round3_rocprof.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", prof)) as f:
+                pj = json.load(f)
+            if pj.get("workload_bytes") == nbytes:
+                rp = pj["k_index_fast"]
+                if traffic is None:
+                    traffic = rp.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, a committed run of the same command)" % prof
+                break
+        except Exception:
+            pass
     out = {
         "metric": "GB/s FASTQ parsed (record-offset scan + count, 150 bp synthetic, HBM-resident)",
         "value": round(gbs, 2),
@@ -271,8 +313,7 @@ def main():
         "hbm_roofline_frac_whole_step": round(gbs / world / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": "k_index_fast", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "traffic_source": "profiles/round3_rocprof.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, a committed run of the "
-                                                           "same command)" if traffic else None,
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": round(k_ms, 4), "kernel_ms_source": "HIP events on the launch stream, this run, mean of the timed steps",
                      "kernel_ms_min": round(float(np.min(index_ms)), 4), "kernel_ms_max": round(float(np.max(index_ms)), 4),
                      "kernel_ms_rocprof_avg": rp.get("avg_ms") if rp else None,
@@ -282,6 +323,11 @@ def main():
     }
 
     out["placement"] = ctx.placement()   # FQH_OPT_PLACE_TRIES (FQH_BENCH_PLACE_TRIES here; default 0 = no search)
+    if first_error:
+        out["first_error"] = first_error
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
     if world == 1:
         # what the last timed step left in the caller's array: record k of the synthetic file starts at 330 k (every record of
         # fqh_synth_fill is RECLEN bytes), so the offsets' sum is known in closed form — a figure outside the library's own
@@ -462,6 +508,49 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(nbytes):
+    """HBM bytes per launch of k_index_fast from THIS box's counters: two short child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md), counters in KiB, FETCH_SIZE
+    calibrated in the same pass on the plain read kernel k_read_ceiling (on gfx950 it reports half of a 16-byte-per-lane
+    stream), as the guide prescribes.  -> dict, or None when rocprofv3 is not there / a pass fails (the caller falls back to
+    the committed profile)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3") or os.environ.get("FQH_BENCH_NO_PMC") == "1":
+        return None
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                       sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-stats",
+                       "--no-stream", "--pmc-child", "--bytes", str(nbytes)]
+                env = dict(os.environ, TMPDIR="/tmp")
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                vals = {}
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        for k in ("k_index_fast", "k_read_ceiling"):
+                            if k in row.get("Kernel_Name", ""):
+                                vals.setdefault(k, []).append(float(row["Counter_Value"]))
+                for k, v in vals.items():
+                    big = [x for x in v if x > 0.5 * max(v)] if max(v) > 0 else v
+                    got[(k, counter)] = sum(big) / len(big)
+        fetch, write = got[("k_index_fast", "FETCH_SIZE")], got.get(("k_index_fast", "WRITE_SIZE"), 0.0)
+        cal = nbytes / (got[("k_read_ceiling", "FETCH_SIZE")] * 1024.0)   # bytes per counted byte of a 16-byte-per-lane stream
+        rd, wr = fetch * 1024.0 * cal, write * 1024.0
+        return {"hbm_bytes_per_launch": int(rd + wr),
+                "source": "this run: rocprofv3 --pmc FETCH_SIZE (%.0f KiB x %.3f, calibrated on k_read_ceiling in the same pass) + "
+                          "--pmc WRITE_SIZE (%.0f KiB), two child runs of 2 steps, average over the full-size launches" % (fetch, cal, write)}
+    except Exception:
+        return None
+
+
 def long_read_leg(pkg, torch, dev, ctx, read_len=5000, gib=4.0):
     """Kilobase reads with PacBio-HiFi-like qualities (80 % '~' = Q93): the reference treats a record of any length up to its
     Buffer alike (src/lib.rs:276-283, src/records.rs:75-90); here they take the exact scan + fqh_index_records + k_stats_long
@@ -518,6 +607,7 @@ def stream_leg(args, pkg, torch, dev, buf, gib, threads):
     slot = min(args.slot_mib << 20, (buf.numel() - 16) // RECLEN * RECLEN)
     region = slot // RECLEN * RECLEN      # record-aligned, so replaying it keeps the stream valid FASTQ
     region_recs = region // RECLEN
+    numa = numa_pin(torch, dev.index, args.numa_pin)   # (before the pageable source and the pinned ring are first touched)
     host_src = buf[:region].cpu().numpy().copy()   # pageable
     LINK_GBS = 63.0                         # MI355X_MICROARCH.md: PCIe Gen5 x16
     runs = []
@@ -577,7 +667,7 @@ def stream_leg(args, pkg, torch, dev, buf, gib, threads):
                         "(a %d MiB record-aligned region replayed; every slot of every pass is filled again by the producer "
                         "threads), hipMemcpyAsync on a side stream, scan of slot k enqueued before the host waits for slot k-1"
                         % (slot >> 20, region >> 20),
-            "gbs": best["gbs"], "pcie_frac": best["pcie_frac"], "link_gbs": LINK_GBS, "runs": runs,
+            "gbs": best["gbs"], "pcie_frac": best["pcie_frac"], "link_gbs": LINK_GBS, "numa": numa, "runs": runs,
             "note": "PCIe- and producer-inclusive: never `value`.  HIP events per slot on both streams (FQH_STREAM_TIMING)"}
 
 
@@ -607,24 +697,39 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def numa_pin(torch, dev_index):
-    """Best effort: run this process (and first-touch its pinned ring) on the NUMA node of its GPU.  -> node or None."""
+def numa_pin(torch, dev_index, mode="auto"):
+    """Run this process (and first-touch its pinned ring) on the NUMA node of its GPU.  -> {"node", "pinned", "cpus", "why"};
+    mode "require": no pinning is an error, said loudly; "off": not attempted."""
+    info = {"node": None, "pinned": False, "cpus": None, "why": None}
+    if mode == "off":
+        info["why"] = "--numa-pin off"
+        return info
     try:
         p = torch.cuda.get_device_properties(dev_index)
         bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
         with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
             node = int(f.read())
+        info["node"] = node
         if node < 0:
-            return None
-        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
-            cpus = set()
-            for part in f.read().strip().split(","):
-                a, _, b = part.partition("-")
-                cpus.update(range(int(a), int(b or a) + 1))
-        os.sched_setaffinity(0, cpus)
-        return node
-    except Exception:
-        return None
+            info["why"] = "the device reports no NUMA node (%s: numa_node = %d)" % (bdf, node)
+        else:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                cpus = set()
+                for part in f.read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+            allowed = cpus & os.sched_getaffinity(0)
+            if not allowed:
+                info["why"] = "none of node %d's cpus is in this process's affinity mask" % node
+            else:
+                os.sched_setaffinity(0, allowed)
+                info["pinned"] = True
+                info["cpus"] = len(allowed)
+    except Exception as e:   # no sysfs entry, no permission
+        info["why"] = "%s: %s" % (type(e).__name__, e)
+    if mode == "require" and not info["pinned"]:
+        raise SystemExit("bench.py: --numa-pin require, but the process could not be pinned: %s" % info["why"])
+    return info
 
 
 def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
@@ -637,7 +742,7 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     import importlib
     import numpy as np
     sharded = importlib.import_module("fastq_rs_amd.sharded")
-    node = numa_pin(torch, dev.index)
+    numa = numa_pin(torch, dev.index, args.numa_pin)
     LMAX = 150
     blk = (args.slot_mib << 20) // 2640 * 2640          # multiple of the record size (330) and of 16
     total = int(args.stream_gib * (1 << 30))
@@ -651,9 +756,11 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     h_blk = d_blk[:blk].cpu().numpy()
     filled = {}
 
+    inject = int(os.environ.get("FQH_BENCH_INJECT", "-1"))   # (tests only: the '+' at this file offset reads as '-')
+
     def read_into(addr, off, n):
         d = off % blk
-        if n == 0 or filled.get(addr) == d:   # a ring slot that already holds the block at this rotation
+        if n == 0 or (filled.get(addr) == d and inject < 0):   # a ring slot that already holds the block at this rotation
             return
         done = 0
         while done < n:
@@ -662,6 +769,8 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
             done += k
         if n == blk:
             filled[addr] = d
+        if off <= inject < off + n:
+            C.memset(addr + (inject - off), ord("-"), 1)
 
     hist = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
     sc, qh, bh = hist[:8], hist[8: 8 + LMAX * 256], hist[8 + LMAX * 256:]
@@ -705,6 +814,15 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     rates[rank] = (hi - lo) / 1e9 / t_stream
     dist.all_reduce(rates)
     bad = [] if g_status == pkg.OK else [(g_status, g_records, g_err_offset)]
+    if inject >= 0:
+        exp_err = (pkg.E_SEP, inject // RECLEN, inject // RECLEN * RECLEN)
+        assert bad == [exp_err], (bad, exp_err)
+        if rank == 0:
+            print(json.dumps({"mode": "sharded-stream", "n_gpus": world, "backend": backend, "numa": numa,
+                              "first_error": {"status": g_status, "n_records": g_records, "err_offset": g_err_offset,
+                                              "key_rank": (gkey >> 3) & 0xFF, "expected": list(exp_err)}}), flush=True)
+        ctx.close()
+        return
     # ---- what the totals must be: the block's own histograms, times the repetitions, plus the last partial block
     reps, rem = divmod(file_len, blk)
     exp = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
@@ -725,7 +843,7 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
             "n_gpus": world, "backend": backend, "bytes_per_gpu": shard, "seconds": round(dt, 4),
             "gbs_pcie_inclusive_aggregate": round(file_len / 1e9 / dt, 2),
             "gbs_per_rank_streaming": [round(float(x), 2) for x in rates.cpu().numpy()],
-            "records": int(g_records), "records_per_s": round(int(g_records) / dt, 1), "numa_node_rank0": node,
+            "records": int(g_records), "records_per_s": round(int(g_records) / dt, 1), "numa": numa,
             "finish_seconds_rank0": round(t_finish, 4),
             "check": {"records_expected": file_len // RECLEN, "first_error_key": None if g_status == pkg.OK else gkey,
                       "phases_ok": not bad, "histograms_ok": ok_hist}}), flush=True)

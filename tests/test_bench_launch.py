@@ -49,3 +49,43 @@ def test_bench_gpus_2_launches_itself_on_one_gpu():
     assert j["n_gpus"] == 2 and j["rccl"]["ranks"] == 2 and len(j["rccl"]["device_uuids"]) == 2
     assert j["config"]["records_total"] == 2 * (1 << 30) // 330
     assert "0 of 4" in j["config"]["exchange"], j["config"]["exchange"]   # the device-side exchange was used in every step
+
+
+def _bench(args, timeout=1500, **env):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_env(FQH_BENCH_ONE_GPU="1", **env), cwd=ROOT,
+                         capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.gpu
+def test_eight_ranks_hbm_resident_on_one_gpu():
+    """bench.py --gpus 8 as eight gloo ranks on ONE GPU (the functional mode; an 8-GPU node is the driver's): cuts inside records at
+    every rank, the device-side exchange in every step, the totals are the generator's; then one broken separator line in rank
+    5's shard: every rank learns Parser::each's error — kind and record — from the MIN over the ranks (src/lib.rs:544-564)."""
+    shard = 32 << 20
+    j = _bench(["--gpus", "8", "--bytes", str(shard), "--steps", "2", "--warmup", "1"])
+    assert j["n_gpus"] == 8 and j["rccl"]["ranks"] == 8 and len(j["rccl"]["device_uuids"]) == 8
+    assert j["config"]["records_total"] == 8 * shard // 330 and shard % 330 != 0
+    assert "0 of 3" in j["config"]["exchange"], j["config"]["exchange"]      # no fall-back to the host recipe on valid input
+    rec = (5 * shard + shard // 2) // 330
+    j = _bench(["--gpus", "8", "--bytes", str(shard), "--steps", "1", "--warmup", "0"], FQH_BENCH_INJECT=str(rec * 330 + 177))
+    assert j["n_gpus"] == 8 and j["first_error"]["status"] == 2 and j["first_error"]["n_records"] == rec, j["first_error"]
+
+
+@pytest.mark.gpu
+def test_eight_ranks_sharded_and_streamed_on_one_gpu():
+    """bench.py --gpus 8 --stream-gib G (configs[4]) as eight gloo ranks on one GPU: every rank streams its byte range phase-free,
+    one exchange of ten words, every cut's record parsed by the rank it ends in; totals and histograms checked inside bench.py.
+    Then a broken separator line in rank 5's range: the first-error key comes from rank 5 and names the oracle's record."""
+    j = _bench(["--gpus", "8", "--stream-gib", "4", "--slot-mib", "32"])
+    assert j["mode"] == "sharded-stream" and j["n_gpus"] == 8 and j["check"]["phases_ok"] and j["check"]["histograms_ok"]
+    assert j["records"] == j["check"]["records_expected"] and "numa" in j
+    blk = (32 << 20) // 2640 * 2640
+    shard = max(blk, (4 << 30) // 8 // blk * blk) + 997
+    assert j["bytes_per_gpu"] == shard
+    rec = (5 * shard + shard // 2) // 330
+    j = _bench(["--gpus", "8", "--stream-gib", "4", "--slot-mib", "32"], FQH_BENCH_INJECT=str(rec * 330 + 177))
+    fe = j["first_error"]
+    assert (fe["status"], fe["n_records"], fe["err_offset"], fe["key_rank"]) == (2, rec, rec * 330, 5), fe

@@ -186,6 +186,20 @@ def test_too_long_band(fqref, gpu):
     assert gpu.pkg.E_TOO_LONG in statuses and gpu.pkg.OK in statuses
 
 
+@pytest.mark.parametrize("delta", [16384, 32768, -16384])
+def test_length_mismatch_by_a_multiple_of_the_tile_size(fqref, gpu, delta):
+    """The tile index keeps 14-bit offsets; two raw line lengths that differ by exactly 16 384 must still differ (src/records.rs:233):
+    a quality line one or two tiles longer than its sequence line, early in the file and in the middle of a tile, with tiles full
+    of ordinary records on either side (no tile is short of line starts)."""
+    def rec(i, sl, ql):
+        return b"@r%d\n" % i + b"A" * sl + b"\n+\n" + b"I" * ql + b"\n"
+    for where in (3, 700):
+        parts = [rec(i, 150, 150) for i in range(1500)]
+        parts[where] = rec(where, 150, 150 + delta) if delta > 0 else rec(where, 150 - delta, 150)
+        s, *_ = assert_scan_equal(fqref, gpu, b"".join(parts))
+        assert (s.parse_status, s.n_records) == (gpu.pkg.E_LEN_MISMATCH, where)
+
+
 def test_huge_line_without_newline(fqref, gpu):
     data = b"@" + b"longid" * 200000  # 1.2 MB, no newline at all (huge_incomplete at scale)
     s, *_ = assert_scan_equal(fqref, gpu, data)

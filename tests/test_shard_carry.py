@@ -1,7 +1,8 @@
 """Host logic of byte-range sharding on CPU: fqh_carry_combine folds per-shard
 zero-carry summaries into each shard's true carry-in.  Checked against the carry computed directly
 from the file prefix, single-process and across 2 ranks over gloo (the N > 1 path of bench.py:
-all_gather of 7 words per rank, fold in rank order)."""
+all_gather of 7 words per rank, fold in rank order); the 2-rank exchange is driven by the words the byte-scan kernel produced
+on an MI355X (tests/golden/shard_words_gpu.json)."""
 import os
 import subprocess
 import sys
@@ -65,9 +66,16 @@ from test_shard_carry import shard_summary, truth_carry
 pkg = g.load_package()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-data = fuzzgen.valid_file(np.random.default_rng(123), 300, maxlen=60)
-cut = [0, len(data) // 2 + 7, len(data)]
-mine = shard_summary(data, cut[rank], cut[rank + 1])
+# the words are the byte-scan KERNEL's (fqh_shard_prescan on an MI355X, tests/golden/shard_words_gpu.json), the file is
+# regenerated from its seed; numpy says what the words must be
+import json
+from test_shard_fixture import fixture_file
+fx = json.load(open(os.path.join({root!r}, "tests", "golden", "shard_words_gpu.json")))["hbm_ranks2"]
+data = fixture_file(fx["file"])
+cut = [0] + fx["cuts"] + [len(data)]
+row = fx["prescan_words"][rank]
+mine = (row[0], row[1], row[2], row[3:7])
+assert list(shard_summary(data, cut[rank], cut[rank + 1])[:3]) == row[:3] and shard_summary(data, cut[rank], cut[rank + 1])[3] == row[3:7]
 t = torch.tensor([mine[0], mine[1], mine[2]] + mine[3], dtype=torch.int64)
 outs = [torch.zeros(7, dtype=torch.int64) for _ in range(world)]
 dist.all_gather(outs, t)

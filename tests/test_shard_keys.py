@@ -35,13 +35,20 @@ cases = {{
 }}
 want = {{"clean": (OK, 17, 0), "error_rank1": (LEN, 13, 1300), "error_rank0": (LEN, 4, 400), "wrong_phase": (pkg.E_DEVICE, 10, 1000),
         "rank1_failed": (pkg.E_IO, 10, 1000), "empty_rank1": (OK, 10, 0)}}
+# ... and the words two ranks REALLY produced (fqh_shard_stream_run on an MI355X, tests/golden/shard_words_gpu.json: a file of
+# 6000 records cut at a record start, so that no rank has a gap to parse and the finish is host arithmetic)
+import json
+fx = json.load(open(os.path.join({root!r}, "tests", "golden", "shard_words_gpu.json")))["stream_ranks2_cut_at_record_start"]
+cases["gpu_words"] = fx["words"]
+want["gpu_words"] = (fx["oracle"]["status"], fx["oracle"]["n_records"], 0)
+flen = {{"gpu_words": fx["len"]}}
 for name, rows in cases.items():
     mine = torch.tensor(rows[rank], dtype=torch.int64)
     allw = torch.zeros(world * NW, dtype=torch.int64)
     dist.all_gather_into_tensor(allw, mine)                         # the one exchange
     words = allw.numpy().astype(np.uint64)
     out = (C.c_uint64 * 2)()
-    st = L.fqh_shard_stream_finish(None, pkg.READ_FN(), None, 1700, words.ctypes.data, world, rank, 1 << 16, 2, 0, None, None, None, C.byref(out))
+    st = L.fqh_shard_stream_finish(None, pkg.READ_FN(), None, flen.get(name, 1700), words.ctypes.data, world, rank, 1 << 16, 2, 0, None, None, None, C.byref(out))
     if name == "wrong_phase" and rank == 1:
         assert st == pkg.E_ARG, st                                  # (a gap to parse and no context: this rank's finish fails ...)
         out[0], out[1] = 0, pkg.shard_failure_key(rank, rows[rank][8], st)   # ... and it goes on with a failure key

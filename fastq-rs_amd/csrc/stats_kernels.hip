@@ -489,7 +489,13 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         c.sel[k] = 0x0C0C0004u + k + (j << 8);
         c.slots |= ((m + 8u * j) * 4u) << (8u * k);
     }
-    const uint32_t cb = blockIdx.x % a.n_cb, slice = blockIdx.x / a.n_cb;
+    // Workgroups go to the eight XCDs round-robin (blockIdx % 8), and every XCD has an L2 of its own.  The column blocks of ONE
+    // slice of the records read neighbouring 256-byte pieces of the same lines — pieces that are not aligned to the 128-byte
+    // cache lines, so that neighbours share the line at either edge — at about the same time: they are put on one XCD (slice =
+    // 8 * (i / n_cb) + xcd), where the shared lines are fetched once.  (Numbered across the XCDs, every column block of a slice
+    // pulled its edge lines through another L2: 1.7 x the input's bytes from memory, PMC FETCH_SIZE.)
+    const uint32_t xcd = blockIdx.x & 7u, bi = blockIdx.x >> 3;
+    const uint32_t cb = bi % a.n_cb, slice = (bi / a.n_cb) * 8u + xcd;
     const uint32_t col0 = cb * SO_LC_MAX;
     const uint32_t lc = a.lmax > col0 ? (a.lmax - col0 < SO_LC_MAX ? a.lmax - col0 : SO_LC_MAX) : 0u;  // rows of this block that the caller has
     StatsArgs sa = {};           // what so_exact_step wants to know
@@ -502,84 +508,140 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     unsigned long long recs = 0, bases = 0, quals = 0, over_s = 0, over_q = 0;   // per lane (lane m == 0 of a record's group adds)
     uint32_t newn = 0, newi = 0;
     const uint8_t *const bend = a.buf + a.len;
-    for (uint64_t r0 = r_lo + (uint64_t)wv * 8; r0 < r_hi; r0 += (uint64_t)SO_WAVES * 8) {
-        const uint64_t r = r0 + g8;
-        const bool has = r < r_hi;
-        fqh_idx_record ir = {};
-        if (has) ir = a.idx[r];
-        uint32_t any_n = 0, any_inv = 0;
-        // both lines' words first (sixteen loads in flight per lane), then the counting
+    // A wavefront's round is eight records' pieces of this column block: sixteen loads per lane, then 128 LDS atomics per lane.
+    // Counted one round at a time, a wavefront alternates between waiting for its loads and counting (the loads alone take
+    // 1.29 ms per 4 GiB of 5 kbp reads, loads + count 2.35: the sum, not the maximum).  So the rounds are software-pipelined:
+    //   * the words of round k + 1 are loaded (buffer B) before round k (buffer A) is counted, and the other way round;
+    //   * the three dependent loads of a round — the record's index entry, the byte in front of each line's '\n'
+    //     (trim_winline), the lines' words — are spread over three rounds: the entry of round k + 2 is fetched at the top of
+    //     round k, its two probe bytes between the counts of round k's two lines (the entry has arrived by then), its words at
+    //     the top of round k + 1.
+    constexpr uint64_t STEP = (uint64_t)SO_WAVES * 8;
+    const uint64_t r_first = r_lo + (uint64_t)wv * 8 + g8;   // this lane group's record of the first round
+    struct Round {               // a round whose words are in flight / loaded
+        uint64_t r;
+        bool has;
         uint32_t segs[2], ws[2][8];
+    };
+    auto entry_of = [&](uint64_t r) {
+        fqh_idx_record ir = {};
+        if (r < r_hi) ir = a.idx[r];
+        return ir;
+    };
+    auto probe = [&](const fqh_idx_record &ir, uint64_t r, uint32_t cr[2]) {   // the byte in front of each line's '\n'
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+            cr[kind] = 0;
+            if (r < r_hi) {
+                const uint32_t len = (kind ? ir.qual - ir.sep : ir.seq - ir.head) - 1u;
+                if (len) cr[kind] = (a.buf + (ir.start - a.base_offset) + (kind ? ir.sep : ir.head) + 1)[len - 1];
+            }
+        }
+    };
+    // geometry of record r's two lines in this column block, the record's totals (column block 0), and the loads of its words
+    auto issue = [&](Round &R, uint64_t r, const fqh_idx_record &ir, const uint32_t cr[2]) {
+        R.r = r;
+        R.has = r < r_hi;
 #pragma unroll
         for (int kind = 0; kind < 2; ++kind) {
             const uint8_t *line = a.buf + (ir.start - a.base_offset) + (kind ? ir.sep : ir.head) + 1;
-            uint32_t len = has ? (kind ? ir.qual - ir.sep : ir.seq - ir.head) - 1u : 0u;   // raw line, without its '\n'
-            if (len && line[len - 1] == '\r') --len;                                        // trim_winline, src/records.rs:66-73
-            if (cb == 0 && m == 0 && has) {
+            uint32_t len = R.has ? (kind ? ir.qual - ir.sep : ir.seq - ir.head) - 1u : 0u;   // raw line, without its '\n'
+            if (len && cr[kind] == '\r') --len;                                               // trim_winline, src/records.rs:66-73
+            if (cb == 0 && m == 0 && R.has) {
                 if (kind) { quals += len; over_q += len > a.lmax ? len - a.lmax : 0u; }
                 else { ++recs; bases += len; over_s += len > a.lmax ? len - a.lmax : 0u; }
             }
             // this block's columns of the line: [col0, col0 + 256); sequence lines are LOOKED AT to their end (the alphabet
             // flags cover every base), counted up to the caller's rows
             const uint32_t seg = len > col0 ? (len - col0 < SO_LC_MAX ? len - col0 : SO_LC_MAX) : 0u;  // columns of the line in this block
-            segs[kind] = seg;
+            R.segs[kind] = seg;
             const uint8_t *p = line + col0 + m4;
             if (__ballot(seg != 0 && p + 256 > bend) == 0) {   // (wave-uniform) every load of the round lies inside the buffer
 #pragma unroll
-                for (uint32_t u = 0; u < 8; ++u) ws[kind][u] = 32u * u + m4 < seg ? load4_fast(p + 32u * u) : 0u;
+                for (uint32_t u = 0; u < 8; ++u) R.ws[kind][u] = 32u * u + m4 < seg ? load4_fast(p + 32u * u) : 0u;
             } else {
 #pragma unroll
-                for (uint32_t u = 0; u < 8; ++u) ws[kind][u] = 32u * u + m4 < seg ? load4_any(p + 32u * u, bend) : 0u;
+                for (uint32_t u = 0; u < 8; ++u) R.ws[kind][u] = 32u * u + m4 < seg ? load4_any(p + 32u * u, bend) : 0u;
             }
         }
+    };
+    auto count_line = [&](const Round &R, const int kind, uint32_t &any_n, uint32_t &any_inv) {
+        const uint32_t seg = R.segs[kind];
+        if (__ballot(seg != 0) == 0) return;
+        constexpr uint32_t RB = SO_LRB;
 #pragma unroll
-        for (int kind = 0; kind < 2; ++kind) {
-            const uint32_t seg = segs[kind];
-            if (__ballot(seg != 0) == 0) continue;
-            constexpr uint32_t RB = SO_LRB;
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t wu = R.ws[kind][u];
+            const uint32_t pos = 32u * u + m4;                      // column of the dword's first byte, relative to col0
+            const bool whole = pos + 4 <= seg && pos + 4 <= lc;    // four bytes of the line, all inside the caller's rows
+            uint32_t pb, chk;
+            if (kind == 0) {
+                pb = wu & 0x07070707u;
+                chk = wu ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pb);   // != 0: a byte outside ACGTN
+                if (whole && !chk) any_n |= wu & 0x08080808u;                      // (bit 3 is set in 'N' only)
+            } else {
+                pb = wu - 0x21212121u;
+                chk = pb & 0x80808080u;                                             // != 0: a byte outside '!' .. 0xA0 (128 bins)
+                pb &= 0x7F7F7F7Fu;                                                  // (whatever the bytes are, the address stays inside the rows)
+            }
+            const uint32_t f = (whole && !chk) ? 0xFFFFFFFFu : 0u;
+            const uint32_t off = (kind ? SO_SBYTES : 0u) + 128u * (u & 1u) + (kind ? RB : 2048u) * (u >> 1);
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t wu = ws[kind][u];
-                const uint32_t pos = 32u * u + m4;                      // column of the dword's first byte, relative to col0
-                const bool whole = pos + 4 <= seg && pos + 4 <= lc;    // four bytes of the line, all inside the caller's rows
-                uint32_t pb, chk;
-                if (kind == 0) {
-                    pb = wu & 0x07070707u;
-                    chk = wu ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pb);   // != 0: a byte outside ACGTN
-                    if (whole && !chk) any_n |= wu & 0x08080808u;                      // (bit 3 is set in 'N' only)
-                } else {
-                    pb = wu - 0x21212121u;
-                    chk = pb & 0x80808080u;                                             // != 0: a byte outside '!' .. 0xA0 (128 bins)
-                    pb &= 0x7F7F7F7Fu;                                                  // (whatever the bytes are, the address stays inside the rows)
-                }
-                const uint32_t f = (whole && !chk) ? 0xFFFFFFFFu : 0u;
-                const uint32_t off = (kind ? SO_SBYTES : 0u) + 128u * (u & 1u) + (kind ? RB : 2048u) * (u >> 1);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off), f,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__ballot(pos < seg && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
-                    if (pos < seg && !f) {
-                        uint32_t an = 0, ai = 0;
-                        if (kind == 0) so_exact_step<true, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
-                        else so_exact_step<false, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
-                        any_n |= an;
-                        any_inv |= ai;
-                    }
+            for (int k = 0; k < 4; ++k)
+                (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off), f,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__ballot(pos < seg && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
+                if (pos < seg && !f) {
+                    uint32_t an = 0, ai = 0;
+                    if (kind == 0) so_exact_step<true, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
+                    else so_exact_step<false, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
+                    any_n |= an;
+                    any_inv |= ai;
                 }
             }
         }
-        // a record's alphabet flags: ORed over the 8 lanes of its group here, over its column blocks through the flag maps
+    };
+    // a record's alphabet flags: ORed over the 8 lanes of its group here, over its column blocks through the flag maps
+    auto flags = [&](const Round &R, uint32_t any_n, uint32_t any_inv) {
         const unsigned long long bi = __ballot(any_inv != 0), bn = __ballot(any_n != 0) | bi;
         if (bn) {
             const uint32_t sh = lane & 56u;
             const bool gn = ((bn >> sh) & 0xFFull) != 0, gi = ((bi >> sh) & 0xFFull) != 0;
-            if (m == 0 && gn && has) {
-                const uint32_t bit = 1u << (r & 31u);
-                if (!(atomicOr(&a.flagmap[r >> 5], bit) & bit)) ++newn;
-                if (gi && !(atomicOr(&a.flagmap[a.flag_words + (r >> 5)], bit) & bit)) ++newi;
+            if (m == 0 && gn && R.has) {
+                const uint32_t bit = 1u << (R.r & 31u);
+                if (!(atomicOr(&a.flagmap[R.r >> 5], bit) & bit)) ++newn;
+                if (gi && !(atomicOr(&a.flagmap[a.flag_words + (R.r >> 5)], bit) & bit)) ++newi;
             }
         }
+    };
+    // one round: the NEXT round's words into `N`, then the words of `R` (loaded a round ago) are counted; q: the entry two rounds
+    // ahead, fetched here; e1 / cr1: the next round's entry and probe bytes (ready), replaced by the ones after them
+    Round A, B;
+    fqh_idx_record e1 = entry_of(r_first + STEP), e2;
+    uint32_t cr1[2], cr2[2];
+    {
+        const fqh_idx_record e0 = entry_of(r_first);
+        uint32_t cr0[2];
+        probe(e0, r_first, cr0);
+        probe(e1, r_first + STEP, cr1);
+        issue(A, r_first, e0, cr0);
+    }
+    auto round = [&](Round &R, Round &N) {
+        issue(N, R.r + STEP, e1, cr1);
+        e2 = entry_of(R.r + 2 * STEP);
+        uint32_t any_n = 0, any_inv = 0;
+        count_line(R, 0, any_n, any_inv);
+        probe(e2, R.r + 2 * STEP, cr2);
+        count_line(R, 1, any_n, any_inv);
+        flags(R, any_n, any_inv);
+        e1 = e2;
+        cr1[0] = cr2[0];
+        cr1[1] = cr2[1];
+    };
+    for (uint64_t r0 = r_lo + (uint64_t)wv * 8; r0 < r_hi; r0 += 2 * STEP) {   // (wave-uniform bounds; two rounds per trip: the buffers swap roles)
+        round(A, B);
+        if (r0 + STEP < r_hi) round(B, A);
+        else break;
     }
     // ---- the block's rows -> the caller's arrays (u64), totals
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -632,7 +694,8 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
     a.n_slices = (4 * cus + a.n_cb - 1) / a.n_cb;                       // ~4 blocks per CU over the launch (one resident at a time: LDS)
     const uint64_t max_slices = (n + 8 * SO_WAVES - 1) / (8 * SO_WAVES);
     if (a.n_slices > max_slices) a.n_slices = (uint32_t)max_slices;
-    if (a.n_slices == 0) a.n_slices = 1;
+    a.n_slices = (a.n_slices + 7u) & ~7u;                               // (a multiple of the XCDs: slice = 8 * (i / n_cb) + xcd in the kernel)
+    if (a.n_slices == 0) a.n_slices = 8;
     a.flagmap = flagmap;
     a.flag_words = flag_words;
     a.qual_hist = qual_hist;

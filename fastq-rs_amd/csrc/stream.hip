@@ -275,7 +275,7 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         fqh_internal_fused_drop(ctx);
         stats_done = true;
     }
-    bool dev_tail_done = false;
+    bool dev_tail_done = false, idle_early = false;
     if (clean) {
         if (single) {
             fqh_internal_fused_commit(ctx);
@@ -288,6 +288,13 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         }
         if (stats_done && !s.is_final && st->col + 1 < st->sub && nx.state == 2 && !nx.launched) {
             nx.lead = sum.tail_len;
+            // everything the context's stream has to do on THIS slot's device data is enqueued (commit, tail move): the event its
+            // next copy waits for goes in front of the next slot's scan, not behind it — with two slots the refill of this one
+            // would otherwise wait for that scan instead of running under it
+            if (!want_stats || dev_tail_done || !sum.tail_len) {
+                HIPCHK(ctx, hipEventRecord(s.idle, ctx->stream));
+                idle_early = true;
+            }
             rc = launch_slot(st, nx, cout, false);
             if (rc != FQH_OK) return rc;
         }
@@ -374,7 +381,7 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
             nx.lead = tail;
         }
     }
-    HIPCHK(ctx, hipEventRecord(s.idle, ctx->stream));
+    if (!idle_early) HIPCHK(ctx, hipEventRecord(s.idle, ctx->stream));
     s.idle_set = true;
     if (c.parse_status != FQH_OK || s.is_final) st->ended = true;
     st->records_done += n;

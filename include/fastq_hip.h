@@ -372,7 +372,11 @@ fqh_status fqh_gather_records(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, 
  * slot (carry chained from the previous one, so slots may end anywhere), brings the record index
  * back and copies the partial trailing record in front of the next slot, so every record is
  * contiguous in host memory when the caller walks it.  Copies of later slots overlap the scan and
- * the caller's work on earlier ones.  Single producer/consumer, one thread. */
+ * the caller's work on earlier ones.  Single producer/consumer, one thread.
+ * Between two fqh_stream_collect calls the CONTEXT belongs to the stream: a collect may already have enqueued the next slot's
+ * scan on it (the scan then runs while the caller walks this chunk), so other calls on the same context — fqh_scan, fqh_stats,
+ * fqh_record_flags, fqh_gather_records — return FQH_E_ARG ("a launch is pending") until the stream is drained or destroyed.  A
+ * consumer that filters a collected chunk on the device (d_data / d_rec_start) does so on a second context of the same device. */
 typedef struct fqh_stream fqh_stream;
 typedef struct {
     int32_t parse_status;  /* FQH_OK or FQH_E_HEADER..FQH_E_TOO_LONG; an error ends the stream         */

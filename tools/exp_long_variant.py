@@ -1,0 +1,27 @@
+"""tools/exp_long_variant.py LIB — time of the histogram kernels of a cold fqh_stats over 4 GiB of 5 kbp reads with another build
+of the library (FQH_LIB_PATH), results NOT checked (knock-out builds count nothing)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["FQH_LIB_PATH"] = os.path.abspath(sys.argv[1])
+import numpy as np, torch
+import __graft_entry__ as g
+pkg = g.load_package()
+dev = torch.device("cuda:0")
+ctx = pkg.Ctx(0)
+read_len = int(os.environ.get("READ_LEN", "5000"))
+rng = np.random.default_rng(7)
+nrec = 1024
+seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (nrec, read_len))
+qual = np.where(rng.random((nrec, read_len)) < 0.8, 126, rng.integers(33, 127, (nrec, read_len))).astype(np.uint8)
+block = b"".join(b"@m%06d/ccs\n" % i + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n" for i in range(nrec))
+reps = (4 << 30) // len(block)
+n = reps * len(block)
+d = torch.cat([torch.from_numpy(np.frombuffer(block, dtype=np.uint8).copy()).to(dev).repeat(reps), torch.zeros(16, dtype=torch.uint8, device=dev)])
+qh = torch.zeros(read_len * 256, dtype=torch.int64, device=dev); bh = torch.zeros(read_len * 8, dtype=torch.int64, device=dev); sc = torch.zeros(8, dtype=torch.int64, device=dev)
+best = 1e9
+for _ in range(4):
+    ctx.invalidate(); torch.cuda.synchronize()
+    ctx.stats(d.data_ptr(), n, read_len, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    best = min(best, ctx.timing().stats_ms)
+print("%s: histogram kernels %.3f ms (%.0f GB/s)" % (os.path.basename(sys.argv[1]), best, n / 1e6 / best))

@@ -12,11 +12,11 @@ import shutil
 import sys
 from collections import defaultdict
 
-out, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "round3")
+out, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "round4")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
-HOT = ("k_index_fast", "k_scan_stats", "k_emit_fast", "k_prefix", "k_finalize", "k_stats_commit", "k_stats_edge", "k_stats_long", "k_index_t", "k_stats_oct",
+HOT = ("k_index_fast", "k_scan_stats", "k_emit_fast", "k_prefix", "k_finalize", "k_stats_commit", "k_stats_declined", "k_stats_edge", "k_stats_long", "k_index_t", "k_stats_oct",
        "k_emit(", "k_read_ceiling", "k_stats_reduce")
 txt = []
 
@@ -80,7 +80,7 @@ if "k_read_ceiling" in res and res.get("workload_bytes") and "FETCH_SIZE" in res
     res["fetch_size_calibration"] = {"kernel": "k_read_ceiling", "bytes_read": res["workload_bytes"],
                                      "FETCH_SIZE_KiB": res["k_read_ceiling"]["pmc_per_launch"]["FETCH_SIZE"],
                                      "bytes_per_counted_byte": round(cal, 4)}
-for k in ("k_index_fast", "k_scan_stats", "k_index_t", "k_stats_oct"):
+for k in ("k_index_fast", "k_scan_stats", "k_index_t", "k_stats_oct", "k_stats_long"):
     p = res.get(k, {}).get("pmc_per_launch", {})
     if "FETCH_SIZE" in p:
         rd = p["FETCH_SIZE"] * 1024.0 * (cal if cal else 2.0)

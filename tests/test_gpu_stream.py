@@ -330,3 +330,53 @@ def test_chunked_stats_take_the_single_pass(fqref, env):
     assert np.array_equal(gs.cpu().numpy().astype(np.uint64), sc)
     assert np.array_equal(gq.cpu().numpy().astype(np.uint64).reshape(lmax, 256), qh)
     assert np.array_equal(gb.cpu().numpy().astype(np.uint64).reshape(lmax, 8), bh)
+
+
+def test_filter_between_collects_takes_a_second_context(fqref, env):
+    """Between two collects the context belongs to the stream (a collect may already have enqueued the next slot's scan on it,
+    include/fastq_hip.h): a statistics / filter call on the SAME context says so (FQH_E_ARG, no crash, the stream goes on), the
+    same call on a second context of the device works on the collected chunk's device data, and a two-slot ring still delivers
+    the oracle's records (the refill of a slot waits for the event recorded in front of the look-ahead scan)."""
+    torch, pkg = env
+    rng = np.random.default_rng(77)
+    data = fuzzgen.valid_file(rng, 30000, maxlen=100, crlf=False)
+    r, off = fqref.offsets(data)
+    ctx, side = pkg.Ctx(0), pkg.Ctx(0)
+    st = pkg.Stream(ctx, 1 << 18, 2, 0)          # two slots, no index: the look-ahead launch is taken whenever a slot is waiting
+    pos, n_rec, refused, flagged = 0, 0, 0, 0
+    sub = col = 0
+    done = False
+    while True:
+        while not done:
+            a = st.acquire()
+            if a is None:
+                break
+            n = min(a[1], len(data) - pos)
+            C.memmove(a[0], data[pos: pos + n], n)
+            pos += n
+            done = pos >= len(data)
+            st.submit(n, done)
+            sub += 1
+        if col == sub:
+            break
+        c = st.collect()
+        col += 1
+        assert c.parse_status == pkg.OK
+        if c.n_records:
+            dummy = torch.zeros(64, dtype=torch.uint8, device="cuda")
+            try:                                  # the stream's own context: refused while a launch of the stream is pending
+                ctx.scan(dummy.data_ptr(), 16)
+            except pkg.FqhError as e:
+                assert e.status == pkg.E_ARG
+                refused += 1
+            s2 = side.scan(c.d_data, c.data_len, bool(c.is_final))[0]   # a second context scans the chunk's device twin
+            assert s2.n_newlines == data[c.base_offset: c.base_offset + c.data_len].count(b"\n")
+            flagged += 1
+        n_rec += c.n_records
+        st.release()
+        if c.is_final:
+            break
+    st.close()
+    ctx.close()
+    side.close()
+    assert n_rec == r.n_records == 30000 and flagged >= 5 and refused >= 1

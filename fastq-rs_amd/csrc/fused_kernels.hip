@@ -881,7 +881,7 @@ void launch_stats_edge(hipStream_t s, const DevOut *out, const uint8_t *buf, uin
 // src/records.rs:19-33).
 constexpr uint32_t DECL_BINS = 264;               // per row: base classes 0..7, then quality values 0..255
 constexpr uint32_t DECL_LINES_PER_BLOCK = 60000;  // (16-bit counters)
-__global__ __launch_bounds__(256) void k_stats_declined(const DevOut *__restrict__ out, const uint32_t *__restrict__ decl_b, uint32_t nsl,
+__global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restrict__ out, const uint32_t *__restrict__ decl_b, uint32_t nsl,
                                                         const uint64_t *__restrict__ decl_l, uint32_t cap, const uint8_t *__restrict__ buf,
                                                         uint32_t lmax, uint32_t rows, unsigned long long *__restrict__ qual_hist,
                                                         unsigned long long *__restrict__ base_hist, unsigned long long *__restrict__ scalars) {
@@ -985,7 +985,7 @@ hipError_t launch_stats_declined(hipStream_t s, const DevOut *out, const FusedAr
         if (e != hipSuccess) return e;
         set = true;
     }
-    hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(256), lds, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap, z.buf, z.lmax, lc,
+    hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(1024), lds, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap, z.buf, z.lmax, lc,
                        qual_hist, base_hist, scalars);
     return hipSuccess;
 }

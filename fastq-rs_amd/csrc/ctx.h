@@ -75,6 +75,9 @@ struct fqh_ctx {
     bool dev_carry = false;       // the launch in flight took its carry from d_carry
     fqh_idx_record *idx = nullptr;
     size_t idx_cap = 0;
+    fqh_idx_record *scan_idx = nullptr;  // set around a scan launch: its emit step also writes the record index there
+    uint64_t scan_idx_cap = 0;
+    bool idx_emitted = false;     // the last scan's emit step wrote the index of its records to ctx->idx
     uint64_t *tmp_rec = nullptr;
     size_t tmp_rec_cap = 0;
     uint32_t *stats_scratch = nullptr;

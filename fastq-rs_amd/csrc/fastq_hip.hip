@@ -557,8 +557,9 @@ static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     a.n_blocks = (a.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     a.rec_start = d_rec_start;
     a.cap = d_rec_start ? cap : 0;
-    a.idx = nullptr;
-    a.idx_cap = 0;
+    a.idx = ctx->scan_idx;       // (a statistics call over kilobase reads asks the scan's own emit step for the record index)
+    a.idx_cap = ctx->scan_idx ? ctx->scan_idx_cap : 0;
+    ctx->idx_emitted = ctx->scan_idx != nullptr;
     // fast path: when the caller does not need full line lists and no earlier input needed the exact
     // path; a rescan on a retained index uses whichever kind of index is there
     bool fast = reuse_index ? !ctx->index_full : (ctx->spec_enabled && !ctx->exact_holds && ctx->list_cap >= LIST_CAP_DEFAULT);
@@ -1059,10 +1060,28 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         // taking the fast path and indexing a second time
         const bool spec = ctx->spec_enabled;
         ctx->spec_enabled = false;
+        if (lmax > 2 * 256) {
+            // rows beyond two passes of k_stats_oct: the caller expects kilobase reads, which k_stats_long counts over the record
+            // index — the scan's emit step writes it on the way (one entry per 512 bytes of input fits; denser input, or reads
+            // that turn out short, take the separate emit below as before)
+            const uint64_t cap = len / 512 + 16;
+            if (ctx->idx_cap < cap) {
+                (void)hipFree(ctx->idx);
+                ctx->idx = nullptr;
+                ctx->idx_cap = 0;
+                HIPCHK(ctx, hipMalloc((void **)&ctx->idx, cap * sizeof(fqh_idx_record)));
+                ctx->idx_cap = cap;
+            }
+            ctx->scan_idx = ctx->idx;
+            ctx->scan_idx_cap = ctx->idx_cap;
+        }
         st = do_scan_launch(ctx, d_buf, len, is_final, in, nullptr, 0);
+        ctx->scan_idx = nullptr;
         if (st == FQH_OK) st = do_scan_finish(ctx, nullptr, nullptr);
         ctx->spec_enabled = spec;
         if (st != FQH_OK) return st;
+    } else {
+        ctx->idx_emitted = false;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     st = ensure_full_index(ctx);  // the histogram kernel walks complete line lists
@@ -1129,8 +1148,10 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
                 HIPCHK(ctx, hipMalloc((void **)&ctx->idx, n * sizeof(fqh_idx_record)));
                 ctx->idx_cap = n;
             }
-            st = emit_index(ctx, ctx->idx, n);
-            if (st != FQH_OK) return st;
+            if (!(ctx->idx_emitted && ctx->used_spec == false && n <= ctx->idx_cap && ctx->args.idx == ctx->idx)) {
+                st = emit_index(ctx, ctx->idx, n);
+                if (st != FQH_OK) return st;
+            }
             HIPCHK(ctx, launch_stats_long(s, d_buf, len, ctx->carry_in.base_offset, ctx->idx + skip, n - skip, lmax, max_line, sa.flagmap,
                                           flag_words, sa.qual_hist, sa.base_hist, sa.scalars, ctx->n_cu));
         } else {

@@ -529,7 +529,7 @@ def pmc_traffic(nbytes):
                        sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-stats",
                        "--no-stream", "--pmc-child", "--bytes", str(nbytes)]
                 env = dict(os.environ, TMPDIR="/tmp")
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
                 vals = {}
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for row in csv.DictReader(open(f)):

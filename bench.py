@@ -128,6 +128,8 @@ def main():
     # library's default is to sleep, which wakes up ~15 us late); FQH_BENCH_SPIN_US=0 measures the default
     spin_us = int(os.environ.get("FQH_BENCH_SPIN_US", "20000"))
     ctx.set_spin_wait(spin_us)
+    if os.environ.get("FQH_BENCH_ADAPT_LINES"):   # (A/B of the library default, 3; 0 = one line buffer, whatever kind it is for this input)
+        ctx.set_adapt_lines(int(os.environ["FQH_BENCH_ADAPT_LINES"]))
     LEAD = 2 * pkg.BUFSIZE  # room in front of the shard for the tail of the previous rank's shard (--shard-stats)
     store = torch.empty(LEAD + nbytes + 16, dtype=torch.uint8, device=dev)
     buf = store[LEAD:]
@@ -223,6 +225,12 @@ def main():
     if args.stream_gib > 0:
         print(json.dumps(dict(stream_leg(args, pkg, torch, dev, buf, args.stream_gib, args.producer_threads), mode="stream")), flush=True)
         return
+    # FQH_OPT_ADAPT_LINES (default on): the library learns from its first calls on an input which of two line buffers that input
+    # runs faster with (calls 1-2 on the first, then one call per alternate tried: DESIGN.md 4b).  A few untimed steps in
+    # front of the warm-up let that settle, so that no alternate is allocated or tried inside the timed region.
+    settle = 0 if args.pmc_child else int(os.environ.get("FQH_BENCH_SETTLE_STEPS", "8"))
+    for _ in range(settle):
+        s = step()
     for _ in range(args.warmup):
         s = step()
     index_ms.clear()
@@ -304,6 +312,8 @@ def main():
                                "record-offset scan + count + validation" % (world, nbytes / 2**30),
                    "bytes_per_gpu": nbytes, "records_total": total_records,
                    "host_wait": "FQH_OPT_SPIN_WAIT %d us (opt-in of this harness; library default 0)" % spin_us,
+                   "line_buffer": "FQH_OPT_ADAPT_LINES (library default): %d untimed steps in front of the warm-up let the context settle "
+                                  "which of its line buffers this input takes" % settle,
                    "sharding": "byte-range, cuts at multiples of %d" % shard if world > 1 else "none",
                    "exchange": ("on the device: all_gather of 8 words per rank, fold + emit, all_reduce of the counts, one "
                                 "host wait per step (%d of %d timed+warmup steps fell back to the host recipe)"

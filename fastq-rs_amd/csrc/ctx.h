@@ -69,6 +69,27 @@ struct fqh_ctx {
     int spin_wait_us = 0;            // FQH_OPT_SPIN_WAIT: poll the stream this long in fqh_*_finish before sleeping on it
     float place_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // what the candidates measured (0: not tried); [8] = the chosen one's, [9] = without stores
     int place_n = 0;                 // candidates the search tried (0: no search ran)
+    // Adaptive choice of the fast path's line buffer (FQH_OPT_ADAPT_LINES): whether the index kernel runs at 2.65 or
+    // at 2.83 ms per 16 GiB is a property of the PAIR (input allocation, line-buffer allocation).  A context therefore keeps up
+    // to two line buffers and learns, per big input it sees again (address, length, kernel), which one that input runs faster
+    // with — from the HIP-event time of the real scans, one buffer per call: no extra launches, no blocking search.
+    struct LinesAdapt {
+        const uint8_t *buf = nullptr;
+        uint64_t len = 0;
+        bool fused = false;
+        int state = 0;            // 0 new (the first buffer is being measured), 1 measured: the next call takes the alternate, 3 settled
+        int choice = 0;           // settled: which of fr[] this input takes
+        int tries = 0;            // alternates that measured like the primary and were given back
+        int seen = 0, seen_alt = 0;  // measurements of the first buffer / of the alternate being tried (two each, the faster counts)
+        float ms[2] = {0, 0};
+        uint64_t stamp = 0;
+    } adapt[4];
+    uint16_t *fr[2] = {nullptr, nullptr};  // fr[0]: the buffer the workspace was allocated with; fr[1]: the alternate (same size), or NULL
+    int adapt_max = 3;            // alternates tried per input (0: off)
+    uint16_t *fr_rejects[8] = {};  // alternates that measured like fr[0], held until the input they were tried for is settled
+    int n_rejects = 0;
+    int adapt_entry = -1, adapt_used = 0;  // the launch in flight: which entry is being measured, with which buffer
+    uint64_t adapt_clock = 0;
     uint16_t *list_dummy = nullptr;  // 1 KiB: where k_index_fast's list-area writes go while the context has no line lists
     DevCarry *d_carry = nullptr;  // device-side shard protocol: the folded carry, and its pinned twin the host reads at finish
     DevCarry *h_carry = nullptr;

@@ -99,6 +99,10 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->list);
     (void)hipFree(ctx->tile_count);
     (void)hipFree(ctx->tile_prefix);
+    if (ctx->fr[1] && ctx->fr[1] != ctx->fast_rs) (void)hipFree(ctx->fr[1]);
+    if (ctx->fr[0] && ctx->fr[0] != ctx->fast_rs) (void)hipFree(ctx->fr[0]);
+    for (int i = 0; i < ctx->n_rejects; ++i)
+        if (ctx->fr_rejects[i] != ctx->fast_rs) (void)hipFree(ctx->fr_rejects[i]);
     (void)hipFree(ctx->fast_rs);
     (void)hipFree(ctx->block_prefix);
     (void)hipFree(ctx->d_out);
@@ -263,6 +267,13 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_lis
     if (n_tiles > ctx->tiles_cap) {
         (void)hipFree(ctx->tile_count);
         (void)hipFree(ctx->tile_prefix);
+        if (ctx->fr[1] && ctx->fr[1] != ctx->fast_rs) (void)hipFree(ctx->fr[1]);
+        if (ctx->fr[0] && ctx->fr[0] != ctx->fast_rs) (void)hipFree(ctx->fr[0]);
+        for (int i = 0; i < ctx->n_rejects; ++i)
+            if (ctx->fr_rejects[i] != ctx->fast_rs) (void)hipFree(ctx->fr_rejects[i]);
+        ctx->n_rejects = 0;
+        ctx->fr[0] = ctx->fr[1] = nullptr;
+        for (auto &e : ctx->adapt) e = fqh_ctx::LinesAdapt{};
         (void)hipFree(ctx->fast_rs);
         (void)hipFree(ctx->block_prefix);
         ctx->tile_count = ctx->tile_prefix = nullptr;
@@ -298,6 +309,102 @@ static void enqueue_fused_commit(fqh_ctx *ctx) {
     ctx->f_commit_owed = false;
 }
 
+static void adapt_free_rejects(fqh_ctx *ctx) {
+    for (int i = 0; i < ctx->n_rejects; ++i)
+        if (ctx->fr_rejects[i] != ctx->fast_rs) (void)hipFree(ctx->fr_rejects[i]);
+    ctx->n_rejects = 0;
+}
+// Which line buffer does this scan store to?  (ctx.h: LinesAdapt.)  Called for fresh fast-path scans of 2 GiB or more.
+static void adapt_choose(fqh_ctx *ctx, bool fused) {
+    const ScanArgs &a = ctx->args;
+    ctx->adapt_entry = -1;
+    if (ctx->fast_rs != ctx->fr[0] && ctx->fast_rs != ctx->fr[1]) {  // a new workspace (or the placement search's pick): start over
+        if (ctx->fr[1]) (void)hipFree(ctx->fr[1]);
+        adapt_free_rejects(ctx);
+        ctx->fr[0] = ctx->fast_rs;
+        ctx->fr[1] = nullptr;
+        for (auto &e : ctx->adapt) e = fqh_ctx::LinesAdapt{};
+    }
+    if (ctx->adapt_max <= 0 || a.len < (2ull << 30) || ctx->skip_emit) {
+        ctx->fast_rs = ctx->fr[0];
+        return;
+    }
+    int k = -1, lru = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (ctx->adapt[i].buf == a.buf && ctx->adapt[i].len == a.len && ctx->adapt[i].fused == fused) k = i;
+        if (ctx->adapt[i].stamp < ctx->adapt[lru].stamp) lru = i;
+    }
+    if (k < 0) {
+        k = lru;
+        ctx->adapt[k] = fqh_ctx::LinesAdapt{};
+        ctx->adapt[k].buf = a.buf;
+        ctx->adapt[k].len = a.len;
+        ctx->adapt[k].fused = fused;
+    }
+    fqh_ctx::LinesAdapt &e = ctx->adapt[k];
+    e.stamp = ++ctx->adapt_clock;
+    int use = e.state == 3 ? e.choice : 0;
+    if (e.state == 1) {
+        if (!ctx->fr[1]) {
+            const size_t bytes = (2 * ctx->tiles_cap + 128) * 64 * sizeof(uint16_t);
+            if (hipMalloc((void **)&ctx->fr[1], bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->fr[1] = nullptr;
+                e.state = 3;
+                e.choice = 0;
+            }
+        }
+        if (ctx->fr[1]) use = 1;
+    }
+    if (use == 1 && !ctx->fr[1]) use = 0;
+    ctx->fast_rs = ctx->fr[use];
+    if (e.state < 3) {
+        ctx->adapt_entry = k;
+        ctx->adapt_used = use;
+    }
+}
+// ... and what its index kernel took with it (HIP events of the launch: ctx->timing.index_ms)
+static void adapt_record(fqh_ctx *ctx, bool clean) {
+    const int k = ctx->adapt_entry;
+    ctx->adapt_entry = -1;
+    if (k < 0 || !clean || ctx->timing.index_ms <= 0) return;
+    fqh_ctx::LinesAdapt &e = ctx->adapt[k];
+    if (e.state == 0 && ctx->adapt_used == 0) {   // the first buffer is measured twice (the first big launch of a context runs cold)
+        e.ms[0] = e.ms[0] > 0 ? std::min(e.ms[0], ctx->timing.index_ms) : ctx->timing.index_ms;
+        if (++e.seen >= 2) e.state = 1;
+        return;
+    }
+    if (e.state == 1 && ctx->adapt_used == 1) {   // ... and so is every alternate: one sample 2.5 % off is within the noise of a launch
+        e.ms[1] = e.seen_alt ? std::min(e.ms[1], ctx->timing.index_ms) : ctx->timing.index_ms;
+        if (++e.seen_alt < 2) return;
+        e.seen_alt = 0;
+    }
+    if (e.state == 1 && ctx->adapt_used == 1) {
+        const float a0 = e.ms[0], a1 = e.ms[1];
+        if (getenv("FQH_DEBUG_WS")) fprintf(stderr, "adapt ctx %p input %p: first buffer %.3f ms, alternate %p %.3f ms (try %d)\n", (void *)ctx, (const void *)e.buf, a0, (void *)ctx->fr[1], a1, e.tries);
+        if (a1 < 0.975f * a0 || a0 < 0.975f * a1) {   // the two buffers are of different kinds for this input: keep both, take the faster
+            e.choice = a1 < a0 ? 1 : 0;
+            e.state = 3;
+            adapt_free_rejects(ctx);
+        } else {                                      // alike: this alternate tells nothing.  Give it back unless another input has chosen it
+            bool wanted = false;
+            for (const auto &o : ctx->adapt) wanted = wanted || (&o != &e && o.buf && o.state == 3 && o.choice == 1);
+            ++e.tries;
+            if (!wanted && e.tries < ctx->adapt_max && ctx->n_rejects < 8) {
+                // held, not freed, until this input is settled: a free followed by an allocation of the same size hands the
+                // same memory out again (and the tile index of the scan just finished lives in it)
+                ctx->fr_rejects[ctx->n_rejects++] = ctx->fr[1];
+                ctx->fr[1] = nullptr;
+                e.state = 1;           // the next call allocates another one
+            } else {
+                e.choice = 0;
+                e.state = 3;
+                adapt_free_rejects(ctx);
+            }
+        }
+    }
+}
+
 // fast == true: the speculative path (k_index_fast + k_emit_fast + k_finalize_fast)
 static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     ScanArgs &a = ctx->args;
@@ -309,6 +416,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         place_fast_rs(ctx, (2 * ctx->tiles_cap + 128) * 64 * sizeof(uint16_t));
         ctx->placed = true;
     }
+    if (fast && !reuse_index) adapt_choose(ctx, ctx->fused);
     a.list = with_list ? ctx->list : nullptr;
     a.list_cap = ctx->list_cap;
     a.tile_count = ctx->tile_count;
@@ -592,6 +700,8 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->dout_clean = true;  // the finalize kernel has run
+    const int adapt_k = ctx->adapt_entry;   // (a rerun below measures something else: only a launch that stood is recorded)
+    int reruns = 0;
     if (ctx->dev_carry) {  // the carry was folded on the device (fqh_shard_rescan_launch): the host learns it here
         ctx->dev_carry = false;
         const DevCarry hc = *ctx->h_carry;
@@ -613,6 +723,7 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
         // not a doubt about the input: a tile holds more record starts than its two lines take (reads shorter than ~50 bp)
         // and this context has no line-list workspace yet.  Allocate it and run the fast path again; it stays.
         ctx->fast_needs_list = true;
+        ++reruns;
         fqh_status st = enqueue_scan(ctx, false, true);
         if (st != FQH_OK) return st;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -628,6 +739,7 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
         // inputs the fast path cannot handle should not pay for an attempt every time)
         ctx->spec_backoff = ctx->spec_backoff ? (ctx->spec_backoff < 64 ? ctx->spec_backoff * 2 : 64) : 1;
         ctx->spec_skip = ctx->spec_backoff;
+        ++reruns;
         fqh_status st = enqueue_scan(ctx, false, false);
         if (st != FQH_OK) return st;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -641,6 +753,7 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
         while (ctx->h_out->overflow) {
             if (ctx->list_cap >= WT_BYTES) return fail(ctx, FQH_E_DEVICE, "line list overflow with full-size lists");
             ctx->list_cap = ctx->list_cap < 2048 ? 2048 : WT_BYTES;
+            ++reruns;
             fqh_status st = enqueue_scan(ctx, false, false);
             if (st != FQH_OK) return st;
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -655,6 +768,10 @@ static fqh_status do_scan_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carr
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[3]) == hipSuccess) ctx->timing.total_ms = ms;
     fqh_status st = resolve(ctx, out, carry_out);
     ctx->last_valid = (st == FQH_OK || st == FQH_E_CAPACITY);
+    {
+        ctx->adapt_entry = adapt_k;
+        adapt_record(ctx, adapt_k >= 0 && ctx->used_spec && reruns == 0 && !ctx->h_out->stats_declined);
+    }
     ctx->fused = false;  // (the launch is over; a deferred commit, f_commit_owed, stays owed if the fast path stood)
     ctx->f_defer_commit = false;
     if (!ctx->used_spec) ctx->f_commit_owed = false;
@@ -902,6 +1019,9 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
         return FQH_OK;
     case FQH_OPT_REUSE_INDEX:
         ctx->reuse_index = value != 0;
+        return FQH_OK;
+    case FQH_OPT_ADAPT_LINES:
+        ctx->adapt_max = value < 0 ? 0 : value > 8 ? 8 : value;
         return FQH_OK;
     case FQH_OPT_SPIN_WAIT:
         ctx->spin_wait_us = value < 0 ? 0 : value > 1000000 ? 1000000 : value;

@@ -772,8 +772,13 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         (void)run;
     };
 
-    uint64_t tile = wave0;
-    if (tile < n_full) {
+    // A wavefront takes a contiguous RUN of tiles (round 4; it took every nwaves-th tile before): 4 096 streams of 4 MiB each
+    // instead of one 64 MiB window that 4 096 wavefronts sweep together — 2.84 against 2.87–2.90 ms per 16 GiB step on inputs of
+    // the fast kind, 3.00 against 2.96 on the slow kind (tools/exp_buf_ab.py; DESIGN.md 4b: the kind is the input allocation's)
+    const uint64_t per_w = (n_full + nwaves - 1) / nwaves;
+    uint64_t tile = wave0 * per_w;
+    const uint64_t tend = tile + per_w < n_full ? tile + per_w : n_full;
+    if (tile < tend) {
         const uint8_t *p = buf + (tile << WT_SHIFT) + lo;
         uint32_t pb = tile ? buf[(tile << WT_SHIFT) - 1] : 0u;  // the byte before the tile
         uint4 n0 = load16_nt(p), n1 = load16_nt(p + PIECE_BYTES);
@@ -781,8 +786,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         bool pending = false;          // the previous tile's two lines are still in registers
         uint64_t ptile = 0;
         uint32_t prv = 0, prun = 0;
-        for (; tile < n_full; tile += nwaves) {
-            const uint64_t nxt = tile + nwaves < n_full ? tile + nwaves : tile;  // clamped: the prefetch is unconditional
+        for (; tile < tend; tile += 1) {
+            const uint64_t nxt = tile + 1 < tend ? tile + 1 : tile;  // clamped: the prefetch is unconditional
             uint32_t run = 0, nstaged = 0;
             uint32_t prev = (tile && pb == '\n') ? 1u : 0u;
 #pragma unroll 1

@@ -117,6 +117,16 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           tile index instead of scanning again (two-pass route only).  The caller thereby VOUCHES that the bytes
  *                           have not changed since the scan: pointer identity proves nothing about a buffer the caller's own
  *                           kernels may have rewritten.  Off: every statistics call reads its input itself.
+ *   FQH_OPT_ADAPT_LINES [3] whether the byte scan of 16 GiB takes 2.65 or 2.83 ms is a property of the PAIR (the caller's input
+ *                           allocation, the context's allocation of the fast path's per-tile lines): the same line buffer is of the
+ *                           fast kind for one input and of the slow kind for another.  A context therefore keeps up to
+ *                           TWO line buffers (1.6 % of the input size each) and learns, for each input of 2 GiB or more that it is
+ *                           given AGAIN (same address, length and kind of call; four inputs are remembered), which one that input
+ *                           runs faster with — from the HIP-event time of the real calls, one buffer per call, no extra launches:
+ *                           calls 1 and 2 store to the first, calls 3 and 4 to a second one (allocated then), later calls to the faster (of each pair of
+ *                           measurements the faster one counts); an
+ *                           alternate that measures like the first (within 2.5 %) is given back and another is tried, at most this
+ *                           many times per input.  0 = off.  Results never depend on the choice.
  *   FQH_OPT_SPIN_WAIT [0]   microseconds fqh_*_finish polls the stream before it sleeps on it (hipStreamSynchronize wakes up
  *                           ~15 us after the last kernel); a host core spinning inside a library call is the caller's choice.
  * fqh_last_scan_fast: did the last finished scan (or single-pass statistics call) keep the fast path's result (1), or
@@ -126,6 +136,7 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
 #define FQH_OPT_PLACE_TRIES 3
 #define FQH_OPT_SPIN_WAIT 4
 #define FQH_OPT_REUSE_INDEX 5
+#define FQH_OPT_ADAPT_LINES 6
 fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
 int fqh_last_scan_fast(fqh_ctx *ctx);
 /* How the last finished statistics call (fqh_stats*, fqh_scan_stats*) counted: 1 = in the scan's own pass over the input

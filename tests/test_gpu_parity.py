@@ -886,3 +886,38 @@ def test_workspace_placement_is_invisible(fqref, torch, pkg):
     head = buf[: 330 * 4000].cpu().numpy()
     r, off = fqref.offsets(head)
     assert np.array_equal(outs[0][:4000].cpu().numpy().astype(np.uint64), off)
+
+
+def test_adaptive_line_buffer_is_invisible(fqref, torch, pkg):
+    """FQH_OPT_ADAPT_LINES: a context that is given the same big input again tries a second (third ..) allocation for the fast
+    path's per-tile lines and keeps the one the input runs faster with.  Whatever it tries and keeps: every call's offsets,
+    counts and histograms are the same, and the same as with the option off."""
+    dev = torch.device("cuda:0")
+    n = (2 << 30) // 330 * 330 + 330 * 7      # just above the 2 GiB from which the library adapts
+    d = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    ref = pkg.Ctx(0)
+    ref.set_adapt_lines(0)
+    ref.synth_fill(d.data_ptr(), 0, n)
+    nrec = n // 330
+    rs0 = torch.zeros(nrec + 16, dtype=torch.int64, device=dev)
+    s0 = ref.scan(d.data_ptr(), n, True, None, rs0.data_ptr(), rs0.numel())[0]
+    assert (s0.parse_status, s0.n_records) == (pkg.OK, nrec)
+    assert int(rs0[:nrec].sum().item()) == 330 * nrec * (nrec - 1) // 2
+    q0 = torch.zeros(150 * 256, dtype=torch.int64, device=dev); b0 = torch.zeros(150 * 8, dtype=torch.int64, device=dev)
+    c0 = torch.zeros(8, dtype=torch.int64, device=dev)
+    ref.stats(d.data_ptr(), n, 150, q0.data_ptr(), b0.data_ptr(), c0.data_ptr())
+    ref.close()
+    ctx = pkg.Ctx(0)                           # the option is on by default
+    for call in range(7):
+        rs = torch.zeros(nrec + 16, dtype=torch.int64, device=dev)
+        s = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())[0]
+        assert (s.parse_status, s.n_records) == (pkg.OK, nrec) and ctx.last_scan_fast(), call
+        assert torch.equal(rs[: nrec + 1], rs0[: nrec + 1]), call
+        idx = torch.zeros(1000 * 3, dtype=torch.int64, device=dev)   # the index of the scan just finished is readable whatever buffer it used
+        ctx.index_records(idx.data_ptr(), 1000)
+        assert int(idx[0].item()) == 0 and int(idx[3].item()) == 330
+    for call in range(7):
+        q = torch.zeros_like(q0); b = torch.zeros_like(b0); c = torch.zeros_like(c0)
+        ctx.stats(d.data_ptr(), n, 150, q.data_ptr(), b.data_ptr(), c.data_ptr())
+        assert ctx.last_stats_route() == 1 and torch.equal(q, q0) and torch.equal(b, b0) and torch.equal(c, c0), call
+    ctx.close()

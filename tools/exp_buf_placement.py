@@ -30,3 +30,12 @@ for rnd in range(2):
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 15 * 1e3
             t = (C.c_float * 5)(); L.fqh_last_timing(h, t)
             print("round %d context %d input %d (%x): %.3f ms per step (index %.3f emit %.3f)" % (rnd, j, i, b.data_ptr(), dt, t[1], t[3]), flush=True)
+# the bare read of every input (k_read_ceiling): is it the input alone, or the input next to the scan's line stores?
+cs = C.c_uint64(); ms = C.c_float()
+for rnd in range(2):
+    for i, b in enumerate(bufs):
+        best = 1e9
+        for _ in range(3):
+            assert L.fqh_read_ceiling(ctxs[0], b.data_ptr(), n, C.byref(cs), C.byref(ms)) == 0
+            best = min(best, ms.value)
+        print("bare read, input %d: %.3f ms" % (i, best), flush=True)

@@ -325,7 +325,7 @@ static void adapt_choose(fqh_ctx *ctx, bool fused) {
         ctx->fr[1] = nullptr;
         for (auto &e : ctx->adapt) e = fqh_ctx::LinesAdapt{};
     }
-    if (ctx->adapt_max <= 0 || a.len < (2ull << 30) || ctx->skip_emit) {
+    if (ctx->adapt_max <= 0 || a.len < (2ull << 30)) {
         ctx->fast_rs = ctx->fr[0];
         return;
     }

@@ -113,6 +113,8 @@ struct fqh_ctx {
     ScanArgs args = {};
     fqh_carry carry_in = {};
     bool whole_file = false;
+    bool no_long_rule = false;      // set around a launch whose "too long" rule is someone else's (the ring's slots) or has no file offset to go by
+    bool launch_long_rule = true;   // ... as captured by the launch in flight
     bool skip_emit = false;  // shard prescan: only the byte scan, the prefix and the chunk-end summary
     bool head_unchecked = false;  // fqh_shard_align: the record in progress at the chunk start is not validated
     // fast path: prove validity with a quarter of the list traffic; any doubt -> exact rerun

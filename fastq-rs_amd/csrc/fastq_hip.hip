@@ -557,12 +557,14 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
         s.err_record = d.final_key >> 2;
         s.err_offset = a.base_offset + (uint64_t)d.err_start;
     }
-    // "Fastq record is too long" (src/lib.rs:278-283): only a whole-file scan can replay the
-    // reference's buffer alignment exactly; chunked callers resolve it in their driver.
-    if (ctx->bufsize && ctx->whole_file) {
+    // "Fastq record is too long" (src/lib.rs:278-283) depends on a record's file offset mod 16 and on nothing else (the closed form
+    // of the reference's Buffer arithmetic, csrc/replay.h: fqh::TooLong), so a CHUNK with a carry is judged like a whole file —
+    // its boundaries are file offsets.  Not for launches whose carry is made up (prescans, fqh_shard_align) and not for the
+    // ring's slots (the ring applies the same rule to the boundaries it downloads anyway, and holds its commits back for it).
+    if (ctx->bufsize && ctx->launch_long_rule && !a.prescan) {
         const uint64_t B = ctx->bufsize;
         bool cand = d.first_long != NOKEY && d.first_long < r0 + s.n_records;
-        uint64_t need = UINT64_MAX;
+        uint64_t need = TooLong::NO_BAD;
         if (d.final_key != NOKEY) {
             const uint32_t stage = (uint32_t)d.final_key & 3u;
             if (stage == 3) {
@@ -572,6 +574,8 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
                 need = d.err_need;
                 if (need + 15 > B) cand = true;
             }
+        } else if (d.tail_len + 15 >= B) {
+            cand = true;   // the record in progress at the end of a chunk that is not the file's last
         }
         if (cand) {
             // record boundaries on the host
@@ -600,16 +604,14 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
             }
             HIPCHK(ctx, hipMemcpyAsync(rs.data(), src, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            rs[n] = (uint64_t)(d.end_off > 0 ? d.end_off : 0);  // authoritative end of the last good record
+            rs[n] = (uint64_t)((long long)a.base_offset + d.end_off);  // authoritative end of the last good record (a file offset, like the others)
             uint64_t which = 0;
-            BufferReplay rp;
-            rp.reset(B);
-            if (rp.step(rs.data(), 0, n, a.len, true, need == UINT64_MAX ? BufferReplay::NO_BAD : need, &which)) {
+            if (TooLong::first(B, rs.data(), n, a.base_offset + a.len - rs[n], need, &which)) {
                 s.parse_status = FQH_E_TOO_LONG;
                 s.n_records = which;
                 s.err_record = r0 + which;
-                s.err_offset = a.base_offset + rs[which];
-                s.bytes_consumed = rs[which];
+                s.err_offset = rs[which];
+                s.bytes_consumed = which && rs[which] > a.base_offset ? rs[which] - a.base_offset : 0;
             }
         }
     }
@@ -648,6 +650,7 @@ static fqh_status do_scan_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
         if (c.back[i] > c.base_offset) return fail(ctx, FQH_E_ARG, "carry.back exceeds base_offset");
     ctx->carry_in = c;
     ctx->whole_file = is_final && carry_is_zero(c);
+    ctx->launch_long_rule = !ctx->no_long_rule;
     ScanArgs &a = ctx->args;
     a = ScanArgs{};
     a.buf = d_buf;
@@ -910,7 +913,8 @@ fqh_status fqh_shard_rescan_launch(fqh_ctx *ctx, int is_final, const uint64_t *d
     a.cap = d_rec_start ? cap : 0;
     a.dcarry = ctx->d_carry;
     a.prescan = 0;
-    ctx->whole_file = false;  // (the "too long" rule of a sharded file is the driver's, as for chunks)
+    ctx->whole_file = false;
+    ctx->launch_long_rule = true;  // (the folded carry holds the shard's true file offset: "too long" is judged on it, as for any chunk)
     ctx->dev_carry = true;
     ctx->dout_clean = false;
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
@@ -950,7 +954,9 @@ fqh_status fqh_shard_align(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int
         c.back[0] = prev_is_newline ? 0 : 1;
         for (int i = 1; i < 4; ++i) c.back[i] = c.back[i - 1] + 1;
         ctx->head_unchecked = true;
+        ctx->no_long_rule = true;   // (a made-up base offset: nothing to judge "too long" on)
         st = do_scan_launch(ctx, d_buf, len, 0, &c, (uint64_t *)ctx->d_misc, 2, true);
+        ctx->no_long_rule = false;
         fqh_summary s = {};
         if (st == FQH_OK) st = do_scan_finish(ctx, &s, nullptr);
         ctx->head_unchecked = false;

@@ -200,6 +200,11 @@ static fqh_status launch_slot(fqh_stream *st, fqh_stream::Slot &s, const fqh_car
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
     if (s.ts0) HIPCHK(ctx, hipEventRecord(s.ts0, ctx->stream));
     s.fused = false;
+    struct NoLong {   // (the ring judges "too long" itself, on the boundaries it downloads: csrc/replay.h)
+        fqh_ctx *c;
+        explicit NoLong(fqh_ctx *x) : c(x) { c->no_long_rule = true; }
+        ~NoLong() { c->no_long_rule = false; }
+    } no_long(ctx);
     if (!reuse && (st->flags & FQH_STREAM_STATS) && !(st->flags & FQH_STREAM_INDEX) && st->lmax) {
         bool fused = false;
         fqh_status rc = fqh_internal_fused_launch(ctx, s.d, s.n_new, s.is_final, &cy, s.d_rec, s.rec_cap, st->lmax, st->d_qual_hist,

@@ -95,7 +95,10 @@ int fqh_abi_version(void);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own. */
 fqh_status fqh_set_stream(fqh_ctx *ctx, void *hip_stream);
 /* BUFSIZE used for the "record is too long" rule (default FQH_BUFSIZE; 64 = cfg(fuzzing),
- * src/lib.rs:126-127; 0 = no limit). */
+ * src/lib.rs:126-127; 0 = no limit).  The reference's verdict on a record depends on the record's FILE OFFSET mod 16 and on
+ * nothing else (the closed form of src/buffer.rs's arithmetic for a reader that fills every read, csrc/replay.h): whole files,
+ * chunks chained with fqh_carry (base_offset is the chunk's file offset), ring slots and byte-range shards are all judged on
+ * file offsets and give Parser::each's answer. */
 fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
 
 /* Knobs (defaults in brackets; the environment variables FQH_SPEC / FQH_FUSED set the same at fqh_create):

@@ -380,6 +380,41 @@ def test_chunked_scan_with_carry(fqref, gpu, pkg, seed):
     assert starts[: res.n_records] == [int(x) for x in idx[:, 0]]
 
 
+@pytest.mark.parametrize("bufsize", [256, 69632])
+def test_chunked_scan_judges_too_long_on_file_offsets(fqref, gpu, pkg, bufsize):
+    """"Fastq record is too long" (src/lib.rs:278-283) depends on the record's file offset mod 16 (csrc/replay.h, fqh::TooLong), so
+    fqh_scan chained over chunks with the carry gives Parser::each's verdict for records of BUFSIZE - 17 .. BUFSIZE + 2 bytes:
+    complete ones, one that straddles a cut, the record in progress at the end of a chunk, a truncated one at the end."""
+    rng = np.random.default_rng(bufsize)
+
+    def rec(total):
+        body = total - 6
+        sl = int(rng.integers(0, body // 2 + 1))
+        return b"@" + b"h" * (body - 2 * sl) + b"\n" + b"A" * sl + b"\n+\n" + b"I" * sl + b"\n"
+
+    seen = set()
+    for trial in range(10 if bufsize > 1000 else 40):
+        parts = []
+        for i in range(int(rng.integers(3, 40))):
+            L = int(rng.integers(bufsize - 17, bufsize + 3)) if rng.random() < 0.12 else int(rng.integers(6, bufsize // 2))
+            parts.append(rec(max(6, L)))
+        data = b"".join(parts)
+        if trial % 5 == 4:
+            data = data[: len(data) - int(rng.integers(1, min(len(data) - 1, bufsize)))]
+        res = fqref.count(data, bufsize=bufsize)
+        cuts = sorted(set([0, len(data)] + [int(x) for x in rng.integers(0, len(data) + 1, int(rng.integers(1, 5)))]))
+        carry, total, status = None, 0, pkg.OK
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            s, carry, offs = gpu.scan(data[a:b], is_final=(b == len(data)), carry=carry, bufsize=bufsize)
+            total += s.n_records
+            if s.parse_status != pkg.OK:
+                status = s.parse_status
+                break
+        assert (status, total) == (res.status, res.n_records), (trial, cuts, status, total, res.status, res.n_records)
+        seen.add(res.status)
+    assert pkg.E_TOO_LONG in seen and pkg.OK in seen
+
+
 def test_count_only_mode(fqref, gpu):
     rng = np.random.default_rng(2)
     data = fuzzgen.valid_file(rng, 300)

@@ -326,15 +326,16 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
                             const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                             uint64_t *d_base_hist, uint64_t *d_scalars);
 fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
-/* Record scan AND statistics of one buffer in a single call — for a whole file (is_final, no carry, lmax <= 256) in a
- * single READ of the input: one kernel scans, validates and counts (k_scan_stats), the way the reference's
- * Parser::each hands each record to the closure that reads seq()/qual() (src/lib.rs:226-237).  Outputs as
- * fqh_scan (d_rec_start may be NULL) plus fqh_stats.  fqh_stats on its own takes the same single-pass route.
- * Other shapes of call (chunks with a carry, non-final chunks, lmax > 256) and inputs the fast path cannot
- * prove valid (any parse error, reads longer than ~500 bp) run the exact scan followed by the histogram kernel;
- * results are identical either way.  FQH_E_CAPACITY (d_rec_start shorter than n_records + 1) is reported by the blocking
- * call / the finish on either route, with the summary, the carry-out and the histograms complete, exactly as fqh_scan
- * reports it. */
+/* Record scan AND statistics of one buffer in a single call — with lmax <= 256 in a single READ of the input: one kernel scans,
+ * validates and counts (k_scan_stats), the way the reference's Parser::each hands each record to the closure that reads
+ * seq()/qual() (src/lib.rs:226-237); whole files, chunks with a carry and chunks that are not the file's last alike.  Outputs as
+ * fqh_scan (d_rec_start may be NULL) plus fqh_stats.  fqh_stats on its own takes the same single-pass route.  Lines with bytes
+ * outside ACGTN / '!'..'`' and lines longer than lmax are counted one by one behind that pass (fqh_last_stats_route() == 2).
+ * lmax > 256, reads longer than ~500 bases, or more such lines than one per 512 KiB send the HISTOGRAMS to a second pass over
+ * the input (the scan's result stands); an input the fast path cannot prove valid (any parse error) runs the exact scan
+ * followed by the histogram kernel; results are identical either way.  FQH_E_CAPACITY (d_rec_start shorter than
+ * n_records + 1) is reported by the blocking call / the finish on either route, with the summary, the carry-out and the
+ * histograms complete, exactly as fqh_scan reports it. */
 fqh_status fqh_scan_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                           uint64_t *d_rec_start, uint64_t cap, uint32_t lmax, uint64_t *d_qual_hist,
                           uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out,

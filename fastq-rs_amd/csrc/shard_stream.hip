@@ -38,6 +38,10 @@ constexpr uint64_t ALIGN_WINDOW = 4ull << 20;
 constexpr uint64_t SMALL_RANGE = ALIGN_WINDOW + 4ull * FQH_BUFSIZE;
 enum : int { W_STATUS, W_RECORDS, W_NEWLINES, W_PHASE, W_HEAD, W_TAIL, W_ERR_OFFSET, W_FLAGS, W_LO, W_HI };
 constexpr uint64_t FLAG_NL_INCOMPLETE = 1;  // W_NEWLINES does not cover the whole range (the stream stopped at an error in a large range)
+constexpr uint64_t FLAG_IO_FAILED = 2;      // the read callback failed for bytes of this range: the range parsed nothing by itself (DEFER,
+                                            // with FLAG_NL_INCOMPLETE), what it counted is void; whoever parses the open gap it
+                                            // lies in reads its bytes again IN FILE ORDER and meets a parse error in front of
+                                            // the unreadable bytes, or the failure
 
 uint64_t pack_key(uint64_t offset, int rank, int32_t status) {
     uint64_t code;
@@ -97,10 +101,10 @@ fqh_status stream_span(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t from
         if (st != FQH_OK) return st;
     }
     uint64_t pos = from;
-    bool done_reading = false;
+    bool done_reading = false, io_failed = false;
     uint64_t submitted = 0, collected = 0;
     for (;;) {
-        while (!done_reading) {
+        while (!done_reading && !io_failed) {
             uint8_t *dst = nullptr;
             uint64_t cap = 0;
             st = fqh_stream_acquire(sp, &dst, &cap);
@@ -108,8 +112,10 @@ fqh_status stream_span(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t from
             if (st != FQH_OK) return st;
             const uint64_t n = std::min<uint64_t>(cap, to - pos);
             if (n && read(user, dst, pos, n) != 0) {
-                ctx->err = "fqh_shard_stream: the read callback failed";
-                return FQH_E_IO;
+                // file order: a parse error in the slots already on their way lies in FRONT of the bytes that could not be
+                // read, and the sequential reader would have met it first — collect those before giving up
+                io_failed = true;
+                break;
             }
             pos += n;
             done_reading = pos >= to;
@@ -133,6 +139,10 @@ fqh_status stream_span(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t from
         }
         st = fqh_stream_release(sp);
         if (st != FQH_OK) return st;
+    }
+    if (io_failed && out->status == FQH_OK) {
+        ctx->err = "fqh_shard_stream: the read callback failed";
+        return FQH_E_IO;
     }
     fqh_carry cy;
     st = fqh_stream_carry(sp, &cy);
@@ -159,8 +169,8 @@ bool classify(const uint64_t *all, int n_ranks, int rank, uint64_t file_len, Job
     for (int j = 0; j < n_ranks; ++j)
         if (W(j)[W_PHASE] != FQH_SHARD_EMPTY || (int32_t)W(j)[W_STATUS] > FQH_E_TOO_LONG) last_nonempty = j;
     uint64_t nl_before = 0;
-    bool have_anchor = false;  // a trusted anchor without an error lies in front: a gap begins behind its last complete record
-    uint64_t S = 0;            // ... at this file offset
+    bool have_anchor = true;   // a trusted anchor without an error lies in front (the start of the file is one: phase 0, a
+    uint64_t S = 0;            // record starts there): a gap begins behind its last complete record, at this file offset
     bool dead = false;         // a trusted anchor (or a gap in front of one) holds an error of its own: nothing behind it matters
     bool poisoned = false;     // the true newline count is unknown from here on — an error lies in front, inside the open gap:
                                // nobody behind is an anchor any more, the open gap runs to the end of the file
@@ -279,13 +289,24 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
         // settles that, so it may reach BEHIND the range: a few lines settle nothing — worse, the phase that "gets furthest"
         // in them can be the wrong one (a quality line that starts with '@' right behind the cut looks like a header) — while
         // up to 4 MiB of the file behind lo do, whatever the range's own size.
-        const uint64_t w = std::min<uint64_t>(ALIGN_WINDOW, file_len - lo);
-        const uint64_t own = std::min<uint64_t>(w, hi - lo);
+        uint64_t w = std::min<uint64_t>(ALIGN_WINDOW, file_len - lo);
         std::vector<uint8_t> hostw(w + 1);
-        if (read(user, hostw.data(), lo - 1, w + 1) != 0) {  // one byte more in front: is it a newline?
-            ctx->err = "fqh_shard_stream_run: the read callback failed";
-            return FQH_E_IO;
+        // (one byte more in front: is it a newline?  In pieces: the window reaches behind the range, and bytes there that
+        // cannot be read are not this range's failure — the window ends in front of them)
+        uint64_t got = 0;
+        while (got < w + 1) {
+            const uint64_t k = std::min<uint64_t>(1u << 16, w + 1 - got);
+            if (read(user, hostw.data() + got, lo - 1 + got, k) != 0) break;
+            got += k;
         }
+        if (got < std::min<uint64_t>(w, hi - lo) + 1) {
+            // bytes of the range itself cannot be read: see FLAG_IO_FAILED
+            res->phase = FQH_SHARD_DEFER;
+            res->flags |= FLAG_NL_INCOMPLETE | FLAG_IO_FAILED;
+            return FQH_OK;
+        }
+        w = got - 1;
+        const uint64_t own = std::min<uint64_t>(w, hi - lo);
         const bool prev_nl = hostw[0] == '\n';
         auto newlines_in = [&](uint64_t n) {
             uint64_t c = 0;
@@ -298,8 +319,9 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
             res->phase = kind;
             res->n_newlines = newlines_in(own);
             if (own < hi - lo) {
-                if (count_all) return count_newlines(ctx, read, user, lo + own, hi, &res->n_newlines);
-                res->flags |= FLAG_NL_INCOMPLETE;
+                const fqh_status cs = count_all ? count_newlines(ctx, read, user, lo + own, hi, &res->n_newlines) : FQH_E_IO;
+                if (cs == FQH_E_IO) res->flags |= FLAG_NL_INCOMPLETE | (count_all ? FLAG_IO_FAILED : 0);
+                else if (cs != FQH_OK) return cs;
             }
             return FQH_OK;
         };
@@ -336,6 +358,13 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
     Span sp;
     fqh_status st = stream_span(ctx, read, user, lo + R, hi, hi >= file_len, slot_bytes, n_slots, lmax, d_qual_hist, d_base_hist,
                                 d_scalars, &sp);
+    if (st == FQH_E_IO) {  // (no parse error in what could be read: see FLAG_IO_FAILED)
+        *res = fqh_shard_result{};
+        res->status = FQH_OK;
+        res->phase = FQH_SHARD_DEFER;
+        res->flags = FLAG_NL_INCOMPLETE | FLAG_IO_FAILED;
+        return FQH_OK;
+    }
     if (st != FQH_OK) return st;
     res->status = sp.status;
     res->n_records = sp.n_records;
@@ -345,7 +374,10 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
         if (sp.seen_to < hi) {
             if (hi - lo <= SMALL_RANGE) {
                 st = count_newlines(ctx, read, user, sp.seen_to, hi, &res->n_newlines);
-                if (st != FQH_OK) return st;
+                // (bytes BEHIND the parse error that cannot be read do not hide it: without their count nobody behind this
+                // range is an anchor, as for a large range; whoever parses them for real meets the I/O failure there)
+                if (st == FQH_E_IO) res->flags |= FLAG_NL_INCOMPLETE | FLAG_IO_FAILED;
+                else if (st != FQH_OK) return st;
             } else {
                 res->flags |= FLAG_NL_INCOMPLETE;
             }
@@ -370,9 +402,9 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, fqh_read_fn read, void *user, u
         out[1] = pack_key(job.fail_offset, rank, (int32_t)mine[W_STATUS]);
         return FQH_OK;
     }
-    if (lmax && (uint32_t)mine[W_PHASE] <= 3 && !job.own) {
-        // this rank streamed under a line phase that is not the true one: what it counted is void (the gap's parser counts
-        // its bytes under the true phase)
+    if (lmax && (((uint32_t)mine[W_PHASE] <= 3 && !job.own) || ((mine[W_FLAGS] & FLAG_IO_FAILED) && (uint32_t)mine[W_PHASE] > 3))) {
+        // this rank streamed under a line phase that is not the true one, or up to bytes it could not read: what it counted
+        // is void (the gap's parser counts its bytes under the true phase)
         if (!ctx || !d_qual_hist || !d_base_hist || !d_scalars) return FQH_E_ARG;
         fqh_status st = fqh_memset(ctx, d_qual_hist, 0, (uint64_t)lmax * 256 * sizeof(uint64_t));
         if (st == FQH_OK) st = fqh_memset(ctx, d_base_hist, 0, (uint64_t)lmax * 8 * sizeof(uint64_t));

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <stdexcept>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -269,10 +270,14 @@ int main(int argc, char **argv) {
         const uint64_t nw = 9 + (uint64_t)lmax * 264;
         void *dh = nullptr;
         if (fqh_dev_alloc(ctx, nw * 8, &dh) != FQH_OK || fqh_memset(ctx, dh, 0, nw * 8) != FQH_OK) return 2;
+        const bool fail_io = argc >= 5 && !strcmp(argv[4], "fail-io");   // the read callback throws for the file's second half
         Options o;
-        o.slot_bytes = 1 << 20;
+        o.slot_bytes = fail_io ? 1 << 16 : 1 << 20;   // (slots well below half the file: reads in front of the failing bytes succeed)
         try {
-            const uint64_t n = each_sharded(ctx, nullptr, 1, 0, [&](uint8_t *dst, uint64_t off, uint64_t k) { memcpy(dst, d.data() + off, k); },
+            const uint64_t n = each_sharded(ctx, nullptr, 1, 0, [&](uint8_t *dst, uint64_t off, uint64_t k) {
+                                                if (fail_io && off + k > d.size() / 2) throw std::runtime_error("injected read failure");
+                                                memcpy(dst, d.data() + off, k);
+                                            },
                                             d.size(), lmax, (uint64_t *)dh, o);
             std::vector<uint64_t> h(nw);
             if (fqh_memcpy_d2h(ctx, h.data(), dh, nw * 8) != FQH_OK) return 2;

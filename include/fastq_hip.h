@@ -282,7 +282,12 @@ typedef struct {
     uint64_t err_offset; /* file offset of the failing record                                                 */
     uint64_t head_len;   /* R: [lo, lo + R) ends the record the ranks in front began                           */
     uint64_t tail_len;   /* bytes behind the rank's last complete record                                      */
-    uint64_t flags;      /* bit 0: n_newlines stops where the stream stopped (an error in a range of many MiB) */
+    uint64_t flags;      /* bit 0: n_newlines stops where the stream stopped (an error in a range of many MiB, unreadable bytes);
+                            bit 1: the read callback failed for bytes of this range.  Not a failure of the run: the range
+                            contributes nothing by itself (phase FQH_SHARD_DEFER), and the rank that parses the gap it lies in
+                            reads its bytes again in file order — it reports a parse error in front of the unreadable bytes,
+                            as the sequential reader would, FQH_E_IO when it meets them, and nothing if ITS callback can read
+                            them */
 } fqh_shard_result;
 #define FQH_SHARD_STREAM_WORDS 10
 #define FQH_SHARD_MAX_RANKS 256

@@ -193,6 +193,23 @@ def test_fastq_count_on_gzip_input(gpu_ok, fqref, tmp_path):
     assert out.returncode == 101 and fqref.strerror(fqref.count(bad).status) in out.stderr
 
 
+def test_each_sharded_cpp_mirror_reports_a_failing_reader(gpu_ok, tmp_path):
+    """A read callback that throws inside fastq::each_sharded: the rank still takes part in the exchange and the reductions (it
+    would otherwise leave the other ranks waiting in a collective) and throws afterwards — an I/O failure, not a parse
+    error; with a parse error in front of the failing bytes, the parse error wins (file order)."""
+    rng = np.random.default_rng(92)
+    data = bytearray(fuzzgen.valid_file(rng, 9000, maxlen=120, crlf=False))
+    path = tmp_path / "f.fastq"
+    path.write_bytes(bytes(data))
+    out = subprocess.run([os.path.join(BIN, "host_tests"), "--sharded", str(path), "120", "fail-io"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("err ") and "read callback failed" in out.stdout, out.stdout + out.stderr
+    k = data.index(b"\n+", len(data) // 8)
+    data[k + 1] = ord("-")
+    path.write_bytes(bytes(data))
+    out = subprocess.run([os.path.join(BIN, "host_tests"), "--sharded", str(path), "120", "fail-io"], capture_output=True, text=True, timeout=600)
+    assert out.stdout.strip() == "err Sequence and quality not separated by +", out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("kind", ["valid", "crlf", "mismatch"])
 def test_each_sharded_cpp_mirror_equals_oracle(gpu_ok, fqref, tmp_path, kind):
     """fastq::each_sharded (host/fastq.hpp) over fqh_shard_stream_run / fqh_shard_stream_finish as the only rank: record count,

@@ -31,12 +31,13 @@ def env():
     return torch, pkg, sharded
 
 
-def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, bufsize=None, fail_rank=None):
+def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, bufsize=None, fail_rank=None, fail_from=None):
     """Every "rank" streams its byte range (fqh_shard_stream_run), the exchange is a list of words, every rank finishes
     (fqh_shard_stream_finish: true-phase check, the parse of the gap in front of it, packed first-error key); the per-rank record
     slots, the sum of the histograms and the MINIMUM of the keys are what the all-reduces deliver, fqh_shard_stream_outcome
     turns them into Parser::each's result.  Every rank has histogram arrays of its own.  fail_rank: that rank's read callback
-    raises.  -> (status, n_records, histograms, shards)"""
+    raises; fail_from: every rank's read callback raises for bytes at or behind that file offset.
+    -> (status, n_records, histograms, shards)"""
     torch, pkg, sharded = env
     dev = torch.device("cuda:0")
     n = len(data)
@@ -44,7 +45,7 @@ def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, bufsize=None, fail_ra
 
     def reader(r):
         def read_into(addr, off, nbytes):
-            if r == fail_rank:
+            if r == fail_rank or (fail_from is not None and off + nbytes > fail_from):
                 raise OSError("injected")
             assert off + nbytes <= n
             C.memmove(addr, C.addressof(host) + off, nbytes)
@@ -234,19 +235,51 @@ def test_three_lines_on_eight_ranks(env, fqref):
 
 
 def test_a_rank_that_fails_still_takes_part(env, fqref):
-    """A rank whose read callback fails sends its failure into the exchange and goes on (the others would wait for it forever in
-    a collective); every rank learns FQH_E_IO from the minimum — unless the sequential parser meets a parse error first."""
+    """A rank whose read callback fails says so in its words (flags bit 1) and goes on — the others would wait for it forever in
+    a collective.  Its bytes are part of the open gap: the LAST rank reads them again in file order, and if its callback can, the
+    result is the whole file's; a last rank that cannot read fails with FQH_E_IO, which every rank learns from the minimum —
+    unless the sequential parser meets a parse error first."""
     torch, pkg, sharded = env
     rng = np.random.default_rng(9)
     data = bytearray(fuzzgen.valid_file(rng, 3000, maxlen=100, crlf=False))
     cuts = [len(data) // 4, len(data) // 2, len(data) * 3 // 4]
+    r = fqref.count(bytes(data))
     status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_rank=2)
-    assert status == pkg.E_IO and shards[2].failed == pkg.E_IO
+    assert (status, n_records) == (pkg.OK, r.n_records) and shards[2].res.flags & 2 and shards[2].res.phase == pkg.SHARD_DEFER
+    _, oq, ob, osc = fqref.stats(bytes(data), 100)
+    assert np.array_equal(hist[:8], osc) and np.array_equal(hist[8: 8 + 100 * 256].reshape(100, 256), oq)
+    assert np.array_equal(hist[8 + 100 * 256:].reshape(100, 8), ob)
+    status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_rank=3)
+    assert status == pkg.E_IO
     k = data.index(b"\n+\n", len(data) // 8)
     data[k + 1] = ord("-")      # a parse error in rank 0 lies in front of the failure in file order
     r = fqref.count(bytes(data))
-    status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_rank=2)
+    status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_rank=3)
     assert (status, n_records) == (r.status, r.n_records) == (pkg.E_SEP, r.n_records)
+
+
+def test_unreadable_bytes_behind_a_parse_error_do_not_hide_it(env, fqref):
+    """A file whose bytes cannot be read from some offset on: the sequential reader reports a parse error that lies in FRONT of
+    them and the I/O failure otherwise, whichever rank's range both fall into (the ring reads ahead of the parser: what is
+    already on its way is collected before the failure is reported)."""
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(10)
+    data = bytearray(fuzzgen.valid_file(rng, 12000, maxlen=100, crlf=False))
+    n = len(data)
+    cuts = [n // 4, n // 2, n * 3 // 4]
+    fail_from = n * 11 // 16          # inside rank 2's range, a few slots in
+    status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_from=fail_from)
+    assert status == pkg.E_IO
+    behind = bytearray(data)
+    k = behind.index(b"\n+\n", n * 23 // 32)
+    behind[k + 1] = ord("-")          # behind the unreadable offset: never seen
+    status, n_records, hist, shards = run_sharded(env, bytes(behind), cuts, 100, fail_from=fail_from)
+    assert status == pkg.E_IO
+    k = data.index(b"\n+\n", n // 2 + n // 32)
+    data[k + 1] = ord("-")            # in front of it, in the same rank's range
+    r = fqref.count(bytes(data))
+    status, n_records, hist, shards = run_sharded(env, bytes(data), cuts, 100, fail_from=fail_from)
+    assert (status, n_records) == (r.status, r.n_records) and status == pkg.E_SEP
 
 
 @pytest.mark.parametrize("bufsize", [256, 69632])

@@ -67,7 +67,12 @@ fqh_status fqh_create(int device, fqh_ctx **out) {
         int cu = 0;
         if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0)
             ctx->n_cu = cu;
-        if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        // A BLOCKING stream: a caller that works on the legacy null stream (hipMemsetAsync(.., 0), torch's default stream) and
+        // never calls fqh_set_stream gets the ordering it expects — its fills are done before the kernels here read or
+        // overwrite the memory, and its reads see what they wrote.  (A non-blocking stream raced with a torch.zeros() of the
+        // offsets array in the tests: the fill ran late and wiped part of the result.)  Callers with streams of their own
+        // pass one (fqh_set_stream) and order their work on it.
+        if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }
         ctx->stream = ctx->own_stream;
         if (hipMalloc((void **)&ctx->d_out, 2 * sizeof(DevOut)) != hipSuccess) { st = FQH_E_DEVICE; break; }
         if (hipMalloc((void **)&ctx->d_misc, 64) != hipSuccess) { st = FQH_E_DEVICE; break; }

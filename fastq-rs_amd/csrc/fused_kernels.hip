@@ -72,6 +72,17 @@ static_assert(FZ_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesse
 
 typedef uint32_t fz_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 
+// A kernel argument that only cold paths use (dumps, listings, the list area, the epilogue), re-read from the kernarg segment
+// where it is used: held in scalar registers from the prologue on, the seventeen of them are spilled to vector lanes around
+// the loops (tools/isa.sh: sgpr_spill_count).
+template <class T>
+__device__ __forceinline__ T fz_karg(uint32_t off) {
+    const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));  // (opaque: the load stays where the argument is used)
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(p + off);
+}
+#define FZ_KARG(f) fz_karg<decltype(FusedArgs::f)>((uint32_t)offsetof(FusedArgs, f))
+
 // spans of FZ_SPAN tiles; a last partial tile of at most one group belongs to the span in front of it
 __host__ __device__ __forceinline__ uint32_t fz_spans(uint64_t n_tiles, uint64_t len) {
     const uint64_t tail = len & (WT_BYTES - 1);
@@ -156,13 +167,13 @@ __device__ __forceinline__ void fz_sub4_at(const uint32_t off, const SoLane &c, 
 template <bool IS_SEQ, uint32_t NSL>
 __device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &z) {
     uint32_t slot = 0;
-    if (__lane_id() == 0) slot = (uint32_t)atomicAdd(&z.out->decl_batches, 1ull);
+    if (__lane_id() == 0) slot = (uint32_t)atomicAdd(&FZ_KARG(out)->decl_batches, 1ull);
     slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-    if (slot >= z.decl_cap) {
-        if (__lane_id() == 0) atomicAdd(&z.out->stats_declined, 1ull);
+    if (slot >= FZ_KARG(decl_cap)) {
+        if (__lane_id() == 0) atomicAdd(&FZ_KARG(out)->stats_declined, 1ull);
         return;
     }
-    uint32_t *dst = z.decl_b + (uint64_t)slot * ((1u + NSL) * 64u) + __lane_id();
+    uint32_t *dst = FZ_KARG(decl_b) + (uint64_t)slot * ((1u + NSL) * 64u) + __lane_id();
     dst[0] = (B.P & 0x7FFFFFFFu) | (IS_SEQ ? 0u : 0x80000000u);
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) dst[64u * (1u + u)] = IS_SEQ ? B.w[u] : B.w[u] + 0x21212121u;  // (quality dwords were rebased in place)
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                     if (last_g && last_t) pbv = buf[((uint64_t)(nspan * FZ_SPAN) << WT_SHIFT) - (nspan ? 1 : 0)];
                     fetch_group(last_g ? (last_t ? nspan * FZ_SPAN : tile + 1) : tile, last_g ? 0u : g + 1, n0, n1, n2, n3);
                     if (g == 0 && pending)  // a whole group before the next wait on vmcnt
-                        __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
+                        __builtin_nontemporal_store((uint16_t)prv, FZ_KARG(fast_rs) + (uint64_t)ptile * FR_STRIDE + lane);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     FZ_T(0);  // LDS write, prefetch issue
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         } else if (full) {
                             if (ppos >= 0) yclose = yend + ppos + 1;
                             else if (tb + tile_bytes + FZ_POST <= len) {  // a line that goes on for more than 512 bytes after the span:
-                                if (lane == 0) atomicAdd(&z.out->stats_declined, 1ull);  // not counted here (no doubt about the parse)
+                                if (lane == 0) atomicAdd(&FZ_KARG(out)->stats_declined, 1ull);  // not counted here (no doubt about the parse)
                             }
                             // (else: no '\n' before the end of the buffer: not a line the parser delivers)
                         }
@@ -585,7 +596,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                 l = ((e4 - e3) & 0x3FFFu) - 1u;  // raw line, without its '\n'
                                 const int ys = yc - 1 - (int)l;
                                 if (ys < 0) {
-                                    atomicAdd(&z.out->stats_declined, 1ull);  // began before the kept tail (longer than ~500 bytes): not counted here
+                                    atomicAdd(&FZ_KARG(out)->stats_declined, 1ull);  // began before the kept tail (longer than ~500 bytes): not counted here
                                 } else {
                                     if (l && bcr == '\r') --l;  // trim_winline, src/records.rs:66-73
                                     // (longer than the histogram's rows: the span is bad if this turns out to be a sequence or a
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                         }
                         FZ_T(3);  // per-entry pass
                         span_bad = __ballot(span_bad) != 0;
-                        const bool head_chunk = z.skip_head && span == 0 && (srun | c0) == 0;  // (wave-uniform) the chunk's very first entries
+                        const bool head_chunk = span == 0 && (srun | c0) == 0 && FZ_KARG(skip_head);  // (wave-uniform) the chunk's very first entries
                         if (tile == t0 && g == 0 && c0 == 0) {  // the span's first entries must single out the alignment it is counted under
                             uint32_t cons = 0;
 #pragma unroll
@@ -621,13 +632,13 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                 if (lb) {
                                     uint32_t base = 0;
                                     const uint32_t nl_ = (uint32_t)__popcll(lb);
-                                    if (lane == 0) base = (uint32_t)atomicAdd(&z.out->decl_lines, (unsigned long long)nl_);
+                                    if (lane == 0) base = (uint32_t)atomicAdd(&FZ_KARG(out)->decl_lines, (unsigned long long)nl_);
                                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                                    if (base + nl_ > z.decl_cap) {
-                                        if (lane == 0) atomicAdd(&z.out->stats_declined, 1ull);
+                                    if (base + nl_ > FZ_KARG(decl_cap)) {
+                                        if (lane == 0) atomicAdd(&FZ_KARG(out)->stats_declined, 1ull);
                                     } else if (listed) {
                                         const uint32_t k = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lb, 0));
-                                        uint32_t *e = reinterpret_cast<uint32_t *>(z.decl_l) + 4u * k;   // (tile, y | group << 16, length, kind)
+                                        uint32_t *e = reinterpret_cast<uint32_t *>(FZ_KARG(decl_l)) + 4u * k;   // (tile, y | group << 16, length, kind)
                                         e[0] = tile;
                                         e[1] = (Pent >> 16) | (g << 16);
                                         e[2] = l;
@@ -707,13 +718,13 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                     }
                     const uint32_t nrs = trun > hyp_t ? (trun - hyp_t + 3) >> 2 : 0u;  // record starts of the tile
                     if (nrs > FR_N && hyp_t < 4) {
-                        z.fast_rs[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + lane] = trs[FR_N + lane];
+                        FZ_KARG(fast_rs)[fr2_off(n_tiles) + (uint64_t)tile * FR2_N + lane] = trs[FR_N + lane];
                         if (nrs > FR_N + FR2_N) {
-                            if (z.list) {
-                                for (uint32_t k = FR_N + FR2_N + lane; k < nrs && k < FZ_RS; k += 64) z.list[(uint64_t)tile * z.list_cap + 8 + k] = trs[k];
+                            if (FZ_KARG(list)) {
+                                for (uint32_t k = FR_N + FR2_N + lane; k < nrs && k < FZ_RS; k += 64) FZ_KARG(list)[(uint64_t)tile * FZ_KARG(list_cap) + 8 + k] = trs[k];
                             } else {  // (no line-list workspace yet: the host reruns with it)
                                 span_bad = true;
-                                if (lane == 0) z.out->need_list = 1;
+                                if (lane == 0) FZ_KARG(out)->need_list = 1;
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -729,18 +740,18 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (pending) __builtin_nontemporal_store((uint16_t)prv, z.fast_rs + (uint64_t)ptile * FR_STRIDE + lane);
+        if (pending) __builtin_nontemporal_store((uint16_t)prv, FZ_KARG(fast_rs) + (uint64_t)ptile * FR_STRIDE + lane);
     }
-    if (lane == 0 && n_over) atomicAdd(&z.out->spec_fail, (unsigned long long)n_over);
+    if (lane == 0 && n_over) atomicAdd(&FZ_KARG(out)->spec_fail, (unsigned long long)n_over);
 #ifdef FQH_FZ_TIMING
     if (lane == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd(&z.scalars[8 + i], tph[i]);
+        for (int i = 0; i < 6; ++i) atomicAdd(&FZ_KARG(scalars)[8 + i], tph[i]);
 #endif
 
     // ---- per-block partial histogram, per-wave totals
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    uint32_t *__restrict__ dst = z.scratch + (uint64_t)blockIdx.x * SO_WORDS;
+    uint32_t *__restrict__ dst = FZ_KARG(scratch) + (uint64_t)blockIdx.x * SO_WORDS;
     for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) dst[i] = hist[i];
     unsigned long long sc[5] = {acc_rec, acc_bases, acc_qual, 0, 0};
 #pragma unroll
@@ -755,7 +766,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
         sc[4] = sc[0] - T.not_dnan;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
-            if (sc[j]) atomicAdd(&z.scalars[j], sc[j]);
+            if (sc[j]) atomicAdd(&FZ_KARG(scalars)[j], sc[j]);
     }
 }
 

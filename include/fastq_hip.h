@@ -92,7 +92,10 @@ const char *fqh_strerror(fqh_status s); /* the reference's exact message strings
 const char *fqh_last_error(fqh_ctx *ctx);
 int fqh_abi_version(void);
 
-/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own. */
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own.  Device memory handed to a
+ * call must be ready ON THAT STREAM: the context's own stream is a blocking one, i.e. ordered against work on the legacy null
+ * stream (hipMemsetAsync(.., 0), torch's default stream) and against nothing else; work on any other stream needs an event or
+ * a synchronize before the call, as for any kernel launch. */
 fqh_status fqh_set_stream(fqh_ctx *ctx, void *hip_stream);
 /* BUFSIZE used for the "record is too long" rule (default FQH_BUFSIZE; 64 = cfg(fuzzing),
  * src/lib.rs:126-127; 0 = no limit).  The reference's verdict on a record depends on the record's FILE OFFSET mod 16 and on

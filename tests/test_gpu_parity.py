@@ -956,3 +956,31 @@ def test_adaptive_line_buffer_is_invisible(fqref, torch, pkg):
         ctx.stats(d.data_ptr(), n, 150, q.data_ptr(), b.data_ptr(), c.data_ptr())
         assert ctx.last_stats_route() == 1 and torch.equal(q, q0) and torch.equal(b, b0) and torch.equal(c, c0), call
     ctx.close()
+
+
+def test_own_stream_is_ordered_against_the_null_stream(torch, pkg):
+    """A caller that never sets a stream works on the legacy null stream (torch's default): the context's own stream must be
+    ordered against it.  Here the zero-fill of the offsets array is queued BEHIND a few milliseconds of other null-stream work,
+    so a scan on a stream that does not wait for it finishes first and has part of its offsets wiped (seen once the GPU tests
+    ran in another order: the own stream was a non-blocking one)."""
+    dev = torch.device("cuda:0")
+    assert torch.cuda.current_stream().cuda_stream == 0
+    n = (64 << 20) // 330 * 330
+    nrec = n // 330
+    d = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    ctx = pkg.Ctx(0)                      # (no stream given: the context's own)
+    try:
+        ctx.synth_fill(d.data_ptr(), 0, n)
+        ballast = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+        rs = torch.empty(nrec + 8, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for _ in range(12):
+                ballast.fill_(rep)        # ~ 1 ms each on the null stream
+            rs.zero_()                    # ... and the fill the scan must not overtake
+            s, c, st = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), nrec + 8)
+            assert st == pkg.OK and s.parse_status == pkg.OK and s.n_records == nrec
+            got = rs[: nrec + 1].cpu().numpy().astype(np.uint64)    # (a null-stream read: waits for the scan's stream as well)
+            assert np.array_equal(got, np.arange(nrec + 1, dtype=np.uint64) * 330), rep
+    finally:
+        ctx.close()

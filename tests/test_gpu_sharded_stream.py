@@ -343,6 +343,24 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
             if 0 < j + 1 < n:
                 cuts = sorted(set(cuts + [j + 1]))
         lmax = 150
+        if rng.random() < 0.15:   # bytes that cannot be read from some offset on: the error the sequential reader meets FIRST
+            fail_from = int(rng.integers(1, n))
+            slot = 1 << 16
+            status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=slot, fail_from=fail_from)
+            r = fqref.count(data)
+            # (the reference fills a 68 KiB buffer before it parses it, the ring reads three slots ahead: an error this close in
+            # front of the unreadable bytes may be reported either way)
+            slack = 2 * 69632 + 3 * slot
+            e_off = r.bytes_consumed if r.status != pkg.OK else n   # (the failing record begins where the delivered ones end)
+            ctx_ = (seed, cases, cuts, fail_from, (status, n_records), (r.status, r.n_records, e_off))
+            if r.status != pkg.OK and e_off + slack < fail_from:
+                assert (status, n_records) == (r.status, r.n_records), ctx_
+            elif e_off >= fail_from:
+                assert status == pkg.E_IO, ctx_
+            else:
+                assert status == pkg.E_IO or (status, n_records) == (r.status, r.n_records), ctx_
+            cases += 1
+            continue
         status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=int(rng.choice([1 << 16, 1 << 18, 1 << 20])))
         r, oq, ob, osc = fqref.stats(data, lmax)
         # status and the number of records delivered before the first error are the sequential parser's, whatever the cuts

@@ -32,9 +32,11 @@ cases = {{
                                                                                                          # its records are void, it must parse [1000, 1700) itself — no GPU here: its finish fails
     "rank1_failed": [[OK, 10, 40, 0, 0, 0, 0, 0, 0, 1000], pkg.shard_failed_words(pkg.E_IO, 1000, 1700)],
     "empty_rank1":  [[OK, 10, 40, 0, 0, 0, 0, 0, 0, 1000], [OK, 0, 0, pkg.SHARD_EMPTY, 0, 0, 0, 0, 1000, 1000]],
+    "rank1_unreadable": [[OK, 10, 40, 0, 0, 0, 0, 0, 0, 1000], [OK, 0, 0, pkg.SHARD_DEFER, 0, 0, 0, 3, 1000, 1700]],   # flags bit 1: its read callback failed — no failure
+                                                                                                         # of the run: the last rank reads [1000, 1700) again in file order (no GPU here: that finish fails)
 }}
 want = {{"clean": (OK, 17, 0), "error_rank1": (LEN, 13, 1300), "error_rank0": (LEN, 4, 400), "wrong_phase": (pkg.E_DEVICE, 10, 1000),
-        "rank1_failed": (pkg.E_IO, 10, 1000), "empty_rank1": (OK, 10, 0)}}
+        "rank1_failed": (pkg.E_IO, 10, 1000), "empty_rank1": (OK, 10, 0), "rank1_unreadable": (pkg.E_DEVICE, 10, 1000)}}
 # ... and the words two ranks REALLY produced (fqh_shard_stream_run on an MI355X, tests/golden/shard_words_gpu.json: a file of
 # 6000 records cut at a record start, so that no rank has a gap to parse and the finish is host arithmetic)
 import json
@@ -49,7 +51,7 @@ for name, rows in cases.items():
     words = allw.numpy().astype(np.uint64)
     out = (C.c_uint64 * 2)()
     st = L.fqh_shard_stream_finish(None, pkg.READ_FN(), None, flen.get(name, 1700), words.ctypes.data, world, rank, 1 << 16, 2, 0, None, None, None, C.byref(out))
-    if name == "wrong_phase" and rank == 1:
+    if name in ("wrong_phase", "rank1_unreadable") and rank == 1:
         assert st == pkg.E_ARG, st                                  # (a gap to parse and no context: this rank's finish fails ...)
         out[0], out[1] = 0, pkg.shard_failure_key(rank, rows[rank][8], st)   # ... and it goes on with a failure key
     else:

@@ -21,6 +21,8 @@ pub struct fqh_stream_times { pub wall_ms: f64, pub copy_busy_ms: f64, pub scan_
 #[derive(Clone, Copy)]
 pub struct fqh_shard_result { pub status: i32, pub phase: u32, pub n_records: u64, pub n_newlines: u64, pub err_offset: u64,
                               pub head_len: u64, pub tail_len: u64, pub flags: u64 }
+// flags: bit 0 = n_newlines stops where the stream stopped; bit 1 = the read callback failed for bytes of this range (not a failure
+// of the run: the range defers, the rank that parses the gap it lies in reads its bytes again in file order — include/fastq_hip.h)
 #[repr(C)] pub struct fqh_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct fqh_stream { _p: [u8; 0] }
 

@@ -259,8 +259,11 @@ fqh_status fqh_sync(fqh_ctx *ctx);
  * the rank that parses the gap it lies in (below); an EMPTY range (lo == hi) is fine.  No byte range is refused.
  *
  * Then ONE exchange: fqh_shard_result_words(res, lo, hi) — FQH_SHARD_STREAM_WORDS words — of every rank, all-gathered in rank
- * order (fqh_allgather or the host's own collective).  A rank whose run FAILED (FQH_E_IO from the callback, a device error)
- * must still take part — the others would wait for it forever: it sends fqh_shard_failed_words(status, lo, hi) and goes on.
+ * order (fqh_allgather or the host's own collective).  A rank whose run FAILED (a device error, an exception of the host
+ * around the call) must still take part — the others would wait for it forever: it sends fqh_shard_failed_words(status, lo,
+ * hi) and goes on.  Bytes the `read` callback cannot deliver do NOT fail the run (res->flags bit 1, below): the error the
+ * whole call ends in is the one the sequential reader would meet first, a parse error in front of the unreadable bytes or
+ * FQH_E_IO at them.
  *
  * fqh_shard_stream_finish: every rank derives the same picture from the words — the TRUE newline count in front of every
  * range, hence which ranks parsed under the true line phase.  Between the last complete record of one such rank and the first

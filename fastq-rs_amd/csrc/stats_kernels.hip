@@ -5,6 +5,7 @@
 // src/records.rs:19-33.  Counters are integers: addition commutes, so the result is bit-exact whatever the order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "stats_dev.h"
@@ -473,12 +474,21 @@ struct LongArgs {
     const fqh_idx_record *idx;     // the records that count: idx[0 .. n)
     uint64_t n;
     uint32_t lmax, n_cb, n_slices;
+    uint32_t per_xcd;              // blocks per XCD: block (xcd, j) is work item xcd * per_xcd + j of the n_cb * n_slices
     uint32_t *flagmap;             // 2 x flag_words words, zeroed: [has N or worse | has a byte outside ACGTN]
     uint64_t flag_words;
     unsigned long long *qual_hist, *base_hist, *scalars;
 };
 __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    // Workgroups go to the eight XCDs round-robin (blockIdx % 8), and every XCD has an L2 of its own.  The column blocks of ONE
+    // slice of the records read neighbouring 256-byte pieces of the same lines — pieces that are not aligned to the 128-byte
+    // cache lines, so that neighbours share the line at either edge — at about the same time: the work items (slice-major:
+    // item = slice * n_cb + cb) are dealt out in eight CONTIGUOUS runs, one per XCD, so that a slice's column blocks sit on
+    // one XCD (two at a run's edge) and the shared lines are fetched once.  (Numbered across the XCDs, every column block of a
+    // slice pulled its edge lines through another L2: 1.7 x the input's bytes from memory, PMC FETCH_SIZE.)
+    const uint32_t xcd = blockIdx.x & 7u, item = xcd * a.per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= a.per_xcd || item >= a.n_cb * a.n_slices) return;   // (the grid is padded to whole runs)
     for (uint32_t i = threadIdx.x; i < SO_LWORDS; i += SO_THREADS) hist[i] = 0;
     __syncthreads();
     if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();  // the address registers assume the histogram starts at LDS address 0
@@ -492,13 +502,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         c.sel[k] = 0x0C0C0004u + k + (j << 8);
         c.slots |= ((2u * (m & 3u) + 32u * (m >> 2) + 8u * j) * 4u) << (8u * k);
     }
-    // Workgroups go to the eight XCDs round-robin (blockIdx % 8), and every XCD has an L2 of its own.  The column blocks of ONE
-    // slice of the records read neighbouring 256-byte pieces of the same lines — pieces that are not aligned to the 128-byte
-    // cache lines, so that neighbours share the line at either edge — at about the same time: they are put on one XCD (slice =
-    // 8 * (i / n_cb) + xcd), where the shared lines are fetched once.  (Numbered across the XCDs, every column block of a slice
-    // pulled its edge lines through another L2: 1.7 x the input's bytes from memory, PMC FETCH_SIZE.)
-    const uint32_t xcd = blockIdx.x & 7u, bi = blockIdx.x >> 3;
-    const uint32_t cb = bi % a.n_cb, slice = (bi / a.n_cb) * 8u + xcd;
+    const uint32_t cb = item % a.n_cb, slice = item / a.n_cb;
     const uint32_t col0 = cb * SO_LC_MAX;
     const uint32_t lc = a.lmax > col0 ? (a.lmax - col0 < SO_LC_MAX ? a.lmax - col0 : SO_LC_MAX) : 0u;  // rows of this block that the caller has
     StatsArgs sa = {};           // what so_exact_step wants to know
@@ -699,12 +703,30 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
     a.lmax = lmax;
     a.n_cb = (max_line + SO_LC_MAX - 1) / SO_LC_MAX;
     if (a.n_cb == 0) a.n_cb = 1;
+    // One block is resident per CU (its histogram fills the LDS), so the launch runs in ROUNDS of `cus` blocks, and a block
+    // costs ~0.2 ms beyond its share of the records (zeroing and flushing 136 KiB of counters, the drain of its wavefronts):
+    // measured per 4 GiB, 1 kbp reads in 256 blocks 1.37 ms, in 1024 blocks 1.97; a round that is not full wastes CUs for a
+    // whole block time.  So: R rounds of as many slices as fill them, R = the cheapest of 1 .. 4 under
+    // time ~ R * (cus / blocks + 0.23)  (units: the records' work spread evenly over the CUs).
     const uint32_t cus = stats_blocks(n_cu);
-    a.n_slices = (4 * cus + a.n_cb - 1) / a.n_cb;                       // ~4 blocks per CU over the launch (one resident at a time: LDS)
-    const uint64_t max_slices = (n + 8 * SO_WAVES - 1) / (8 * SO_WAVES);
-    if (a.n_slices > max_slices) a.n_slices = (uint32_t)max_slices;
-    a.n_slices = (a.n_slices + 7u) & ~7u;                               // (a multiple of the XCDs: slice = 8 * (i / n_cb) + xcd in the kernel)
-    if (a.n_slices == 0) a.n_slices = 8;
+    const uint64_t max_slices = std::max<uint64_t>(1, (n + 8 * SO_WAVES - 1) / (8 * SO_WAVES));
+    uint32_t rounds_lo = 1, rounds_hi = 4;
+#ifdef FQH_TUNING
+    if (getenv("FQH_LONG_ROUNDS") && atoi(getenv("FQH_LONG_ROUNDS")) > 0) rounds_lo = rounds_hi = (uint32_t)atoi(getenv("FQH_LONG_ROUNDS"));
+#endif
+    double best = 1e30;
+    a.n_slices = 1;
+    for (uint32_t R = rounds_lo; R <= rounds_hi; ++R) {
+        uint64_t S = std::max<uint64_t>(1, (uint64_t)R * cus / a.n_cb);
+        if (S > max_slices) S = max_slices;
+        const uint64_t blocks = S * a.n_cb, r = (blocks + cus - 1) / cus;
+        const double cost = (double)r * ((double)cus / (double)blocks + 0.23);
+        if (cost < best) {
+            best = cost;
+            a.n_slices = (uint32_t)S;
+        }
+    }
+    a.per_xcd = (a.n_cb * a.n_slices + 7u) / 8u;
     a.flagmap = flagmap;
     a.flag_words = flag_words;
     a.qual_hist = qual_hist;
@@ -717,7 +739,7 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
         if (e != hipSuccess) return e;
         set = true;
     }
-    hipLaunchKernelGGL(k_stats_long, dim3(a.n_cb * a.n_slices), dim3(SO_THREADS), lds, s, a);
+    hipLaunchKernelGGL(k_stats_long, dim3(8u * a.per_xcd), dim3(SO_THREADS), lds, s, a);
     return hipGetLastError();
 }
 

@@ -14,7 +14,9 @@ rng = np.random.default_rng(7)
 nrec = 1024
 seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (nrec, read_len))
 qual = np.where(rng.random((nrec, read_len)) < 0.8, 126, rng.integers(33, 127, (nrec, read_len))).astype(np.uint8)
-block = b"".join(b"@m%06d/ccs\n" % i + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n" for i in range(nrec))
+# READ_LEN_VAR=1: lengths uniform in [READ_LEN / 4, READ_LEN] (the column blocks do not hold equal shares of the bytes any more)
+lens = rng.integers(read_len // 4, read_len + 1, nrec) if os.environ.get("READ_LEN_VAR") == "1" else np.full(nrec, read_len)
+block = b"".join(b"@m%06d/ccs\n" % i + seq[i, :lens[i]].tobytes() + b"\n+\n" + qual[i, :lens[i]].tobytes() + b"\n" for i in range(nrec))
 reps = (4 << 30) // len(block)
 n = reps * len(block)
 d = torch.cat([torch.from_numpy(np.frombuffer(block, dtype=np.uint8).copy()).to(dev).repeat(reps), torch.zeros(16, dtype=torch.uint8, device=dev)])
@@ -24,4 +26,4 @@ for _ in range(4):
     ctx.invalidate(); torch.cuda.synchronize()
     ctx.stats(d.data_ptr(), n, read_len, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
     best = min(best, ctx.timing().stats_ms)
-print("%s: histogram kernels %.3f ms (%.0f GB/s)" % (os.path.basename(sys.argv[1]), best, n / 1e6 / best))
+print("%s: histogram kernels %.3f ms (%.0f GB/s)%s" % (os.path.basename(sys.argv[1]), best, n / 1e6 / best, "  rounds=" + os.environ["FQH_LONG_ROUNDS"] if os.environ.get("FQH_LONG_ROUNDS") else ""))

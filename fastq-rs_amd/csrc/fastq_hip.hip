@@ -1232,7 +1232,9 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         // and alphabet flag (behind the partial histograms in the scratch)
         const uint32_t max_line = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ctx->last_summary.max_record_len / 2, len + ctx->carry_in.back[3]), 0xFFFFFFFFu);
         const bool passes = std::min(max_line ? max_line : lmax, lmax) > 256;
-        const size_t hist_bytes = stats_oct_scratch_bytes(lmax, ctx->n_cu);
+        const bool long_route = passes && max_line > 2 * 256;   // (k_stats_long: its blocks' rows take the place of k_stats_oct's partial histograms)
+        const size_t hist_bytes = long_route ? std::max(stats_oct_scratch_bytes(lmax, ctx->n_cu), stats_long_part_bytes(n - skip, max_line, ctx->n_cu))
+                                             : stats_oct_scratch_bytes(lmax, ctx->n_cu);
         const uint64_t flag_words = passes ? (n - skip + 31) / 32 + 1 : 0;
         const size_t need = hist_bytes + ((size_t)flag_words * 2 + 1) * sizeof(uint32_t);
         if (need > ctx->stats_scratch_bytes) {
@@ -1269,7 +1271,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         sa.qual_hist = (unsigned long long *)d_qual_hist;
         sa.base_hist = (unsigned long long *)d_base_hist;
         sa.scalars = (unsigned long long *)d_scalars;
-        if (passes && max_line > 2 * 256) {
+        if (long_route) {
             // kilobase reads: one walk over the record index (k_stats_long), not one pass of k_stats_oct per 256 columns
             // (two passes of k_stats_oct are still the faster way for reads of up to 512 columns: 2340 vs 1660 GB/s at 300 bp)
             if (ctx->idx_cap < n) {
@@ -1284,7 +1286,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
                 if (st != FQH_OK) return st;
             }
             HIPCHK(ctx, launch_stats_long(s, d_buf, len, ctx->carry_in.base_offset, ctx->idx + skip, n - skip, lmax, max_line, sa.flagmap,
-                                          flag_words, sa.qual_hist, sa.base_hist, sa.scalars, ctx->n_cu));
+                                          flag_words, sa.qual_hist, sa.base_hist, sa.scalars, ctx->n_cu, ctx->stats_scratch));
         } else {
             HIPCHK(ctx, launch_stats_oct(s, sa, ctx->n_cu));
         }

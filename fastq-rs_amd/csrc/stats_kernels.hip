@@ -475,6 +475,7 @@ struct LongArgs {
     uint64_t n;
     uint32_t lmax, n_cb, n_slices;
     uint32_t per_xcd;              // blocks per XCD: block (xcd, j) is work item xcd * per_xcd + j of the n_cb * n_slices
+    uint32_t *part;                // [n_cb * n_slices][SO_LWORDS]: every block's rows as it leaves them (k_stats_long_reduce adds them up)
     uint32_t *flagmap;             // 2 x flag_words words, zeroed: [has N or worse | has a byte outside ACGTN]
     uint64_t flag_words;
     unsigned long long *qual_hist, *base_hist, *scalars;
@@ -656,20 +657,14 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         if (r0 + STEP < r_hi) round(B, A);
         else break;
     }
-    // ---- the block's rows -> the caller's arrays (u64), totals
+    // ---- the block's rows -> scratch, as they are (the S slices of a column block adding ~26 000 counters each to the caller's
+    // arrays with 64-bit atomics took 0.15 of the kernel's 1.37 ms per 4 GiB; plain stores + k_stats_long_reduce: 0.02), totals
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    for (uint32_t id = threadIdx.x; id < SO_LWORDS; id += SO_THREADS) {
-        const uint32_t v = hist[id];
-        if (!v) continue;
-        const bool isq = id >= SO_SBYTES / 4;
-        const uint32_t q = isq ? id - SO_SBYTES / 4 : id;
-        const uint32_t rb = isq ? q >> (6 + SO_LQBITS) : q >> 9;
-        const uint32_t bin = isq ? (q >> 6) & ((1u << SO_LQBITS) - 1u) : (q >> 6) & 7u;
-        const uint32_t row = rb * 64 + so_row6(q & 63u);
-        if (row >= lc) continue;
-        if (isq) atomicAdd(&a.qual_hist[(uint64_t)(col0 + row) * 256 + 33 + bin], (unsigned long long)v);
-        else atomicAdd(&a.base_hist[(uint64_t)(col0 + row) * 8 + bin_to_class(bin)], (unsigned long long)v);
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(a.part + (uint64_t)item * SO_LWORDS);
+        const uint4 *src = reinterpret_cast<const uint4 *>(hist);
+        for (uint32_t i = threadIdx.x; i < SO_LWORDS / 4; i += SO_THREADS) dst[i] = src[i];
     }
     unsigned long long t[7] = {recs, bases, quals, over_s, over_q, newn, newi};
 #pragma unroll
@@ -689,10 +684,65 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         if (t[4]) atomicAdd(&a.scalars[6], t[4]);
     }
 }
-// records [0, n) of idx; max_line: no sequence / quality line is longer (bounds the column blocks); flagmap: 2 * flag_words zeroed words
+// the rows of every slice of a column block, summed and added to the caller's arrays (one thread per counter: no atomics)
+__global__ __launch_bounds__(256) void k_stats_long_reduce(const uint32_t *__restrict__ part, uint32_t n_cb, uint32_t n_slices, uint32_t lmax,
+                                                           unsigned long long *__restrict__ qual_hist, unsigned long long *__restrict__ base_hist) {
+    const uint32_t id = blockIdx.x * 256 + threadIdx.x, cb = blockIdx.y;
+    if (id >= SO_LWORDS) return;
+    unsigned long long v = 0;
+    for (uint32_t sl = 0; sl < n_slices; ++sl) v += part[((uint64_t)sl * n_cb + cb) * SO_LWORDS + id];
+    if (!v) return;
+    const uint32_t col0 = cb * SO_LC_MAX;
+    const uint32_t lc = lmax > col0 ? (lmax - col0 < SO_LC_MAX ? lmax - col0 : SO_LC_MAX) : 0u;
+    const bool isq = id >= SO_SBYTES / 4;
+    const uint32_t q = isq ? id - SO_SBYTES / 4 : id;
+    const uint32_t rb = isq ? q >> (6 + SO_LQBITS) : q >> 9;
+    const uint32_t bin = isq ? (q >> 6) & ((1u << SO_LQBITS) - 1u) : (q >> 6) & 7u;
+    const uint32_t row = rb * 64 + so_row6(q & 63u);
+    if (row >= lc) return;
+    // (sequence bins 0 and 5 both mean "other": two counters of this launch may belong to one of the caller's)
+    if (isq) qual_hist[(uint64_t)(col0 + row) * 256 + 33 + bin] += v;
+    else atomicAdd(&base_hist[(uint64_t)(col0 + row) * 8 + bin_to_class(bin)], v);
+}
+
+// One block is resident per CU (its histogram fills the LDS), so the launch runs in ROUNDS of `cus` blocks, and a block
+// costs ~0.2 ms beyond its share of the records (zeroing and storing 136 KiB of counters, the drain of its wavefronts):
+// measured per 4 GiB, 1 kbp reads in 256 blocks 1.37 ms, in 1024 blocks 1.97; a round that is not full wastes CUs for a
+// whole block time.  So: R rounds of as many slices as fill them, R = the cheapest of 1 .. 4 under
+// time ~ R * (cus / blocks + 0.23)  (units: the records' work spread evenly over the CUs).
+static void stats_long_plan(uint64_t n, uint32_t max_line, int n_cu, uint32_t *n_cb, uint32_t *n_slices) {
+    *n_cb = (max_line + SO_LC_MAX - 1) / SO_LC_MAX;
+    if (*n_cb == 0) *n_cb = 1;
+    const uint32_t cus = stats_blocks(n_cu);
+    const uint64_t max_slices = std::max<uint64_t>(1, (n + 8 * SO_WAVES - 1) / (8 * SO_WAVES));
+    uint32_t rounds_lo = 1, rounds_hi = 4;
+#ifdef FQH_TUNING
+    if (getenv("FQH_LONG_ROUNDS") && atoi(getenv("FQH_LONG_ROUNDS")) > 0) rounds_lo = rounds_hi = (uint32_t)atoi(getenv("FQH_LONG_ROUNDS"));
+#endif
+    double best = 1e30;
+    *n_slices = 1;
+    for (uint32_t R = rounds_lo; R <= rounds_hi; ++R) {
+        uint64_t S = std::max<uint64_t>(1, (uint64_t)R * cus / *n_cb);
+        if (S > max_slices) S = max_slices;
+        const uint64_t blocks = S * *n_cb, r = (blocks + cus - 1) / cus;
+        const double cost = (double)r * ((double)cus / (double)blocks + 0.23);
+        if (cost < best) {
+            best = cost;
+            *n_slices = (uint32_t)S;
+        }
+    }
+}
+// bytes of scratch launch_stats_long wants for its blocks' rows
+size_t stats_long_part_bytes(uint64_t n, uint32_t max_line, int n_cu) {
+    uint32_t n_cb, n_slices;
+    stats_long_plan(n, max_line, n_cu, &n_cb, &n_slices);
+    return (size_t)n_cb * n_slices * SO_LWORDS * sizeof(uint32_t);
+}
+// records [0, n) of idx; max_line: no sequence / quality line is longer (bounds the column blocks); flagmap: 2 * flag_words zeroed words;
+// part: stats_long_part_bytes() of scratch
 hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, uint64_t base_offset, const fqh_idx_record *idx, uint64_t n,
                              uint32_t lmax, uint32_t max_line, uint32_t *flagmap, uint64_t flag_words, unsigned long long *qual_hist,
-                             unsigned long long *base_hist, unsigned long long *scalars, int n_cu) {
+                             unsigned long long *base_hist, unsigned long long *scalars, int n_cu, uint32_t *part) {
     if (!n) return hipSuccess;
     LongArgs a = {};
     a.buf = buf;
@@ -701,31 +751,8 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
     a.idx = idx;
     a.n = n;
     a.lmax = lmax;
-    a.n_cb = (max_line + SO_LC_MAX - 1) / SO_LC_MAX;
-    if (a.n_cb == 0) a.n_cb = 1;
-    // One block is resident per CU (its histogram fills the LDS), so the launch runs in ROUNDS of `cus` blocks, and a block
-    // costs ~0.2 ms beyond its share of the records (zeroing and flushing 136 KiB of counters, the drain of its wavefronts):
-    // measured per 4 GiB, 1 kbp reads in 256 blocks 1.37 ms, in 1024 blocks 1.97; a round that is not full wastes CUs for a
-    // whole block time.  So: R rounds of as many slices as fill them, R = the cheapest of 1 .. 4 under
-    // time ~ R * (cus / blocks + 0.23)  (units: the records' work spread evenly over the CUs).
-    const uint32_t cus = stats_blocks(n_cu);
-    const uint64_t max_slices = std::max<uint64_t>(1, (n + 8 * SO_WAVES - 1) / (8 * SO_WAVES));
-    uint32_t rounds_lo = 1, rounds_hi = 4;
-#ifdef FQH_TUNING
-    if (getenv("FQH_LONG_ROUNDS") && atoi(getenv("FQH_LONG_ROUNDS")) > 0) rounds_lo = rounds_hi = (uint32_t)atoi(getenv("FQH_LONG_ROUNDS"));
-#endif
-    double best = 1e30;
-    a.n_slices = 1;
-    for (uint32_t R = rounds_lo; R <= rounds_hi; ++R) {
-        uint64_t S = std::max<uint64_t>(1, (uint64_t)R * cus / a.n_cb);
-        if (S > max_slices) S = max_slices;
-        const uint64_t blocks = S * a.n_cb, r = (blocks + cus - 1) / cus;
-        const double cost = (double)r * ((double)cus / (double)blocks + 0.23);
-        if (cost < best) {
-            best = cost;
-            a.n_slices = (uint32_t)S;
-        }
-    }
+    stats_long_plan(n, max_line, n_cu, &a.n_cb, &a.n_slices);
+    a.part = part;
     a.per_xcd = (a.n_cb * a.n_slices + 7u) / 8u;
     a.flagmap = flagmap;
     a.flag_words = flag_words;
@@ -740,6 +767,8 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
         set = true;
     }
     hipLaunchKernelGGL(k_stats_long, dim3(8u * a.per_xcd), dim3(SO_THREADS), lds, s, a);
+    hipLaunchKernelGGL(k_stats_long_reduce, dim3((SO_LWORDS + 255) / 256, a.n_cb), dim3(256), 0, s, part, a.n_cb, a.n_slices, lmax, qual_hist,
+                       base_hist);
     return hipGetLastError();
 }
 

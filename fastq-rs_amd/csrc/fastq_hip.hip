@@ -1232,7 +1232,12 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         // and alphabet flag (behind the partial histograms in the scratch)
         const uint32_t max_line = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ctx->last_summary.max_record_len / 2, len + ctx->carry_in.back[3]), 0xFFFFFFFFu);
         const bool passes = std::min(max_line ? max_line : lmax, lmax) > 256;
-        const bool long_route = passes && max_line > 2 * 256;   // (k_stats_long: its blocks' rows take the place of k_stats_oct's partial histograms)
+        // Reads beyond the 256 rows: one walk over the record index (k_stats_long; its blocks' rows take the place of k_stats_oct's
+        // partial histograms in the scratch).  Round 3 kept two passes of k_stats_oct for reads of up to 512 columns (2340 against
+        // 1660 GB/s at 300 bp); since k_stats_long runs in one round of blocks the two are level at 300 bp (1.91 / 1.97 ms per
+        // 4 GiB), k_stats_long is ahead from there (500 bp: 1.98 / 1.34) and it alone keeps 128 quality bins in LDS: with
+        // qualities beyond '`' the passes of k_stats_oct count byte by byte in device memory (300 bp, 80 % '~': 146 ms).
+        const bool long_route = passes;
         const size_t hist_bytes = long_route ? std::max(stats_oct_scratch_bytes(lmax, ctx->n_cu), stats_long_part_bytes(n - skip, max_line, ctx->n_cu))
                                              : stats_oct_scratch_bytes(lmax, ctx->n_cu);
         const uint64_t flag_words = passes ? (n - skip + 31) / 32 + 1 : 0;
@@ -1272,8 +1277,6 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         sa.base_hist = (unsigned long long *)d_base_hist;
         sa.scalars = (unsigned long long *)d_scalars;
         if (long_route) {
-            // kilobase reads: one walk over the record index (k_stats_long), not one pass of k_stats_oct per 256 columns
-            // (two passes of k_stats_oct are still the faster way for reads of up to 512 columns: 2340 vs 1660 GB/s at 300 bp)
             if (ctx->idx_cap < n) {
                 (void)hipFree(ctx->idx);
                 ctx->idx = nullptr;

@@ -14,6 +14,8 @@ rng = np.random.default_rng(7)
 nrec = 1024
 seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (nrec, read_len))
 qual = np.where(rng.random((nrec, read_len)) < 0.8, 126, rng.integers(33, 127, (nrec, read_len))).astype(np.uint8)
+if os.environ.get("QUAL_ILLUMINA") == "1":   # '#'..'I' only: inside every kernel's window
+    qual = rng.integers(35, 74, (nrec, read_len)).astype(np.uint8)
 # READ_LEN_VAR=1: lengths uniform in [READ_LEN / 4, READ_LEN] (the column blocks do not hold equal shares of the bytes any more)
 lens = rng.integers(read_len // 4, read_len + 1, nrec) if os.environ.get("READ_LEN_VAR") == "1" else np.full(nrec, read_len)
 block = b"".join(b"@m%06d/ccs\n" % i + seq[i, :lens[i]].tobytes() + b"\n+\n" + qual[i, :lens[i]].tobytes() + b"\n" for i in range(nrec))

@@ -1191,10 +1191,10 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         // taking the fast path and indexing a second time
         const bool spec = ctx->spec_enabled;
         ctx->spec_enabled = false;
-        if (lmax > 2 * 256) {
-            // rows beyond two passes of k_stats_oct: the caller expects kilobase reads, which k_stats_long counts over the record
-            // index — the scan's emit step writes it on the way (one entry per 512 bytes of input fits; denser input, or reads
-            // that turn out short, take the separate emit below as before)
+        if (lmax > 256) {
+            // rows beyond the single pass: the caller expects reads of more than 256 columns, which k_stats_long counts over the
+            // record index — the scan's emit step writes it on the way (one entry per 512 bytes of input fits; denser input, or
+            // reads that turn out short, take the separate emit below as before)
             const uint64_t cap = len / 512 + 16;
             if (ctx->idx_cap < cap) {
                 (void)hipFree(ctx->idx);
@@ -1277,14 +1277,17 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         sa.base_hist = (unsigned long long *)d_base_hist;
         sa.scalars = (unsigned long long *)d_scalars;
         if (long_route) {
-            if (ctx->idx_cap < n) {
-                (void)hipFree(ctx->idx);
-                ctx->idx = nullptr;
-                ctx->idx_cap = 0;
-                HIPCHK(ctx, hipMalloc((void **)&ctx->idx, n * sizeof(fqh_idx_record)));
-                ctx->idx_cap = n;
-            }
-            if (!(ctx->idx_emitted && ctx->used_spec == false && n <= ctx->idx_cap && ctx->args.idx == ctx->idx)) {
+            // did the scan's own emit step write the whole index?  (Decided BEFORE the array may be replaced: a free followed
+            // by an allocation hands the same address out again, with the old entries in it and nothing behind them.)
+            const bool have_idx = ctx->idx_emitted && ctx->used_spec == false && ctx->args.idx == ctx->idx && n <= ctx->args.idx_cap;
+            if (!have_idx) {
+                if (ctx->idx_cap < n) {
+                    (void)hipFree(ctx->idx);
+                    ctx->idx = nullptr;
+                    ctx->idx_cap = 0;
+                    HIPCHK(ctx, hipMalloc((void **)&ctx->idx, n * sizeof(fqh_idx_record)));
+                    ctx->idx_cap = n;
+                }
                 st = emit_index(ctx, ctx->idx, n);
                 if (st != FQH_OK) return st;
             }

@@ -984,3 +984,17 @@ def test_own_stream_is_ordered_against_the_null_stream(torch, pkg):
             assert np.array_equal(got, np.arange(nrec + 1, dtype=np.uint64) * 330), rep
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("lmax", [300, 600])
+def test_stats_with_many_rows_over_short_reads(fqref, gpu, lmax):
+    """A caller that asks for more than 256 rows gets the record index written by the scan's own emit step, sized for reads of
+    that length (one entry per 512 bytes of input).  Short reads overflow it: the index is emitted again into an array that is
+    large enough — and which a free + allocation may place at the SAME address, old entries and all (the check for "the scan
+    wrote the whole index" used to be made after that replacement: k_stats_long walked whatever lay behind the old entries)."""
+    rng = np.random.default_rng(77)
+    data = fuzzgen.valid_file(rng, 60000, maxlen=100, crlf=False)     # ~ 8 MB: 60 000 records, room for ~ 16 000 entries
+    r, oq, ob, osc = fqref.stats(data, lmax)
+    s, gq, gb, gs = gpu.stats(data, lmax)
+    assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == 60000
+    assert np.array_equal(gs, osc) and np.array_equal(gq, oq) and np.array_equal(gb, ob)

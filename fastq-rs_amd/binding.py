@@ -20,7 +20,7 @@ OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT, OPT_REUSE_INDEX,
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "fqh_create", "fqh_destroy", "fqh_strerror", "fqh_last_error", "fqh_abi_version",
-    "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_last_stats_route", "fqh_placement", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
+    "fqh_set_stream", "fqh_set_bufsize", "fqh_set_option", "fqh_last_scan_fast", "fqh_last_stats_route", "fqh_placement", "fqh_line_buffers", "fqh_scan", "fqh_scan_launch", "fqh_scan_finish",
     "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_len_hist", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
@@ -150,6 +150,7 @@ def lib():
         L.fqh_last_stats_route.argtypes = [vp]
         L.fqh_set_option.argtypes = [vp, i32, i32]
         L.fqh_placement.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float * 10)]
+        L.fqh_line_buffers.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64)]
         L.fqh_stream_create.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
         L.fqh_stream_destroy.argtypes = [vp]
         L.fqh_stream_destroy.restype = None
@@ -408,6 +409,12 @@ class Ctx:
         self._chk(self._L.fqh_placement(self._h, C.byref(n), C.byref(ms)))
         return {"engaged": n.value > 0, "candidates": n.value, "candidate_ms": [round(float(ms[i]), 4) for i in range(n.value)],
                 "no_store_ms": round(float(ms[9]), 4), "best_ms": round(float(ms[8]), 4)}
+
+    def line_buffers(self):
+        """What FQH_OPT_ADAPT_LINES holds -> dict(alive, unsettled, bytes)."""
+        n, u, b = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+        self._chk(self._L.fqh_line_buffers(self._h, C.byref(n), C.byref(u), C.byref(b)))
+        return {"alive": n.value, "unsettled": u.value, "bytes": b.value}
 
     def timing(self):
         t = Timing()

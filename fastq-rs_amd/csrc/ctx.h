@@ -28,7 +28,8 @@ size_t scan_stats_scratch_bytes(int n_cu);
 hipError_t launch_scan_stats(hipStream_t, FusedArgs, int);
 void launch_stats_commit(hipStream_t, const DevOut *, const FusedArgs &, uint32_t, unsigned long long *, unsigned long long *,
                          unsigned long long *);
-hipError_t launch_stats_declined(hipStream_t, const DevOut *, const FusedArgs &, unsigned long long *, unsigned long long *, unsigned long long *);
+hipError_t prepare_stats_declined(uint32_t lmax);
+void launch_stats_declined(hipStream_t, const DevOut *, const FusedArgs &, unsigned long long *, unsigned long long *, unsigned long long *);
 uint32_t scan_stats_nsl(uint32_t lmax);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_stats_edge(hipStream_t, const DevOut *, const uint8_t *, uint64_t, uint64_t, int, uint32_t, unsigned long long *,

@@ -24,6 +24,26 @@ static fqh_status fail(fqh_ctx *ctx, fqh_status s, const char *msg) {
     return s;
 }
 
+// Every line buffer of the fast path the context holds — the one in use (fast_rs), the adaptive choice's two (fr[]) and the
+// alternates held back until an input is settled (fr_rejects[]) — freed once each: the same allocation may sit in several of them.
+static void free_line_buffers(fqh_ctx *ctx) {
+    uint16_t *all[3 + 8];
+    int n = 0;
+    auto add = [&](uint16_t *p) {
+        for (int i = 0; i < n; ++i)
+            if (all[i] == p) return;
+        if (p) all[n++] = p;
+    };
+    add(ctx->fast_rs);
+    add(ctx->fr[0]);
+    add(ctx->fr[1]);
+    for (int i = 0; i < ctx->n_rejects; ++i) add(ctx->fr_rejects[i]);
+    for (int i = 0; i < n; ++i) (void)hipFree(all[i]);
+    ctx->fast_rs = ctx->fr[0] = ctx->fr[1] = nullptr;
+    ctx->n_rejects = 0;
+    for (auto &e : ctx->adapt) e = fqh_ctx::LinesAdapt{};
+}
+
 extern "C" {
 
 int fqh_abi_version(void) { return FQH_ABI_VERSION; }
@@ -104,11 +124,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     (void)hipFree(ctx->list);
     (void)hipFree(ctx->tile_count);
     (void)hipFree(ctx->tile_prefix);
-    if (ctx->fr[1] && ctx->fr[1] != ctx->fast_rs) (void)hipFree(ctx->fr[1]);
-    if (ctx->fr[0] && ctx->fr[0] != ctx->fast_rs) (void)hipFree(ctx->fr[0]);
-    for (int i = 0; i < ctx->n_rejects; ++i)
-        if (ctx->fr_rejects[i] != ctx->fast_rs) (void)hipFree(ctx->fr_rejects[i]);
-    (void)hipFree(ctx->fast_rs);
+    free_line_buffers(ctx);
     (void)hipFree(ctx->block_prefix);
     (void)hipFree(ctx->d_out);
     (void)hipFree(ctx->d_misc);
@@ -272,14 +288,7 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_lis
     if (n_tiles > ctx->tiles_cap) {
         (void)hipFree(ctx->tile_count);
         (void)hipFree(ctx->tile_prefix);
-        if (ctx->fr[1] && ctx->fr[1] != ctx->fast_rs) (void)hipFree(ctx->fr[1]);
-        if (ctx->fr[0] && ctx->fr[0] != ctx->fast_rs) (void)hipFree(ctx->fr[0]);
-        for (int i = 0; i < ctx->n_rejects; ++i)
-            if (ctx->fr_rejects[i] != ctx->fast_rs) (void)hipFree(ctx->fr_rejects[i]);
-        ctx->n_rejects = 0;
-        ctx->fr[0] = ctx->fr[1] = nullptr;
-        for (auto &e : ctx->adapt) e = fqh_ctx::LinesAdapt{};
-        (void)hipFree(ctx->fast_rs);
+        free_line_buffers(ctx);
         (void)hipFree(ctx->block_prefix);
         ctx->tile_count = ctx->tile_prefix = nullptr;
         ctx->fast_rs = nullptr;
@@ -307,29 +316,31 @@ static void enqueue_fused_commit(fqh_ctx *ctx) {
     hipStream_t s = ctx->stream;
     unsigned long long *q = (unsigned long long *)ctx->f_qual, *b = (unsigned long long *)ctx->f_base, *sc = (unsigned long long *)ctx->f_scalars;
     launch_stats_commit(s, &ctx->d_out[0], ctx->f_args, scan_stats_blocks(a.n_tiles, ctx->n_cu), q, b, sc);
-    (void)launch_stats_declined(s, &ctx->d_out[0], ctx->f_args, q, b, sc);  // (batches with a byte outside the alphabets, lines beyond the rows)
+    launch_stats_declined(s, &ctx->d_out[0], ctx->f_args, q, b, sc);  // (batches with a byte outside the alphabets, lines beyond the rows; its set-up ran before the single pass was enqueued)
     const uint64_t back0 = a.back[a.nl_count & 3];
     if (back0 != 0 && ctx->f_lead >= back0) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, back0, +1, ctx->f_lmax, q, b, sc);
     if (!a.is_final) launch_stats_edge(s, &ctx->d_out[0], a.buf, a.len, 0, -1, ctx->f_lmax, q, b, sc);
     ctx->f_commit_owed = false;
 }
 
+// (the buffer in use holds the tile index of the last scan — fqh_index_records, a rescan — and stays on the list until it is not)
 static void adapt_free_rejects(fqh_ctx *ctx) {
-    for (int i = 0; i < ctx->n_rejects; ++i)
-        if (ctx->fr_rejects[i] != ctx->fast_rs) (void)hipFree(ctx->fr_rejects[i]);
-    ctx->n_rejects = 0;
+    int keep = 0;
+    for (int i = 0; i < ctx->n_rejects; ++i) {
+        if (ctx->fr_rejects[i] == ctx->fast_rs) ctx->fr_rejects[keep++] = ctx->fr_rejects[i];
+        else (void)hipFree(ctx->fr_rejects[i]);
+    }
+    ctx->n_rejects = keep;
 }
 // Which line buffer does this scan store to?  (ctx.h: LinesAdapt.)  Called for fresh fast-path scans of 2 GiB or more.
 static void adapt_choose(fqh_ctx *ctx, bool fused) {
     const ScanArgs &a = ctx->args;
     ctx->adapt_entry = -1;
-    if (ctx->fast_rs != ctx->fr[0] && ctx->fast_rs != ctx->fr[1]) {  // a new workspace (or the placement search's pick): start over
-        if (ctx->fr[1]) (void)hipFree(ctx->fr[1]);
-        adapt_free_rejects(ctx);
-        ctx->fr[0] = ctx->fast_rs;
-        ctx->fr[1] = nullptr;
-        for (auto &e : ctx->adapt) e = fqh_ctx::LinesAdapt{};
-    }
+    // A new workspace (ensure_workspace has dropped every line buffer of the old one; fast_rs is the new allocation or the
+    // placement search's pick): it is the primary.  NOT "fast_rs is neither of fr[]": after an alternate was given back, fast_rs
+    // is that alternate — on the held-back list, fr[1] empty — and taking it for a new workspace lost fr[0] for good, one line
+    // buffer of len / 64 bytes every four calls.
+    if (!ctx->fr[0]) ctx->fr[0] = ctx->fast_rs;
     if (ctx->adapt_max <= 0 || a.len < (2ull << 30)) {
         ctx->fast_rs = ctx->fr[0];
         return;
@@ -481,6 +492,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.decl_l = ctx->decl_l;
         fz.decl_cap = ctx->decl_cap;
         ctx->f_args = fz;
+        HIPCHK(ctx, prepare_stats_declined(fz.lmax));  // (may fail; nothing of this call is enqueued yet that could commit without it)
         if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fz, ctx->n_cu));
 #ifdef FQH_TUNING
         if (getenv("FQH_FZ_WHY")) {
@@ -1044,6 +1056,26 @@ fqh_status fqh_placement(fqh_ctx *ctx, int *n_candidates, float ms[10]) {
     if (!ctx || !n_candidates || !ms) return FQH_E_ARG;
     *n_candidates = ctx->place_n;
     for (int i = 0; i < 10; ++i) ms[i] = ctx->place_ms[i];
+    return FQH_OK;
+}
+fqh_status fqh_line_buffers(fqh_ctx *ctx, int *n_alive, int *n_unsettled, uint64_t *bytes) {
+    if (!ctx) return FQH_E_ARG;
+    const uint16_t *all[3 + 8];
+    int n = 0;
+    auto add = [&](const uint16_t *p) {
+        for (int i = 0; i < n; ++i)
+            if (all[i] == p) return;
+        if (p) all[n++] = p;
+    };
+    add(ctx->fast_rs);
+    add(ctx->fr[0]);
+    add(ctx->fr[1]);
+    for (int i = 0; i < ctx->n_rejects; ++i) add(ctx->fr_rejects[i]);
+    int open_inputs = 0;
+    for (const auto &e : ctx->adapt) open_inputs += e.buf && e.state != 3 ? 1 : 0;
+    if (n_alive) *n_alive = n;
+    if (n_unsettled) *n_unsettled = ctx->adapt_max > 0 ? open_inputs : 0;
+    if (bytes) *bytes = (uint64_t)n * (2 * ctx->tiles_cap + 128) * 64 * sizeof(uint16_t);
     return FQH_OK;
 }
 fqh_status fqh_invalidate(fqh_ctx *ctx) {

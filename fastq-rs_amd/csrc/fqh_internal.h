@@ -10,6 +10,7 @@
 //   rec_start    u64 [n_records + 1]              caller-owned output
 //   index        fqh_idx_record [n_records]       optional (stats / RecordSet hand-back)
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/fastq_hip.h"
@@ -147,6 +148,22 @@ struct FusedArgs {
     uint32_t decl_cap;
     uint32_t wave_base;   // set by the launcher: bytes of histogram in front of the wavefronts' LDS areas
     uint32_t dbg;         // knock-out flags for timing experiments (FQH_FZ_DBG; results are wrong by design)
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel: set per DEVICE (a process may hold contexts on several), raised
+// when a launch asks for more than the device's function was last given, and an error is the caller's to report.
+struct LdsAttr {
+    size_t set[64] = {};
+    hipError_t ensure(const void *fn, size_t lds) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (lds <= set[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) set[dev] = lds;
+        return e;
+    }
 };
 
 void launch_len_hist(hipStream_t s, const unsigned long long *base_hist, const unsigned long long *scalars, uint32_t lmax,

@@ -980,25 +980,23 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
         }
     }
 }
-hipError_t launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
-                                 unsigned long long *base_hist, unsigned long long *scalars) {
-    if (!z.decl_cap) return hipSuccess;
+static size_t stats_declined_lds(uint32_t lmax) { return (size_t)(lmax < SO_LC_MAX ? lmax : SO_LC_MAX) * DECL_BINS * 2; }
+// The one thing about k_stats_declined that can fail, done BEFORE the single pass is enqueued: an error behind k_stats_commit
+// would leave the dumped batches and listed lines uncounted in a result that says it is complete.
+hipError_t prepare_stats_declined(uint32_t lmax) {
+    static LdsAttr attr;
+    return attr.ensure(reinterpret_cast<const void *>(k_stats_declined), stats_declined_lds(lmax));
+}
+void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
+                           unsigned long long *base_hist, unsigned long long *scalars) {
+    if (!z.decl_cap) return;
     const uint32_t lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;   // (the rows the caller's arrays and the single pass share)
     const uint32_t nsl = (lc + 31) / 32 <= 5 ? 5u : 8u;
-    const size_t lds = (size_t)lc * DECL_BINS * 2;
     // a block's 16-bit counters hold the lines of its share of the slots: 8 lines per dumped batch, 1 per listed line
     const uint64_t per_block = DECL_LINES_PER_BLOCK / 9;
     const uint32_t blocks = (uint32_t)std::max<uint64_t>(512, ((uint64_t)z.decl_cap + per_block - 1) / per_block);
-    static bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_declined), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(SO_LC_MAX * DECL_BINS * 2));
-        if (e != hipSuccess) return e;
-        set = true;
-    }
-    hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(1024), lds, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap, z.buf, z.lmax, lc,
-                       qual_hist, base_hist, scalars);
-    return hipSuccess;
+    hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(1024), stats_declined_lds(z.lmax), s, out, z.decl_b, nsl, z.decl_l, z.decl_cap,
+                       z.buf, z.lmax, lc, qual_hist, base_hist, scalars);
 }
 uint32_t scan_stats_nsl(uint32_t lmax) {
     const uint32_t lc = lmax < SO_LC_MAX ? lmax : SO_LC_MAX;
@@ -1025,13 +1023,8 @@ static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t block
     // row-block offset): inside the allocation, and harmless wherever it lands (stats_dev.h)
     static_assert(65536 + SO_SBYTES + 128 + ((NSL - 1) / 2) * 16384u <= SO_SBYTES + ((NSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES,
                   "garbage addresses must stay inside the allocation");
-    static bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_stats<NSL, FZ_WAVES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        set = true;
-    }
+    static LdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(k_scan_stats<NSL, FZ_WAVES>), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_scan_stats<NSL, FZ_WAVES>), dim3(blocks), dim3(FZ_WAVES * 64), lds, s, z);
     return hipSuccess;
 }

@@ -403,13 +403,8 @@ static hipError_t launch_stats_oct_n(hipStream_t s, const StatsArgs &a, uint32_t
     // (< 64 KiB) plus the largest row-block offset.  The allocation covers all of them.
     if (lds < SO_ADDR_SPAN) lds = SO_ADDR_SPAN;
     if (lds > SO_LDS_MAX) return hipErrorInvalidValue;
-    static size_t set = 0;
-    if (lds > set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_oct<NSL, DBG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        set = lds;
-    }
+    static LdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(k_stats_oct<NSL, DBG>), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_stats_oct<NSL, DBG>), dim3(blocks), dim3(SO_THREADS), lds, s, a);
     return hipSuccess;
 }
@@ -760,12 +755,8 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
     a.base_hist = base_hist;
     a.scalars = scalars;
     const size_t lds = SO_LADDR_SPAN;  // (a lane without a whole dword subtracts 0 wherever its bytes point: all of that is allocated)
-    static bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        set = true;
-    }
+    static LdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(k_stats_long), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stats_long, dim3(8u * a.per_xcd), dim3(SO_THREADS), lds, s, a);
     hipLaunchKernelGGL(k_stats_long_reduce, dim3((SO_LWORDS + 255) / 256, a.n_cb), dim3(256), 0, s, part, a.n_cb, a.n_slices, lmax, qual_hist,
                        base_hist);

@@ -77,6 +77,7 @@ extern "C" {
     pub fn fqh_last_scan_fast(ctx: *mut fqh_ctx) -> c_int;
     pub fn fqh_last_stats_route(ctx: *mut fqh_ctx) -> c_int;
     pub fn fqh_placement(ctx: *mut fqh_ctx, n_candidates: *mut c_int, ms: *mut f32) -> c_int;   // ms: [f32; 10]
+    pub fn fqh_line_buffers(ctx: *mut fqh_ctx, n_alive: *mut c_int, n_unsettled: *mut c_int, bytes: *mut u64) -> c_int;
 
     // ---- whole buffers in HBM: IdxRecord::from_buffer over every record (src/records.rs:201-247)
     pub fn fqh_scan(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, is_final: c_int, carry_in: *const fqh_carry,

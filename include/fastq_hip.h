@@ -30,6 +30,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libfastq_hip.so is built with -fvisibility=hidden; the functions declared between here and the matching pop are its whole
+ * dynamic symbol table (tests/test_abi.py holds `nm -D` against this header).  A host includes the header without the macro. */
+#ifdef FQH_BUILDING_LIBRARY
+#pragma GCC visibility push(default)
+#endif
 
 #define FQH_ABI_VERSION 1
 #define FQH_BUFSIZE (68u * 1024u) /* BUFSIZE, src/lib.rs:128-129 */
@@ -156,6 +161,12 @@ int fqh_last_stats_route(fqh_ctx *ctx);
  * ran), ms[0 .. n-1] the index kernel's time on the sample with each, ms[8] the kept one's, ms[9] the same kernel without
  * its line stores (the yardstick).  For benchmarks: says whether the search engaged and what it bought. */
 fqh_status fqh_placement(fqh_ctx *ctx, int *n_candidates, float ms[10]);
+/* What FQH_OPT_ADAPT_LINES holds right now: *n_alive line buffers (the one in use, the alternate, alternates held back until the
+ * input they were tried for is settled — never more than 2 + the option's value), *bytes of device memory in all of them, and
+ * *n_unsettled remembered inputs that have not been through their measurements yet (0: every later call on those inputs stores
+ * to its chosen buffer and allocates nothing).  A benchmark warms up until n_unsettled is 0; a test holds n_alive and the
+ * device's free memory against repeated calls. */
+fqh_status fqh_line_buffers(fqh_ctx *ctx, int *n_alive, int *n_unsettled, uint64_t *bytes);
 
 /* Record scan.  d_buf[0..len) are device-resident bytes; `in` (NULL = start of file) describes
  * where in the file they sit.  Writes d_rec_start[0..n_records]: [0] = file offset of the record in
@@ -480,6 +491,9 @@ fqh_status fqh_memcpy_h2d(fqh_ctx *ctx, void *d_dst, const void *h_src, uint64_t
 fqh_status fqh_memcpy_d2h(fqh_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 fqh_status fqh_memset(fqh_ctx *ctx, void *d_dst, int value, uint64_t bytes);
 
+#ifdef FQH_BUILDING_LIBRARY
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -23,11 +23,13 @@ def fqref():
 
 @pytest.fixture(scope="session", autouse=True)
 def poisoned_device_memory():
-    """FQH_TEST_POISON=<byte>: before the first test, fill most of the free device memory with that byte and give it back to
-    the driver — whatever the library allocates afterwards (workspaces, line buffers, lists) starts out as garbage instead of
-    the zeros a fresh box hands out.  A result that depends on memory nobody wrote shows up as a failure here."""
-    v = os.environ.get("FQH_TEST_POISON")
-    if v:
+    """Before the first test, fill most of the free device memory with a byte (0xA5; FQH_TEST_POISON=<byte> picks another,
+    FQH_TEST_POISON=off skips it) and give it back to the driver — whatever the library allocates afterwards (workspaces, line
+    buffers, lists) starts out as garbage instead of the zeros a fresh box hands out.  A result that depends on memory nobody
+    wrote shows up as a failure here; on by default since round 5, so the driver's own `pytest -m gpu` starts from garbage too
+    (round 4's stream race was invisible on zero-filled memory)."""
+    v = os.environ.get("FQH_TEST_POISON", "0xA5")
+    if v.lower() not in ("off", "no", "none", ""):
         import torch
         if torch.cuda.is_available():
             free, _ = torch.cuda.mem_get_info()

@@ -958,6 +958,51 @@ def test_adaptive_line_buffer_is_invisible(fqref, torch, pkg):
     ctx.close()
 
 
+def test_adaptive_line_buffer_settles_and_holds_its_memory(torch, pkg):
+    """an alternate that measured like the first buffer was given back, the NEXT call took the given-back buffer
+    for "a new workspace", lost the first buffer for good and started over — one line buffer of len / 64 bytes leaked every four
+    calls, and the input never settled.  Twenty repeated scans of one big input: the context never holds more than 2 + 3 line
+    buffers, it settles (fqh_line_buffers: no unsettled input) within the eight calls bench.py warms up with, from then on it
+    holds at most two and the device's free memory does not move; fqh_destroy gives everything back."""
+    dev = torch.device("cuda:0")
+    n = (2 << 30) // 330 * 330 + 330 * 11
+    nrec = n // 330
+    d = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    rs = torch.zeros(nrec + 16, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    ctx = pkg.Ctx(0)
+    ctx.synth_fill(d.data_ptr(), 0, n)
+    per_buffer = None
+    free_settled = None
+    for call in range(20):
+        s = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())[0]
+        assert (s.parse_status, s.n_records) == (pkg.OK, nrec) and ctx.last_scan_fast(), call
+        lb = ctx.line_buffers()
+        per_buffer = per_buffer or lb["bytes"] // lb["alive"]
+        assert 1 <= lb["alive"] <= 2 + 3 and lb["bytes"] == lb["alive"] * per_buffer, (call, lb)
+        if call >= 8:
+            assert lb["unsettled"] == 0 and lb["alive"] <= 2, (call, lb)
+            free_now = torch.cuda.mem_get_info()[0]
+            free_settled = free_settled if free_settled is not None else free_now
+            assert free_now == free_settled, (call, free_now, free_settled)
+    # a second big input of the same context goes through the same measurements and settles as well
+    d2 = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    ctx.synth_fill(d2.data_ptr(), 0, n)
+    for call in range(10):
+        ctx.scan(d2.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())
+        assert ctx.line_buffers()["alive"] <= 2 + 3
+    lb = ctx.line_buffers()
+    assert lb["unsettled"] == 0 and lb["alive"] <= 2, lb
+    ctx.set_adapt_lines(0)
+    assert ctx.line_buffers()["unsettled"] == 0
+    ctx.close()
+    del d2
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] >= free_before - (64 << 20), (torch.cuda.mem_get_info()[0], free_before)
+
+
 def test_own_stream_is_ordered_against_the_null_stream(torch, pkg):
     """A caller that never sets a stream works on the legacy null stream (torch's default): the context's own stream must be
     ordered against it.  Here the zero-fill of the offsets array is queued BEHIND a few milliseconds of other null-stream work,

@@ -57,6 +57,14 @@ def main():
     ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
                     help="roofline.traffic from this run's own rocprofv3 --pmc passes (two short child runs, FETCH_SIZE and WRITE_SIZE "
                          "apart, calibrated on the plain read kernel) when rocprofv3 is on the box; otherwise from the committed profile")
+    ap.add_argument("--comm", choices=["auto", "abi", "torch"], default="auto",
+                    help="who runs the collectives of the sharded modes: abi = the library's own RCCL binding (fqh_comm_* / fqh_allgather / "
+                         "fqh_allreduce_u64 / fqh_allreduce_min_u64, csrc/comm.hip: what a Rust or C++ host without torch uses), torch = "
+                         "torch.distributed.  auto: abi when the backend is nccl (or there is one rank), torch under gloo (the one-GPU "
+                         "functional mode: RCCL does not put two ranks on one device)")
+    ap.add_argument("--default-shard-stream-gib", type=float, default=16.0,
+                    help="GiB PER RANK of the configs[4] leg every default run carries (key `sharded_stream`); 128 gives 1 TiB at 8 ranks")
+    ap.add_argument("--no-shard-stream", action="store_true", help="skip the configs[4] leg of the default run")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -104,8 +112,22 @@ def main():
     else:
         rccl = {"ranks": 1, "backend": None, "device_uuids": [my_uuid], "distinct_devices": 1}
 
+    # one real stream for the library's kernels and for the collectives (the device-side exchange is ordered by the
+    # stream alone; torch's default stream is the null stream, which the library would replace by a stream of its own)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    via = args.comm if args.comm != "auto" else ("abi" if (backend == "nccl" or world == 1) else "torch")
+    if via == "abi" and world > 1 and backend != "nccl":
+        raise SystemExit("bench.py: --comm abi needs one GPU per rank (RCCL does not put two ranks on one device); the gloo mode keeps --comm torch")
+
     if args.stream_gib > 0 and world > 1:
-        sharded_stream(args, pkg, torch, dist, dev, rank, world, backend)
+        sctx = pkg.Ctx(dev.index, stream=torch.cuda.current_stream().cuda_stream)
+        coll = Coll(pkg, torch, dist, sctx, dev, world, rank, backend, via)
+        rccl["via"] = coll.via_text
+        j = sharded_stream(args, pkg, torch, dev, sctx, coll, args.stream_gib / world, int(os.environ.get("FQH_BENCH_INJECT", "-1")))
+        if rank == 0:
+            print(json.dumps(dict(j, mode="sharded-stream", n_gpus=world, backend=backend, rccl=rccl)), flush=True)
+        coll.close()
+        sctx.close()
         dist.destroy_process_group()
         return
     if args.stream_gib > 0 and not args.bytes:
@@ -118,10 +140,9 @@ def main():
     hi = min((rank + 1) * shard, file_len)
     nbytes = hi - lo
 
-    # one real stream for the library's kernels and for the collectives (the device-side exchange is ordered by the
-    # stream alone; torch's default stream is the null stream, which the library would replace by a stream of its own)
-    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     ctx = pkg.Ctx(dev.index, stream=torch.cuda.current_stream().cuda_stream)
+    coll = Coll(pkg, torch, dist, ctx, dev, world, rank, backend, via)
+    rccl["via"] = coll.via_text
     if os.environ.get("FQH_BENCH_PLACE_TRIES"):
         ctx.set_place_tries(int(os.environ["FQH_BENCH_PLACE_TRIES"]))
     # the harness blocks on every step anyway: it opts in to polling the stream at the end of a step (FQH_OPT_SPIN_WAIT; the
@@ -174,13 +195,10 @@ def main():
         index_ms.append(ctx.timing().index_ms)
         h_in[0], h_in[1], h_in[2] = nbytes, nn, ns
         h_in[3], h_in[4], h_in[5], h_in[6] = back0
-        if backend == "nccl":
-            gather_in.copy_(h_in, non_blocking=True)
-            dist.all_gather_into_tensor(gather_all, gather_in)
-            h_all.copy_(gather_all, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-        else:
-            dist.all_gather_into_tensor(h_all, h_in)
+        gather_in.copy_(h_in, non_blocking=True)
+        coll.gather_dev(gather_in, gather_all)
+        h_all.copy_(gather_all, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
         rows = h_all.numpy().reshape(world, 7)
         carry = None
         for r in range(rank):
@@ -191,7 +209,7 @@ def main():
         h_counts[0] = s.n_records
         h_counts[1] = 1 if s.parse_status != pkg.OK else 0
         counts.copy_(h_counts, non_blocking=True)
-        dist.all_reduce(counts)
+        coll.sum_dev(counts)
         return s
 
     def step():
@@ -202,15 +220,9 @@ def main():
         if os.environ.get("FQH_BENCH_HOST_PROTOCOL") == "1":
             return step_host()
         ctx.shard_prescan_launch(buf.data_ptr(), nbytes, words.data_ptr())
-        if backend == "nccl":
-            dist.all_gather_into_tensor(all_words, words)   # RCCL, enqueued on the step's stream
-        else:  # gloo (the one-GPU functional mode) gathers host tensors only: two host hops, never a timed configuration
-            hw = words.cpu()
-            ha = torch.empty(world * W, dtype=torch.int64)
-            dist.all_gather_into_tensor(ha, hw)
-            all_words.copy_(ha)
+        coll.gather_dev(words, all_words)    # RCCL (fqh_allgather or torch's), enqueued on the step's stream; gloo: two host hops, never a timed configuration
         ctx.shard_rescan_launch(is_last, all_words.data_ptr(), world, rank, rec_start.data_ptr(), cap, counts.data_ptr())
-        dist.all_reduce(counts)
+        coll.sum_dev(counts)
         try:
             s, c, st = ctx.scan_finish()
         except pkg.FqhError as e:
@@ -229,8 +241,11 @@ def main():
     # runs faster with (calls 1-2 on the first, then one call per alternate tried: DESIGN.md 4b).  A few untimed steps in
     # front of the warm-up let that settle, so that no alternate is allocated or tried inside the timed region.
     settle = 0 if args.pmc_child else int(os.environ.get("FQH_BENCH_SETTLE_STEPS", "8"))
-    for _ in range(settle):
+    for i in range(settle):
         s = step()
+        if world == 1 and i >= 1 and not ctx.line_buffers()["unsettled"]:   # (N > 1: every rank runs the same number of steps)
+            settle = i + 1
+            break
     for _ in range(args.warmup):
         s = step()
     index_ms.clear()
@@ -254,11 +269,7 @@ def main():
         # the first error in file order: MIN over the ranks of (failing record, kind) — what Parser::parallel_each returns
         # (src/lib.rs:544-547, 561-564)
         key = ((int(s.err_record) << 3) | int(s.parse_status)) if s.parse_status != pkg.OK else (1 << 62)
-        kt = torch.tensor([key], dtype=torch.int64, device=dev)
-        if world > 1:
-            kt = kt.to(dev if backend == "nccl" else torch.device("cpu"))
-            dist.all_reduce(kt, op=dist.ReduceOp.MIN)
-        gk = int(kt.item())
+        gk = coll.min_key(key)
         first_error = {"status": gk & 7, "n_records": gk >> 3, "expected": {"status": pkg.E_SEP, "n_records": inject // RECLEN}}
         assert n_err >= 1 and (gk & 7, gk >> 3) == (pkg.E_SEP, inject // RECLEN), first_error
     else:
@@ -476,6 +487,26 @@ def main():
                 d1 = time.perf_counter() - t1
             out["cpu_baseline"]["stats_parallel_gbs"] = round(sample / 1e9 / d1, 3)
             out["cpu_baseline"]["stats_parallel_threads"] = nthr
+    if world == 1 and coll.comm:
+        # the HBM-resident protocol once through the library's own RCCL binding with a communicator of this one rank (untimed):
+        # words -> fqh_allgather -> fold + emit -> fqh_allreduce_u64, one host wait — what every step does at N > 1
+        w1 = torch.zeros(W, dtype=torch.int64, device=dev)
+        ctx.shard_prescan_launch(buf.data_ptr(), nbytes, words.data_ptr())
+        coll.gather_dev(words, w1)
+        ctx.shard_rescan_launch(True, w1.data_ptr(), 1, 0, rec_start.data_ptr(), cap, counts.data_ptr())
+        coll.sum_dev(counts)
+        s1, _, _ = ctx.scan_finish()
+        assert (s1.parse_status, int(s1.n_records)) == (pkg.OK, total_records) and counts.cpu().tolist() == [total_records, 0]
+        out["rccl"]["protocol_check"] = "one HBM-resident sharded step (prescan, fqh_allgather, fold + emit, fqh_allreduce_u64) through a 1-rank fqh_comm: %d records" % total_records
+    if not args.no_shard_stream:
+        # configs[4] in every default line: the sharded, host-streamed leg at this world size next to the same
+        # function at world size 1
+        inj = int(os.environ.get("FQH_BENCH_INJECT_STREAM", "-1"))   # (tests only)
+        if inj >= 0:
+            rec = sharded_stream(args, pkg, torch, dev, ctx, coll, args.default_shard_stream_gib, inj)
+        else:
+            rec = sharded_stream_record(args, pkg, torch, dist, dev, ctx, coll, backend, via, args.default_shard_stream_gib)
+        out["sharded_stream"] = rec
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 and args.shard_stats:
@@ -484,7 +515,7 @@ def main():
         # (world x 136 KiB) and rank r puts rank r-1's in front of its buffer; then one all_reduce of
         # [scalars, quality histogram, base histogram].
         tails = torch.empty(world * LEAD, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(tails, buf[nbytes - LEAD: nbytes].contiguous())
+        coll.gather_dev(buf[nbytes - LEAD: nbytes].contiguous(), tails)
         if rank:
             store[:LEAD].copy_(tails[(rank - 1) * LEAD: rank * LEAD])
         rows = h_all.numpy().reshape(world, 7)
@@ -500,7 +531,7 @@ def main():
         ctx.stats_launch_lead(buf.data_ptr(), nbytes, LEAD if rank else 0, LMAX, qh.data_ptr(), bh.data_ptr(),
                               sc.data_ptr(), is_final=is_last, carry=carry)
         s2, _ = ctx.stats_finish()
-        dist.all_reduce(hist)
+        coll.sum_dev(hist)
         barrier()
         dts = time.perf_counter() - t1
         assert s2.parse_status == pkg.OK
@@ -513,6 +544,7 @@ def main():
                               "seconds_incl_full_index_and_allreduce": round(dts, 4),
                               "check": "sum over ranks: records, bases, quality and base histogram totals match the "
                                        "generator's; every cut-straddling record counted exactly once"}), flush=True)
+    coll.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -742,98 +774,175 @@ def numa_pin(torch, dev_index, mode="auto"):
     return info
 
 
-def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
-    """configs[4]: byte-range sharded AND host-streamed.  The file is the endless repetition of one pinned block (a slot's
-    worth of synthetic records), cut at multiples of a shard size that is NOT a multiple of the record size: every cut
-    falls inside a record.  Each rank streams its range phase-free (fastq-rs_amd/sharded.py), then: one all_gather of ten
-    words per rank, the true-phase check, the record that straddles each cut parsed by the rank it ends in (through that rank's
-    own read callback), one all_reduce SUM of per-rank record slots + histograms and one MIN of the first-error keys."""
+class Coll:
+    """The collectives of the sharded modes.  via "abi": the library's own RCCL binding (fqh_comm_create with an id that rank 0
+    makes and torch's process group only carries to the others; fqh_allgather / fqh_allreduce_u64 / fqh_allreduce_min_u64 on the
+    context's stream, csrc/comm.hip) — what fastq::each_sharded and a Rust host use, the gather of parallel_each's results
+    (src/lib.rs:553-559) and the parse error it returns (src/lib.rs:544-547, 561-564).  via "torch": torch.distributed (the same
+    RCCL under the nccl backend; gloo in the one-GPU functional mode, through host tensors).  The harness's own barrier and
+    max-over-ranks timing stay with torch.distributed either way, as the launch contract prescribes."""
+
+    def __init__(self, pkg, torch, dist, ctx, dev, world, rank, backend, via, local=False):
+        self.pkg, self.torch, self.dist, self.ctx, self.dev = pkg, torch, dist, ctx, dev
+        self.world, self.rank, self.backend, self.comm, self.local = world, rank, backend, None, local
+        self.via_text = "torch.distributed (%s)" % backend if world > 1 else "none (one rank)"
+        if via != "abi":
+            return
+        # rank 0 makes the id; the process group's object broadcast is only the messenger.  A rank that cannot bind RCCL says
+        # so BEFORE anybody enters ncclCommInitRank (the others would wait there): then every rank stays with torch.
+        uid, why = None, None
+        if rank == 0 or local:
+            try:
+                uid = pkg.Comm.unique_id()
+            except pkg.FqhError as e:
+                why = str(e)
+        if world > 1 and not local:
+            box = [uid, why]
+            dist.broadcast_object_list(box, src=0)
+            uid, why = box
+        if uid is None:
+            self.via_text += "; fqh_comm unavailable: %s" % why
+            return
+        self.comm = pkg.Comm(ctx, world, rank, uid)
+        self.via_text = "fqh_comm (libfastq_hip.so's own RCCL binding, %d rank%s)" % (world, "" if world == 1 else "s")
+
+    def close(self):
+        if self.comm:
+            self.comm.close()
+            self.comm = None
+
+    @staticmethod
+    def _nbytes(t):
+        return t.numel() * t.element_size()
+
+    def gather_dev(self, send, recv):
+        """all-gather of a device tensor's bytes, enqueued on the context's (= torch's current) stream."""
+        if self.comm:
+            self.comm.allgather(send.data_ptr(), recv.data_ptr(), self._nbytes(send))
+        elif self.world == 1:
+            recv.view(-1)[: send.numel()].copy_(send.view(-1))
+        elif self.backend == "nccl":
+            self.dist.all_gather_into_tensor(recv, send)
+        else:   # gloo gathers host tensors
+            ha = self.torch.empty(recv.shape, dtype=recv.dtype)
+            self.dist.all_gather_into_tensor(ha, send.cpu())
+            recv.copy_(ha)
+
+    def sum_dev(self, t):
+        """element-wise SUM of u64 counters (int64 tensors: the same bits), in place, enqueued."""
+        if self.comm:
+            self.comm.allreduce_u64(t.data_ptr(), t.numel())
+        elif self.world == 1:
+            pass
+        elif self.backend == "nccl":
+            self.dist.all_reduce(t)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+
+    def min_key(self, key):
+        """MINIMUM over the ranks of one u64 key (the first error in file order)."""
+        torch = self.torch
+        if self.comm:   # ncclMin over ncclUint64: the u64 bit pattern travels in an int64 tensor
+            kt = torch.tensor([key - (1 << 64) if key >= (1 << 63) else key], dtype=torch.int64, device=self.dev)
+            self.comm.allreduce_min_u64(kt.data_ptr(), 1)
+            self.comm.sync()
+            v = int(kt.item())
+            return v + (1 << 64) if v < 0 else v
+        if self.world == 1:
+            return key
+        kt = torch.tensor([key - (1 << 63)], dtype=torch.int64,   # (order-preserving map of the u64 key into torch's i64)
+                          device=self.dev if self.backend == "nccl" else torch.device("cpu"))
+        self.dist.all_reduce(kt, op=self.dist.ReduceOp.MIN)
+        return int(kt.item()) + (1 << 63)
+
+    def gather_words(self, words):
+        """all-gather of a short list of u64 host words -> [world][len(words)] ints (host)."""
+        torch = self.torch
+        n = len(words)
+        t_in = torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in words], dtype=torch.int64, device=self.dev)
+        t_all = torch.empty(self.world * n, dtype=torch.int64, device=self.dev)
+        self.gather_dev(t_in, t_all)
+        if self.comm:
+            self.comm.sync()
+        return [[int(x) & ((1 << 64) - 1) for x in row] for row in t_all.cpu().numpy().reshape(self.world, n)]
+
+    # ---- the harness's own synchronisation (never the product's): torch.distributed, or nothing for a group of one
+    def barrier(self):
+        if self.world > 1 and not self.local:
+            self.dist.barrier()
+        if self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+
+    def objects(self, obj):
+        if self.world == 1 or self.local:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+def sharded_stream(args, pkg, torch, dev, ctx, coll, gib_per_rank, inject=-1, sub_runs=("producer", "pinned_replay")):
+    """configs[4]: byte-range sharded AND host-streamed.  The file is the endless repetition of one block (a slot's worth of
+    synthetic records), cut at multiples of a shard size that is NOT a multiple of the record size: every cut falls inside a
+    record.  Each rank streams its range phase-free (fastq-rs_amd/sharded.py -> fqh_shard_stream_run), then: one all-gather of
+    ten words per rank, the true-phase check, the record that straddles each cut parsed by the rank it ends in (through that
+    rank's own read callback), one SUM of per-rank record slots + histograms and one MIN of the first-error keys.
+    The SAME function runs at every world size (world 1 is the denominator of `ratio_vs_n1`), in two sub-runs:
+      producer       the N = 1 leg's producer model (stream_leg): a PAGEABLE source, --producer-threads threads per rank, every
+                     slot of every pass filled again — host-side work a real reader has;
+      pinned_replay  no producer: a ring slot that already holds the block at this rotation is submitted as it is (after the
+                     first three slots: always) — the link and the kernels alone, labelled as such."""
     import ctypes as C
     import importlib
+    from concurrent.futures import ThreadPoolExecutor
     import numpy as np
     sharded = importlib.import_module("fastq_rs_amd.sharded")
-    numa = numa_pin(torch, dev.index, args.numa_pin)
+    rank, world = coll.rank, coll.world
+    numa = numa_pin(torch, dev.index, args.numa_pin)    # (before the pageable source and the pinned rings are first touched)
     LMAX = 150
     blk = (args.slot_mib << 20) // 2640 * 2640          # multiple of the record size (330) and of 16
-    total = int(args.stream_gib * (1 << 30))
-    shard = max(blk, total // world // blk * blk) + 997  # cuts inside records
+    shard = max(blk, int(gib_per_rank * (1 << 30)) // blk * blk) + 997   # cuts inside records
     file_len = world * shard // RECLEN * RECLEN          # (the last rank's range is a few bytes shorter)
     lo, hi = rank * shard, min((rank + 1) * shard, file_len)
-    ctx = pkg.Ctx(dev.index)
-    # the block, generated on the GPU, and its image in host memory
+    T = args.producer_threads or max(1, min(8, (os.cpu_count() or 1) // max(1, world if not coll.local else 1)))
+    # the block, generated on the GPU, and its image in PAGEABLE host memory
     d_blk = torch.empty(blk + 16, dtype=torch.uint8, device=dev)
     ctx.synth_fill(d_blk.data_ptr(), 0, blk)
-    h_blk = d_blk[:blk].cpu().numpy()
-    filled = {}
+    h_blk = d_blk[:blk].cpu().numpy().copy()
+    src = h_blk.ctypes.data
+    pool = ThreadPoolExecutor(T)
 
-    inject = int(os.environ.get("FQH_BENCH_INJECT", "-1"))   # (tests only: the '+' at this file offset reads as '-')
-
-    def read_into(addr, off, n):
-        d = off % blk
-        if n == 0 or (filled.get(addr) == d and inject < 0):   # a ring slot that already holds the block at this rotation
-            return
+    def copy_range(addr, off, n):       # file bytes [off, off + n) -> addr; the file wraps around the block
         done = 0
         while done < n:
             k = min(n - done, blk - (off + done) % blk)
-            C.memmove(addr + done, h_blk.ctypes.data + (off + done) % blk, k)
+            C.memmove(addr + done, src + (off + done) % blk, k)
             done += k
-        if n == blk:
-            filled[addr] = d
-        if off <= inject < off + n:
-            C.memset(addr + (inject - off), ord("-"), 1)
 
-    hist = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
-    sc, qh, bh = hist[:8], hist[8: 8 + LMAX * 256], hist[8 + LMAX * 256:]
-    xdev = dev if backend == "nccl" else torch.device("cpu")
+    def reader(replay):
+        filled = {}
 
-    def barrier():
-        dist.barrier()
-        torch.cuda.synchronize()
+        def read_into(addr, off, n):
+            if n == 0:
+                return
+            if replay and filled.get(addr) == (off % blk, n) and not (off <= inject < off + n):
+                return                   # pinned replay: the slot already holds these bytes
+            if T == 1 or n < (4 << 20):
+                copy_range(addr, off, n)
+            else:                        # the producer: T threads, memmove outside the GIL
+                piece = (n + T - 1) // T // 64 * 64 + 64
+                jobs = [pool.submit(copy_range, addr + o, off + o, min(piece, n - o)) for o in range(0, n, piece)]
+                for jb in jobs:
+                    jb.result()
+            filled[addr] = (off % blk, n)
+            if off <= inject < off + n:
+                C.memset(addr + (inject - off), ord("-"), 1)
+                filled.pop(addr, None)
+        return read_into
 
-    barrier()
-    t0 = time.perf_counter()
-    stats = (LMAX, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
-    sh = sharded.stream_shard(ctx, read_into, lo, hi, file_len, blk, stats=stats)     # fqh_shard_stream_run (a failure goes into the words)
-    t_stream = time.perf_counter() - t0
-    # ---- the one exchange: FQH_SHARD_STREAM_WORDS words of every rank (bytes of another rank's range, where a rank needs
-    # them, come through its own read callback)
-    NW = pkg.SHARD_STREAM_WORDS
-    t_in = torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in sh.words()], dtype=torch.int64).to(xdev)
-    t_all = torch.empty(world * NW, dtype=torch.int64, device=xdev)
-    dist.all_gather_into_tensor(t_all, t_in)
-    words = [[int(x) & ((1 << 64) - 1) for x in row] for row in t_all.cpu().numpy().reshape(world, NW)]
-    # ---- true-phase check + the gap in front of this rank + its first-error key (fqh_shard_stream_finish), then SUM and MIN
-    t1 = time.perf_counter()
-    rec, key = sharded.finish(ctx, read_into, file_len, words, rank, blk, stats=stats)
-    t_finish = time.perf_counter() - t1
-    slots = torch.zeros(world, dtype=torch.int64, device=dev)
-    slots[rank] = rec
-    both = torch.cat([slots, hist]).to(xdev)
-    dist.all_reduce(both)
-    kt = torch.tensor([key - (1 << 63)], dtype=torch.int64, device=xdev)   # (order-preserving map of the u64 key into torch's i64)
-    dist.all_reduce(kt, op=dist.ReduceOp.MIN)
-    gkey = int(kt.item()) + (1 << 63)
-    tot = both.cpu().numpy()
-    g_status, g_records, g_err_offset = sharded.outcome([int(x) for x in tot[:world]], gkey)
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt, t_stream], dtype=torch.float64, device=xdev)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax[0].item())
-    rates = torch.zeros(world, dtype=torch.float64, device=xdev)
-    rates[rank] = (hi - lo) / 1e9 / t_stream
-    dist.all_reduce(rates)
-    bad = [] if g_status == pkg.OK else [(g_status, g_records, g_err_offset)]
-    if inject >= 0:
-        exp_err = (pkg.E_SEP, inject // RECLEN, inject // RECLEN * RECLEN)
-        assert bad == [exp_err], (bad, exp_err)
-        if rank == 0:
-            print(json.dumps({"mode": "sharded-stream", "n_gpus": world, "backend": backend, "numa": numa,
-                              "first_error": {"status": g_status, "n_records": g_records, "err_offset": g_err_offset,
-                                              "key_rank": (gkey >> 3) & 0xFF, "expected": list(exp_err)}}), flush=True)
-        ctx.close()
-        return
-    # ---- what the totals must be: the block's own histograms, times the repetitions, plus the last partial block
+    # what the totals must be: the block's own histograms, times the repetitions, plus the last partial block
     reps, rem = divmod(file_len, blk)
     exp = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
     one = torch.zeros_like(exp)
@@ -842,25 +951,98 @@ def sharded_stream(args, pkg, torch, dist, dev, rank, world, backend):
     if rem:
         ctx.stats(d_blk.data_ptr(), rem, LMAX, exp[8: 8 + LMAX * 256].data_ptr(), exp[8 + LMAX * 256:].data_ptr(), exp[:8].data_ptr())
     exp = exp.cpu().numpy()
-    ok_hist = bool((tot[world:] == exp).all())
+    ctx.invalidate()
+
+    def once(replay):
+        read_into = reader(replay)
+        hist = torch.zeros(8 + LMAX * 264, dtype=torch.int64, device=dev)
+        sc, qh, bh = hist[:8], hist[8: 8 + LMAX * 256], hist[8 + LMAX * 256:]
+        stats = (LMAX, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+        coll.barrier()
+        t0 = time.perf_counter()
+        sh = sharded.stream_shard(ctx, read_into, lo, hi, file_len, blk, stats=stats)     # fqh_shard_stream_run (a failure goes into the words)
+        t_stream = time.perf_counter() - t0
+        # ---- the one exchange: FQH_SHARD_STREAM_WORDS words of every rank (bytes of another rank's range, where a rank needs
+        # them, come through its own read callback)
+        words = coll.gather_words(sh.words())
+        # ---- true-phase check + the gap in front of this rank + its first-error key (fqh_shard_stream_finish), then SUM and MIN
+        t1 = time.perf_counter()
+        rec, key = sharded.finish(ctx, read_into, file_len, words, rank, blk, stats=stats)
+        t_finish = time.perf_counter() - t1
+        slots = torch.zeros(world, dtype=torch.int64, device=dev)
+        slots[rank] = rec
+        both = torch.cat([slots, hist])
+        coll.sum_dev(both)
+        gkey = coll.min_key(key)
+        tot = both.cpu().numpy()
+        g_status, g_records, g_err_offset = sharded.outcome([int(x) for x in tot[:world]], gkey)
+        coll.barrier()
+        dt = time.perf_counter() - t0
+        per = coll.objects({"seconds": dt, "stream_seconds": t_stream, "finish_seconds": t_finish, "bytes": hi - lo})
+        dt = max(p["seconds"] for p in per)
+        r = {"seconds": round(dt, 4), "gbs_aggregate": round(file_len / 1e9 / dt, 2),
+             "gbs_per_rank": [round(p["bytes"] / 1e9 / p["stream_seconds"], 2) for p in per],
+             "finish_seconds": [round(p["finish_seconds"], 4) for p in per]}
+        return r, (g_status, int(g_records), int(g_err_offset), gkey), tot
+
+    out = {"workload": "configs[4]: %.2f GiB in %d byte-range shard%s of %d B (cuts inside records), each streamed from host memory "
+                       "through a 3 x %d MiB pinned ring (a %d MiB record-aligned block replayed), phase-free; one all-gather of ten "
+                       "words per rank, true-phase check, the record at every cut parsed by the rank it ends in, one SUM and one MIN"
+                       % (file_len / 2**30, world, "" if world == 1 else "s", shard, blk >> 20, blk >> 20),
+           "ranks": world, "bytes_per_gpu": shard, "comm": coll.via_text, "numa": coll.objects(numa)}
+    if inject >= 0:
+        r, (g_status, g_records, g_err_offset, gkey), tot = once(False)
+        exp_err = (pkg.E_SEP, inject // RECLEN, inject // RECLEN * RECLEN)
+        assert (g_status, g_records, g_err_offset) == exp_err, ((g_status, g_records, g_err_offset), exp_err)
+        out["first_error"] = {"status": g_status, "n_records": g_records, "err_offset": g_err_offset,
+                              "key_rank": (gkey >> 3) & 0xFF, "expected": list(exp_err)}
+        pool.shutdown()
+        return out
+    for name in sub_runs:
+        r, (g_status, g_records, g_err_offset, gkey), tot = once(name == "pinned_replay")
+        ok_hist = bool((tot[world:] == exp).all())
+        assert g_status == pkg.OK, (name, g_status, g_records, g_err_offset)
+        assert g_records == file_len // RECLEN, (name, g_records, file_len // RECLEN)
+        assert ok_hist, name
+        r["records"] = g_records
+        r["records_per_s"] = round(g_records / r["seconds"], 1)
+        r["check"] = {"records_expected": file_len // RECLEN, "first_error_key": None, "phases_ok": True, "histograms_ok": ok_hist}
+        if name == "producer":
+            r["producer"] = {"threads_per_rank": T, "source": "pageable host memory; every slot of every pass is filled again "
+                                                              "(memmove outside the GIL), as in the N = 1 `stream` leg"}
+        else:
+            r["producer"] = {"threads_per_rank": 0, "source": "none: one pinned block replayed, a slot that already holds its bytes is "
+                                                              "submitted as it is — link and kernels only, no host-side work"}
+        out[name] = r
+    pool.shutdown()
+    return out
+
+
+def sharded_stream_record(args, pkg, torch, dist, dev, ctx, coll, backend, via, gib_per_rank):
+    """The `sharded_stream` object of the default line: the configs[4] leg at this world size AND — what `ratio_vs_n1` is a
+    ratio of — the same function at world size 1, run by rank 0 alone on its GPU while the other ranks wait (nothing else uses
+    the host's memory or the links meanwhile).  north_star's ">= 6x at 8 GPUs on the sharded host-streamed path" is
+    producer.ratio_vs_n1."""
+    world, rank = coll.world, coll.rank
+    n1 = None
+    if world > 1:
+        if rank == 0:
+            c1 = Coll(pkg, torch, dist, ctx, dev, 1, 0, backend, via, local=True)
+            n1 = sharded_stream(args, pkg, torch, dev, ctx, c1, gib_per_rank)
+            c1.close()
+        coll.barrier()
+    rec = sharded_stream(args, pkg, torch, dev, ctx, coll, gib_per_rank)
+    if world == 1:
+        n1 = rec
     if rank == 0:
-        print(json.dumps({
-            "mode": "sharded-stream",
-            "workload": "configs[4]: %.2f GiB in %d byte-range shards of %d B (cuts inside records), each streamed from pinned "
-                        "host memory through a 3 x %d MiB ring (one pinned block replayed), phase-free; one all_gather "
-                        "(8 words + tail bytes per rank), phase check, one-record stitch, one all_reduce" % (
-                            file_len / 2**30, world, shard, blk >> 20),
-            "n_gpus": world, "backend": backend, "bytes_per_gpu": shard, "seconds": round(dt, 4),
-            "gbs_pcie_inclusive_aggregate": round(file_len / 1e9 / dt, 2),
-            "gbs_per_rank_streaming": [round(float(x), 2) for x in rates.cpu().numpy()],
-            "records": int(g_records), "records_per_s": round(int(g_records) / dt, 1), "numa": numa,
-            "finish_seconds_rank0": round(t_finish, 4),
-            "check": {"records_expected": file_len // RECLEN, "first_error_key": None if g_status == pkg.OK else gkey,
-                      "phases_ok": not bad, "histograms_ok": ok_hist}}), flush=True)
-    assert not bad, bad
-    assert int(g_records) == file_len // RECLEN, (g_records, file_len // RECLEN)
-    assert ok_hist
-    ctx.close()
+        for name in ("producer", "pinned_replay"):
+            rec[name]["n1_gbs"] = n1[name]["gbs_aggregate"]
+            rec[name]["ratio_vs_n1"] = round(rec[name]["gbs_aggregate"] / n1[name]["gbs_aggregate"], 3)
+        rec["n1"] = ("the same function (sharded_stream) at world size 1: %.2f GiB, run by rank 0 alone while the other ranks wait"
+                     % (n1["bytes_per_gpu"] / 2**30)) if world > 1 else "this run"
+        rec["gbs_aggregate"] = rec["producer"]["gbs_aggregate"]
+        rec["ratio_vs_n1"] = rec["producer"]["ratio_vs_n1"]
+    return rec
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (FQH_LIB_PATH: a tuning build of the same library, tools/exp_fztime.sh; never a fallback)
 LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.so")
 
-__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "shard_stream_outcome", "shard_failed_words", "shard_failure_key", "SHARD_EMPTY", "SHARD_PASS", "SHARD_DEFER", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
+__all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Comm", "COMM_ID_BYTES", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "shard_stream_outcome", "shard_failed_words", "shard_failure_key", "SHARD_EMPTY", "SHARD_PASS", "SHARD_DEFER", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
            "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "OPT_REUSE_INDEX", "OPT_ADAPT_LINES", "EXPORTS"]
 
@@ -428,6 +428,49 @@ class Ctx:
         cs, ms = C.c_uint64(0), C.c_float(0)
         self._chk(self._L.fqh_read_ceiling(self._h, d_buf, length, C.byref(cs), C.byref(ms)))
         return cs.value, ms.value
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """fqh_comm_*: the library's own RCCL binding (csrc/comm.hip) — the exchange steps of the sharded modes for hosts without a
+    collective library; every call is enqueued on the context's stream.  The gather of Parser::parallel_each's results,
+    src/lib.rs:553-559, and the parse error it returns, src/lib.rs:544-547, 561-564."""
+
+    @staticmethod
+    def unique_id():
+        """One rank makes the id (-> 128 bytes) and hands it to the others by any means."""
+        uid = C.create_string_buffer(COMM_ID_BYTES)
+        st = lib().fqh_comm_unique_id(uid)
+        if st != OK:
+            raise FqhError(st, "fqh_comm_unique_id: librccl.so could not be loaded or ncclGetUniqueId failed")
+        return uid.raw
+
+    def __init__(self, ctx, n_ranks, rank, uid):
+        self.ctx = ctx
+        self._L = ctx._L
+        self.n_ranks, self.rank = n_ranks, rank
+        h = C.c_void_p()
+        ctx._chk(self._L.fqh_comm_create(ctx._h, n_ranks, rank, C.create_string_buffer(bytes(uid), COMM_ID_BYTES), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._L.fqh_comm_destroy(self._h)
+            self._h = None
+
+    def allgather(self, d_send, d_recv, bytes_per_rank):
+        self.ctx._chk(self._L.fqh_allgather(self.ctx._h, self._h, d_send, d_recv, bytes_per_rank))
+
+    def allreduce_u64(self, d_buf, n):
+        self.ctx._chk(self._L.fqh_allreduce_u64(self.ctx._h, self._h, d_buf, n))
+
+    def allreduce_min_u64(self, d_buf, n):
+        self.ctx._chk(self._L.fqh_allreduce_min_u64(self.ctx._h, self._h, d_buf, n))
+
+    def sync(self):
+        self.ctx._chk(self._L.fqh_sync(self.ctx._h))
 
 
 class Stream:

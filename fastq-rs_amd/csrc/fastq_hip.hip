@@ -24,6 +24,23 @@ static fqh_status fail(fqh_ctx *ctx, fqh_status s, const char *msg) {
     return s;
 }
 
+// Bytes of one line buffer: first lines (+ 64 tiles: k_emit_fast loads whole rounds of tiles without clamping), then the second
+// lines (+ 64 again).  Tuning builds keep 4 MiB of slack behind it so that an experiment can shift the lines inside the
+// allocation (FQH_TUNE_LINES_OFFSET, tools/exp_lines_offset.py).
+static size_t lines_bytes(size_t n_tiles) {
+#ifdef FQH_TUNING
+    return (2 * n_tiles + 128) * 64 * sizeof(uint16_t) + (4u << 20);
+#else
+    return (2 * n_tiles + 128) * 64 * sizeof(uint16_t);
+#endif
+}
+static uint16_t *lines_in_use(fqh_ctx *ctx) {
+#ifdef FQH_TUNING
+    if (const char *e = getenv("FQH_TUNE_LINES_OFFSET")) return ctx->fast_rs + (((size_t)atoll(e) & ~(size_t)127) & ((4u << 20) - 1)) / sizeof(uint16_t);
+#endif
+    return ctx->fast_rs;
+}
+
 // Every line buffer of the fast path the context holds — the one in use (fast_rs), the adaptive choice's two (fr[]) and the
 // alternates held back until an input is settled (fr_rejects[]) — freed once each: the same allocation may sit in several of them.
 static void free_line_buffers(fqh_ctx *ctx) {
@@ -297,8 +314,7 @@ static fqh_status ensure_workspace(fqh_ctx *ctx, uint64_t n_tiles, bool with_lis
         const size_t nb = (n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_count, n_tiles * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->tile_prefix, n_tiles * sizeof(uint32_t)));
-        // first lines (+ 64 tiles: k_emit_fast loads whole rounds of tiles without clamping), then the second lines (+ 64 again)
-        HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, (2 * n_tiles + 128) * 64 * sizeof(uint16_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->fast_rs, lines_bytes(n_tiles)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->block_prefix, nb * sizeof(uint64_t)));
         ctx->tiles_cap = n_tiles;
         ctx->placed = false;  // (the first scan on the fast path tries placements of the new line buffer: place_fast_rs)
@@ -362,7 +378,7 @@ static void adapt_choose(fqh_ctx *ctx, bool fused) {
     int use = e.state == 3 ? e.choice : 0;
     if (e.state == 1) {
         if (!ctx->fr[1]) {
-            const size_t bytes = (2 * ctx->tiles_cap + 128) * 64 * sizeof(uint16_t);
+            const size_t bytes = lines_bytes(ctx->tiles_cap);
             if (hipMalloc((void **)&ctx->fr[1], bytes) != hipSuccess) {
                 (void)hipGetLastError();
                 ctx->fr[1] = nullptr;
@@ -429,14 +445,14 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
     fqh_status st = ensure_workspace(ctx, a.n_tiles, with_list);
     if (st != FQH_OK) return st;
     if (fast && !ctx->placed) {
-        place_fast_rs(ctx, (2 * ctx->tiles_cap + 128) * 64 * sizeof(uint16_t));
+        place_fast_rs(ctx, lines_bytes(ctx->tiles_cap));
         ctx->placed = true;
     }
     if (fast && !reuse_index) adapt_choose(ctx, ctx->fused);
     a.list = with_list ? ctx->list : nullptr;
     a.list_cap = ctx->list_cap;
     a.tile_count = ctx->tile_count;
-    a.fast_rs = ctx->fast_rs;
+    a.fast_rs = lines_in_use(ctx);
     a.tile_prefix = ctx->tile_prefix;
     a.block_prefix = ctx->block_prefix;
     ctx->used_spec = fast;
@@ -482,7 +498,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.n_tiles = a.n_tiles;
         fz.list = const_cast<uint16_t *>(a.list);
         fz.list_cap = ctx->list_cap;
-        fz.fast_rs = ctx->fast_rs;
+        fz.fast_rs = lines_in_use(ctx);
         fz.out = &ctx->d_out[0];
         fz.lmax = ctx->f_lmax;
         fz.scratch = ctx->stats_scratch;
@@ -519,12 +535,12 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         // (the fast path without a line-list workspace: what a tile with more than 116 record starts would put there goes
         // to a 1 KiB dummy — list_cap 0 — and k_emit_fast reports such a tile, need_list)
         launch_index(s, a.buf, a.len, a.list ? const_cast<uint16_t *>(a.list) : ctx->list_dummy, a.list ? ctx->list_cap : 0u,
-                     ctx->tile_count, ctx->fast_rs, a.n_tiles, &ctx->d_out[0], ctx->n_cu, fast);
+                     ctx->tile_count, const_cast<uint16_t *>(a.fast_rs), a.n_tiles, &ctx->d_out[0], ctx->n_cu, fast);
         ctx->index_full = !fast;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
     if (!reuse_index)
-        launch_prefix(s, ctx->tile_count, fast ? ctx->fast_rs : nullptr, ctx->tile_prefix, ctx->block_prefix, a.n_tiles,
+        launch_prefix(s, ctx->tile_count, fast ? a.fast_rs : nullptr, ctx->tile_prefix, ctx->block_prefix, a.n_tiles,
                       a.n_blocks);
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     if (fast) {
@@ -1075,7 +1091,7 @@ fqh_status fqh_line_buffers(fqh_ctx *ctx, int *n_alive, int *n_unsettled, uint64
     for (const auto &e : ctx->adapt) open_inputs += e.buf && e.state != 3 ? 1 : 0;
     if (n_alive) *n_alive = n;
     if (n_unsettled) *n_unsettled = ctx->adapt_max > 0 ? open_inputs : 0;
-    if (bytes) *bytes = (uint64_t)n * (2 * ctx->tiles_cap + 128) * 64 * sizeof(uint16_t);
+    if (bytes) *bytes = (uint64_t)n * lines_bytes(ctx->tiles_cap);
     return FQH_OK;
 }
 fqh_status fqh_invalidate(fqh_ctx *ctx) {

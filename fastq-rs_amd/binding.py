@@ -24,7 +24,7 @@ EXPORTS = [
     "fqh_shard_prescan", "fqh_shard_prescan_launch", "fqh_shard_rescan_launch", "fqh_shard_align", "fqh_stream_carry", "fqh_carry_combine", "fqh_rescan_launch", "fqh_invalidate", "fqh_index_records", "fqh_record_flags", "fqh_gather_records", "fqh_len_hist", "fqh_stats", "fqh_stats_launch", "fqh_stats_finish", "fqh_stats_launch_lead",
     "fqh_scan_stats", "fqh_scan_stats_launch", "fqh_scan_stats_finish", "fqh_last_timing",
     "fqh_stream_create", "fqh_stream_destroy", "fqh_stream_set_stats", "fqh_stream_acquire", "fqh_stream_submit",
-    "fqh_stream_collect", "fqh_stream_release", "fqh_stream_timing", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
+    "fqh_stream_collect", "fqh_stream_release", "fqh_stream_timing", "fqh_stream_note_read", "fqh_comm_unique_id", "fqh_comm_create", "fqh_comm_destroy", "fqh_allgather",
     "fqh_allreduce_u64", "fqh_allreduce_min_u64", "fqh_sync", "fqh_shard_stream_run", "fqh_shard_result_words",
     "fqh_shard_failed_words", "fqh_shard_failure_key",
     "fqh_shard_stream_finish", "fqh_shard_stream_outcome", "fqh_stream_set_origin", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
@@ -176,6 +176,7 @@ def lib():
         L.fqh_shard_stream_finish.argtypes = [vp, READ_FN, vp, u64, vp, i32, i32, u64, u32, u32, vp, vp, vp, C.POINTER(u64 * 2)]
         L.fqh_shard_stream_outcome.argtypes = [u64, vp, i32, C.POINTER(C.c_int32), C.POINTER(u64), C.POINTER(u64)]
         L.fqh_stream_set_origin.argtypes = [vp, u64]
+        L.fqh_stream_note_read.argtypes = [vp, u64, u64]
         L.fqh_sync.argtypes = [vp]
         L.fqh_synth_fill.argtypes = [vp, vp, u64, u64, u64]
         L.fqh_read_ceiling.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(C.c_float)]
@@ -499,6 +500,10 @@ class Stream:
             return None
         self.ctx._chk(st)
         return p.value, cap.value
+
+    def note_read(self, got, asked):
+        """One read() of the host's reader into the acquired slot: got of asked bytes (a reader that may come back short)."""
+        self.ctx._chk(self._L.fqh_stream_note_read(self._h, got, asked))
 
     def submit(self, nbytes, is_final):
         self.ctx._chk(self._L.fqh_stream_submit(self._h, nbytes, 1 if is_final else 0))

@@ -31,6 +31,24 @@ struct BufferReplay {
     // completes (the first one is empty: lib.rs:381-391).
     bool sets = false;
     uint64_t set_first = 0;       // global index of the first record of the set under construction
+    // Short reads (pipes, decompressors): Buffer::read_into makes ONE reader.read() per refill and takes what it gets
+    // (src/buffer.rs:74-100), so with a reader that returns less than it is asked for the buffer's end is no multiple of 16 any
+    // more, clean() leaves the record in progress somewhere else, and whether a record of BUFSIZE - 15 .. BUFSIZE bytes fits
+    // depends on the sizes of the reads.  The host notes the reads IT made (note_read); the replay then gives the reference's
+    // read at stream offset p what a reader that "hands out at most c bytes per call" would give it: min(asked, c).  c is what
+    // the host's own reads say about the reader at p: a read that came back SHORT (got < asked) sets c = got; a read that came
+    // back full says "c >= got" — it lifts the cap if it got more than c, and says nothing otherwise (the last read of a slot
+    // asks for the few bytes the slot has left).  The host's slots must be at least BUFSIZE bytes, so that its first ask of
+    // a slot is at least anything the reference ever asks for.  For a reader with one cap for every call — the oracle's
+    // max_read, tests/replay_fuzz.cpp — that is exactly the reference's sequence of reads; for a pipe whose reads depend on
+    // timing it is the closest statement there is (the reference's own outcome depends on that timing).  No note_read at all,
+    // or full reads only: the case of a file.
+    struct ReadCap {
+        uint64_t upto, cap;       // bytes [previous upto, upto) of the stream came in reads of `cap` bytes (UINT64_MAX: full reads)
+    };
+    std::vector<ReadCap> caps;
+    uint64_t noted = 0;           // stream offset up to which reads have been noted
+    uint64_t cap_now = UINT64_MAX; // what the reads so far say the reader hands out per call
 
     void reset(uint64_t bufsize, bool record_sets = false) {
         B = bufsize;
@@ -38,6 +56,25 @@ struct BufferReplay {
         pend.assign(1, 0);
         sets = record_sets;
         set_first = 0;
+        caps.clear();
+        noted = 0;
+        cap_now = UINT64_MAX;
+    }
+    // One reader.read() of the host: `got` bytes of `asked` (got < asked: the reader came back short; got == 0: nothing to note).
+    void note_read(uint64_t got, uint64_t asked) {
+        if (!got) return;
+        if (got < asked) cap_now = got;
+        else if (got > cap_now) cap_now = UINT64_MAX;
+        const uint64_t cap = cap_now;
+        noted += got;
+        if (!caps.empty() && caps.back().cap == cap) caps.back().upto = noted;
+        else if (cap != UINT64_MAX || !caps.empty()) caps.push_back(ReadCap{noted, cap});
+    }
+    uint64_t cap_at(uint64_t pos) {
+        size_t drop = 0;
+        while (drop < caps.size() && caps[drop].upto <= pos) ++drop;
+        if (drop) caps.erase(caps.begin(), caps.begin() + (long)drop);
+        return caps.empty() ? UINT64_MAX : caps.front().cap;
     }
 
     // New information: boundaries rs[0..n] of the records that end in the latest chunk (rs[0] is the
@@ -92,7 +129,8 @@ struct BufferReplay {
                 }
             }
             const uint64_t n_free = B - nend;
-            const uint64_t num = n_free < 4096 ? n_free : n_free - n_free % 4096;
+            uint64_t num = n_free < 4096 ? n_free : n_free - n_free % 4096;
+            num = std::min(num, cap_at(rd));   // (a reader that comes back short: note_read)
             uint64_t got;
             if (rd + num <= known_end) got = num;
             else if (eof) got = known_end - rd;

@@ -45,6 +45,10 @@ struct fqh_stream {
     // FQH_STREAM_STATS
     uint32_t lmax = 0;
     uint64_t *d_qual_hist = nullptr, *d_base_hist = nullptr, *d_scalars = nullptr;
+    // fqh_stream_note_read: the host's reader may come back short (a pipe, a decompressor); "too long" is then judged by the
+    // replay of the reference's Buffer under the noted read sizes instead of the closed form (csrc/replay.h)
+    bool replay_on = false;
+    fqh::BufferReplay replay;
 };
 
 static fqh_status grow_rec(fqh_stream *st, fqh_stream::Slot &s, uint64_t need) {
@@ -340,7 +344,15 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     uint64_t which = 0;
     const bool bad_here = sum.parse_status != FQH_OK;
     const uint64_t need = bad_here ? need0 : fqh::TooLong::NO_BAD;
-    if (fqh::TooLong::first(ctx->bufsize, s.h_rec, n, known_end - s.h_rec[n], need, &which)) {
+    bool too_long;
+    if (st->replay_on) {   // (a reader that comes back short: the reference's reads are replayed, fqh_stream_note_read)
+        uint64_t k = 0;
+        too_long = st->replay.step(s.h_rec, st->records_done, n, known_end, s.is_final || bad_here, need, &k);
+        which = k >= st->records_done ? std::min<uint64_t>(k - st->records_done, n) : 0;
+    } else {
+        too_long = fqh::TooLong::first(ctx->bufsize, s.h_rec, n, known_end - s.h_rec[n], need, &which);
+    }
+    if (too_long) {
         c.parse_status = FQH_E_TOO_LONG;
         c.err_record = st->records_done + which;
         c.n_records = which;
@@ -423,6 +435,18 @@ fqh_status fqh_stream_set_origin(fqh_stream *st, uint64_t file_offset) {
     if (!st || st->head || st->sub || st->col) return FQH_E_ARG;  // before the first acquire
     st->carry = fqh_carry{};
     st->carry.base_offset = file_offset;
+    return FQH_OK;
+}
+
+fqh_status fqh_stream_note_read(fqh_stream *st, uint64_t got, uint64_t asked) {
+    if (!st || got > asked) return FQH_E_ARG;
+    if (!st->replay_on) {
+        // the replay walks the reference's Buffer from the first byte of the file: the notes must begin with the first slot
+        if (st->sub || st->col || st->carry.base_offset) return FQH_E_ARG;
+        st->replay.reset(st->ctx->bufsize);
+        st->replay_on = true;
+    }
+    st->replay.note_read(got, asked);
     return FQH_OK;
 }
 

@@ -349,16 +349,26 @@ class Parser {
             fqh_status st = fqh_stream_acquire(h_.st, &dst, &cap);
             if (st == FQH_E_CAPACITY) return;
             if (st != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
+            // Until the stream has delivered its FIRST record, a chunk ends as soon as the reads so far may hold it — four
+            // newlines have come in — or after BUFSIZE bytes, is submitted at once and collected before anything else is read:
+            // record 0 reaches the caller after no more input than the reference's refills take to hold it (src/lib.rs:264-275;
+            // a producer on a pipe may be waiting for an answer to it).  Every later chunk fills its slot.
+            const bool first = startup_;
+            const uint64_t target = first ? std::min<uint64_t>(cap, opt_.bufsize ? opt_.bufsize : BUFSIZE) : cap;
             uint64_t n = 0;
-            while (n < cap) {
-                const size_t want = (size_t)(cap - n);
+            while (n < target) {
+                const size_t want = (size_t)(target - n);
                 size_t got = reader_.read(dst + n, want);
                 if (got == 0) { eof_ = true; break; }
+                replay_.note_read(got, want);   // (a reader that comes back short decides the "too long" band: csrc/replay.h)
+                if (first) startup_newlines_ += (uint64_t)std::count(dst + n, dst + n + got, (uint8_t)'\n');
                 n += got;
+                if (first && startup_newlines_ >= 4) break;
                 if (opt_.low_latency && got < want && in_flight_ == 0) break;  // what there is, now
             }
             if (fqh_stream_submit(h_.st, n, eof_ ? 1 : 0) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
             ++in_flight_;
+            if (first) return;
         }
     }
 
@@ -368,6 +378,7 @@ class Parser {
         if (fqh_stream_collect(h_.st, &c) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
         --in_flight_;
         held_ = true;
+        if (c.n_records) startup_ = false;
         Chunk out;
         out.n = c.n_records;
         out.status = c.parse_status;
@@ -399,8 +410,8 @@ class Parser {
     Options opt_;
     detail::Handles h_;
     fqh::BufferReplay replay_;
-    bool sets_ = false, eof_ = false, held_ = false;
-    uint64_t records_done_ = 0;
+    bool sets_ = false, eof_ = false, held_ = false, startup_ = true;
+    uint64_t records_done_ = 0, startup_newlines_ = 0;
     int in_flight_ = 0;
 };
 

@@ -163,6 +163,50 @@ struct DribbleReader {
     size_t read(uint8_t *dst, size_t n) { return m.read(dst, n < 3001 ? n : 3001); }
 };
 
+// a reader that hands out at most `cap` bytes per call (the oracle's max_read) and counts what it has handed out
+struct CappedReader {
+    MemReader m;
+    size_t cap;
+    size_t *handed;
+    CappedReader(const std::string &s, size_t c, size_t *h) : m(s), cap(c), handed(h) {}
+    size_t read(uint8_t *dst, size_t n) {
+        const size_t k = m.read(dst, n < cap ? n : cap);
+        *handed += k;
+        return k;
+    }
+};
+
+// --pipe FILE CAP BUFSIZE SLOT: Parser::each and record_sets over a reader that comes back with at most CAP bytes per read()
+// (0: a reader that fills every read).  The reference's outcome for records of BUFSIZE - 15 .. BUFSIZE bytes depends on the
+// reader's read sizes (src/buffer.rs:51-100): the mirror notes its own reads and replays the reference's (csrc/replay.h).
+// Also prints how many bytes the reader had handed out when the closure saw record 0 (src/lib.rs:264-275: one refill).
+static int pipe_mode(const char *file, size_t cap, uint64_t bufsize, uint64_t slot) {
+    std::ifstream f(file, std::ios::binary);
+    std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    Options o;
+    o.bufsize = bufsize;
+    o.slot_bytes = slot;
+    if (!cap) cap = (size_t)-1;
+    {
+        size_t handed = 0, n = 0, bases = 0, first_after = 0;
+        Parser<CappedReader> p(CappedReader(d, cap, &handed), o);
+        std::string err = "ok";
+        try { p.each([&](const RefRecord &r) { if (!n) first_after = handed; ++n; bases += r.seq().size(); return true; }); }
+        catch (const Error &e) { err = e.what(); }
+        printf("each %zu %zu %s\n", n, bases, err.c_str());
+        printf("first %zu\n", first_after);
+    }
+    {
+        size_t handed = 0;
+        Parser<CappedReader> p(CappedReader(d, cap, &handed), o);
+        std::string err = "ok", sizes;
+        try { p.record_sets([&](RecordSet &&s) { sizes += std::to_string(s.len()) + ","; return true; }); }
+        catch (const Error &e) { err = e.what(); }
+        printf("sets %s %s\n", sizes.empty() ? "-" : sizes.c_str(), err.c_str());
+    }
+    return 0;
+}
+
 static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) {
     std::ifstream f(file, std::ios::binary);
     std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -293,6 +337,8 @@ int main(int argc, char **argv) {
         fqh_destroy(ctx);
         return 0;
     }
+    if (argc >= 6 && !strcmp(argv[1], "--pipe"))
+        return pipe_mode(argv[2], (size_t)strtoull(argv[3], 0, 0), strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0));
     if (argc >= 5 && !strcmp(argv[1], "--dump"))
         return dump(argv[2], atoi(argv[3]), strtoull(argv[4], 0, 0), argc > 5 ? strtoull(argv[5], 0, 0) : (1 << 20));
 #define RUN(t) do { t(); printf("ok %s\n", #t); fflush(stdout); } while (0)

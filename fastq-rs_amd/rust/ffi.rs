@@ -150,6 +150,7 @@ extern "C" {
     pub fn fqh_stream_release(st: *mut fqh_stream) -> c_int;
     pub fn fqh_stream_carry(st: *mut fqh_stream, out: *mut fqh_carry) -> c_int;
     pub fn fqh_stream_set_origin(st: *mut fqh_stream, file_offset: u64) -> c_int;
+    pub fn fqh_stream_note_read(st: *mut fqh_stream, got: u64, asked: u64) -> c_int;   // a reader that comes back short (src/buffer.rs:74-100)
     pub fn fqh_stream_timing(st: *mut fqh_stream, out: *mut fqh_stream_times) -> c_int;
     // histograms per delivered record (FQH_STREAM_STATS) and the device-side filter (flags + gather);
     // not needed by Parser itself, bound for consumers that want them
@@ -171,6 +172,7 @@ extern "C" {
 }
 
 const FQH_OK: c_int = 0;
+const FQH_BUFSIZE: usize = 68 * 1024;   // src/lib.rs:128-129
 const FQH_E_CAPACITY: c_int = 9;
 const FQH_STREAM_INDEX: u32 = 1;
 #[allow(dead_code)]
@@ -183,6 +185,8 @@ pub struct GpuScanner<R: Read> {
     reader: R, ctx: *mut fqh_ctx, st: *mut fqh_stream, eof: bool,
     /// a chunk's parse error waits here while the records in front of it are handed out
     pending: Option<Error>,
+    /// no record delivered yet: chunks end as soon as four newlines have come in (the first record early, src/lib.rs:264-275)
+    startup: bool, startup_newlines: usize,
 }
 
 impl<R: Read> GpuScanner<R> {
@@ -196,7 +200,7 @@ impl<R: Read> GpuScanner<R> {
                 fqh_destroy(ctx);
                 return Err(Error::new(ErrorKind::Other, "fqh_stream_create"));
             }
-            Ok(GpuScanner { reader, ctx, st, eof: false, pending: None })
+            Ok(GpuScanner { reader, ctx, st, eof: false, pending: None, startup: true, startup_newlines: 0 })
         }
     }
 
@@ -210,12 +214,21 @@ impl<R: Read> GpuScanner<R> {
                     FQH_E_CAPACITY => return Ok(()),
                     _ => return Err(Error::new(ErrorKind::Other, "fqh_stream_acquire")),
                 }
-                let slot = std::slice::from_raw_parts_mut(dst, cap as usize);
+                let first = self.startup;
+                let target = if first { (cap as usize).min(FQH_BUFSIZE) } else { cap as usize };
+                let slot = std::slice::from_raw_parts_mut(dst, target);
                 let mut n = 0usize;
                 while n < slot.len() {
+                    let asked = slot.len() - n;
                     match self.reader.read(&mut slot[n..]) {
                         Ok(0) => { self.eof = true; break; }
-                        Ok(k) => n += k,
+                        Ok(k) => {
+                            // a reader that comes back short decides the 69 618 .. 69 632-byte band (src/buffer.rs:74-100)
+                            fqh_stream_note_read(self.st, k as u64, asked as u64);
+                            if first { self.startup_newlines += slot[n..n + k].iter().filter(|&&b| b == b'\n').count(); }
+                            n += k;
+                            if first && self.startup_newlines >= 4 { break; }
+                        }
                         Err(ref e) if e.kind() == ErrorKind::Interrupted => {} // src/buffer.rs:85-97
                         Err(e) => return Err(e),
                     }
@@ -223,6 +236,7 @@ impl<R: Read> GpuScanner<R> {
                 if fqh_stream_submit(self.st, n as u64, self.eof as c_int) != FQH_OK {
                     return Err(Error::new(ErrorKind::Other, "fqh_stream_submit"));
                 }
+                if first { return Ok(()); }   // collect it before anything else is read
             }
             Ok(())
         }
@@ -241,6 +255,7 @@ impl<R: Read> GpuScanner<R> {
             let mut c: fqh_chunk = std::mem::zeroed();
             fqh_stream_release(self.st); // releases the previous chunk, if any
             if fqh_stream_collect(self.st, &mut c) != FQH_OK { return Ok(None); }
+            if c.n_records != 0 { self.startup = false; }
             if c.parse_status != FQH_OK {
                 // the error text is the crate's own (fqh_strerror returns the exact strings)
                 let msg = std::ffi::CStr::from_ptr(fqh_strerror(c.parse_status)).to_string_lossy().into_owned();

@@ -463,6 +463,15 @@ fqh_status fqh_stream_timing(fqh_stream *st, fqh_stream_times *out);
  * offset mod 16 and on nothing else (csrc/replay.h) — is judged as the reference judges it in the whole file.  Before the
  * first fqh_stream_acquire. */
 fqh_status fqh_stream_set_origin(fqh_stream *st, uint64_t file_offset);
+/* For hosts whose reader may come back SHORT (a pipe, a socket, a decompressor): Buffer::read_into makes one reader.read() per
+ * refill and takes what it gets (src/buffer.rs:74-100), so with such a reader the reference's verdict on a record of
+ * BUFSIZE - 15 .. BUFSIZE bytes depends on the sizes of the reads, not only on the record's file offset.  Call this once per
+ * read() the host makes into an acquired slot — `got` bytes of the `asked` — from the stream's first slot on (FQH_E_ARG later,
+ * or for a stream with an origin); slots of at least BUFSIZE bytes.  "Fastq record is too long" is then decided by the replay of
+ * the reference's Buffer under a reader that hands out what the notes say (csrc/replay.h: exact for a reader with one cap per
+ * call, tests/replay_fuzz.cpp; for a pipe whose reads depend on timing, the closest statement there is).  Without any note the
+ * reader is taken to fill every read — a file — and the rule's closed form is used. */
+fqh_status fqh_stream_note_read(fqh_stream *st, uint64_t got, uint64_t asked);
 /* Parser state behind the last collected chunk (nl_count = newlines the stream has seen: what the next shard's phase is
  * checked against in the sharded mode). */
 fqh_status fqh_stream_carry(fqh_stream *st, fqh_carry *out);

@@ -133,7 +133,7 @@ def record_sets(data, n_threads=1, bufsize=BUFSIZE, max_read=0):
     """-> (Result, set_sizes, worker_counts)."""
     a, p, n = _buf(data)
     r = Result()
-    cap = max(4, 2 * (n // max(1, bufsize // 2)) + 8)
+    cap = max(4, 2 * (n // max(1, min(bufsize // 2, max_read or bufsize))) + 8)   # (one set per refill: per read of a reader that comes back short)
     sizes = np.zeros(cap, dtype=np.uint64)
     workers = np.zeros(max(1, n_threads), dtype=np.uint64)
     nsets = C.c_uint64(0)

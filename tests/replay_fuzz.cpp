@@ -28,7 +28,7 @@ static std::string record(std::mt19937_64 &rng, uint64_t total) {  // a valid re
 int main(int argc, char **argv) {
     const uint64_t iters = argc > 1 ? strtoull(argv[1], 0, 0) : 2000;
     std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], 0, 0) : 12345);
-    uint64_t fails = 0, tripped_cases = 0;
+    uint64_t fails = 0, tripped_cases = 0, short_trips = 0;
     for (uint64_t it = 0; it < iters; ++it) {
         const uint64_t B = (it % 4 == 3) ? 69632 : 64;
         std::string data;
@@ -136,6 +136,60 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < got.size() && i < nsets; ++i)
             if (got[i] != sizes[i]) ok = false;
         if (ws.status == 0 && got.size() != nsets) ok = false;
+        // ---- a reader that comes back short (the oracle's max_read: at most that many bytes per read() call).  The host's own
+        // reads — any sizes asked for, each answered with min(asked, max_read) — are noted; the replay must then walk the
+        // reference's sequence of reads: Parser::each's verdict and RecordSetIter's cuts under the same reader.
+        {
+            const uint64_t mr = 1 + rng() % (B == 64 ? 70 : (rng() % 2 ? 4096 : 70000));
+            fqref_result wm;
+            fqref_count(p, data.size(), B, mr, &wm);
+            std::vector<uint64_t> msizes(data.size() + 16), mgot;
+            uint64_t mnsets = 0;
+            fqref_result wms;
+            fqref_record_sets(p, data.size(), B, mr, 1, msizes.data(), msizes.size(), &mnsets, nullptr, &wms);
+            for (int mode = 0; mode < 2; ++mode) {
+                fqh::BufferReplay rm;
+                rm.reset(B, mode == 1);
+                for (uint64_t pos = 0; pos < data.size();) {   // the host's reads: slots of at least BUFSIZE bytes, filled read by read
+                    const uint64_t slot = B + rng() % (4 * B);
+                    for (uint64_t filled = 0; filled < slot && pos < data.size();) {
+                        const uint64_t asked = slot - filled;
+                        const uint64_t gotb = std::min<uint64_t>(std::min(asked, mr), data.size() - pos);
+                        rm.note_read(gotb, asked);
+                        pos += gotb;
+                        filled += gotb;
+                        if (rng() % 7 == 0) break;   // (a host that submits a slot before it is full: Options::low_latency)
+                    }
+                }
+                uint64_t wq = 0, dn = 0;
+                bool tq = false, fq = false;
+                while (!tq) {   // boundaries in random chunks, as the ring delivers them
+                    const uint64_t take = (rng() % 3 == 0) ? n - dn : (n - dn ? rng() % (n - dn + 1) : 0);
+                    const bool last = dn + take == n;
+                    const uint64_t ke = last ? data.size() : rs[dn + take];
+                    tq = rm.step(rs.data() + dn, dn, take, ke, last, (last && truncated) ? 0 : fqh::BufferReplay::NO_BAD, &wq,
+                                 mode ? &mgot : nullptr, &fq);
+                    dn += take;
+                    if (last) break;
+                }
+                bool okm;
+                if (mode == 0) {
+                    okm = tq == (wm.status == FQREF_E_TOO_LONG) && (!tq || wq == wm.n_records);
+                    if (!tq && okm) okm = wm.n_records == n && (wm.status == 0 || wm.status == FQREF_E_TRUNCATED);
+                } else {
+                    okm = tq == (wms.status == FQREF_E_TOO_LONG) && mgot.size() <= mnsets && (wms.status != 0 || mgot.size() == mnsets);
+                    for (size_t i = 0; i < mgot.size() && i < mnsets; ++i) okm = okm && mgot[i] == msizes[i];
+                }
+                if (!okm) {
+                    ++fails;
+                    if (fails < 5)
+                        fprintf(stderr, "SHORT-READ MISMATCH it=%llu B=%llu max_read=%llu mode=%d trip=%d which=%llu want status=%d n=%llu sets %zu / %llu\n",
+                                (unsigned long long)it, (unsigned long long)B, (unsigned long long)mr, mode, tq, (unsigned long long)wq,
+                                mode ? wms.status : wm.status, (unsigned long long)wm.n_records, mgot.size(), (unsigned long long)mnsets);
+                }
+                short_trips += tq;
+            }
+        }
         tripped_cases += trip;
         if (!ok) {
             ++fails;
@@ -145,7 +199,7 @@ int main(int argc, char **argv) {
                         (unsigned long long)want.n_records, got.size(), (unsigned long long)nsets, t2, ws.status);
         }
     }
-    printf("replay_fuzz: %llu inputs, %llu too-long cases, %llu mismatches\n", (unsigned long long)iters,
-           (unsigned long long)tripped_cases, (unsigned long long)fails);
+    printf("replay_fuzz: %llu inputs, %llu too-long cases (%llu more under short reads), %llu mismatches\n", (unsigned long long)iters,
+           (unsigned long long)tripped_cases, (unsigned long long)short_trips, (unsigned long long)fails);
     return fails ? 1 : 0;
 }

@@ -42,7 +42,7 @@ def test_dynamic_symbol_table_is_the_header(pkg):
     out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
     syms = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
     assert syms == declared_symbols(), sorted(set(syms) ^ set(declared_symbols()))
-    assert len(syms) == 64
+    assert len(syms) >= 65
 
 
 def test_no_oracle_in_product(pkg):

@@ -98,6 +98,56 @@ def test_each_sets_parallel_each_equal_oracle(gpu_ok, fqref, tmp_path, seed):
             assert w_counts == ",".join(str(int(x)) for x in workers) + ","
 
 
+def _sized_record(rng, total):
+    """A valid record of exactly `total` bytes (>= 6): '@' h '\\n' s '\\n+\\n' q '\\n' with |s| == |q|."""
+    body = total - 6
+    s = int(rng.integers(0, body // 2 + 1))
+    h = body - 2 * s
+    return b"@" + b"h" * h + b"\n" + b"A" * s + b"\n+\n" + b"I" * s + b"\n"
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_pipes_short_reads_and_the_first_record(gpu_ok, fqref, tmp_path, seed):
+    """A reader that comes back with at most CAP bytes per read() (the oracle's max_read; src/buffer.rs:74-100 takes what one
+    read() returns): whether a record of BUFSIZE - 15 .. BUFSIZE bytes is "too long" then depends on the sizes of the reads.  The
+    mirror notes its own reads and replays the reference's (csrc/replay.h): Parser::each's records and error and record_sets'
+    cuts equal the oracle's under the same reader, for caps from 1 to 4096 bytes and for a reader that fills every read.  And
+    record 0 reaches the closure after no more input than the reference needs to hold it (src/lib.rs:264-275), not after a
+    whole ring slot."""
+    rng = np.random.default_rng(4200 + seed)
+    B = 256 if seed < 3 else fqref.BUFSIZE
+    sizes = []
+    for _ in range(60 if B == 256 else 6):
+        r = int(rng.integers(0, 10))
+        sizes.append(int(rng.integers(6, B // 2)) if r < 6 else int(rng.integers(B - 20, B + 1)))
+    if seed == 1:
+        sizes.append(B + 1 + int(rng.integers(0, 40)))          # certainly too long, behind records the band decides
+    data = b"".join(_sized_record(rng, t) for t in sizes)
+    if seed == 2:
+        data = data[:-3]                                        # a truncated tail
+    path = tmp_path / "pipe.fq"
+    path.write_bytes(data)
+    slot = 1 << 16 if B == 256 else 1 << 20
+    verdicts = set()
+    for cap in (0, 1, 5, 16, 37, 100, 255, 4095, 4096):
+        out = subprocess.run([os.path.join(BIN, "host_tests"), "--pipe", str(path), str(cap), str(B), str(slot)],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        got = {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in out.stdout.strip().split("\n")}
+        r = fqref.count(data, bufsize=B, max_read=cap)
+        each = got["each"].split(" ", 2)
+        assert (int(each[0]), each[2]) == (r.n_records, fqref.strerror(r.status) if r.status else "ok"), (cap, got["each"], r.status, r.n_records)
+        verdicts.add((r.status, r.n_records))
+        rs, set_sizes, _ = fqref.record_sets(data, n_threads=1, bufsize=B, max_read=cap)
+        s_sizes, s_err = got["sets"].rsplit(" ", 1) if got["sets"].endswith("ok") else got["sets"].split(" ", 1)
+        want_sizes = ",".join(str(int(x)) for x in set_sizes) + ","
+        assert s_sizes == want_sizes and s_err == ("ok" if rs.status == 0 else SETS_MSG.get(rs.status, fqref.strerror(rs.status))), (cap, B)
+        if r.n_records:
+            assert int(got["first"]) <= max(sizes[0] + (cap or fqref.BUFSIZE), min(fqref.BUFSIZE, len(data))), (cap, got["first"])
+    if B == 256:
+        assert len(verdicts) > 1, verdicts      # (the reader's read sizes DID decide some record of the band)
+
+
 @pytest.mark.parametrize("seed", range(5))
 def test_each_zipped_equals_oracle(gpu_ok, fqref, tmp_path, seed):
     """each_zipped (src/lib.rs:577-609): two files of different lengths, a scripted callback with random advance flags

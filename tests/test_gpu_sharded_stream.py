@@ -168,8 +168,10 @@ def test_bench_sharded_streamed_three_ranks_one_gpu():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-2000:]
     j = json.loads(lines[-1])
-    assert j["mode"] == "sharded-stream" and j["n_gpus"] == 3 and j["check"]["phases_ok"] and j["check"]["histograms_ok"]
-    assert j["records"] == j["check"]["records_expected"]
+    assert j["mode"] == "sharded-stream" and j["n_gpus"] == 3 and j["ranks"] == 3
+    for name in ("producer", "pinned_replay"):   # (real producer threads / one pinned block replayed: both sub-runs, same function)
+        assert j[name]["check"]["phases_ok"] and j[name]["check"]["histograms_ok"]
+        assert j[name]["records"] == j[name]["check"]["records_expected"]
 
 
 def test_no_byte_range_is_refused(env, fqref):

@@ -103,6 +103,71 @@ def test_stream_short_reads_and_tiny_slots(fqref, env):
     assert [r[1] for r in recs] == [fqref.accessors(data, idx[i])[1] for i in range(res.n_records)]
 
 
+def test_stream_noted_reads_decide_the_too_long_band(fqref, env):
+    """fqh_stream_note_read: a host whose reader comes back with at most CAP bytes per read() notes its reads; the ring then
+    replays the reference's Buffer under that reader (src/buffer.rs:51-100 takes what ONE read() returns) and its "too long"
+    verdict on records of BUFSIZE - 15 .. BUFSIZE bytes equals the oracle's for the same max_read — which differs from cap to
+    cap.  Without notes the reader is a file."""
+    torch, pkg = env
+    rng = np.random.default_rng(77)
+    B = 256
+
+    def sized(total):
+        body = total - 6
+        s = int(rng.integers(0, body // 2 + 1))
+        return b"@" + b"h" * (body - 2 * s) + b"\n" + b"A" * s + b"\n+\n" + b"I" * s + b"\n"
+
+    data = b"".join(sized(int(rng.integers(6, B // 2)) if rng.integers(0, 10) < 6 else int(rng.integers(B - 20, B + 1))) for _ in range(80))
+    seen = set()
+    for cap in (0, 1, 5, 16, 37, 100, 255, 4096):
+        ctx = pkg.Ctx(0, bufsize=B)
+        st = pkg.Stream(ctx, 4096, 3)
+        pos, nrec, status, done = 0, 0, pkg.OK, False
+        submitted = collected = 0
+        while True:
+            while not done:
+                a = st.acquire()
+                if a is None:
+                    break
+                addr, room = a
+                n = 0
+                while n < room and pos < len(data):      # the host fills the slot read by read
+                    asked = room - n
+                    got = min(asked, len(data) - pos, cap or asked)
+                    C.memmove(addr + n, data[pos: pos + got], got)
+                    if cap:
+                        st.note_read(got, asked)
+                    n += got
+                    pos += got
+                done = pos >= len(data)
+                st.submit(n, done)
+                submitted += 1
+            if collected == submitted:
+                break
+            c = st.collect()
+            collected += 1
+            nrec += c.n_records
+            st.release()
+            if c.parse_status != pkg.OK or c.is_final:
+                status = c.parse_status
+                break
+        st.close()
+        ctx.close()
+        r = fqref.count(data, bufsize=B, max_read=cap)
+        assert (status, nrec) == (r.status, r.n_records), (cap, status, nrec, r.status, r.n_records)
+        seen.add((r.status, r.n_records))
+    assert len(seen) > 1, seen   # (the caps DID decide)
+    # notes that begin after the first submit are refused
+    ctx = pkg.Ctx(0, bufsize=B)
+    st = pkg.Stream(ctx, 4096, 3)
+    st.acquire()
+    st.submit(0, False)
+    with pytest.raises(pkg.FqhError):
+        st.note_read(10, 20)
+    st.close()
+    ctx.close()
+
+
 def test_stream_too_long_and_truncation(fqref, env):
     torch, pkg = env
     rng = np.random.default_rng(5)

@@ -69,11 +69,22 @@ __device__ __forceinline__ uint32_t so_slot(uint32_t r) {  // r = row % 64
 __device__ __forceinline__ uint32_t so_row6(uint32_t slot) {
     return ((slot & 7u) << 2) | ((slot >> 3) & 3u) | (slot & 32u);
 }
+// k_stats_long's lanes hold EIGHT contiguous columns (two registers, h = 0 / 1): row % 64 = 8 m + 4 h + j.  Its slot is
+// m + 8 j + 32 h — the half h is the instruction's immediate, so the 32 lanes of a lane group (four line slots: four values of
+// j; eight lanes: m) sit on the 32 banks m + 8 j.  (Round 4 used so_slot for these rows, which puts bit 2 of m into slot bit 5:
+// lanes m and m + 4 on ONE bank at different addresses, a two-way conflict in every atomic — SQ_LDS_BANK_CONFLICT was exactly
+// half of SQ_LDS_IDX_ACTIVE, whatever the data.)
+__device__ __forceinline__ uint32_t so_slot_long(uint32_t r) {  // r = row % 64
+    return ((r >> 3) & 7u) | ((r & 3u) << 3) | ((r & 4u) << 3);
+}
+__device__ __forceinline__ uint32_t so_row6_long(uint32_t slot) {
+    return ((slot & 7u) << 3) | ((slot >> 3) & 3u) | ((slot >> 3) & 4u);
+}
 // word index of (bin, row): quality bins 0 .. 2^QBITS - 1 (6: the window '!'..'`' of every kernel but k_stats_long, 7: '!'..0xA0,
-// which holds PacBio HiFi's '~'), sequence bins 0..7
-template <bool IS_SEQ, uint32_t QBITS = 6>
+// which holds PacBio HiFi's '~'), sequence bins 0..7.  LONGMAP: k_stats_long's slot order
+template <bool IS_SEQ, uint32_t QBITS = 6, bool LONGMAP = false>
 __device__ __forceinline__ uint32_t so_word(uint32_t bin, uint32_t row) {
-    const uint32_t rb = row >> 6, slot = so_slot(row & 63u);
+    const uint32_t rb = row >> 6, slot = LONGMAP ? so_slot_long(row & 63u) : so_slot(row & 63u);
     return IS_SEQ ? ((rb << 9) | (bin << 6) | slot) : SO_SBYTES / 4 + ((rb << (6 + QBITS)) | (bin << 6) | slot);
 }
 __device__ __forceinline__ uint32_t load4_any(const uint8_t *__restrict__ p, const uint8_t *__restrict__ end) {
@@ -109,7 +120,7 @@ __device__ __forceinline__ void lds_add(uint32_t byte_addr, uint32_t v) {
 // to the overflow counters, which are plain arithmetic on the line's length; the alphabet flags cover every byte.
 // (lc is the tile's view of the bank-scheduled rows: 0 in tiles that take the exact path for everything; columns the
 // LDS rows do not take — and quality bytes outside '!'..'`' — go to the caller's arrays.)
-template <bool IS_SEQ, uint32_t QBITS = 6>
+template <bool IS_SEQ, uint32_t QBITS = 6, bool LONGMAP = false>
 __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, uint32_t pos, uint32_t len, uint32_t lc,
                                               uint32_t *hist, uint32_t &any_n, uint32_t &any_inv) {
     const int rem = (int)len - (int)pos;
@@ -123,11 +134,11 @@ __device__ __forceinline__ void so_exact_step(const StatsArgs &a, uint32_t w, ui
             any_inv |= valid ? 0u : 1u;
             any_n |= b == 'N' ? 1u : 0u;
             if (col >= a.lc) continue;
-            if (col < lc) atomicAdd(hist + so_word<true>(bin, col), 1u);
+            if (col < lc) atomicAdd(hist + so_word<true, 6, LONGMAP>(bin, col), 1u);
             else atomicAdd(&a.base_hist[(uint64_t)(a.col0 + col) * 8 + bin_to_class(bin)], 1ull);
         } else {
             if (col >= a.lc) continue;
-            if (col < lc && b - 33u < (1u << QBITS)) atomicAdd(hist + so_word<false, QBITS>(b - 33u, col), 1u);
+            if (col < lc && b - 33u < (1u << QBITS)) atomicAdd(hist + so_word<false, QBITS, LONGMAP>(b - 33u, col), 1u);
             else atomicAdd(&a.qual_hist[(uint64_t)(a.col0 + col) * 256 + b], 1ull);
         }
     }

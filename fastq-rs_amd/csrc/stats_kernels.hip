@@ -454,9 +454,9 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
 //     '!' .. 0xA0 — HiFi reads are mostly '~' (Q93), and a 64-bin window sent every such byte to the caller's arrays);
 //   * eight lanes walk a line's 256 columns, eight records per wavefront and round.  A lane loads EIGHT contiguous bytes four
 //     times (columns 64 v + 8 m .. + 7: half the load instructions of one dword per lane and step, 2.21 -> 2.13 ms per 4 GiB
-//     of 5 kbp reads) and counts them under the same bank-scheduled layout as k_stats_oct (so_slot): byte j of register
-//     2 v + h is row 64 v + 8 m + 4 h + j, i.e. slot 2 (m % 4) + h + 8 j + 32 (m / 4) — h goes into the instruction's
-//     immediate, the rest is the lane's slot byte; the 32 lanes of four line slots are on 32 distinct banks as before.
+//     of 5 kbp reads) and counts them under a bank-scheduled layout of its own (so_slot_long): byte j of register
+//     2 v + h is row 64 v + 8 m + 4 h + j, slot m + 8 j + 32 h — the half h (128 bytes) goes into the instruction's
+//     immediate, m + 8 j is the lane's slot byte: the 32 lanes of four line slots are on 32 distinct banks.
 //     Whole dwords of bytes inside the alphabet / window cost one v_perm_b32 and one ds_sub_u32 per byte; a dword with a byte outside, or with fewer than four bytes of the line, takes the per-byte
 //     statement (so_exact_step: window bytes to LDS, the rest to the caller's arrays);
 //   * per-record facts: lengths and the columns beyond lmax are arithmetic, done by column block 0; "has an N / a byte
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t j = k ^ (g8 & 3u);
         c.sel[k] = 0x0C0C0004u + k + (j << 8);
-        c.slots |= ((2u * (m & 3u) + 32u * (m >> 2) + 8u * j) * 4u) << (8u * k);
+        c.slots |= ((m + 8u * j) * 4u) << (8u * k);
     }
     const uint32_t cb = item % a.n_cb, slice = item / a.n_cb;
     const uint32_t col0 = cb * SO_LC_MAX;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
                 pb &= 0x7F7F7F7Fu;                                                  // (whatever the bytes are, the address stays inside the rows)
             }
             const uint32_t f = (whole && !chk) ? 0xFFFFFFFFu : 0u;
-            const uint32_t off = (kind ? SO_SBYTES : 0u) + 4u * (u & 1u) + (kind ? RB : 2048u) * (u >> 1);
+            const uint32_t off = (kind ? SO_SBYTES : 0u) + 128u * (u & 1u) + (kind ? RB : 2048u) * (u >> 1);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off), f,
@@ -602,8 +602,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
             if (__ballot(pos < seg && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
                 if (pos < seg && !f) {
                     uint32_t an = 0, ai = 0;
-                    if (kind == 0) so_exact_step<true, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
-                    else so_exact_step<false, SO_LQBITS>(sa, wu, pos, seg, lc, hist, an, ai);
+                    if (kind == 0) so_exact_step<true, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
+                    else so_exact_step<false, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
                     any_n |= an;
                     any_inv |= ai;
                 }
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void k_stats_long_reduce(const uint32_t *__res
     const uint32_t q = isq ? id - SO_SBYTES / 4 : id;
     const uint32_t rb = isq ? q >> (6 + SO_LQBITS) : q >> 9;
     const uint32_t bin = isq ? (q >> 6) & ((1u << SO_LQBITS) - 1u) : (q >> 6) & 7u;
-    const uint32_t row = rb * 64 + so_row6(q & 63u);
+    const uint32_t row = rb * 64 + so_row6_long(q & 63u);
     if (row >= lc) return;
     // (sequence bins 0 and 5 both mean "other": two counters of this launch may belong to one of the caller's)
     if (isq) qual_hist[(uint64_t)(col0 + row) * 256 + 33 + bin] += v;

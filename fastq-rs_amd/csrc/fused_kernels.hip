@@ -67,7 +67,14 @@ constexpr uint32_t FZ_DATA = FZ_TAIL + FZ_GROUP + FZ_POST;
 constexpr uint32_t FZ_GLIST = 251;                  // line starts per group that can be staged (+ one virtual entry)
 constexpr uint32_t FZ_RS = 256;                    // record starts of a tile staged in LDS (4 x 251 entries / 4, rounded)
 constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 16 + FZ_RS * 2 + (4 + FZ_GLIST + 1) * 2;  // 6160
-constexpr uint32_t FZ_SLACK = 512;                  // a batch reads up to 32 NSL + 32 bytes past a line's start
+constexpr uint32_t FZ_SLACK = 1024;                 // a batch reads up to 32 NSL + 32 bytes past a line's start (NSL 16: 544)
+// The PACKED instance (reads of 257 .. 511 columns): 512 rows x 64 quality bins of 32-bit counters are 128 KiB
+// — no room for the wavefronts' areas — so two rows share a word, 16-bit counters: step U of a line (columns 32 U ..) counts in
+// half U & 1 of the word that step U & ~1 uses, and the histogram has the geometry of the 256-row instance (a row block of
+// 128 columns: slot bit 5 = (U >> 1) & 1).  A counter may not pass 65 535 between two flushes: a span holds at most
+// 4 tiles x 4 groups x 251 line starts / 4 = 1 004 records (denser input marks the span bad), so the block's wavefronts walk
+// FZ_EPOCH spans each, meet at a barrier, add the 16-bit halves to the block's 32-bit rows in scratch, clear the LDS and go on.
+__host__ __device__ constexpr uint32_t fz_epoch(uint32_t waves) { return 65535u / (1004u * waves); }
 static_assert(FZ_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesses");
 
 typedef uint32_t fz_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
@@ -179,7 +186,12 @@ __device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &
     for (uint32_t u = 0; u < NSL; ++u) dst[64u * (1u + u)] = IS_SEQ ? B.w[u] : B.w[u] + 0x21212121u;  // (quality dwords were rebased in place)
 }
 
-template <bool IS_SEQ, uint32_t NSL>
+// byte offset (the instruction's immediate) of step u's rows: region, row block, half of the 256-byte bin row
+template <bool PACK>
+__host__ __device__ constexpr uint32_t fz_off(uint32_t region, uint32_t rb, uint32_t u) {
+    return PACK ? region + ((u >> 1) & 1u) * 128u + (u >> 2) * rb : region + (u & 1u) * 128u + (u >> 1) * rb;
+}
+template <bool IS_SEQ, uint32_t NSL, bool PACK>
 __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const FzLane &L, SoTotals &T, bool &bad, const FusedArgs &z) {
     (void)bad;  // (not written any more: a batch the kernel will not count is dumped.  The parameter stays: without it the register
                 // allocator spills 116 instead of 21 vector registers around the tile loop — tools/isa.sh)
@@ -223,26 +235,27 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
     }
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
-        const uint32_t pb = IS_SEQ ? B.w[u] & 0x07070707u : B.w[u], f = S.cm[u];
+        const uint32_t pb = IS_SEQ ? B.w[u] & 0x07070707u : B.w[u];
+        // PACK: an odd step counts in the upper half of its word (subtracting 0xFFFF0000 adds 0x10000)
+        const uint32_t f = (PACK && (u & 1u)) ? S.cm[u] & 0xFFFF0000u : S.cm[u];
         // (the row block and slot half go into the instruction's immediate offset)
-        constexpr uint32_t OFFS[8] = {REGION, REGION + 128u, REGION + RB, REGION + RB + 128u, REGION + 2 * RB, REGION + 2 * RB + 128u,
-                                      REGION + 3 * RB, REGION + 3 * RB + 128u};
+        const uint32_t off_u = fz_off<PACK>(REGION, RB, u);
         if (u == tus) {  // (wave-uniform) the step that also holds the partial last dwords: per-byte values.  ADDs of 0 / 1, so
             // that the compiler cannot merge the two arms into one with four v_mov / v_cndmask per step in front of it
-            const uint32_t o = OFFS[u < 8 ? u : 7];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + o), S.tv[k],
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off_u),
+                                             (PACK && (u & 1u)) ? S.tv[k] << 16 : S.tv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            fz_sub4_at<IS_SEQ>(OFFS[u < 8 ? u : 7], c, pb, f, f, f, f);
+            fz_sub4_at<IS_SEQ>(off_u, c, pb, f, f, f, f);
         }
     }
     if (ragged_tails) {
-        const uint32_t off = REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
+        const uint32_t off = PACK ? REGION + (((S.tu >> 1) & 1u) << 7) + (S.tu >> 2) * RB : REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
+        const uint32_t sh = PACK ? (S.tu & 1u) << 4 : 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off), S.tv[k],
+            (void)__hip_atomic_fetch_add((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pt, c.sel[k]) + off), S.tv[k] << sh,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (IS_SEQ) {  // sequence lines with an 'N' (bit 3 is set in 'N' only): the 8 lanes of a line OR their flags
@@ -277,7 +290,7 @@ __device__ __forceinline__ void fz_align(FzBatch<NSL> &B, const FzRaw<NSL> &R) {
 struct FzKind {          // one kind's lines of the chunk
     uint32_t l0, n;      // lanes l0, l0 + 4, ..: n lines
 };
-template <uint32_t NSL>
+template <uint32_t NSL, bool PACK>
 __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKind ks, FzBatch<NSL> &PBq, uint32_t &nfq, FzKind kq,
                                           uint32_t Pent, bool flush, const FzLane &L, const uint8_t *lds8, FzShape<NSL> &S,
                                           SoTotals &T, bool &bad, const FusedArgs &z, bool do_count) {
@@ -299,9 +312,9 @@ __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKi
         Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)(is0 + 8) + L.g16), (int)Pent);
         Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)(iq0 + 8) + L.g16), (int)Pent);
         if (news) fz_align<NSL>(PBs, Rs);
-        if (act_s && b < nits && do_count) fz_count<true, NSL>(PBs, S, L, T, bad, z);
+        if (act_s && b < nits && do_count) fz_count<true, NSL, PACK>(PBs, S, L, T, bad, z);
         if (newq) fz_align<NSL>(PBq, Rq);
-        if (act_q && b < nitq && do_count) fz_count<false, NSL>(PBq, S, L, T, bad, z);
+        if (act_q && b < nitq && do_count) fz_count<false, NSL, PACK>(PBq, S, L, T, bad, z);
     }
     nfs = flush ? 0u : rems;
     nfq = flush ? 0u : remq;
@@ -313,7 +326,7 @@ __device__ __attribute__((noinline)) uint4 fz_load16_tail(const uint8_t *__restr
     return load16(buf, off, len);
 }
 
-template <uint32_t NSL, uint32_t FZ_WAVES>
+template <uint32_t NSL, uint32_t FZ_WAVES, bool PACK>
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
     constexpr uint32_t FZ_THREADS = FZ_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
@@ -387,6 +400,25 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
         }
     };
 
+    // PACK: the block's 16-bit halves -> its 32-bit rows in scratch (zeroed by the host), the LDS cleared; every wavefront of the
+    // block calls it the same number of times
+    auto flush_rows = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint32_t *__restrict__ rows32 = z.scratch + (uint64_t)blockIdx.x * (2u * SO_WORDS);
+        for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) {
+            const uint32_t v = hist[i];
+            if (v) {
+                if (v & 0xFFFFu) rows32[2u * i] += v & 0xFFFFu;
+                if (v >> 16) rows32[2u * i + 1u] += v >> 16;
+                hist[i] = 0;
+            }
+        }
+        __syncthreads();
+    };
+    constexpr uint32_t EPOCH = fz_epoch(FZ_WAVES);
+    uint32_t it = 0;         // PACK: spans this wavefront has begun (the block flushes when it is a multiple of EPOCH)
+
     uint32_t span = blockIdx.x * FZ_WAVES + wv;
     if (span < n_spans) {
         uint4 n0, n1, n2, n3;
@@ -396,6 +428,10 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
         bool pending = false;  // the previous tile's line is still in a register
         uint32_t ptile = 0, prv = 0;
         for (; span < n_spans; span += nw) {
+            if (PACK) {
+                if (it && it % EPOCH == 0) flush_rows();
+                ++it;
+            }
             const uint32_t nspan = span + nw < n_spans ? span + nw : span;  // clamped: the prefetch is unconditional
             const uint32_t t0 = span * FZ_SPAN;
             const uint32_t t1 = span + 1 == n_spans ? n_tiles : t0 + FZ_SPAN;
@@ -670,7 +706,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
                             const bool cnt = !FZ_DBG(2u);
                             FZ_T(5);
-                            fz_lines2<NSL>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, z, cnt);
+                            fz_lines2<NSL, PACK>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, z, cnt);
                             FZ_T(4);  // lines: lookups, reads, counts
                         }
                     }
@@ -749,10 +785,17 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
 #endif
 
     // ---- per-block partial histogram, per-wave totals
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    uint32_t *__restrict__ dst = FZ_KARG(scratch) + (uint64_t)blockIdx.x * SO_WORDS;
-    for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) dst[i] = hist[i];
+    if (PACK) {   // (the wavefronts that ran out of spans early take part in the flushes of the others, then in the last one)
+        const uint32_t rounds = (n_spans + nw - 1) / nw;
+        for (; it < rounds; ++it)
+            if (it && it % EPOCH == 0) flush_rows();
+        flush_rows();
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint32_t *__restrict__ dst = FZ_KARG(scratch) + (uint64_t)blockIdx.x * SO_WORDS;
+        for (uint32_t i = threadIdx.x; i < wb0 / 4; i += FZ_THREADS) dst[i] = hist[i];
+    }
     unsigned long long sc[5] = {acc_rec, acc_bases, acc_qual, 0, 0};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -793,6 +836,34 @@ __global__ __launch_bounds__(256) void k_stats_commit(const DevOut *__restrict__
     const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
     unsigned long long s = 0;
     for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * SO_WORDS + id];
+    if (!s) return;
+    if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
+    else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+}
+
+// ... and the packed instance's rows: the blocks' 32-bit rows in scratch, [2 i + h] = half h of LDS word i (k_scan_stats<16, .., true>:
+// step U of a line counts in half U & 1, slot bit 5 = (U >> 1) & 1, row block U >> 2 of 128 columns)
+__global__ __launch_bounds__(256) void k_stats_commit_packed(const DevOut *__restrict__ out, const uint32_t *__restrict__ scratch,
+                                                             uint32_t n_blocks, uint32_t lc, const unsigned long long *__restrict__ src_scalars,
+                                                             unsigned long long *__restrict__ qual_hist,
+                                                             unsigned long long *__restrict__ base_hist,
+                                                             unsigned long long *__restrict__ scalars) {
+    if (!out->stats_commit) return;
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0 && id < FQH_NSCALARS && src_scalars[id]) atomicAdd(&scalars[id], src_scalars[id]);
+    if (id >= 2u * SO_WORDS) return;
+    const uint32_t w = id >> 1, half = id & 1u;
+    const bool isq = w >= SO_SBYTES / 4;
+    const uint32_t r = isq ? w - SO_SBYTES / 4 : w;
+    const uint32_t rb = isq ? r >> 12 : r >> 9;
+    const uint32_t bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
+    const uint32_t slot = r & 63u;
+    const uint32_t row = rb * 128u + ((slot >> 5) & 1u) * 64u + half * 32u + (slot & 7u) * 4u + ((slot >> 3) & 3u);
+    if (row >= lc) return;
+    const uint32_t b0 = blockIdx.y * RED_GROUP;
+    const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
+    unsigned long long s = 0;
+    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * (2u * SO_WORDS) + id];
     if (!s) return;
     if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
     else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
@@ -894,8 +965,12 @@ constexpr uint32_t DECL_BINS = 264;               // per row: base classes 0..7,
 constexpr uint32_t DECL_LINES_PER_BLOCK = 60000;  // (16-bit counters)
 __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restrict__ out, const uint32_t *__restrict__ decl_b, uint32_t nsl,
                                                         const uint64_t *__restrict__ decl_l, uint32_t cap, const uint8_t *__restrict__ buf,
-                                                        uint32_t lmax, uint32_t rows, unsigned long long *__restrict__ qual_hist,
+                                                        uint32_t lmax, uint32_t lc, uint32_t row0, uint32_t rows,
+                                                        unsigned long long *__restrict__ qual_hist,
                                                         unsigned long long *__restrict__ base_hist, unsigned long long *__restrict__ scalars) {
+    // lc: the rows the caller's arrays and the single pass share; this launch counts columns row0 .. row0 + rows - 1 of them (a
+    // window of at most 256 rows fits the LDS; the launch with row0 == 0 also settles the lines' alphabet verdicts and the
+    // columns beyond lc)
     if (!out->stats_commit) return;
     const uint32_t nb = (uint32_t)(out->decl_b < cap ? out->decl_b : cap), nl = (uint32_t)(out->decl_l < cap ? out->decl_l : cap);
     if (!nb && !nl) return;
@@ -919,20 +994,21 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
             const uint32_t w = src[64u * (1u + u)];
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t col = 32u * u + 4u * m + j;
-                if (!act || col >= n || col >= rows) continue;   // (n <= lmax: longer lines are listed, not batched)
+                if (!act || col >= n || col >= lc) continue;   // (n <= lmax: longer lines are listed, not batched)
                 const uint32_t b = (w >> (8u * j)) & 0xFFu;
+                const bool mine = col - row0 < rows;
                 if (isq) {
-                    count(col, 8u + b);
+                    if (mine) count(col - row0, 8u + b);
                 } else {
                     const uint32_t c = base_class(b);
                     inv |= c == 5 ? 1u : 0u;
                     hasn |= c == 4 ? 1u : 0u;
-                    count(col, c);
+                    if (mine) count(col - row0, c);
                 }
             }
         }
         const unsigned long long bi = __ballot(inv != 0), bn = __ballot(hasn != 0);
-        if (m == 0 && act && !isq) {
+        if (m == 0 && act && !isq && row0 == 0) {
             const bool li = ((bi >> lane) & 0xFFull) != 0, ln = ((bn >> lane) & 0xFFull) != 0;
             if (li || ln) atomicAdd(&scalars[3], ~0ull);
             if (li) atomicAdd(&scalars[4], ~0ull);
@@ -954,13 +1030,17 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
                 inv |= bin == 5 ? 1u : 0u;
                 hasn |= bin == 4 ? 1u : 0u;
             }
-            if (col < rows) count(col, bin);
-            else ++over;
+            if (col >= lmax) ++over;
+            else if (col - row0 < rows) count(col - row0, bin);
+            else if (col >= lc && row0 == 0) {   // (lmax 512: the one row beyond the packed instance's 511)
+                if (bin < 8) atomicAdd(&base_hist[(uint64_t)col * 8 + bin], 1ull);
+                else atomicAdd(&qual_hist[(uint64_t)col * 256 + (bin - 8)], 1ull);
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) over += __shfl_xor(over, d);
         const bool li = __ballot(inv != 0) != 0, ln = __ballot(hasn != 0) != 0;
-        if (lane == 0) {
+        if (lane == 0 && row0 == 0) {
             if (over) atomicAdd(&scalars[isq ? 6 : 5], over);
             if (!isq && (li || ln)) atomicAdd(&scalars[3], ~0ull);
             if (!isq && li) atomicAdd(&scalars[4], ~0ull);
@@ -974,65 +1054,79 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
         for (uint32_t h = 0; h < 2; ++h) {
             const uint32_t c = (v >> (16u * h)) & 0xFFFFu;
             if (!c) continue;
-            const uint32_t k = 2u * i + h, row = k / DECL_BINS, bin = k - row * DECL_BINS;
+            const uint32_t k = 2u * i + h, rw = k / DECL_BINS, bin = k - rw * DECL_BINS, row = row0 + rw;
             if (bin < 8) atomicAdd(&base_hist[(uint64_t)row * 8 + bin], (unsigned long long)c);
             else atomicAdd(&qual_hist[(uint64_t)row * 256 + (bin - 8)], (unsigned long long)c);
         }
     }
 }
-static size_t stats_declined_lds(uint32_t lmax) { return (size_t)(lmax < SO_LC_MAX ? lmax : SO_LC_MAX) * DECL_BINS * 2; }
+constexpr uint32_t FZ_LC_MAX = 511;   // rows of the packed instance: a line's length travels in nine bits, and the kept tail holds 511 bytes
+static uint32_t fz_lc(uint32_t lmax) { return lmax < FZ_LC_MAX ? lmax : FZ_LC_MAX; }
+static size_t stats_declined_lds(uint32_t lmax) { return (size_t)std::min<uint32_t>(fz_lc(lmax), SO_LC_MAX) * DECL_BINS * 2; }
 // The one thing about k_stats_declined that can fail, done BEFORE the single pass is enqueued: an error behind k_stats_commit
 // would leave the dumped batches and listed lines uncounted in a result that says it is complete.
 hipError_t prepare_stats_declined(uint32_t lmax) {
     static LdsAttr attr;
     return attr.ensure(reinterpret_cast<const void *>(k_stats_declined), stats_declined_lds(lmax));
 }
+uint32_t scan_stats_nsl(uint32_t lmax) {
+    const uint32_t steps = (fz_lc(lmax) + 31) / 32;
+    return steps <= 5 ? 5u : steps <= 8 ? 8u : 16u;
+}
 void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
                            unsigned long long *base_hist, unsigned long long *scalars) {
     if (!z.decl_cap) return;
-    const uint32_t lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;   // (the rows the caller's arrays and the single pass share)
-    const uint32_t nsl = (lc + 31) / 32 <= 5 ? 5u : 8u;
+    const uint32_t lc = fz_lc(z.lmax);   // (the rows the caller's arrays and the single pass share)
+    const uint32_t nsl = scan_stats_nsl(z.lmax);
     // a block's 16-bit counters hold the lines of its share of the slots: 8 lines per dumped batch, 1 per listed line
     const uint64_t per_block = DECL_LINES_PER_BLOCK / 9;
     const uint32_t blocks = (uint32_t)std::max<uint64_t>(512, ((uint64_t)z.decl_cap + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(1024), stats_declined_lds(z.lmax), s, out, z.decl_b, nsl, z.decl_l, z.decl_cap,
-                       z.buf, z.lmax, lc, qual_hist, base_hist, scalars);
-}
-uint32_t scan_stats_nsl(uint32_t lmax) {
-    const uint32_t lc = lmax < SO_LC_MAX ? lmax : SO_LC_MAX;
-    return (lc + 31) / 32 <= 5 ? 5u : 8u;
+    for (uint32_t row0 = 0; row0 < lc; row0 += SO_LC_MAX) {   // (windows of 256 rows: what the LDS holds)
+        const uint32_t rows = std::min<uint32_t>(lc - row0, SO_LC_MAX);
+        hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(1024), (size_t)rows * DECL_BINS * 2, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap,
+                           z.buf, z.lmax, lc, row0, rows, qual_hist, base_hist, scalars);
+    }
 }
 
 uint32_t stats_blocks(int n_cu);
 
-// can the single-pass kernel take this call's lmax?  (its histogram has the 256 bank-scheduled rows and nothing else)
-bool scan_stats_supports(uint32_t lmax) { return lmax >= 1 && lmax <= SO_LC_MAX; }
+// can the single-pass kernel take this call's lmax?  (up to 160 / 256 rows of 32-bit counters, up to 512 of packed 16-bit ones;
+// a line of 512 columns or more is listed or declined like any line beyond the rows)
+bool scan_stats_supports(uint32_t lmax) { return lmax >= 1 && lmax <= 512; }
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu) {
     const uint64_t want = ((n_tiles + FZ_SPAN - 1) / FZ_SPAN + FZ_WAVES_MAX - 1) / FZ_WAVES_MAX;
     const uint32_t cus = stats_blocks(n_cu);
     return (uint32_t)(want < cus ? (want ? want : 1) : cus);
 }
-size_t scan_stats_scratch_bytes(int n_cu) { return (size_t)stats_blocks(n_cu) * SO_WORDS * sizeof(uint32_t); }
+size_t scan_stats_scratch_bytes(int n_cu) { return (size_t)stats_blocks(n_cu) * 2 * SO_WORDS * sizeof(uint32_t); }   // (the packed instance's rows: two per LDS word)
 
-template <uint32_t NSL, uint32_t FZ_WAVES>
+#ifndef FQH_FZ_WP
+#define FQH_FZ_WP 12
+#endif
+template <uint32_t NSL, uint32_t FZ_WAVES, bool PACK = false>
 static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t blocks) {
-    z.wave_base = SO_SBYTES + ((NSL + 1) / 2) * 16384u;
+    constexpr uint32_t HNSL = PACK ? NSL / 2 : NSL;   // (packed: the histogram's geometry is that of half the steps)
+    z.wave_base = SO_SBYTES + ((HNSL + 1) / 2) * 16384u;
     const size_t lds = (size_t)z.wave_base + (size_t)FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK;
-    static_assert(SO_SBYTES + ((NSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK <= SO_LDS_MAX, "LDS budget");
+    static_assert(SO_SBYTES + ((HNSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK <= SO_LDS_MAX, "LDS budget");
     // lanes without a whole dword subtract 0 at the address their bytes form (any bin byte plus the largest
     // row-block offset): inside the allocation, and harmless wherever it lands (stats_dev.h)
-    static_assert(65536 + SO_SBYTES + 128 + ((NSL - 1) / 2) * 16384u <= SO_SBYTES + ((NSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES,
+    static_assert(65536 + SO_SBYTES + 128 + ((HNSL - 1) / 2) * 16384u <= SO_SBYTES + ((HNSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES,
                   "garbage addresses must stay inside the allocation");
+    static_assert(!PACK || (SO_SBYTES + ((HNSL + 1) / 2) * 16384u) / 4 == SO_WORDS, "the packed instance flushes SO_WORDS words");
     static LdsAttr attr;
-    if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(k_scan_stats<NSL, FZ_WAVES>), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_scan_stats<NSL, FZ_WAVES>), dim3(blocks), dim3(FZ_WAVES * 64), lds, s, z);
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(k_scan_stats<NSL, FZ_WAVES, PACK>), lds); e != hipSuccess) return e;
+    if (PACK) {   // the blocks ADD to their rows in scratch, epoch by epoch
+        if (hipError_t e = hipMemsetAsync(z.scratch, 0, (size_t)blocks * 2 * SO_WORDS * sizeof(uint32_t), s); e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_scan_stats<NSL, FZ_WAVES, PACK>), dim3(blocks), dim3(FZ_WAVES * 64), lds, s, z);
     return hipSuccess;
 }
 
 // z: buf, len, n_tiles, the fast path's outputs, lmax, scratch (scan_stats_scratch_bytes), scalars = ZEROED side
 // array of FQH_NSCALARS u64 (not the caller's: see k_stats_commit)
 hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
-    z.lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
+    z.lc = fz_lc(z.lmax);
 #ifdef FQH_TUNING  // knock-out flags of the timing experiments (tools/exp_fzdbg.py); not part of the product library
     z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
 #else
@@ -1040,14 +1134,21 @@ hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
 #endif
     const uint32_t blocks = scan_stats_blocks(z.n_tiles, n_cu);
     const uint32_t nsl = (z.lc + 31) / 32;
-    hipError_t e = nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks) : launch_scan_stats_n<8, 12>(s, z, blocks);
+    hipError_t e = nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks)
+                 : nsl <= 8 ? launch_scan_stats_n<8, 12>(s, z, blocks)
+                            : launch_scan_stats_n<16, FQH_FZ_WP, true>(s, z, blocks);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, uint32_t blocks,
                          unsigned long long *qual_hist, unsigned long long *base_hist, unsigned long long *scalars) {
-    const uint32_t lc = z.lmax < SO_LC_MAX ? z.lmax : SO_LC_MAX;
+    const uint32_t lc = fz_lc(z.lmax);
     const uint32_t nsl = (lc + 31) / 32;
+    if (nsl > 8) {
+        hipLaunchKernelGGL(k_stats_commit_packed, dim3((2 * SO_WORDS + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
+                           z.scratch, blocks, lc, z.scalars, qual_hist, base_hist, scalars);
+        return;
+    }
     const uint32_t words = (SO_SBYTES + ((nsl <= 5 ? 5u : 8u) + 1) / 2 * 16384u) / 4;
     hipLaunchKernelGGL(k_stats_commit, dim3((words + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
                        z.scratch, blocks, lc, words, z.scalars, qual_hist, base_hist, scalars);

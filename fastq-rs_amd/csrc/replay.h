@@ -65,10 +65,16 @@ struct BufferReplay {
         if (!got) return;
         if (got < asked) cap_now = got;
         else if (got > cap_now) cap_now = UINT64_MAX;
-        const uint64_t cap = cap_now;
+        const uint64_t cap = cap_now, before = noted;
         noted += got;
-        if (!caps.empty() && caps.back().cap == cap) caps.back().upto = noted;
-        else if (cap != UINT64_MAX || !caps.empty()) caps.push_back(ReadCap{noted, cap});
+        if (!caps.empty() && caps.back().cap == cap) {
+            caps.back().upto = noted;
+        } else if (cap != UINT64_MAX || !caps.empty()) {
+            // (full reads are not listed while nothing else is: the first short read must not claim the bytes in front of it —
+            // a file's LAST read comes back short, and took every earlier refill of the replay for one of its size)
+            if (caps.empty() && before) caps.push_back(ReadCap{before, UINT64_MAX});
+            caps.push_back(ReadCap{noted, cap});
+        }
     }
     uint64_t cap_at(uint64_t pos) {
         size_t drop = 0;

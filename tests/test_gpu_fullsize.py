@@ -100,3 +100,34 @@ def test_histograms_16gib_properties(env, fqref):
     assert np.array_equal(q3.cpu().numpy().astype(np.uint64).reshape(150, 256), oq)
     assert np.array_equal(b3.cpu().numpy().astype(np.uint64).reshape(150, 8), ob)
     assert np.array_equal(s3.cpu().numpy().astype(np.uint64), osc)
+
+
+def test_packed_rows_do_not_wrap_12gib(env):
+    """Reads of 300 columns at full size through the packed instance of the single pass (two rows per LDS word, 16-bit halves,
+    flushed every few spans): 12 GiB of ONE record repeated — every quality byte 'I', every base 'A' — puts ~ 76 000 counts per
+    block on a single (column, bin), more than a 16-bit half holds: a flush that came late would wrap.  Properties that need no
+    oracle: every row's one bin holds the record count exactly (src/records.rs:75-90 — the consumer's loop over seq() / qual())."""
+    torch, pkg, ctx, buf, dev = env
+    L = 300
+    rec = b"@M01234:56:000000000-ABCDE:1:1101:12345:6789 1:N:0:1\n" + b"A" * L + b"\n+\n" + b"I" * L + b"\n"
+    reps_blk = 4096
+    blk = torch.from_numpy(np.frombuffer(rec * reps_blk, dtype=np.uint8).copy()).to(dev)
+    n_blk = (12 << 30) // blk.numel()
+    n = n_blk * blk.numel()
+    assert n <= NBYTES
+    view = buf[:n].view(n_blk, blk.numel())
+    view.copy_(blk.unsqueeze(0).expand(n_blk, -1))          # (the module's buffer, overwritten: this test runs last in the file)
+    nrec = n_blk * reps_blk
+    qh = torch.zeros(L * 256, dtype=torch.int64, device=dev)
+    bh = torch.zeros(L * 8, dtype=torch.int64, device=dev)
+    sc = torch.zeros(8, dtype=torch.int64, device=dev)
+    ctx.invalidate()
+    s, c = ctx.stats(buf.data_ptr(), n, L, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    assert (s.parse_status, s.n_records) == (pkg.OK, nrec) and ctx.last_stats_route() == 1 and ctx.last_scan_fast()
+    assert nrec // 256 > 65535                              # (a CU's share of the records does not fit a 16-bit half)
+    q, b = qh.view(L, 256), bh.view(L, 8)
+    assert torch.all(q[:, ord("I")] == nrec) and int(q.sum()) == nrec * L
+    assert torch.all(b[:, 0] == nrec) and int(b.sum()) == nrec * L
+    assert sc.cpu().tolist()[:5] == [nrec, nrec * L, nrec * L, nrec, nrec]
+    ctx.synth_fill(buf.data_ptr(), 0, NBYTES)               # (leave the buffer as the fixture made it)
+    ctx.invalidate()

@@ -79,7 +79,7 @@ def run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets, want_route=
         assert fused == want_fused, "route: single pass kept = %s, expected %s" % (fused, want_fused)
         if want_route is None:
             want_route = 1 if want_fused else 0
-    if want_route is not None:
+    if want_route is not None and want_route >= 0:
         assert ctx.last_stats_route() == want_route, "statistics route %d, expected %d" % (ctx.last_stats_route(), want_route)
     return s
 
@@ -133,6 +133,74 @@ def test_single_pass_shapes(env, fqref, shape):
     for lmax in lmaxes:
         run(env, fqref, data, lmax, want_fused=True)
     run(env, fqref, data, lmaxes[0], want_fused=True, offsets=True)
+
+
+@pytest.mark.parametrize("shape", ["fixed300", "fixed500", "fixed511", "ragged511", "crlf300", "mixed", "plusid300", "empty_and_long"])
+def test_single_pass_counts_up_to_511_columns(env, fqref, shape):
+    """Reads of 257 .. 511 columns (MiSeq 2 x 300, merged pairs) take the scan's own pass too (the reference
+    treats every record up to BUFSIZE alike, src/records.rs:75-90, src/lib.rs:276-283): the packed instance of k_scan_stats —
+    sixteen steps per line, two rows per LDS word, flushed before a 16-bit half can wrap.  Values == oracle, route pinned."""
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
+    kw = {}
+    if shape == "fixed300":
+        seqlen, nrec, lmaxes = 300, 3000, (300, 301, 320, 384, 512, 257)
+    elif shape == "fixed500":
+        seqlen, nrec, lmaxes = 500, 2500, (500, 512)
+    elif shape == "fixed511":
+        seqlen, nrec, lmaxes = 511, 2500, (511, 512)
+    elif shape == "ragged511":
+        seqlen, nrec, lmaxes = (lambda i: int(rng.integers(0, 512))), 5000, (511, 512)
+    elif shape == "crlf300":
+        seqlen, nrec, lmaxes, kw = 300, 3000, (300, 400), {"crlf": 0.3}
+    elif shape == "mixed":      # batches of eight hold lines on both sides of every step boundary
+        seqlen, nrec, lmaxes = (lambda i: int(rng.choice([100, 150, 255, 256, 257, 259, 288, 300, 320, 383, 384, 385, 510, 511, 4, 1]))), 6000, (511,)
+    elif shape == "plusid300":
+        seqlen, nrec, lmaxes, kw = 300, 3000, (300,), {"plus_id": True, "hdr": lambda i: b"M01234:56:000000000-ABCDE:1:1101:%05d:%05d 1:N:0:1" % (i * 7 % 30000, i * 3 % 30000)}
+    else:
+        seqlen, nrec, lmaxes = (lambda i: 0 if i % 5 == 0 else 300), 4000, (300,)
+    data = make(rng, nrec, seqlen, **kw)
+    for lmax in lmaxes:
+        run(env, fqref, data, lmax, want_fused=True)
+    run(env, fqref, data, lmaxes[0], want_fused=True, offsets=True)
+
+
+@pytest.mark.parametrize("shape", ["dirty_both_halves", "few_longer_than_lmax", "lines_of_512_and_more"])
+def test_declined_counts_beyond_256_columns(env, fqref, shape):
+    """... and what that pass does not count itself goes the same ways as below the 256th column: batches with a byte outside the
+    alphabets are dumped with all sixteen steps (k_stats_declined counts them in two windows of 256 rows), lines beyond lmax are
+    listed; a line of 512 columns or more is listed if the kept tail still holds its beginning and sends the histograms to a
+    second pass if not.  The scan's result stands either way."""
+    torch, pkg = env
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
+    lmax, route = 300, 2
+    if shape == "dirty_both_halves":
+        recs = [bytearray(make(rng, 1, 300, hdr=lambda i: b"r%d" % j)) for j in range(3000)]
+        for j in rng.choice(3000, 300, replace=False):
+            r = recs[j]
+            h = r.index(b"\n") + 1
+            col = int(rng.choice([0, 1, 3, 100, 255, 256, 257, 258, 259, 287, 288, 296, 299]))
+            if rng.random() < 0.5:
+                r[h + col] = int(rng.choice(np.frombuffer(b"acgtnRYKM.-*", dtype=np.uint8)))
+            else:
+                r[h + 301 + 2 + col] = int(rng.choice([97, 105, 126, 125, 200, 255, 0, 32]))
+        data = b"".join(bytes(r) for r in recs)
+    elif shape == "few_longer_than_lmax":
+        data = make(rng, 3000, lambda i: 420 if i % 400 == 7 else 300)
+    else:
+        data = make(rng, 3000, lambda i: int(rng.choice([512, 513, 600])) if i % 300 == 11 else 300)
+        lmax, route = 512, -1        # (listed or declined, by where the line happens to lie in its 4 KiB group)
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        for _ in range(2):
+            run_ctx(torch, pkg, ctx, fqref, data, lmax, True, False, want_route=route)
+        if route < 0:
+            assert ctx.last_stats_route() in (0, 2)
+        a = np.frombuffer(data, dtype=np.uint8)
+        d = torch.from_numpy(a.copy()).cuda()
+        s = ctx.scan(d.data_ptr(), a.size)[0]
+        assert ctx.last_scan_fast() and s.parse_status == pkg.OK
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("shape", ["lowercase", "qual_high", "both_many", "few_long", "crlf_dirty", "lmax_short", "long_reads"])

@@ -68,10 +68,17 @@ constexpr uint32_t FZ_GLIST = 251;                  // line starts per group tha
 constexpr uint32_t FZ_RS = 256;                    // record starts of a tile staged in LDS (4 x 251 entries / 4, rounded)
 constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 16 + FZ_RS * 2 + (4 + FZ_GLIST + 1) * 2;  // 6160
 constexpr uint32_t FZ_SLACK = 1024;                 // a batch reads up to 32 NSL + 32 bytes past a line's start (NSL 16: 544)
-// The PACKED instance (reads of 257 .. 511 columns): 512 rows x 64 quality bins of 32-bit counters are 128 KiB
-// — no room for the wavefronts' areas — so two rows share a word, 16-bit counters: step U of a line (columns 32 U ..) counts in
-// half U & 1 of the word that step U & ~1 uses, and the histogram has the geometry of the 256-row instance (a row block of
-// 128 columns: slot bit 5 = (U >> 1) & 1).  A counter may not pass 65 535 between two flushes: a span holds at most
+// The WIDE instance (reads of 257 .. 511 columns).  Two things change against the 256-row instance, whose
+// registers and wavefront count (12) it keeps:
+//   * SIXTEEN lanes walk a line, 64 columns per step, four lines per batch: eight steps cover 512 columns with the same eight
+//     words per lane, and a batch stops at the last step any of its lines reaches (five steps for 300 columns: 94 % of the
+//     lane-dwords it issues are bytes of a line; eight lanes per line and sixteen steps of 32 — measured — need 246 registers,
+//     eight wavefronts, and ran the 300-column file at 1.55 TB/s, below the two-read route).  Lane (line slot g, dword m) adds
+//     byte j = k ^ (g & 1) at its k-th atomic: row 64 u + 4 m + j, slot m + 16 j — the two line slots of a lane group differ in
+//     j & 1, so its 32 lanes sit on the 32 banks (m + 16 j) % 32 whatever the bins are;
+//   * 512 rows x 64 quality bins of 32-bit counters are 128 KiB — no room for the wavefronts' areas — so two rows share a word,
+//     16-bit counters: step u counts in half u & 1 of its word, a row block (u >> 1) holds 128 columns, and the histogram has
+//     the geometry (72 KiB) of the 256-row instance.  A counter may not pass 65 535 between two flushes: a span holds at most
 // 4 tiles x 4 groups x 251 line starts / 4 = 1 004 records (denser input marks the span bad), so the block's wavefronts walk
 // FZ_EPOCH spans each, meet at a barrier, add the 16-bit halves to the block's 32-bit rows in scratch, clear the LDS and go on.
 __host__ __device__ constexpr uint32_t fz_epoch(uint32_t waves) { return 65535u / (1004u * waves); }
@@ -102,8 +109,8 @@ __host__ __device__ __forceinline__ uint32_t fz_spans(uint64_t n_tiles, uint64_t
 constexpr uint32_t FZ_P_ACT = 0x1000u;
 
 struct FzLane {              // what a lane needs to read and count lines; constant over the kernel
-    uint32_t wm4;            // LDS address of the wave's data area + 4 * (lane % 8)
-    uint32_t m, g8, g16;     // lane % 8, lane / 8, 16 * (lane / 8)
+    uint32_t wm4;            // LDS address of the wave's data area + 4 * m
+    uint32_t m, g8, g16;     // the lane's dword of its line (lane % 8; WIDE: lane % 16), its line slot in the batch (lane / 8; WIDE: lane / 16), 16 * slot
     SoLane c;                // the bank schedule's selectors and slot offsets
 };
 
@@ -124,14 +131,15 @@ struct FzShape {
     uint32_t cm[NSL];        // check mask of this lane's dword at step u; also the value of its atomics (0 / ~0) in all steps but tus
     uint32_t tv[4];          // what the k-th atomic ADDS (1: byte k ^ (g & 3) counts) at step tus / in the pass of the partial dwords
     uint32_t tb, tu;         // ragged mode: byte mask of the lane's partial dword (0: none) and its step
-    uint32_t mode;           // wave-uniform: bits 0-7 tus (0xFF: ragged), bit 8: some line ends in a partial dword
+    uint32_t mode;           // wave-uniform: bits 0-7 tus (0xFF: ragged), bit 8: some line ends in a partial dword, bits 16-19: steps to issue
 };
-template <uint32_t NSL>
+template <uint32_t NSL, bool WIDE>
 __device__ __forceinline__ void fz_shape(FzShape<NSL> &S, uint32_t P, uint32_t m) {
+    constexpr uint32_t CPS = WIDE ? 64u : 32u;   // columns per step
     S.key = P & 0xFFFFu;
     const uint32_t len = P & 0x1FFu;
     const uint32_t nfull4 = len & ~3u, nbt = len & 3u;
-    const uint32_t tu = nfull4 >> 5, mt = (nfull4 >> 2) & 7u, g3 = (__lane_id() >> 3) & 3u;
+    const uint32_t tu = nfull4 / CPS, mt = (nfull4 >> 2) & (CPS / 4u - 1u), g3 = WIDE ? (__lane_id() >> 4) & 1u : (__lane_id() >> 3) & 3u;
     const unsigned long long tl = __ballot(nbt != 0);
     uint32_t tus = 0xFFu;
     if (tl) {
@@ -145,14 +153,22 @@ __device__ __forceinline__ void fz_shape(FzShape<NSL> &S, uint32_t P, uint32_t m
     const uint32_t pmask = (nbt && m == mt) ? (1u << (8u * nbt)) - 1u : 0u;  // this lane's partial dword (at step tu)
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u)
-        S.cm[u] = tt > (int)(32u * u) ? 0xFFFFFFFFu : (uni && tu == u) ? pmask : 0u;
-    const bool whole_at_tus = uni && tus < NSL && tt > (int)(32u * tus);
+        S.cm[u] = tt > (int)(CPS * u) ? 0xFFFFFFFFu : (uni && tu == u) ? pmask : 0u;
+    const bool whole_at_tus = uni && tus < NSL && tt > (int)(CPS * tus);
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         S.tv[k] = (whole_at_tus || (nbt && m == mt && (k ^ g3) < nbt)) ? 1u : 0u;
     S.tb = uni ? 0u : pmask;
     S.tu = nbt ? tu : 0u;
-    S.mode = tus | (tl ? 0x100u : 0u);
+    // WIDE: bits 16-19 the steps this batch has to issue (the last one any of its lines reaches, partial dwords included)
+    uint32_t nst = NSL;
+    if (WIDE) {
+        nst = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < NSL; ++u)
+            if (__ballot((int)len > (int)(CPS * u)) != 0) nst = u + 1;
+    }
+    S.mode = tus | (tl ? 0x100u : 0u) | (nst << 16);
 }
 
 // four atomics of one step: ds_sub_u32 of v_k at the address byte k of the bins gives, `off` in the instruction's immediate
@@ -187,26 +203,39 @@ __device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &
 }
 
 // byte offset (the instruction's immediate) of step u's rows: region, row block, half of the 256-byte bin row
-template <bool PACK>
+template <bool WIDE>
 __host__ __device__ constexpr uint32_t fz_off(uint32_t region, uint32_t rb, uint32_t u) {
-    return PACK ? region + ((u >> 1) & 1u) * 128u + (u >> 2) * rb : region + (u & 1u) * 128u + (u >> 1) * rb;
+    return WIDE ? region + (u >> 1) * rb : region + (u & 1u) * 128u + (u >> 1) * rb;
 }
-template <bool IS_SEQ, uint32_t NSL, bool PACK>
+__device__ __forceinline__ uint32_t so_groups16(unsigned long long lanes) {  // 16-lane groups with a lane set
+    lanes |= lanes >> 8;
+    lanes |= lanes >> 4;
+    lanes |= lanes >> 2;
+    lanes |= lanes >> 1;
+    return (uint32_t)__builtin_popcountll(lanes & 0x0001000100010001ull);
+}
+template <bool IS_SEQ, uint32_t NSL, bool WIDE>
 __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const FzLane &L, SoTotals &T, bool &bad, const FusedArgs &z) {
     (void)bad;  // (not written any more: a batch the kernel will not count is dumped.  The parameter stays: without it the register
                 // allocator spills 116 instead of 21 vector registers around the tile loop — tools/isa.sh)
     const SoLane &c = L.c;
-    if (__ballot((B.P & 0xFFFFu) != S.key) != 0) fz_shape<NSL>(S, B.P, L.m);
+    constexpr bool PACK = WIDE;   // (the wide instance is the packed one)
+    if (__ballot((B.P & 0xFFFFu) != S.key) != 0) fz_shape<NSL, WIDE>(S, B.P, L.m);
     constexpr uint32_t RB = IS_SEQ ? 2048u : 16384u;
     constexpr uint32_t REGION = IS_SEQ ? 0u : SO_SBYTES;
     const uint32_t mode = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.mode);
     const uint32_t tus = mode & 0xFFu;
+    const uint32_t nst = WIDE ? mode >> 16 : NSL;   // (wave-uniform) steps behind the last line's end are not issued
     const bool ragged_tails = tus == 0xFFu;
     uint32_t chk = 0, orw = 0, pt = 0;
     if (ragged_tails) {  // lines of different lengths in one batch: each lane picks the step of its line's partial dword
         uint32_t x = B.w[0];
 #pragma unroll
-        for (uint32_t u = 1; u < NSL; ++u) x = S.tu == u ? B.w[u] : x;
+        for (uint32_t u = 1; u < NSL; ++u) {
+            x = S.tu == u ? B.w[u] : x;
+            if (WIDE) asm volatile("" : "+v"(x));   // (a select per step: taken together the compiler makes them ONE indexed load — of a
+                                                    // batch it then keeps in scratch memory, 80 bytes per lane, stored to at every update)
+        }
         if (IS_SEQ) {
             pt = x & 0x07070707u;
             chk |= (x ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pt)) & S.tb;
@@ -218,15 +247,17 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
     }
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
-        const uint32_t w = B.w[u], f = S.cm[u];
-        if (IS_SEQ) {
-            const uint32_t bins = w & 0x07070707u;
-            chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;
-            orw |= w & f;
-        } else {
-            const uint32_t t = w - 0x21212121u;  // byte - 33 < 64 for all four bytes <=> bits 6-7 clear (stats_dev.h)
-            chk |= t & f;
-            B.w[u] = t;
+        if (!WIDE || u < nst) {   // (a guard, not a break: the loop stays unrolled and the batch's words stay in registers)
+            const uint32_t w = B.w[u], f = S.cm[u];
+            if (IS_SEQ) {
+                const uint32_t bins = w & 0x07070707u;
+                chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;
+                orw |= w & f;
+            } else {
+                const uint32_t t = w - 0x21212121u;  // byte - 33 < 64 for all four bytes <=> bits 6-7 clear (stats_dev.h)
+                chk |= t & f;
+                B.w[u] = t;
+            }
         }
     }
     if (__ballot(IS_SEQ ? chk != 0 : (chk & 0xC0C0C0C0u) != 0) != 0) {
@@ -235,11 +266,12 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
     }
 #pragma unroll
     for (uint32_t u = 0; u < NSL; ++u) {
+        if (WIDE && u >= nst) continue;   // (not a break: the loop stays unrolled, the batch's words stay in registers)
         const uint32_t pb = IS_SEQ ? B.w[u] & 0x07070707u : B.w[u];
         // PACK: an odd step counts in the upper half of its word (subtracting 0xFFFF0000 adds 0x10000)
         const uint32_t f = (PACK && (u & 1u)) ? S.cm[u] & 0xFFFF0000u : S.cm[u];
         // (the row block and slot half go into the instruction's immediate offset)
-        const uint32_t off_u = fz_off<PACK>(REGION, RB, u);
+        const uint32_t off_u = fz_off<WIDE>(REGION, RB, u);
         if (u == tus) {  // (wave-uniform) the step that also holds the partial last dwords: per-byte values.  ADDs of 0 / 1, so
             // that the compiler cannot merge the two arms into one with four v_mov / v_cndmask per step in front of it
 #pragma unroll
@@ -251,7 +283,7 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
         }
     }
     if (ragged_tails) {
-        const uint32_t off = PACK ? REGION + (((S.tu >> 1) & 1u) << 7) + (S.tu >> 2) * RB : REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
+        const uint32_t off = WIDE ? REGION + (S.tu >> 1) * RB : REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
         const uint32_t sh = PACK ? (S.tu & 1u) << 4 : 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -260,7 +292,7 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
     }
     if (IS_SEQ) {  // sequence lines with an 'N' (bit 3 is set in 'N' only): the 8 lanes of a line OR their flags
         const unsigned long long bn = __ballot((orw & 0x08080808u) != 0);
-        if (bn) T.not_dna += so_groups(bn);
+        if (bn) T.not_dna += WIDE ? so_groups16(bn) : so_groups(bn);
     }
 }
 
@@ -275,11 +307,11 @@ template <uint32_t NSL>
 struct FzRaw {
     fz_u32x2 v[NSL];
 };
-template <uint32_t NSL>
+template <uint32_t NSL, bool WIDE>
 __device__ __forceinline__ void fz_issue(const FzBatch<NSL> &B, FzRaw<NSL> &R, const FzLane &L, const uint8_t *lds8) {
     const uint32_t la = L.wm4 + ((B.P >> 16) & ~3u);
 #pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) R.v[u] = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + 32u * u);
+    for (uint32_t u = 0; u < NSL; ++u) R.v[u] = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + (WIDE ? 64u : 32u) * u);
 }
 template <uint32_t NSL>
 __device__ __forceinline__ void fz_align(FzBatch<NSL> &B, const FzRaw<NSL> &R) {
@@ -290,31 +322,32 @@ __device__ __forceinline__ void fz_align(FzBatch<NSL> &B, const FzRaw<NSL> &R) {
 struct FzKind {          // one kind's lines of the chunk
     uint32_t l0, n;      // lanes l0, l0 + 4, ..: n lines
 };
-template <uint32_t NSL, bool PACK>
+template <uint32_t NSL, bool WIDE>
 __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKind ks, FzBatch<NSL> &PBq, uint32_t &nfq, FzKind kq,
                                           uint32_t Pent, bool flush, const FzLane &L, const uint8_t *lds8, FzShape<NSL> &S,
                                           SoTotals &T, bool &bad, const FusedArgs &z, bool do_count) {
-    const uint32_t q0s = nfs, tots = q0s + ks.n, nbs = tots >> 3, rems = tots & 7u, nits = nbs + ((rems && flush) ? 1u : 0u);
-    const uint32_t q0q = nfq, totq = q0q + kq.n, nbq = totq >> 3, remq = totq & 7u, nitq = nbq + ((remq && flush) ? 1u : 0u);
+    constexpr uint32_t LPB = WIDE ? 4u : 8u, LPB_SH = WIDE ? 2u : 3u;   // lines per batch
+    const uint32_t q0s = nfs, tots = q0s + ks.n, nbs = tots >> LPB_SH, rems = tots & (LPB - 1u), nits = nbs + ((rems && flush) ? 1u : 0u);
+    const uint32_t q0q = nfq, totq = q0q + kq.n, nbq = totq >> LPB_SH, remq = totq & (LPB - 1u), nitq = nbq + ((remq && flush) ? 1u : 0u);
     const uint32_t nbm = nbs > nbq ? nbs : nbq;
     int is0 = -(int)q0s, iq0 = -(int)q0q;  // slot g8 of batch b takes new line i = 8 b - q0 + g8, held by lane l0 + 4 i
     uint32_t Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)is0 + L.g16), (int)Pent);
     uint32_t Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)iq0 + L.g16), (int)Pent);
-    for (uint32_t b = 0; b <= nbm; ++b, is0 += 8, iq0 += 8) {
+    for (uint32_t b = 0; b <= nbm; ++b, is0 += (int)LPB, iq0 += (int)LPB) {
         const bool act_s = b <= nbs, act_q = b <= nbq;  // (wave-uniform) the kind still assembles a batch in this iteration
         const bool news = act_s && (uint32_t)(is0 + (int)L.g8) < ks.n;  // (a negative index wraps: the unsigned compare rejects it)
         const bool newq = act_q && (uint32_t)(iq0 + (int)L.g8) < kq.n;
         if (act_s && (b != 0 || L.g8 >= q0s)) PBs.P = news ? Pns : 0u;  // (slots below q0 of the first batch keep their lines)
         if (act_q && (b != 0 || L.g8 >= q0q)) PBq.P = newq ? Pnq : 0u;
         FzRaw<NSL> Rs, Rq;
-        if (news) fz_issue<NSL>(PBs, Rs, L, lds8);
-        if (newq) fz_issue<NSL>(PBq, Rq, L, lds8);
-        Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)(is0 + 8) + L.g16), (int)Pent);
-        Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)(iq0 + 8) + L.g16), (int)Pent);
+        if (news) fz_issue<NSL, WIDE>(PBs, Rs, L, lds8);
+        if (newq) fz_issue<NSL, WIDE>(PBq, Rq, L, lds8);
+        Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)(is0 + (int)LPB) + L.g16), (int)Pent);
+        Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)(iq0 + (int)LPB) + L.g16), (int)Pent);
         if (news) fz_align<NSL>(PBs, Rs);
-        if (act_s && b < nits && do_count) fz_count<true, NSL, PACK>(PBs, S, L, T, bad, z);
+        if (act_s && b < nits && do_count) fz_count<true, NSL, WIDE>(PBs, S, L, T, bad, z);
         if (newq) fz_align<NSL>(PBq, Rq);
-        if (act_q && b < nitq && do_count) fz_count<false, NSL, PACK>(PBq, S, L, T, bad, z);
+        if (act_q && b < nitq && do_count) fz_count<false, NSL, WIDE>(PBq, S, L, T, bad, z);
     }
     nfs = flush ? 0u : rems;
     nfq = flush ? 0u : remq;
@@ -326,8 +359,9 @@ __device__ __attribute__((noinline)) uint4 fz_load16_tail(const uint8_t *__restr
     return load16(buf, off, len);
 }
 
-template <uint32_t NSL, uint32_t FZ_WAVES, bool PACK>
+template <uint32_t NSL, uint32_t FZ_WAVES, bool WIDE>
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
+    constexpr bool PACK = WIDE;
     constexpr uint32_t FZ_THREADS = FZ_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const uint32_t lc = z.lc;
@@ -342,16 +376,16 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wbase = wb0 + wv * FZ_WAVE_BYTES;  // LDS address of y = 0 of the wave's data area
     FzLane L;
-    L.m = lane & 7u;
+    L.m = WIDE ? lane & 15u : lane & 7u;
     L.wm4 = wbase + L.m * 4u;
-    L.g8 = lane >> 3;
+    L.g8 = WIDE ? lane >> 4 : lane >> 3;
     L.g16 = L.g8 * 16u;
     L.c.slots = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
-        const uint32_t j = k ^ (L.g8 & 3u);
+        const uint32_t j = k ^ (WIDE ? L.g8 & 1u : L.g8 & 3u);
         L.c.sel[k] = 0x0C0C0004u + k + (j << 8);
-        L.c.slots |= ((L.m + 8u * j) * 4u) << (8u * k);
+        L.c.slots |= ((WIDE ? L.m + 16u * j : L.m + 8u * j) * 4u) << (8u * k);
     }
     uint8_t *const wptr = lds8 + wbase + FZ_TAIL + 16u * lane;      // chunk 64 j + lane of the group: + 1024 j
     const uint32_t rbase = wbase + FZ_TAIL + 64u * lane;            // this lane's 64 contiguous bytes
@@ -706,7 +740,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
                             const bool cnt = !FZ_DBG(2u);
                             FZ_T(5);
-                            fz_lines2<NSL, PACK>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, z, cnt);
+                            fz_lines2<NSL, WIDE>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, z, cnt);
                             FZ_T(4);  // lines: lookups, reads, counts
                         }
                     }
@@ -841,8 +875,8 @@ __global__ __launch_bounds__(256) void k_stats_commit(const DevOut *__restrict__
     else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
 }
 
-// ... and the packed instance's rows: the blocks' 32-bit rows in scratch, [2 i + h] = half h of LDS word i (k_scan_stats<16, .., true>:
-// step U of a line counts in half U & 1, slot bit 5 = (U >> 1) & 1, row block U >> 2 of 128 columns)
+// ... and the wide instance's rows: the blocks' 32-bit rows in scratch, [2 i + h] = half h of LDS word i (k_scan_stats<8, 12, true>:
+// step u of a line — 64 columns — counts in half u & 1 of row block u >> 1, slot m + 16 j for row 64 u + 4 m + j)
 __global__ __launch_bounds__(256) void k_stats_commit_packed(const DevOut *__restrict__ out, const uint32_t *__restrict__ scratch,
                                                              uint32_t n_blocks, uint32_t lc, const unsigned long long *__restrict__ src_scalars,
                                                              unsigned long long *__restrict__ qual_hist,
@@ -858,7 +892,7 @@ __global__ __launch_bounds__(256) void k_stats_commit_packed(const DevOut *__res
     const uint32_t rb = isq ? r >> 12 : r >> 9;
     const uint32_t bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
     const uint32_t slot = r & 63u;
-    const uint32_t row = rb * 128u + ((slot >> 5) & 1u) * 64u + half * 32u + (slot & 7u) * 4u + ((slot >> 3) & 3u);
+    const uint32_t row = rb * 128u + half * 64u + (slot & 15u) * 4u + (slot >> 4);
     if (row >= lc) return;
     const uint32_t b0 = blockIdx.y * RED_GROUP;
     const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
@@ -965,12 +999,12 @@ constexpr uint32_t DECL_BINS = 264;               // per row: base classes 0..7,
 constexpr uint32_t DECL_LINES_PER_BLOCK = 60000;  // (16-bit counters)
 __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restrict__ out, const uint32_t *__restrict__ decl_b, uint32_t nsl,
                                                         const uint64_t *__restrict__ decl_l, uint32_t cap, const uint8_t *__restrict__ buf,
-                                                        uint32_t lmax, uint32_t lc, uint32_t row0, uint32_t rows,
+                                                        uint32_t lmax, uint32_t lc, uint32_t row0, uint32_t rows, uint32_t wide,
                                                         unsigned long long *__restrict__ qual_hist,
                                                         unsigned long long *__restrict__ base_hist, unsigned long long *__restrict__ scalars) {
     // lc: the rows the caller's arrays and the single pass share; this launch counts columns row0 .. row0 + rows - 1 of them (a
     // window of at most 256 rows fits the LDS; the launch with row0 == 0 also settles the lines' alphabet verdicts and the
-    // columns beyond lc)
+    // columns beyond lc); wide: the batches were dumped by the wide instance (sixteen lanes per line, 64 columns per step)
     if (!out->stats_commit) return;
     const uint32_t nb = (uint32_t)(out->decl_b < cap ? out->decl_b : cap), nl = (uint32_t)(out->decl_l < cap ? out->decl_l : cap);
     if (!nb && !nl) return;
@@ -983,7 +1017,7 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
         atomicAdd(&dh[i >> 1], 1u << (16u * (i & 1u)));
     };
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t m = lane & 7u;
+    const uint32_t m = wide ? lane & 15u : lane & 7u, cps = wide ? 64u : 32u;
     for (uint32_t sidx = wave; sidx < nb; sidx += nw) {
         const uint32_t *src = decl_b + (uint64_t)sidx * ((1u + nsl) * 64u) + lane;
         const uint32_t P = src[0];
@@ -993,7 +1027,7 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
         for (uint32_t u = 0; u < nsl; ++u) {
             const uint32_t w = src[64u * (1u + u)];
             for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t col = 32u * u + 4u * m + j;
+                const uint32_t col = cps * u + 4u * m + j;
                 if (!act || col >= n || col >= lc) continue;   // (n <= lmax: longer lines are listed, not batched)
                 const uint32_t b = (w >> (8u * j)) & 0xFFu;
                 const bool mine = col - row0 < rows;
@@ -1009,7 +1043,8 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
         }
         const unsigned long long bi = __ballot(inv != 0), bn = __ballot(hasn != 0);
         if (m == 0 && act && !isq && row0 == 0) {
-            const bool li = ((bi >> lane) & 0xFFull) != 0, ln = ((bn >> lane) & 0xFFull) != 0;
+            const unsigned long long gm = wide ? 0xFFFFull : 0xFFull;   // (the lanes of this line)
+            const bool li = ((bi >> lane) & gm) != 0, ln = ((bn >> lane) & gm) != 0;
             if (li || ln) atomicAdd(&scalars[3], ~0ull);
             if (li) atomicAdd(&scalars[4], ~0ull);
         }
@@ -1071,7 +1106,7 @@ hipError_t prepare_stats_declined(uint32_t lmax) {
 }
 uint32_t scan_stats_nsl(uint32_t lmax) {
     const uint32_t steps = (fz_lc(lmax) + 31) / 32;
-    return steps <= 5 ? 5u : steps <= 8 ? 8u : 16u;
+    return steps <= 5 ? 5u : 8u;   // (beyond 256 rows: the wide instance's eight steps of 64 columns)
 }
 void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
                            unsigned long long *base_hist, unsigned long long *scalars) {
@@ -1084,7 +1119,7 @@ void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z,
     for (uint32_t row0 = 0; row0 < lc; row0 += SO_LC_MAX) {   // (windows of 256 rows: what the LDS holds)
         const uint32_t rows = std::min<uint32_t>(lc - row0, SO_LC_MAX);
         hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(1024), (size_t)rows * DECL_BINS * 2, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap,
-                           z.buf, z.lmax, lc, row0, rows, qual_hist, base_hist, scalars);
+                           z.buf, z.lmax, lc, row0, rows, lc > SO_LC_MAX ? 1u : 0u, qual_hist, base_hist, scalars);
     }
 }
 
@@ -1105,7 +1140,7 @@ size_t scan_stats_scratch_bytes(int n_cu) { return (size_t)stats_blocks(n_cu) * 
 #endif
 template <uint32_t NSL, uint32_t FZ_WAVES, bool PACK = false>
 static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t blocks) {
-    constexpr uint32_t HNSL = PACK ? NSL / 2 : NSL;   // (packed: the histogram's geometry is that of half the steps)
+    constexpr uint32_t HNSL = NSL;   // (wide + packed: eight steps of 64 columns in the geometry of eight steps of 32)
     z.wave_base = SO_SBYTES + ((HNSL + 1) / 2) * 16384u;
     const size_t lds = (size_t)z.wave_base + (size_t)FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK;
     static_assert(SO_SBYTES + ((HNSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES + FZ_SLACK <= SO_LDS_MAX, "LDS budget");
@@ -1136,7 +1171,7 @@ hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
     const uint32_t nsl = (z.lc + 31) / 32;
     hipError_t e = nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks)
                  : nsl <= 8 ? launch_scan_stats_n<8, 12>(s, z, blocks)
-                            : launch_scan_stats_n<16, FQH_FZ_WP, true>(s, z, blocks);
+                            : launch_scan_stats_n<8, FQH_FZ_WP, true>(s, z, blocks);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

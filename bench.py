@@ -294,7 +294,7 @@ def main():
         live = pmc_traffic(nbytes)
         if live:
             traffic, traffic_source = live["hbm_bytes_per_launch"], live["source"]
-    for prof in ("round4_rocprof.json", "round3_rocprof.json"):
+    for prof in ("round5_rocprof.json", "round4_rocprof.json", "round3_rocprof.json"):
         try:
             with open(os.path.join(ROOT, "profiles", prof)) as f:
                 pj = json.load(f)

@@ -202,6 +202,37 @@ __device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &
     for (uint32_t u = 0; u < NSL; ++u) dst[64u * (1u + u)] = IS_SEQ ? B.w[u] : B.w[u] + 0x21212121u;  // (quality dwords were rebased in place)
 }
 
+// Steps 0 .. n - 1 of a batch, each a call of f(integral_constant<u>).  The 8 x 32 instances issue every step (unrolled); the wide
+// instance stops at the last step some line of the batch reaches — ONE jump into a fall-through switch, highest step first, not
+// a compare and branch per step (steps commute: pass 1 ORs, pass 2 adds).
+template <uint32_t U>
+struct FzStep { static constexpr uint32_t value = U; };
+template <uint32_t U, uint32_t N, class F>
+__device__ __forceinline__ void fz_steps_all(F &f) {
+    if constexpr (U < N) {
+        f(FzStep<U>{});
+        fz_steps_all<U + 1, N>(f);
+    }
+}
+template <uint32_t NSL, bool WIDE, class F>
+__device__ __forceinline__ void fz_steps(uint32_t n, F &&f) {
+    if constexpr (!WIDE) {
+        fz_steps_all<0, NSL>(f);
+    } else {
+        static_assert(NSL == 8, "the wide instance has eight steps");
+        switch (n) {
+        default: f(FzStep<7>{}); [[fallthrough]];
+        case 7: f(FzStep<6>{}); [[fallthrough]];
+        case 6: f(FzStep<5>{}); [[fallthrough]];
+        case 5: f(FzStep<4>{}); [[fallthrough]];
+        case 4: f(FzStep<3>{}); [[fallthrough]];
+        case 3: f(FzStep<2>{}); [[fallthrough]];
+        case 2: f(FzStep<1>{}); [[fallthrough]];
+        case 1: f(FzStep<0>{}); [[fallthrough]];
+        case 0: break;
+        }
+    }
+}
 // byte offset (the instruction's immediate) of step u's rows: region, row block, half of the 256-byte bin row
 template <bool WIDE>
 __host__ __device__ constexpr uint32_t fz_off(uint32_t region, uint32_t rb, uint32_t u) {
@@ -245,33 +276,31 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
             chk |= pt & S.tb;
         }
     }
-#pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) {
-        if (!WIDE || u < nst) {   // (a guard, not a break: the loop stays unrolled and the batch's words stay in registers)
-            const uint32_t w = B.w[u], f = S.cm[u];
-            if (IS_SEQ) {
-                const uint32_t bins = w & 0x07070707u;
-                chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;
-                orw |= w & f;
-            } else {
-                const uint32_t t = w - 0x21212121u;  // byte - 33 < 64 for all four bytes <=> bits 6-7 clear (stats_dev.h)
-                chk |= t & f;
-                B.w[u] = t;
-            }
+    auto check_step = [&](auto U) {
+        constexpr uint32_t u = decltype(U)::value;
+        const uint32_t w = B.w[u], f = S.cm[u];
+        if (IS_SEQ) {
+            const uint32_t bins = w & 0x07070707u;
+            chk |= (w ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, bins)) & f;
+            orw |= w & f;
+        } else {
+            const uint32_t t = w - 0x21212121u;  // byte - 33 < 64 for all four bytes <=> bits 6-7 clear (stats_dev.h)
+            chk |= t & f;
+            B.w[u] = t;
         }
-    }
+    };
+    fz_steps<NSL, WIDE>(nst, check_step);
     if (__ballot(IS_SEQ ? chk != 0 : (chk & 0xC0C0C0C0u) != 0) != 0) {
         fz_dump<IS_SEQ, NSL>(B, z);
         return;
     }
-#pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) {
-        if (WIDE && u >= nst) continue;   // (not a break: the loop stays unrolled, the batch's words stay in registers)
+    auto count_step = [&](auto U) {
+        constexpr uint32_t u = decltype(U)::value;
         const uint32_t pb = IS_SEQ ? B.w[u] & 0x07070707u : B.w[u];
         // PACK: an odd step counts in the upper half of its word (subtracting 0xFFFF0000 adds 0x10000)
         const uint32_t f = (PACK && (u & 1u)) ? S.cm[u] & 0xFFFF0000u : S.cm[u];
         // (the row block and slot half go into the instruction's immediate offset)
-        const uint32_t off_u = fz_off<WIDE>(REGION, RB, u);
+        constexpr uint32_t off_u = fz_off<WIDE>(REGION, RB, u);
         if (u == tus) {  // (wave-uniform) the step that also holds the partial last dwords: per-byte values.  ADDs of 0 / 1, so
             // that the compiler cannot merge the two arms into one with four v_mov / v_cndmask per step in front of it
 #pragma unroll
@@ -281,7 +310,8 @@ __device__ __forceinline__ void fz_count(FzBatch<NSL> &B, FzShape<NSL> &S, const
         } else {
             fz_sub4_at<IS_SEQ>(off_u, c, pb, f, f, f, f);
         }
-    }
+    };
+    fz_steps<NSL, WIDE>(nst, count_step);
     if (ragged_tails) {
         const uint32_t off = WIDE ? REGION + (S.tu >> 1) * RB : REGION + ((S.tu & 1u) << 7) + (S.tu >> 1) * RB;
         const uint32_t sh = PACK ? (S.tu & 1u) << 4 : 0u;
@@ -307,17 +337,22 @@ template <uint32_t NSL>
 struct FzRaw {
     fz_u32x2 v[NSL];
 };
+// (nrd: the steps to read — all of them but in the wide instance, which reads up to the longest line it has met so far)
 template <uint32_t NSL, bool WIDE>
-__device__ __forceinline__ void fz_issue(const FzBatch<NSL> &B, FzRaw<NSL> &R, const FzLane &L, const uint8_t *lds8) {
+__device__ __forceinline__ void fz_issue(const FzBatch<NSL> &B, FzRaw<NSL> &R, const FzLane &L, const uint8_t *lds8, uint32_t nrd) {
     const uint32_t la = L.wm4 + ((B.P >> 16) & ~3u);
-#pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) R.v[u] = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + (WIDE ? 64u : 32u) * u);
+    fz_steps<NSL, WIDE>(nrd, [&](auto U) {
+        constexpr uint32_t u = decltype(U)::value;
+        R.v[u] = *reinterpret_cast<const fz_u32x2 *>(lds8 + la + (WIDE ? 64u : 32u) * u);
+    });
 }
-template <uint32_t NSL>
-__device__ __forceinline__ void fz_align(FzBatch<NSL> &B, const FzRaw<NSL> &R) {
+template <uint32_t NSL, bool WIDE>
+__device__ __forceinline__ void fz_align(FzBatch<NSL> &B, const FzRaw<NSL> &R, uint32_t nrd) {
     const uint32_t sh = (B.P >> 16) & 3u;
-#pragma unroll
-    for (uint32_t u = 0; u < NSL; ++u) B.w[u] = __builtin_amdgcn_alignbyte(R.v[u].y, R.v[u].x, sh);
+    fz_steps<NSL, WIDE>(nrd, [&](auto U) {
+        constexpr uint32_t u = decltype(U)::value;
+        B.w[u] = __builtin_amdgcn_alignbyte(R.v[u].y, R.v[u].x, sh);
+    });
 }
 struct FzKind {          // one kind's lines of the chunk
     uint32_t l0, n;      // lanes l0, l0 + 4, ..: n lines
@@ -325,7 +360,7 @@ struct FzKind {          // one kind's lines of the chunk
 template <uint32_t NSL, bool WIDE>
 __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKind ks, FzBatch<NSL> &PBq, uint32_t &nfq, FzKind kq,
                                           uint32_t Pent, bool flush, const FzLane &L, const uint8_t *lds8, FzShape<NSL> &S,
-                                          SoTotals &T, bool &bad, const FusedArgs &z, bool do_count) {
+                                          SoTotals &T, bool &bad, const FusedArgs &z, bool do_count, uint32_t &lmx) {
     constexpr uint32_t LPB = WIDE ? 4u : 8u, LPB_SH = WIDE ? 2u : 3u;   // lines per batch
     const uint32_t q0s = nfs, tots = q0s + ks.n, nbs = tots >> LPB_SH, rems = tots & (LPB - 1u), nits = nbs + ((rems && flush) ? 1u : 0u);
     const uint32_t q0q = nfq, totq = q0q + kq.n, nbq = totq >> LPB_SH, remq = totq & (LPB - 1u), nitq = nbq + ((remq && flush) ? 1u : 0u);
@@ -340,13 +375,27 @@ __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKi
         if (act_s && (b != 0 || L.g8 >= q0s)) PBs.P = news ? Pns : 0u;  // (slots below q0 of the first batch keep their lines)
         if (act_q && (b != 0 || L.g8 >= q0q)) PBq.P = newq ? Pnq : 0u;
         FzRaw<NSL> Rs, Rq;
-        if (news) fz_issue<NSL, WIDE>(PBs, Rs, L, lds8);
-        if (newq) fz_issue<NSL, WIDE>(PBq, Rq, L, lds8);
+        uint32_t nrd = NSL;
+        if (WIDE) {   // lmx (wave-uniform): the longest line this wavefront has met; steps behind it are neither read nor aligned
+            const uint32_t ls = news ? PBs.P & 0x1FFu : 0u, lq = newq ? PBq.P & 0x1FFu : 0u;
+            uint32_t ln = ls > lq ? ls : lq;
+            if (__ballot(ln > lmx) != 0) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)ln, d);
+                    ln = o > ln ? o : ln;
+                }
+                lmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)ln);
+            }
+            nrd = (lmx + 63u) >> 6;
+        }
+        if (news) fz_issue<NSL, WIDE>(PBs, Rs, L, lds8, nrd);
+        if (newq) fz_issue<NSL, WIDE>(PBq, Rq, L, lds8, nrd);
         Pns = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * ks.l0 + 16u * (uint32_t)(is0 + (int)LPB) + L.g16), (int)Pent);
         Pnq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * kq.l0 + 16u * (uint32_t)(iq0 + (int)LPB) + L.g16), (int)Pent);
-        if (news) fz_align<NSL>(PBs, Rs);
+        if (news) fz_align<NSL, WIDE>(PBs, Rs, nrd);
         if (act_s && b < nits && do_count) fz_count<true, NSL, WIDE>(PBs, S, L, T, bad, z);
-        if (newq) fz_align<NSL>(PBq, Rq);
+        if (newq) fz_align<NSL, WIDE>(PBq, Rq, nrd);
         if (act_q && b < nitq && do_count) fz_count<false, NSL, WIDE>(PBq, S, L, T, bad, z);
     }
     nfs = flush ? 0u : rems;
@@ -450,6 +499,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
         }
         __syncthreads();
     };
+    uint32_t lmx = 0;        // WIDE: the longest sequence / quality line this wavefront has met (columns)
     constexpr uint32_t EPOCH = fz_epoch(FZ_WAVES);
     uint32_t it = 0;         // PACK: spans this wavefront has begun (the block flushes when it is a multiple of EPOCH)
 
@@ -740,7 +790,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                             const bool flush = last_g && last_t && c0 + 64 >= totv;
                             const bool cnt = !FZ_DBG(2u);
                             FZ_T(5);
-                            fz_lines2<NSL, WIDE>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, z, cnt);
+                            fz_lines2<NSL, WIDE>(PBs, nfill_s, FzKind{ps, nls}, PBq, nfill_q, FzKind{pq0, nlq}, Pent, flush, L, lds8, S, T, span_bad, z, cnt, lmx);
                             FZ_T(4);  // lines: lookups, reads, counts
                         }
                     }
@@ -1106,7 +1156,7 @@ hipError_t prepare_stats_declined(uint32_t lmax) {
 }
 uint32_t scan_stats_nsl(uint32_t lmax) {
     const uint32_t steps = (fz_lc(lmax) + 31) / 32;
-    return steps <= 5 ? 5u : 8u;   // (beyond 256 rows: the wide instance's eight steps of 64 columns)
+    return steps <= 2 ? 2u : steps <= 5 ? steps : 8u;   // (beyond 256 rows: the wide instance's eight steps of 64 columns)
 }
 void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
                            unsigned long long *base_hist, unsigned long long *scalars) {
@@ -1169,7 +1219,12 @@ hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
 #endif
     const uint32_t blocks = scan_stats_blocks(z.n_tiles, n_cu);
     const uint32_t nsl = (z.lc + 31) / 32;
-    hipError_t e = nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks)
+    // (short reads, VERDICT r4 item 8: an instance issues all its steps for every batch, so rows of 36 .. 128 columns get
+    // instances of 2, 3 and 4 steps — at 50 bp three of the five steps of <5,16> count nothing)
+    hipError_t e = nsl <= 2 ? launch_scan_stats_n<2, FQH_FZ_W5>(s, z, blocks)
+                 : nsl == 3 ? launch_scan_stats_n<3, FQH_FZ_W5>(s, z, blocks)
+                 : nsl == 4 ? launch_scan_stats_n<4, FQH_FZ_W5>(s, z, blocks)
+                 : nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks)
                  : nsl <= 8 ? launch_scan_stats_n<8, 12>(s, z, blocks)
                             : launch_scan_stats_n<8, FQH_FZ_WP, true>(s, z, blocks);
     if (e != hipSuccess) return e;
@@ -1184,7 +1239,7 @@ void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, u
                            z.scratch, blocks, lc, z.scalars, qual_hist, base_hist, scalars);
         return;
     }
-    const uint32_t words = (SO_SBYTES + ((nsl <= 5 ? 5u : 8u) + 1) / 2 * 16384u) / 4;
+    const uint32_t words = (SO_SBYTES + (scan_stats_nsl(z.lmax) + 1) / 2 * 16384u) / 4;
     hipLaunchKernelGGL(k_stats_commit, dim3((words + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
                        z.scratch, blocks, lc, words, z.scalars, qual_hist, base_hist, scalars);
 }

@@ -169,8 +169,8 @@ bool classify(const uint64_t *all, int n_ranks, int rank, uint64_t file_len, Job
     for (int j = 0; j < n_ranks; ++j)
         if (W(j)[W_PHASE] != FQH_SHARD_EMPTY || (int32_t)W(j)[W_STATUS] > FQH_E_TOO_LONG) last_nonempty = j;
     uint64_t nl_before = 0;
-    bool have_anchor = true;   // a trusted anchor without an error lies in front (the start of the file is one: phase 0, a
-    uint64_t S = 0;            // record starts there): a gap begins behind its last complete record, at this file offset
+    // A trusted anchor without an error always lies in front: the start of the file is one (phase 0, a record starts there).
+    uint64_t S = 0;            // the open gap begins behind that anchor's last complete record, at this file offset
     bool dead = false;         // a trusted anchor (or a gap in front of one) holds an error of its own: nothing behind it matters
     bool poisoned = false;     // the true newline count is unknown from here on — an error lies in front, inside the open gap:
                                // nobody behind is an anchor any more, the open gap runs to the end of the file
@@ -181,7 +181,7 @@ bool classify(const uint64_t *all, int n_ranks, int rank, uint64_t file_len, Job
         if (status > FQH_E_TOO_LONG || status < 0) {  // this rank failed locally: the sequential reader would have failed here at the latest
             if (j == rank) {
                 job->failed = true;
-                job->fail_offset = have_anchor ? S : w[W_LO];
+                job->fail_offset = S;
             }
             dead = true;
             break;
@@ -194,7 +194,7 @@ bool classify(const uint64_t *all, int n_ranks, int rank, uint64_t file_len, Job
             if (trusted) {
                 if (j == rank) {
                     job->own = true;
-                    if (have_anchor && S < A) {
+                    if (S < A) {
                         job->gap = true;
                         job->gap_from = S;
                         job->gap_to = A;
@@ -204,7 +204,6 @@ bool classify(const uint64_t *all, int n_ranks, int rank, uint64_t file_len, Job
                     dead = true;
                     break;
                 }
-                have_anchor = true;
                 S = w[W_HI] - w[W_TAIL];
             }
         }
@@ -212,7 +211,7 @@ bool classify(const uint64_t *all, int n_ranks, int rank, uint64_t file_len, Job
         if (w[W_FLAGS] & FLAG_NL_INCOMPLETE) poisoned = true;
         nl_before += w[W_NEWLINES];
     }
-    if (!dead && have_anchor && S < file_len && rank == last_nonempty && !job->own) {
+    if (!dead && S < file_len && rank == last_nonempty && !job->own) {
         job->gap = true;
         job->gap_final = true;
         job->gap_from = S;

@@ -59,7 +59,10 @@ typedef enum {
  * bit-exact without seeing earlier bytes.  All-zero = start of file.  (The reference keeps the same
  * information implicitly in its 68 KiB window: src/lib.rs:255-303.) */
 typedef struct {
-    uint64_t base_offset; /* file offset of the chunk's first byte                               */
+    uint64_t base_offset; /* file offset of the chunk's first byte — the TRUE one whenever bufsize != 0: "Fastq record is
+                             too long" is judged on the record's file offset mod 16 (fqh_set_bufsize), for every chunk of a
+                             chain, not only the last; a driver that numbers its chunks from 0 sets bufsize 0 and applies
+                             the rule itself                                                     */
     uint64_t nl_count;    /* '\n' seen before the chunk (nl_count % 4 = line phase, / 4 = record) */
     uint64_t back[4];     /* back[i] = chunk_start - (i-th most recent line start <= chunk_start);
                              back[0] is the column of the chunk's first byte; starts older than
@@ -97,7 +100,10 @@ const char *fqh_strerror(fqh_status s); /* the reference's exact message strings
 const char *fqh_last_error(fqh_ctx *ctx);
 int fqh_abi_version(void);
 
-/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own.  Device memory handed to a
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the context's own.  The context's OWN stream is a
+ * blocking stream: every call on it is ordered, in both directions, against whatever the process does on the legacy null
+ * stream — safe for a host that never thinks about streams, and a hidden coupling for one that overlaps other null-stream work
+ * with its scans: such a host passes a stream of its own.  Device memory handed to a
  * call must be ready ON THAT STREAM: the context's own stream is a blocking one, i.e. ordered against work on the legacy null
  * stream (hipMemsetAsync(.., 0), torch's default stream) and against nothing else; work on any other stream needs an event or
  * a synchronize before the call, as for any kernel launch. */

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --pmc-traffic off --default-stream-gib 32"
-PMC_CMD="$CMD --no-stream"
+PMC_CMD="$CMD --no-stream --no-shard-stream"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -18,4 +18,4 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
 done
 # configs[3]: the streamed leg on its own, kernels AND memory copies (no counters in this pass)
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/stream -o stream -- python bench.py --stream-gib 32 --producer-threads 8 > $OUT/stream.log 2>&1
-python3 tools/prof_summary.py $OUT ${1:-round4}
+python3 tools/prof_summary.py $OUT ${1:-round5}

@@ -214,10 +214,28 @@ __device__ __forceinline__ void fz_steps_all(F &f) {
         fz_steps_all<U + 1, N>(f);
     }
 }
+// Measured and NOT taken (tools/build_variant.sh, 8 GiB of 300 / 500 bp reads): one jump into a fall-through switch of steps instead
+// of a compare per step: 2 011 / 2 199 GB/s against 2 078 / 2 262; reading only the steps the longest line so far reaches: 1 870 /
+// 2 042; both: 1 609 / 1 763.  Less work, slower code: the join points cost the waits more than the skipped steps save.
+#ifndef FQH_WIDE_SWITCH
+#define FQH_WIDE_SWITCH 0
+#endif
+#ifndef FQH_WIDE_NRD
+#define FQH_WIDE_NRD 0
+#endif
+template <uint32_t U, uint32_t N, class F>
+__device__ __forceinline__ void fz_steps_guard(uint32_t n, F &f) {
+    if constexpr (U < N) {
+        if (U < n) f(FzStep<U>{});
+        fz_steps_guard<U + 1, N>(n, f);
+    }
+}
 template <uint32_t NSL, bool WIDE, class F>
 __device__ __forceinline__ void fz_steps(uint32_t n, F &&f) {
-    if constexpr (!WIDE) {
+    if constexpr (!WIDE || NSL < 8) {   // (the instances of up to six steps issue all of them)
         fz_steps_all<0, NSL>(f);
+    } else if constexpr (!FQH_WIDE_SWITCH) {
+        fz_steps_guard<0, NSL>(n, f);
     } else {
         static_assert(NSL == 8, "the wide instance has eight steps");
         switch (n) {
@@ -387,7 +405,7 @@ __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKi
                 }
                 lmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)ln);
             }
-            nrd = (lmx + 63u) >> 6;
+            nrd = FQH_WIDE_NRD ? (lmx + 63u) >> 6 : NSL;
         }
         if (news) fz_issue<NSL, WIDE>(PBs, Rs, L, lds8, nrd);
         if (newq) fz_issue<NSL, WIDE>(PBq, Rq, L, lds8, nrd);
@@ -1145,8 +1163,19 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
         }
     }
 }
+#ifndef FQH_FZ_WP
+#define FQH_FZ_WP 12
+#endif
+#ifndef FQH_FZ_W6
+#define FQH_FZ_W6 16
+#endif
+#ifndef FQH_FZ_WIDE_FROM
+#define FQH_FZ_WIDE_FROM 160   // rows above this take a wide instance (sixteen lanes per line, packed counters); 256: rows 161 .. 256 through <8,12>
+#endif
 constexpr uint32_t FZ_LC_MAX = 511;   // rows of the packed instance: a line's length travels in nine bits, and the kept tail holds 511 bytes
 static uint32_t fz_lc(uint32_t lmax) { return lmax < FZ_LC_MAX ? lmax : FZ_LC_MAX; }
+// which rows take a wide (packed, sixteen lanes per line) instance
+static bool fz_is_wide(uint32_t lc) { return lc > FQH_FZ_WIDE_FROM; }
 static size_t stats_declined_lds(uint32_t lmax) { return (size_t)std::min<uint32_t>(fz_lc(lmax), SO_LC_MAX) * DECL_BINS * 2; }
 // The one thing about k_stats_declined that can fail, done BEFORE the single pass is enqueued: an error behind k_stats_commit
 // would leave the dumped batches and listed lines uncounted in a result that says it is complete.
@@ -1155,8 +1184,12 @@ hipError_t prepare_stats_declined(uint32_t lmax) {
     return attr.ensure(reinterpret_cast<const void *>(k_stats_declined), stats_declined_lds(lmax));
 }
 uint32_t scan_stats_nsl(uint32_t lmax) {
-    const uint32_t steps = (fz_lc(lmax) + 31) / 32;
-    return steps <= 2 ? 2u : steps <= 5 ? steps : 8u;   // (beyond 256 rows: the wide instance's eight steps of 64 columns)
+    const uint32_t lc = fz_lc(lmax), steps = (lc + 31) / 32;
+    if (fz_is_wide(lc)) {   // the wide instances' steps of 64 columns
+        const uint32_t ws = (lc + 63) / 64;
+        return ws <= 3 ? 3u : ws <= 6 ? ws : 8u;
+    }
+    return steps <= 2 ? 2u : steps <= 5 ? steps : 8u;
 }
 void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
                            unsigned long long *base_hist, unsigned long long *scalars) {
@@ -1169,7 +1202,7 @@ void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z,
     for (uint32_t row0 = 0; row0 < lc; row0 += SO_LC_MAX) {   // (windows of 256 rows: what the LDS holds)
         const uint32_t rows = std::min<uint32_t>(lc - row0, SO_LC_MAX);
         hipLaunchKernelGGL(k_stats_declined, dim3(blocks), dim3(1024), (size_t)rows * DECL_BINS * 2, s, out, z.decl_b, nsl, z.decl_l, z.decl_cap,
-                           z.buf, z.lmax, lc, row0, rows, lc > SO_LC_MAX ? 1u : 0u, qual_hist, base_hist, scalars);
+                           z.buf, z.lmax, lc, row0, rows, fz_is_wide(lc) ? 1u : 0u, qual_hist, base_hist, scalars);
     }
 }
 
@@ -1185,9 +1218,6 @@ uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu) {
 }
 size_t scan_stats_scratch_bytes(int n_cu) { return (size_t)stats_blocks(n_cu) * 2 * SO_WORDS * sizeof(uint32_t); }   // (the packed instance's rows: two per LDS word)
 
-#ifndef FQH_FZ_WP
-#define FQH_FZ_WP 12
-#endif
 template <uint32_t NSL, uint32_t FZ_WAVES, bool PACK = false>
 static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t blocks) {
     constexpr uint32_t HNSL = NSL;   // (wide + packed: eight steps of 64 columns in the geometry of eight steps of 32)
@@ -1198,7 +1228,7 @@ static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t block
     // row-block offset): inside the allocation, and harmless wherever it lands (stats_dev.h)
     static_assert(65536 + SO_SBYTES + 128 + ((HNSL - 1) / 2) * 16384u <= SO_SBYTES + ((HNSL + 1) / 2) * 16384u + FZ_WAVES * FZ_WAVE_BYTES,
                   "garbage addresses must stay inside the allocation");
-    static_assert(!PACK || (SO_SBYTES + ((HNSL + 1) / 2) * 16384u) / 4 == SO_WORDS, "the packed instance flushes SO_WORDS words");
+    static_assert(!PACK || (SO_SBYTES + ((HNSL + 1) / 2) * 16384u) / 4 <= SO_WORDS, "a packed instance flushes at most SO_WORDS words");
     static LdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(k_scan_stats<NSL, FZ_WAVES, PACK>), lds); e != hipSuccess) return e;
     if (PACK) {   // the blocks ADD to their rows in scratch, epoch by epoch
@@ -1221,20 +1251,34 @@ hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
     const uint32_t nsl = (z.lc + 31) / 32;
     // (short reads, VERDICT r4 item 8: an instance issues all its steps for every batch, so rows of 36 .. 128 columns get
     // instances of 2, 3 and 4 steps — at 50 bp three of the five steps of <5,16> count nothing)
-    hipError_t e = nsl <= 2 ? launch_scan_stats_n<2, FQH_FZ_W5>(s, z, blocks)
-                 : nsl == 3 ? launch_scan_stats_n<3, FQH_FZ_W5>(s, z, blocks)
-                 : nsl == 4 ? launch_scan_stats_n<4, FQH_FZ_W5>(s, z, blocks)
-                 : nsl <= 5 ? launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks)
-                 : nsl <= 8 ? launch_scan_stats_n<8, 12>(s, z, blocks)
-                            : launch_scan_stats_n<8, FQH_FZ_WP, true>(s, z, blocks);
+    hipError_t e;
+    if (fz_is_wide(z.lc)) {
+        // wide instances (sixteen lanes per line, 64 columns per step, packed counters): up to 384 columns (MiSeq 2 x 300) at the
+        // sixteen wavefronts of the 150 bp instance, up to 511 at twelve
+        const uint32_t ws = (z.lc + 63) / 64;
+        e = ws <= 3 ? launch_scan_stats_n<3, FQH_FZ_W5, true>(s, z, blocks)
+          : ws == 4 ? launch_scan_stats_n<4, FQH_FZ_W5, true>(s, z, blocks)
+          : ws == 5 ? launch_scan_stats_n<5, FQH_FZ_W5, true>(s, z, blocks)
+          : ws == 6 ? launch_scan_stats_n<6, FQH_FZ_W6, true>(s, z, blocks)
+                    : launch_scan_stats_n<8, FQH_FZ_WP, true>(s, z, blocks);
+    } else {
+        // (short reads, VERDICT r4 item 8: an instance issues all its steps for every batch, so rows of 36 .. 128 columns get
+        // instances of 2, 3 and 4 steps — at 50 bp three of the five steps of <5,16> count nothing)
+        e = nsl <= 2 ? launch_scan_stats_n<2, FQH_FZ_W5>(s, z, blocks)
+          : nsl == 3 ? launch_scan_stats_n<3, FQH_FZ_W5>(s, z, blocks)
+          : nsl == 4 ? launch_scan_stats_n<4, FQH_FZ_W5>(s, z, blocks)
+#if FQH_FZ_WIDE_FROM > 160   // (experiments only: rows 161 .. 256 through eight steps of 32 columns at twelve wavefronts)
+          : nsl > 5 ? launch_scan_stats_n<8, 12>(s, z, blocks)
+#endif
+                    : launch_scan_stats_n<5, FQH_FZ_W5>(s, z, blocks);
+    }
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, uint32_t blocks,
                          unsigned long long *qual_hist, unsigned long long *base_hist, unsigned long long *scalars) {
     const uint32_t lc = fz_lc(z.lmax);
-    const uint32_t nsl = (lc + 31) / 32;
-    if (nsl > 8) {
+    if (fz_is_wide(lc)) {
         hipLaunchKernelGGL(k_stats_commit_packed, dim3((2 * SO_WORDS + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
                            z.scratch, blocks, lc, z.scalars, qual_hist, base_hist, scalars);
         return;

@@ -803,8 +803,45 @@ class Coll:
         if uid is None:
             self.via_text += "; fqh_comm unavailable: %s" % why
             return
-        self.comm = pkg.Comm(ctx, world, rank, uid)
-        self.via_text = "fqh_comm (libfastq_hip.so's own RCCL binding, %d rank%s)" % (world, "" if world == 1 else "s")
+        # Every rank creates its end, runs the three collectives once on known values and says whether they came out right; one
+        # torch MIN over those verdicts decides for all: the library's binding, or torch.distributed for every rank (a binding
+        # that fails on the first node that ever gives it more than one rank must not cost that node's whole record).
+        ok, why = 1, None
+        try:
+            self.comm = pkg.Comm(ctx, world, rank, uid)
+            if world > 1 and not local:
+                mine = torch.tensor([rank + 1, 7], dtype=torch.int64, device=dev)
+                allv = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+                self.comm.allgather(mine.data_ptr(), allv.data_ptr(), 16)
+                tot = torch.tensor([rank + 1, 1], dtype=torch.int64, device=dev)
+                self.comm.allreduce_u64(tot.data_ptr(), 2)
+                low = torch.tensor([1000 + rank], dtype=torch.int64, device=dev)
+                self.comm.allreduce_min_u64(low.data_ptr(), 1)
+                self.comm.sync()
+                want = [x for r in range(world) for x in (r + 1, 7)]
+                if allv.cpu().tolist() != want or tot.cpu().tolist() != [world * (world + 1) // 2, world] or int(low.item()) != 1000:
+                    ok, why = 0, "self-test: wrong values (%s, %s, %s)" % (allv.cpu().tolist(), tot.cpu().tolist(), int(low.item()))
+        except Exception as e:   # FqhError, or anything the runtime throws
+            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+        if world > 1 and not local:
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, (ok, why))
+            bad = [(r, w) for r, (o, w) in enumerate(verdicts) if not o]
+            if bad:
+                if self.comm:
+                    try:
+                        self.comm.close()
+                    except Exception:
+                        pass
+                self.comm = None
+                self.via_text += "; fqh_comm given up: rank %d: %s" % bad[0]
+                return
+        elif not ok:
+            self.comm = None
+            self.via_text += "; fqh_comm unavailable: %s" % why
+            return
+        self.via_text = "fqh_comm (libfastq_hip.so's own RCCL binding, %d rank%s%s)" % (
+            world, "" if world == 1 else "s", "" if world == 1 or local else "; its three collectives checked on known values at start-up")
 
     def close(self):
         if self.comm:

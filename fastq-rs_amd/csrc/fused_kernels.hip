@@ -68,19 +68,20 @@ constexpr uint32_t FZ_GLIST = 251;                  // line starts per group tha
 constexpr uint32_t FZ_RS = 256;                    // record starts of a tile staged in LDS (4 x 251 entries / 4, rounded)
 constexpr uint32_t FZ_WAVE_BYTES = FZ_DATA + 16 + FZ_RS * 2 + (4 + FZ_GLIST + 1) * 2;  // 6160
 constexpr uint32_t FZ_SLACK = 1024;                 // a batch reads up to 32 NSL + 32 bytes past a line's start (NSL 16: 544)
-// The WIDE instance (reads of 257 .. 511 columns).  Two things change against the 256-row instance, whose
-// registers and wavefront count (12) it keeps:
-//   * SIXTEEN lanes walk a line, 64 columns per step, four lines per batch: eight steps cover 512 columns with the same eight
-//     words per lane, and a batch stops at the last step any of its lines reaches (five steps for 300 columns: 94 % of the
-//     lane-dwords it issues are bytes of a line; eight lanes per line and sixteen steps of 32 — measured — need 246 registers,
-//     eight wavefronts, and ran the 300-column file at 1.55 TB/s, below the two-read route).  Lane (line slot g, dword m) adds
-//     byte j = k ^ (g & 1) at its k-th atomic: row 64 u + 4 m + j, slot m + 16 j — the two line slots of a lane group differ in
-//     j & 1, so its 32 lanes sit on the 32 banks (m + 16 j) % 32 whatever the bins are;
+// The WIDE instances (rows 161 .. 511: MiSeq 2 x 300, merged pairs).  Two things change against the instances
+// of eight lanes per line:
+//   * SIXTEEN lanes walk a line, 64 columns per step, four lines per batch: a lane keeps one word per step, so three to six
+//     steps (192 .. 384 columns) fit the 128 registers of sixteen wavefronts per CU and eight steps (511 columns) the 168 of
+//     twelve; the eight-step instance stops at the last step any line of the batch reaches.  (Eight lanes per line and sixteen
+//     steps of 32 — measured — need 246 registers, eight wavefronts, and ran the 300-column file at 1.55 TB/s, below the
+//     two-read route.)  Lane (line slot g, dword m) adds byte j = k ^ (g & 1) at its k-th atomic: row 64 u + 4 m + j, slot
+//     m + 16 j — the two line slots of a lane group differ in j & 1, so its 32 lanes sit on the 32 banks (m + 16 j) % 32
+//     whatever the bins are;
 //   * 512 rows x 64 quality bins of 32-bit counters are 128 KiB — no room for the wavefronts' areas — so two rows share a word,
-//     16-bit counters: step u counts in half u & 1 of its word, a row block (u >> 1) holds 128 columns, and the histogram has
-//     the geometry (72 KiB) of the 256-row instance.  A counter may not pass 65 535 between two flushes: a span holds at most
+//     16-bit counters: step u counts in half u & 1 of its word, a row block (u >> 1) holds 128 columns: 16 KiB of quality
+//     histogram per 128 columns.  A counter may not pass 65 535 between two flushes: a span holds at most
 // 4 tiles x 4 groups x 251 line starts / 4 = 1 004 records (denser input marks the span bad), so the block's wavefronts walk
-// FZ_EPOCH spans each, meet at a barrier, add the 16-bit halves to the block's 32-bit rows in scratch, clear the LDS and go on.
+// fz_epoch spans each, meet at a barrier, add the 16-bit halves to the block's 32-bit rows in scratch, clear the LDS and go on.
 __host__ __device__ constexpr uint32_t fz_epoch(uint32_t waves) { return 65535u / (1004u * waves); }
 static_assert(FZ_WAVE_BYTES % 16 == 0, "wave areas are read with 16-byte accesses");
 

@@ -159,7 +159,7 @@ int fqh_last_scan_fast(fqh_ctx *ctx);
 /* How the last finished statistics call (fqh_stats*, fqh_scan_stats*) counted: 1 = in the scan's own pass over the input
  * (k_scan_stats); 2 = the same, and the lines that pass does not count itself — batches of eight with a byte outside ACGTN
  * or '!'..'`', lines longer than lmax — were counted one by one behind it (a few KiB re-read); 0 = in a second pass over the
- * input (lmax > 256, reads of more than ~500 bases, a parse error, or more such lines than one per 512 KiB).  Results are
+ * input (lmax > 512, reads of 512 bases and more, a parse error, or more such lines than one per 512 KiB).  Results are
  * identical; for benchmarks and tests.  A count the single pass declines is no doubt about the parse: it neither reruns the
  * scan nor touches the fast path's back-off. */
 int fqh_last_stats_route(fqh_ctx *ctx);
@@ -354,12 +354,12 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
                             const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                             uint64_t *d_base_hist, uint64_t *d_scalars);
 fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
-/* Record scan AND statistics of one buffer in a single call — with lmax <= 256 in a single READ of the input: one kernel scans,
+/* Record scan AND statistics of one buffer in a single call — with lmax <= 512 in a single READ of the input: one kernel scans,
  * validates and counts (k_scan_stats), the way the reference's Parser::each hands each record to the closure that reads
  * seq()/qual() (src/lib.rs:226-237); whole files, chunks with a carry and chunks that are not the file's last alike.  Outputs as
  * fqh_scan (d_rec_start may be NULL) plus fqh_stats.  fqh_stats on its own takes the same single-pass route.  Lines with bytes
  * outside ACGTN / '!'..'`' and lines longer than lmax are counted one by one behind that pass (fqh_last_stats_route() == 2).
- * lmax > 256, reads longer than ~500 bases, or more such lines than one per 512 KiB send the HISTOGRAMS to a second pass over
+ * lmax > 512, reads of 512 bases and more, or more such lines than one per 512 KiB send the HISTOGRAMS to a second pass over
  * the input (the scan's result stands); an input the fast path cannot prove valid (any parse error) runs the exact scan
  * followed by the histogram kernel; results are identical either way.  FQH_E_CAPACITY (d_rec_start shorter than
  * n_records + 1) is reported by the blocking call / the finish on either route, with the summary, the carry-out and the

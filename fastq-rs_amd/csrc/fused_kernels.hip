@@ -1170,6 +1170,9 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
 #ifndef FQH_FZ_W6
 #define FQH_FZ_W6 16
 #endif
+#ifndef FQH_FZ_W7
+#define FQH_FZ_W7 0    // wavefronts of a seven-step wide instance for rows 385 .. 448 (0: those rows take <8,12,wide>)
+#endif
 #ifndef FQH_FZ_WIDE_FROM
 #define FQH_FZ_WIDE_FROM 160   // rows above this take a wide instance (sixteen lanes per line, packed counters); 256: rows 161 .. 256 through <8,12>
 #endif
@@ -1188,7 +1191,7 @@ uint32_t scan_stats_nsl(uint32_t lmax) {
     const uint32_t lc = fz_lc(lmax), steps = (lc + 31) / 32;
     if (fz_is_wide(lc)) {   // the wide instances' steps of 64 columns
         const uint32_t ws = (lc + 63) / 64;
-        return ws <= 3 ? 3u : ws <= 6 ? ws : 8u;
+        return ws <= 3 ? 3u : ws <= 6 ? ws : (FQH_FZ_W7 && ws == 7) ? 7u : 8u;
     }
     return steps <= 2 ? 2u : steps <= 5 ? steps : 8u;
 }
@@ -1261,6 +1264,9 @@ hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
           : ws == 4 ? launch_scan_stats_n<4, FQH_FZ_W5, true>(s, z, blocks)
           : ws == 5 ? launch_scan_stats_n<5, FQH_FZ_W5, true>(s, z, blocks)
           : ws == 6 ? launch_scan_stats_n<6, FQH_FZ_W6, true>(s, z, blocks)
+#if FQH_FZ_W7
+          : ws == 7 ? launch_scan_stats_n<7, FQH_FZ_W7, true>(s, z, blocks)
+#endif
                     : launch_scan_stats_n<8, FQH_FZ_WP, true>(s, z, blocks);
     } else {
         // (short reads, VERDICT r4 item 8: an instance issues all its steps for every batch, so rows of 36 .. 128 columns get

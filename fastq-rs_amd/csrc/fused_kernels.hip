@@ -203,9 +203,8 @@ __device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &
     for (uint32_t u = 0; u < NSL; ++u) dst[64u * (1u + u)] = IS_SEQ ? B.w[u] : B.w[u] + 0x21212121u;  // (quality dwords were rebased in place)
 }
 
-// Steps 0 .. n - 1 of a batch, each a call of f(integral_constant<u>).  The 8 x 32 instances issue every step (unrolled); the wide
-// instance stops at the last step some line of the batch reaches — ONE jump into a fall-through switch, highest step first, not
-// a compare and branch per step (steps commute: pass 1 ORs, pass 2 adds).
+// Steps 0 .. n - 1 of a batch, each a call of f(FzStep<u>).  Every instance issues all its steps (unrolled) but the wide one of
+// eight, which stops at the last step some line of the batch reaches: a wave-uniform compare and branch per step (fz_steps_guard).
 template <uint32_t U>
 struct FzStep { static constexpr uint32_t value = U; };
 template <uint32_t U, uint32_t N, class F>
@@ -395,7 +394,7 @@ __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKi
         if (act_q && (b != 0 || L.g8 >= q0q)) PBq.P = newq ? Pnq : 0u;
         FzRaw<NSL> Rs, Rq;
         uint32_t nrd = NSL;
-        if (WIDE) {   // lmx (wave-uniform): the longest line this wavefront has met; steps behind it are neither read nor aligned
+        if (WIDE && FQH_WIDE_NRD) {   // lmx (wave-uniform): the longest line this wavefront has met; steps behind it are neither read nor aligned
             const uint32_t ls = news ? PBs.P & 0x1FFu : 0u, lq = newq ? PBq.P & 0x1FFu : 0u;
             uint32_t ln = ls > lq ? ls : lq;
             if (__ballot(ln > lmx) != 0) {
@@ -406,7 +405,7 @@ __device__ __forceinline__ void fz_lines2(FzBatch<NSL> &PBs, uint32_t &nfs, FzKi
                 }
                 lmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)ln);
             }
-            nrd = FQH_WIDE_NRD ? (lmx + 63u) >> 6 : NSL;
+            nrd = (lmx + 63u) >> 6;
         }
         if (news) fz_issue<NSL, WIDE>(PBs, Rs, L, lds8, nrd);
         if (newq) fz_issue<NSL, WIDE>(PBq, Rq, L, lds8, nrd);

@@ -32,7 +32,7 @@ def fuzz_streams(torch, pkg, fqref, seed, budget, max_cases=None):
     t_end = time.time() + budget
     cases = single = 0
     while time.time() < t_end and (max_cases is None or cases < max_cases):
-        L = int(rng.choice([36, 75, 100, 150, 151, 250, 400, 2000]))
+        L = int(rng.choice([36, 75, 100, 150, 151, 180, 250, 300, 320, 400, 500, 511, 520, 2000]))
         kind = rng.random()
         if kind < 0.6:
             data = clean(int(rng.integers(500, 1 + (6 << 20) // (2 * L + 20))), L, rng.random() < 0.2, int(rng.choice([0, 0, 5, 60])))
@@ -42,7 +42,7 @@ def fuzz_streams(torch, pkg, fqref, seed, budget, max_cases=None):
             data = fuzzgen.mutate(rng, data, 1)
         if rng.random() < 0.1:
             data = data[: len(data) - int(rng.integers(1, 200))]
-        lmax = int(rng.choice([64, 150, 256, 300]))
+        lmax = int(rng.choice([36, 64, 100, 128, 150, 192, 256, 300, 320, 384, 500, 512, 600]))
         r, oq, ob, osc = fqref.stats(data, lmax)
         a = np.frombuffer(data, dtype=np.uint8)
         qh = torch.zeros(lmax * 256, dtype=torch.int64, device=dev); bh = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)

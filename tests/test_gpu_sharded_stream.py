@@ -327,7 +327,7 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
     t_end = time.time() + budget
     cases = errs = 0
     while time.time() < t_end and (max_cases is None or cases < max_cases):
-        L = int(rng.choice([20, 75, 150, 300]))
+        L = int(rng.choice([20, 75, 150, 300, 500]))
         data = fuzzgen.valid_file(rng, int(rng.integers(300, 12000)), maxlen=L, crlf=bool(rng.random() < 0.15))
         kind = rng.random()
         if kind < 0.25:
@@ -344,7 +344,7 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
             j = data.find(b"\n", cuts[0])
             if 0 < j + 1 < n:
                 cuts = sorted(set(cuts + [j + 1]))
-        lmax = 150
+        lmax = int(rng.choice([150, 150, 64, 300, 512]))
         if rng.random() < 0.15:   # bytes that cannot be read from some offset on: the error the sequential reader meets FIRST
             fail_from = int(rng.integers(1, n))
             slot = 1 << 16

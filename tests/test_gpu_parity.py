@@ -277,7 +277,7 @@ def test_stats_kilobase_reads(fqref, gpu, shape):
 
 
 @pytest.mark.parametrize("shape", ["fixed150", "fixed36", "ragged", "binned", "crlf", "dirty", "len4k"])
-def test_stats_fast_path_shapes(fqref, gpu, shape):
+def test_stats_fast_path_shapes(fqref, torch, pkg, shape):
     """Multi-tile buffers (so that the whole-dword LDS path runs, not only the exact one): fixed and
     ragged read lengths, binned qualities (four distinct values: the worst case for LDS atomics
     keyed by bin), CRLF, sprinkled bytes outside the alphabet / quality window, and lengths that
@@ -313,12 +313,19 @@ def test_stats_fast_path_shapes(fqref, gpu, shape):
     assert len(data) > 20 * 16384
     lmaxes = {"fixed150": (150, 149, 151, 160, 128, 64), "fixed36": (36, 40, 64), "ragged": (100, 101, 250, 256, 300),
               "binned": (150, 300), "crlf": (150, 257), "dirty": (64, 150, 300), "len4k": (148, 152, 256, 260)}[shape]
+    gpu = Gpu(torch, pkg.Ctx(0), pkg)   # (a context of its own: the route is pinned, and list sizes / back-offs stick to a context)
     for lmax in lmaxes:
         r, qh, bh, sc = fqref.stats(data, lmax)
         s, gq, gb, gs = gpu.stats(data, lmax)
         assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == nrec
         assert np.array_equal(gs, sc), (shape, lmax, gs, sc)
         assert np.array_equal(gq, qh) and np.array_equal(gb, bh), (shape, lmax)
+        # the route: every row count up to 512 takes the scan's own pass (1; 2 where lines hold bytes outside the alphabets or are
+        # longer than lmax: counted behind it) unless the lines it cannot count itself outnumber its list (one per 512 KiB)
+        longest = {"fixed150": 150, "fixed36": 36, "len4k": 260}.get(shape, 300)
+        want = {1} if (shape != "dirty" and longest <= lmax) else {0, 2}
+        assert gpu.ctx.last_stats_route() in want, (shape, lmax, gpu.ctx.last_stats_route())
+    gpu.ctx.close()
 
 
 def test_synth_generator_and_medium_parity(fqref, gpu, torch):
@@ -1032,14 +1039,26 @@ def test_own_stream_is_ordered_against_the_null_stream(torch, pkg):
 
 
 @pytest.mark.parametrize("lmax", [300, 600])
-def test_stats_with_many_rows_over_short_reads(fqref, gpu, lmax):
+def test_stats_with_many_rows_over_short_reads(fqref, torch, pkg, lmax):
     """A caller that asks for more than 256 rows gets the record index written by the scan's own emit step, sized for reads of
     that length (one entry per 512 bytes of input).  Short reads overflow it: the index is emitted again into an array that is
     large enough — and which a free + allocation may place at the SAME address, old entries and all (the check for "the scan
     wrote the whole index" used to be made after that replacement: k_stats_long walked whatever lay behind the old entries)."""
     rng = np.random.default_rng(77)
+    gpu = Gpu(torch, pkg.Ctx(0), pkg)   # (a context of its own: the route is pinned)
     data = fuzzgen.valid_file(rng, 60000, maxlen=100, crlf=False)     # ~ 8 MB: 60 000 records, room for ~ 16 000 entries
     r, oq, ob, osc = fqref.stats(data, lmax)
     s, gq, gb, gs = gpu.stats(data, lmax)
     assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == 60000
     assert np.array_equal(gs, osc) and np.array_equal(gq, oq) and np.array_equal(gb, ob)
+    # the route: 300 rows over reads of up to 100 bases take the scan's own pass (its wide instance of five
+    # steps) — valid_file's lines hold bytes of every kind, so some batches are counted behind it —; 600 rows are beyond the single pass
+    assert gpu.ctx.last_stats_route() in ((0, 2) if lmax == 300 else (0,)), gpu.ctx.last_stats_route()
+    # ... and clean reads of 100 bases under 300 rows are counted by that pass alone
+    clean = b"".join(b"@r%d\n" % i + bytes(rng.choice(fuzzgen.ALPH, 100).tolist()) + b"\n+\n" + bytes(rng.integers(33, 75, 100).astype(np.uint8).tolist()) + b"\n"
+                     for i in range(20000))
+    r, oq, ob, osc = fqref.stats(clean, lmax)
+    s, gq, gb, gs = gpu.stats(clean, lmax)
+    assert np.array_equal(gs, osc) and np.array_equal(gq, oq) and np.array_equal(gb, ob)
+    assert gpu.ctx.last_stats_route() == (1 if lmax == 300 else 0), gpu.ctx.last_stats_route()
+    gpu.ctx.close()

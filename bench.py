@@ -806,10 +806,38 @@ class Coll:
         # Every rank creates its end, runs the three collectives once on known values and says whether they came out right; one
         # torch MIN over those verdicts decides for all: the library's binding, or torch.distributed for every rank (a binding
         # that fails on the first node that ever gives it more than one rank must not cost that node's whole record).
+        def agree(ok, why):
+            """-> None if every rank says ok, else the first (rank, why); all ranks get the same answer."""
+            if world == 1 or local:
+                return None if ok else (rank, why)
+            verdicts = [None] * world
+            dist.all_gather_object(verdicts, (ok, why))
+            bad = [(r, w) for r, (o, w) in enumerate(verdicts) if not o]
+            return bad[0] if bad else None
+
+        def give_up(bad):
+            if self.comm:
+                try:
+                    self.comm.close()
+                except Exception:
+                    pass
+            self.comm = None
+            self.via_text += "; fqh_comm given up: rank %d: %s" % bad
+
+        # Stage 1: every rank creates its end.  Stage 2: the three collectives once, on known values.  After each stage one object
+        # gather decides for ALL ranks: the library's binding, or torch.distributed for everybody (a binding that fails on the first
+        # node that ever gives it more than one rank must not cost that node's whole record; and no rank may enter a collective
+        # of a communicator that another rank has given up).
         ok, why = 1, None
         try:
             self.comm = pkg.Comm(ctx, world, rank, uid)
-            if world > 1 and not local:
+        except Exception as e:   # FqhError, or anything the runtime throws
+            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+        bad = agree(ok, why)
+        if bad:
+            return give_up(bad)
+        if world > 1 and not local:
+            try:
                 mine = torch.tensor([rank + 1, 7], dtype=torch.int64, device=dev)
                 allv = torch.zeros(2 * world, dtype=torch.int64, device=dev)
                 self.comm.allgather(mine.data_ptr(), allv.data_ptr(), 16)
@@ -820,26 +848,12 @@ class Coll:
                 self.comm.sync()
                 want = [x for r in range(world) for x in (r + 1, 7)]
                 if allv.cpu().tolist() != want or tot.cpu().tolist() != [world * (world + 1) // 2, world] or int(low.item()) != 1000:
-                    ok, why = 0, "self-test: wrong values (%s, %s, %s)" % (allv.cpu().tolist(), tot.cpu().tolist(), int(low.item()))
-        except Exception as e:   # FqhError, or anything the runtime throws
-            ok, why = 0, "%s: %s" % (type(e).__name__, e)
-        if world > 1 and not local:
-            verdicts = [None] * world
-            dist.all_gather_object(verdicts, (ok, why))
-            bad = [(r, w) for r, (o, w) in enumerate(verdicts) if not o]
+                    ok, why = 0, "start-up check: wrong values (%s, %s, %s)" % (allv.cpu().tolist(), tot.cpu().tolist(), int(low.item()))
+            except Exception as e:
+                ok, why = 0, "%s: %s" % (type(e).__name__, e)
+            bad = agree(ok, why)
             if bad:
-                if self.comm:
-                    try:
-                        self.comm.close()
-                    except Exception:
-                        pass
-                self.comm = None
-                self.via_text += "; fqh_comm given up: rank %d: %s" % bad[0]
-                return
-        elif not ok:
-            self.comm = None
-            self.via_text += "; fqh_comm unavailable: %s" % why
-            return
+                return give_up(bad)
         self.via_text = "fqh_comm (libfastq_hip.so's own RCCL binding, %d rank%s%s)" % (
             world, "" if world == 1 else "s", "" if world == 1 or local else "; its three collectives checked on known values at start-up")
 

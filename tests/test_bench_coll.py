@@ -64,3 +64,102 @@ def test_coll_over_two_gloo_ranks(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+# ---- the "abi" route of Coll with a stand-in for the library's RCCL binding: a Comm whose three collectives move host bytes
+# through gloo (addresses in, addresses out — as the real one takes device addresses).  What is under test is bench.py's side:
+# the id made by rank 0 and carried by the process group, the start-up check of the three collectives on known values, the
+# verdict every rank takes together, and the fall-back of ALL ranks when one rank's end fails.
+FAKE_WORKER = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cpu")
+MODE = os.environ["FAKE_MODE"]
+
+class FqhError(Exception):
+    pass
+
+def view(addr, n, dtype=torch.uint8):
+    buf = (C.c_uint8 * n).from_address(addr)
+    return torch.frombuffer(buf, dtype=torch.uint8).view(dtype)
+
+class Comm:
+    @staticmethod
+    def unique_id():
+        if MODE == "no_rccl":
+            raise FqhError("librccl.so could not be loaded")
+        return bytes(range(128))
+    def __init__(self, ctx, n_ranks, rank_, uid):
+        assert bytes(uid) == bytes(range(128)) and n_ranks == world and rank_ == rank
+        if MODE == "rank1_fails" and rank == 1:
+            raise FqhError("ncclCommInitRank: unhandled system error")
+        self.closed = False
+    def close(self):
+        self.closed = True
+    def allgather(self, d_send, d_recv, nbytes):
+        out = view(d_recv, nbytes * world)
+        dist.all_gather_into_tensor(out, view(d_send, nbytes).clone())
+    def allreduce_u64(self, d_buf, n):
+        t = view(d_buf, 8 * n, torch.int64)
+        if MODE == "wrong_sum" and rank == 0:
+            t += 1
+        dist.all_reduce(t)
+    def allreduce_min_u64(self, d_buf, n):
+        t = view(d_buf, 8 * n, torch.int64)      # (the test's keys stay below 2^63: signed order == unsigned order)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    def sync(self):
+        pass
+
+class Pkg:
+    pass
+pkg = Pkg(); pkg.Comm = Comm; pkg.FqhError = FqhError
+coll = bench.Coll(pkg, torch, dist, None, dev, world, rank, "gloo", "abi")
+if MODE == "ok":
+    assert coll.comm is not None and coll.via_text.startswith("fqh_comm") and "checked on known values" in coll.via_text, coll.via_text
+else:
+    assert coll.comm is None and coll.via_text.startswith("torch.distributed (gloo)"), coll.via_text
+    want = {{"no_rccl": "fqh_comm unavailable", "rank1_fails": "fqh_comm given up: rank 1", "wrong_sum": "fqh_comm given up: rank"}}[MODE]
+    assert want in coll.via_text, coll.via_text
+# whichever route was agreed on, the collectives work and every rank took the same one
+rows = coll.gather_words([rank, 5, (1 << 64) - 1])
+assert rows == [[r, 5, (1 << 64) - 1] for r in range(world)], rows
+t = torch.tensor([rank + 1, 10], dtype=torch.int64)
+coll.sum_dev(t)
+assert t.tolist() == [3, 20]
+assert coll.min_key(900 + rank) == 900
+coll.barrier()
+coll.close()
+dist.destroy_process_group()
+open(os.path.join({out!r}, "ok_%d" % rank), "w").write("ok")
+'''
+
+
+def _run_fake(tmp_path, mode):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / ("fake_%s.py" % mode)
+    script.write_text(FAKE_WORKER.format(root=ROOT, out=str(tmp_path)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FAKE_MODE=mode)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for r in range(2):
+        f = tmp_path / ("ok_%d" % r)
+        assert f.exists()
+        f.unlink()
+
+
+def test_coll_abi_route_agreement_over_two_ranks(tmp_path):
+    """--comm abi with more than one rank (never possible on this one-GPU box with the real RCCL): the route through a stand-in
+    Comm is taken when every rank's end passes its start-up check, and given up by EVERY rank together when rank 0 cannot make an
+    id, when one rank's communicator fails to come up, or when a collective returns wrong values."""
+    for mode in ("ok", "no_rccl", "rank1_fails", "wrong_sum"):
+        _run_fake(tmp_path, mode)

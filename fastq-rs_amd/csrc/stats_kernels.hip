@@ -574,37 +574,42 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
             }
         }
     };
+    const int lim_rows = (int)lc - (int)m8;   // (the caller's rows, seen from this lane's first column)
     auto count_line = [&](const Round &R, const int kind, uint32_t &any_n, uint32_t &any_inv) {
         const uint32_t seg = R.segs[kind];
         if (__ballot(seg != 0) == 0) return;
         constexpr uint32_t RB = SO_LRB;
+        // a dword at column C + 8 m (C a constant of the step) is whole iff C + 4 <= min(seg, lc) - 8 m, and holds bytes of the
+        // line at all iff C < seg - 8 m: one compare with a constant each (the limits are per line, not per dword)
+        const int lim_any = (int)seg - (int)m8, lim_whole = lim_any < lim_rows ? lim_any : lim_rows;
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) {
             const uint32_t wu = R.ws[kind][u];
-            const uint32_t pos = 64u * (u >> 1) + 4u * (u & 1u) + m8;   // column of the dword's first byte, relative to col0
-            const bool whole = pos + 4 <= seg && pos + 4 <= lc;    // four bytes of the line, all inside the caller's rows
+            const int C = (int)(64u * (u >> 1) + 4u * (u & 1u));   // column of the dword's first byte for lane m == 0, relative to col0
+            const bool whole = lim_whole >= C + 4;                  // four bytes of the line, all inside the caller's rows
             uint32_t pb, chk;
             if (kind == 0) {
                 pb = wu & 0x07070707u;
                 chk = wu ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, pb);   // != 0: a byte outside ACGTN
-                if (whole && !chk) any_n |= wu & 0x08080808u;                      // (bit 3 is set in 'N' only)
             } else {
                 pb = wu - 0x21212121u;
                 chk = pb & 0x80808080u;                                             // != 0: a byte outside '!' .. 0xA0 (128 bins)
                 pb &= 0x7F7F7F7Fu;                                                  // (whatever the bytes are, the address stays inside the rows)
             }
             const uint32_t f = (whole && !chk) ? 0xFFFFFFFFu : 0u;
+            if (kind == 0) any_n |= wu & f;   // (bit 3 of a byte is set in 'N' only: masked once, in flags())
             const uint32_t off = (kind ? SO_SBYTES : 0u) + 128u * (u & 1u) + (kind ? RB : 2048u) * (u >> 1);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off), f,
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__ballot(pos < seg && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
-                if (pos < seg && !f) {
+            if (__ballot(lim_any > C && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
+                if (lim_any > C && !f) {
+                    const uint32_t pos = (uint32_t)C + m8;
                     uint32_t an = 0, ai = 0;
                     if (kind == 0) so_exact_step<true, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
                     else so_exact_step<false, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
-                    any_n |= an;
+                    any_n |= an ? 0x08u : 0u;   // (flags() looks at bit 3 of each byte)
                     any_inv |= ai;
                 }
             }
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     };
     // a record's alphabet flags: ORed over the 8 lanes of its group here, over its column blocks through the flag maps
     auto flags = [&](const Round &R, uint32_t any_n, uint32_t any_inv) {
-        const unsigned long long bi = __ballot(any_inv != 0), bn = __ballot(any_n != 0) | bi;
+        const unsigned long long bi = __ballot(any_inv != 0), bn = __ballot((any_n & 0x08080808u) != 0) | bi;
         if (bn) {
             const uint32_t sh = lane & 56u;
             const bool gn = ((bn >> sh) & 0xFFull) != 0, gi = ((bi >> sh) & 0xFFull) != 0;

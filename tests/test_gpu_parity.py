@@ -1058,7 +1058,8 @@ def test_stats_with_many_rows_over_short_reads(fqref, torch, pkg, lmax):
     clean = b"".join(b"@r%d\n" % i + bytes(rng.choice(fuzzgen.ALPH, 100).tolist()) + b"\n+\n" + bytes(rng.integers(33, 75, 100).astype(np.uint8).tolist()) + b"\n"
                      for i in range(20000))
     r, oq, ob, osc = fqref.stats(clean, lmax)
-    gpu.ctx.set_spec(True)   # (forget the back-off the file above may have left: its odd lines can send a scan to the exact path)
+    gpu.ctx.close()
+    gpu = Gpu(torch, pkg.Ctx(0), pkg)   # (the file above has tiles of more than 512 line starts: its context keeps the longer lists — and the exact path)
     s, gq, gb, gs = gpu.stats(clean, lmax)
     assert np.array_equal(gs, osc) and np.array_equal(gq, oq) and np.array_equal(gb, ob)
     assert gpu.ctx.last_stats_route() == (1 if lmax == 300 else 0), gpu.ctx.last_stats_route()

@@ -75,6 +75,7 @@ def test_eight_ranks_hbm_resident_on_one_gpu():
     ss = j["sharded_stream"]
     blk = (32 << 20) // 2640 * 2640
     assert ss["ranks"] == 8 and ss["bytes_per_gpu"] == max(blk, (256 << 20) // blk * blk) + 997 and len(ss["numa"]) == 8
+    assert len(ss["ring_setup_seconds"]) == 8 and all(x > 0 for x in ss["ring_setup_seconds"])
     for name in ("producer", "pinned_replay"):
         r = ss[name]
         assert r["check"]["phases_ok"] and r["check"]["histograms_ok"] and r["records"] == r["check"]["records_expected"]

@@ -164,6 +164,18 @@ def test_single_pass_counts_up_to_511_columns(env, fqref, shape):
     run(env, fqref, data, lmaxes[0], want_fused=True, offsets=True)
 
 
+@pytest.mark.parametrize("nrec", [1, 2, 3, 7, 24, 25, 26, 99, 100, 101])
+def test_tiny_and_tile_edge_inputs_of_300_columns(env, fqref, nrec):
+    """Files of a few records of 300 columns, and files that end around tile (16 KiB) and span (64 KiB) edges, through the wide
+    instances' rows (300, 320, 511): whatever route the call takes — the fast path cannot prove a file of fewer than eight
+    line starts — the values are the oracle's."""
+    rng = np.random.default_rng(1000 + nrec)
+    data = make(rng, nrec, 300, hdr=lambda i: b"M%05d:%012d" % (i, i))   # 621-byte records: 26.4 per tile
+    for lmax in (300, 320, 511):
+        run(env, fqref, data, lmax, want_fused=None)
+    run(env, fqref, data, 300, want_fused=None, offsets=True)
+
+
 @pytest.mark.parametrize("shape", ["dirty_both_halves", "few_longer_than_lmax", "lines_of_512_and_more"])
 def test_declined_counts_beyond_256_columns(env, fqref, shape):
     """... and what that pass does not count itself goes the same ways as below the 256th column: batches with a byte outside the

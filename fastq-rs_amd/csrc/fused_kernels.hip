@@ -50,6 +50,9 @@ namespace fqh {
 #ifndef FQH_FZ_W5
 #define FQH_FZ_W5 16
 #endif
+#ifndef FQH_WIDE_GUARD
+#define FQH_WIDE_GUARD 0   // 1: the eight-step wide instance stops at the last step a line of the batch reaches (measured: slower, see fz_steps)
+#endif
 #ifdef FQH_TUNING
 #define FZ_DBG(bit) ((z.dbg & (bit)) != 0)
 #else
@@ -72,7 +75,7 @@ constexpr uint32_t FZ_SLACK = 1024;                 // a batch reads up to 32 NS
 // of eight lanes per line:
 //   * SIXTEEN lanes walk a line, 64 columns per step, four lines per batch: a lane keeps one word per step, so three to six
 //     steps (192 .. 384 columns) fit the 128 registers of sixteen wavefronts per CU and eight steps (511 columns) the 168 of
-//     twelve; the eight-step instance stops at the last step any line of the batch reaches.  (Eight lanes per line and sixteen
+//     twelve.  (Eight lanes per line and sixteen
 //     steps of 32 — measured — need 246 registers, eight wavefronts, and ran the 300-column file at 1.55 TB/s, below the
 //     two-read route.)  Lane (line slot g, dword m) adds byte j = k ^ (g & 1) at its k-th atomic: row 64 u + 4 m + j, slot
 //     m + 16 j — the two line slots of a lane group differ in j & 1, so its 32 lanes sit on the 32 banks (m + 16 j) % 32
@@ -163,7 +166,7 @@ __device__ __forceinline__ void fz_shape(FzShape<NSL> &S, uint32_t P, uint32_t m
     S.tu = nbt ? tu : 0u;
     // WIDE: bits 16-19 the steps this batch has to issue (the last one any of its lines reaches, partial dwords included)
     uint32_t nst = NSL;
-    if (WIDE) {
+    if (WIDE && NSL == 8 && FQH_WIDE_GUARD) {
         nst = 0;
 #pragma unroll
         for (uint32_t u = 0; u < NSL; ++u)
@@ -203,8 +206,7 @@ __device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &
     for (uint32_t u = 0; u < NSL; ++u) dst[64u * (1u + u)] = IS_SEQ ? B.w[u] : B.w[u] + 0x21212121u;  // (quality dwords were rebased in place)
 }
 
-// Steps 0 .. n - 1 of a batch, each a call of f(FzStep<u>).  Every instance issues all its steps (unrolled) but the wide one of
-// eight, which stops at the last step some line of the batch reaches: a wave-uniform compare and branch per step (fz_steps_guard).
+// Steps 0 .. n - 1 of a batch, each a call of f(FzStep<u>).  Every instance issues all its steps, unrolled (n is the experiments').
 template <uint32_t U>
 struct FzStep { static constexpr uint32_t value = U; };
 template <uint32_t U, uint32_t N, class F>
@@ -214,9 +216,12 @@ __device__ __forceinline__ void fz_steps_all(F &f) {
         fz_steps_all<U + 1, N>(f);
     }
 }
-// Measured and NOT taken (tools/build_variant.sh, 8 GiB of 300 / 500 bp reads): one jump into a fall-through switch of steps instead
-// of a compare per step: 2 011 / 2 199 GB/s against 2 078 / 2 262; reading only the steps the longest line so far reaches: 1 870 /
-// 2 042; both: 1 609 / 1 763.  Less work, slower code: the join points cost the waits more than the skipped steps save.
+// Measured and NOT taken, all in the eight-step wide instance (tools/build_variant.sh, cold fqh_stats of 8 GiB): stopping at the
+// last step some line of the batch reaches — a wave-uniform compare and branch per step (FQH_WIDE_GUARD): 450 / 500 / 511 bp
+// 2 192 / 2 260 / 2 269 GB/s against 2 357 / 2 424 / 2 442 with every step issued; one jump into a fall-through switch of steps
+// instead of those compares (FQH_WIDE_SWITCH): 3 % below the compares; reading only the steps the longest line so far reaches
+// (FQH_WIDE_NRD): 10 % below; switch and bounded reads together: 23 % below.  Less work, slower code: the join points cost the
+// waits more than the skipped steps save.
 #ifndef FQH_WIDE_SWITCH
 #define FQH_WIDE_SWITCH 0
 #endif
@@ -232,7 +237,7 @@ __device__ __forceinline__ void fz_steps_guard(uint32_t n, F &f) {
 }
 template <uint32_t NSL, bool WIDE, class F>
 __device__ __forceinline__ void fz_steps(uint32_t n, F &&f) {
-    if constexpr (!WIDE || NSL < 8) {   // (the instances of up to six steps issue all of them)
+    if constexpr (!WIDE || NSL < 8 || !FQH_WIDE_GUARD) {   // (every instance issues all its steps)
         fz_steps_all<0, NSL>(f);
     } else if constexpr (!FQH_WIDE_SWITCH) {
         fz_steps_guard<0, NSL>(n, f);
@@ -1170,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
 #define FQH_FZ_W6 16
 #endif
 #ifndef FQH_FZ_W7
-#define FQH_FZ_W7 0    // wavefronts of a seven-step wide instance for rows 385 .. 448 (0: those rows take <8,12,wide>)
+#define FQH_FZ_W7 12   // wavefronts of the seven-step wide instance for rows 385 .. 448 (0: those rows take <8,12,wide>; 14: measured, slower)
 #endif
 #ifndef FQH_FZ_WIDE_FROM
 #define FQH_FZ_WIDE_FROM 160   // rows above this take a wide instance (sixteen lanes per line, packed counters); 256: rows 161 .. 256 through <8,12>

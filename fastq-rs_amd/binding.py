@@ -9,13 +9,13 @@ LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.s
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Comm", "COMM_ID_BYTES", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "shard_stream_outcome", "shard_failed_words", "shard_failure_key", "SHARD_EMPTY", "SHARD_PASS", "SHARD_DEFER", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
-           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "OPT_REUSE_INDEX", "OPT_ADAPT_LINES", "EXPORTS"]
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "OPT_REUSE_INDEX", "OPT_ADAPT_LINES", "OPT_OWN_STREAM_NONBLOCKING", "EXPORTS"]
 
 OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY, E_AGAIN = range(11)
 SHARD_WORDS = 8
 BUFSIZE = 68 * 1024
 NSCALARS = 8
-OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT, OPT_REUSE_INDEX, OPT_ADAPT_LINES = 1, 2, 3, 4, 5, 6
+OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT, OPT_REUSE_INDEX, OPT_ADAPT_LINES, OPT_OWN_STREAM_NONBLOCKING = 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -395,6 +395,10 @@ class Ctx:
     def set_adapt_lines(self, n):
         """Alternate line buffers a context may try per big input it is given again (FQH_OPT_ADAPT_LINES; 0: off)."""
         self._chk(self._L.fqh_set_option(self._h, OPT_ADAPT_LINES, int(n)))
+
+    def set_own_stream_nonblocking(self, on):
+        """The context's own stream as a non-blocking one (no ordering against the legacy null stream); default: blocking."""
+        self._chk(self._L.fqh_set_option(self._h, OPT_OWN_STREAM_NONBLOCKING, 1 if on else 0))
 
     def set_reuse_index(self, on):
         """Let fqh_stats* count over the last scan's tile index when buffer, length and carry match (the caller vouches for the bytes)."""

@@ -1065,6 +1065,20 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
     case FQH_OPT_SPIN_WAIT:
         ctx->spin_wait_us = value < 0 ? 0 : value > 1000000 ? 1000000 : value;
         return FQH_OK;
+    case FQH_OPT_OWN_STREAM_NONBLOCKING: {
+        // the context's own stream again, blocking (ordered against the legacy null stream: the safe default) or not (no
+        // coupling with the process's null-stream work: the caller orders what it hands in with events, as for any stream)
+        if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is pending");
+        if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, FQH_E_DEVICE, "hipSetDevice");
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, value ? hipStreamNonBlocking : hipStreamDefault) != hipSuccess) return fail(ctx, FQH_E_DEVICE, "hipStreamCreateWithFlags");
+        (void)hipStreamSynchronize(ctx->own_stream);
+        const bool in_use = ctx->stream == ctx->own_stream;
+        (void)hipStreamDestroy(ctx->own_stream);
+        ctx->own_stream = fresh;
+        if (in_use) ctx->stream = fresh;
+        return FQH_OK;
+    }
     }
     return fail(ctx, FQH_E_ARG, "unknown option");
 }

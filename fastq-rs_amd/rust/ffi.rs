@@ -54,6 +54,7 @@ pub const FQH_OPT_SINGLE_PASS: c_int = 2;
 pub const FQH_OPT_PLACE_TRIES: c_int = 3;
 pub const FQH_OPT_SPIN_WAIT: c_int = 4;
 pub const FQH_OPT_REUSE_INDEX: c_int = 5;      // default 0: fqh_stats after fqh_scan on the same buffer reads the input again
+pub const FQH_OPT_OWN_STREAM_NONBLOCKING: c_int = 7;   // default 0: the context's own stream is ordered against the legacy null stream
 pub const FQH_OPT_ADAPT_LINES: c_int = 6;       // default 3: a second line buffer is tried for big inputs that are scanned again
 pub const FQH_SHARD_WORDS: usize = 8;
 pub const FQH_SHARD_STREAM_WORDS: usize = 10;

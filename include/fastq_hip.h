@@ -144,6 +144,11 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           measurements the faster one counts); an
  *                           alternate that measures like the first (within 2.5 %) is given back and another is tried, at most this
  *                           many times per input.  0 = off.  Results never depend on the choice.
+ *   FQH_OPT_OWN_STREAM_NONBLOCKING [0]  1: the context's own stream (used while fqh_set_stream has not given it another) is
+ *                           created again as a NON-blocking stream: no implicit ordering against the process's legacy
+ *                           null-stream work in either direction — for hosts that overlap other null-stream work with their
+ *                           scans and order what they hand in with events.  0: the blocking stream of fqh_create.  Not while a
+ *                           launch is pending.
  *   FQH_OPT_SPIN_WAIT [0]   microseconds fqh_*_finish polls the stream before it sleeps on it (hipStreamSynchronize wakes up
  *                           ~15 us after the last kernel); a host core spinning inside a library call is the caller's choice.
  * fqh_last_scan_fast: did the last finished scan (or single-pass statistics call) keep the fast path's result (1), or
@@ -154,6 +159,7 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
 #define FQH_OPT_SPIN_WAIT 4
 #define FQH_OPT_REUSE_INDEX 5
 #define FQH_OPT_ADAPT_LINES 6
+#define FQH_OPT_OWN_STREAM_NONBLOCKING 7
 fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
 int fqh_last_scan_fast(fqh_ctx *ctx);
 /* How the last finished statistics call (fqh_stats*, fqh_scan_stats*) counted: 1 = in the scan's own pass over the input

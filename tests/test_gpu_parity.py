@@ -965,6 +965,30 @@ def test_adaptive_line_buffer_is_invisible(fqref, torch, pkg):
     ctx.close()
 
 
+def test_own_stream_can_be_made_nonblocking(fqref, torch, pkg):
+    """FQH_OPT_OWN_STREAM_NONBLOCKING: a host that overlaps null-stream work with its scans takes the implicit coupling
+    out and orders its buffers itself (a synchronize here); results are the same, and the option is refused while a launch is pending."""
+    dev = torch.device("cuda:0")
+    n = 330 * 20000
+    d = torch.empty(n + 16, dtype=torch.uint8, device=dev)
+    ctx = pkg.Ctx(0)
+    ctx.synth_fill(d.data_ptr(), 0, n)
+    ctx.set_own_stream_nonblocking(True)
+    rs = torch.zeros(20001, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()                 # (the caller's ordering: the zero-fill above ran on the null stream)
+    s = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())[0]
+    assert (s.parse_status, s.n_records) == (pkg.OK, 20000)
+    assert torch.equal(rs, torch.arange(20001, dtype=torch.int64, device=dev) * 330)
+    ctx.scan_launch(d.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())
+    with pytest.raises(pkg.FqhError):
+        ctx.set_own_stream_nonblocking(False)
+    ctx.scan_finish()
+    ctx.set_own_stream_nonblocking(False)
+    s = ctx.scan(d.data_ptr(), n, True, None, rs.data_ptr(), rs.numel())[0]
+    assert s.n_records == 20000
+    ctx.close()
+
+
 def test_adaptive_line_buffer_settles_and_holds_its_memory(torch, pkg):
     """an alternate that measured like the first buffer was given back, the NEXT call took the given-back buffer
     for "a new workspace", lost the first buffer for good and started over — one line buffer of len / 64 bytes leaked every four

@@ -23,6 +23,26 @@ sys.path.insert(0, ROOT)
 
 RECLEN = 330
 SHARD = 1 << 34
+
+# The contract: rank 0 prints ONE JSON line on stdout.  Libraries under this process write to file descriptor 1 as well (RCCL
+# prints a version banner when a communicator is created — the library's own binding makes one even at N = 1 — and C stdio
+# flushes it at exit, BEHIND the line).  So the line goes to a private copy of the original stdout and descriptor 1 itself is
+# pointed at stderr for everything else.
+_LINE_OUT = None
+
+
+def own_stdout():
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    own_stdout()
+    _LINE_OUT.write(json.dumps(obj) + "\n")
+    _LINE_OUT.flush()
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -72,6 +92,7 @@ def main():
         # `python bench.py --gpus N` with no launcher around it: be the launcher (one rank per GPU, the contract's command line)
         sys.exit(self_launch(args.gpus))
 
+    own_stdout()   # (before anything below can write to descriptor 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -125,7 +146,7 @@ def main():
         rccl["via"] = coll.via_text
         j = sharded_stream(args, pkg, torch, dev, sctx, coll, args.stream_gib / world, int(os.environ.get("FQH_BENCH_INJECT", "-1")))
         if rank == 0:
-            print(json.dumps(dict(j, mode="sharded-stream", n_gpus=world, backend=backend, rccl=rccl)), flush=True)
+            emit_line(dict(j, mode="sharded-stream", n_gpus=world, backend=backend, rccl=rccl))
         coll.close()
         sctx.close()
         dist.destroy_process_group()
@@ -257,7 +278,7 @@ def main():
         return s
 
     if args.stream_gib > 0:
-        print(json.dumps(dict(stream_leg(args, pkg, torch, dev, buf, args.stream_gib, args.producer_threads), mode="stream")), flush=True)
+        emit_line(dict(stream_leg(args, pkg, torch, dev, buf, args.stream_gib, args.producer_threads), mode="stream"))
         return
     # FQH_OPT_ADAPT_LINES (default on): the library learns from its first calls on an input which of two line buffers that input
     # runs faster with (calls 1-2 on the first, then one call per alternate tried: DESIGN.md 4b).  A few untimed steps in
@@ -309,7 +330,7 @@ def main():
     traffic = rp = None
     traffic_source = None
     if args.pmc_child:   # (a child of pmc_traffic below: the counters are rocprofv3's business, the line is not looked at)
-        print(json.dumps({"pmc_child": True, "kernel_ms": round(k_ms, 4)}), flush=True)
+        emit_line({"pmc_child": True, "kernel_ms": round(k_ms, 4)})
         ctx.read_ceiling(buf.data_ptr(), nbytes)
         return
     if world == 1 and args.pmc_traffic == "auto":
@@ -370,7 +391,7 @@ def main():
     if first_error:
         out["first_error"] = first_error
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit_line(out)
         return
     if world == 1:
         # what the last timed step left in the caller's array: record k of the synthetic file starts at 330 k (every record of
@@ -531,7 +552,7 @@ def main():
             rec = sharded_stream_record(args, pkg, torch, dist, dev, ctx, coll, backend, via, args.default_shard_stream_gib)
         out["sharded_stream"] = rec
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_line(out)
     if world > 1 and args.shard_stats:
         # histograms over byte-range shards.  The record that straddles a cut is counted by the
         # rank it ENDS in, which needs its beginning: the last LEAD bytes of every shard are all-gathered
@@ -563,10 +584,10 @@ def main():
         assert int(tot[1]) == int(tot[2]) == total_records * 150
         assert int(tot[8: 8 + LMAX * 256].sum()) == total_records * 150 == int(tot[8 + LMAX * 256:].sum())
         if rank == 0:
-            print(json.dumps({"mode": "shard-stats", "n_gpus": world, "records_total": int(tot[0]),
-                              "seconds_incl_full_index_and_allreduce": round(dts, 4),
-                              "check": "sum over ranks: records, bases, quality and base histogram totals match the "
-                                       "generator's; every cut-straddling record counted exactly once"}), flush=True)
+            emit_line({"mode": "shard-stats", "n_gpus": world, "records_total": int(tot[0]),
+                       "seconds_incl_full_index_and_allreduce": round(dts, 4),
+                       "check": "sum over ranks: records, bases, quality and base histogram totals match the "
+                                "generator's; every cut-straddling record counted exactly once"})
     coll.close()
     ctx.close()
     if world > 1:

@@ -289,6 +289,9 @@ def main():
         if world == 1 and i >= 1 and not ctx.line_buffers()["unsettled"]:   # (N > 1: every rank runs the same number of steps)
             settle = i + 1
             break
+    import gc
+    gc.collect()
+    gc.disable()   # (the timed region is 20 steps of < 3 ms: one collector pause of the interpreter would be a tenth of it)
     for _ in range(args.warmup):
         s = step()
     index_ms.clear()
@@ -298,6 +301,7 @@ def main():
         s = step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

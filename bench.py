@@ -485,6 +485,7 @@ def main():
                 "bound": "vector ALU issue, then LDS atomics (DESIGN.md 5b); HBM is read once"}
         if not args.no_stats and not args.no_long_reads:
             out["long_reads"] = long_read_leg(pkg, torch, dev, ctx)
+            out["long_reads_varied"] = long_read_leg(pkg, torch, dev, ctx, varied=True)
         if not args.no_stream:
             out["stream"] = stream_leg(args, pkg, torch, dev, buf, args.default_stream_gib, args.producer_threads)
         if not args.no_cpu_baseline:
@@ -641,22 +642,26 @@ def pmc_traffic(nbytes):
         return None
 
 
-def long_read_leg(pkg, torch, dev, ctx, read_len=5000, gib=4.0):
+def long_read_leg(pkg, torch, dev, ctx, read_len=5000, gib=4.0, varied=False):
     """Kilobase reads with PacBio-HiFi-like qualities (80 % '~' = Q93): the reference treats a record of any length up to its
     Buffer alike (src/lib.rs:276-283, src/records.rs:75-90); here they take the exact scan + fqh_index_records + k_stats_long
-    (128 quality bins per column in LDS).  Not part of `value`: evidence that the long-read route has no cliff."""
+    (128 quality bins per column in LDS).  varied: the reads' lengths are log-normal around read_len (sigma 0.8,
+    200 .. 6 x read_len: a long-read run, not a simulator's output) — the plan k_stats_long follows is made on the device from
+    the lengths it finds.  Not part of `value`: evidence that the long-read route has no cliff."""
     import numpy as np
     rng = np.random.default_rng(7)
     nrec = 1024
-    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (nrec, read_len))
-    qual = np.where(rng.random((nrec, read_len)) < 0.8, 126, rng.integers(33, 127, (nrec, read_len))).astype(np.uint8)
-    block = b"".join(b"@m%06d/ccs\n" % i + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n" for i in range(nrec))
+    max_len = 6 * read_len if varied else read_len
+    lens = np.clip(rng.lognormal(np.log(read_len), 0.8, nrec), 200, max_len).astype(np.int64) if varied else np.full(nrec, read_len)
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (nrec, max_len))
+    qual = np.where(rng.random((nrec, max_len)) < 0.8, 126, rng.integers(33, 127, (nrec, max_len))).astype(np.uint8)
+    block = b"".join(b"@m%06d/ccs\n" % i + seq[i, :lens[i]].tobytes() + b"\n+\n" + qual[i, :lens[i]].tobytes() + b"\n" for i in range(nrec))
     reps = int(gib * (1 << 30)) // len(block)
     n = reps * len(block)
     hb = torch.from_numpy(np.frombuffer(block, dtype=np.uint8).copy()).to(dev)
     d = torch.cat([hb.repeat(reps), torch.zeros(16, dtype=torch.uint8, device=dev)])
-    qh = torch.zeros(read_len * 256, dtype=torch.int64, device=dev)
-    bh = torch.zeros(read_len * 8, dtype=torch.int64, device=dev)
+    qh = torch.zeros(max_len * 256, dtype=torch.int64, device=dev)
+    bh = torch.zeros(max_len * 8, dtype=torch.int64, device=dev)
     sc = torch.zeros(8, dtype=torch.int64, device=dev)
     best = None
     for _ in range(4):
@@ -664,23 +669,29 @@ def long_read_leg(pkg, torch, dev, ctx, read_len=5000, gib=4.0):
         ctx.invalidate()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ctx.stats(d.data_ptr(), n, read_len, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+        ctx.stats(d.data_ptr(), n, max_len, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
         torch.cuda.synchronize()
         w = (time.perf_counter() - t1) * 1e3
         tt = ctx.timing()
         if best is None or w < best[0]:
             best = (w, tt.stats_ms)
     # the block's own histograms, counted on the host with numpy, times the repetitions
-    exp_q = np.zeros((read_len, 256), dtype=np.int64)
-    for c in range(0, read_len, 500):
-        for v in np.unique(qual[:, c:c + 500]):
-            exp_q[c:c + 500, v] = (qual[:, c:c + 500] == v).sum(axis=0)
-    got_q = qh.cpu().numpy().reshape(read_len, 256)
+    exp_q = np.zeros((max_len, 256), dtype=np.int64)
+    if varied:
+        for i in range(nrec):
+            np.add.at(exp_q, (np.arange(lens[i]), qual[i, :lens[i]]), 1)
+    else:
+        for c in range(0, read_len, 500):
+            for v in np.unique(qual[:, c:c + 500]):
+                exp_q[c:c + 500, v] = (qual[:, c:c + 500] == v).sum(axis=0)
+    got_q = qh.cpu().numpy().reshape(max_len, 256)
     assert int(sc[0].item()) == reps * nrec and np.array_equal(got_q, exp_q * reps), "long-read histograms differ from the host count"
-    assert int(bh.sum().item()) == reps * nrec * read_len
+    assert int(bh.sum().item()) == reps * int(lens.sum())
     del d
-    return {"workload": "%.2f GiB of %d bp reads, 80 %% of the quality bytes '~' (Q93, PacBio HiFi-like), cold fqh_stats" % (n / 2**30, read_len),
-            "route": "exact scan + record index + k_stats_long (128 quality bins per column in LDS)",
+    what = ("reads of log-normal length (median %d bp, sigma 0.8, %d .. %d bp)" % (read_len, int(lens.min()), int(lens.max()))) if varied \
+        else "%d bp reads" % read_len
+    return {"workload": "%.2f GiB of %s, 80 %% of the quality bytes '~' (Q93, PacBio HiFi-like), cold fqh_stats" % (n / 2**30, what),
+            "route": "exact scan + record index + k_stats_long (128 quality bins per column in LDS; work items cut on the device from the reads' lengths)",
             "end_to_end_ms": round(best[0], 3), "histogram_kernels_ms": round(best[1], 3),
             "gbs_end_to_end": round(n / 1e6 / best[0], 1), "gbs_histograms": round(n / 1e6 / best[1], 1),
             "check": "quality histogram == numpy count of the repeated block x repetitions, bit-exact"}

@@ -18,7 +18,7 @@ size_t stats_oct_scratch_bytes(uint32_t, int);
 hipError_t launch_stats_oct(hipStream_t, StatsArgs, int);
 hipError_t launch_stats_long(hipStream_t, const uint8_t *, uint64_t, uint64_t, const fqh_idx_record *, uint64_t, uint32_t, uint32_t, uint32_t *,
                              uint64_t, unsigned long long *, unsigned long long *, unsigned long long *, int, uint32_t *);
-size_t stats_long_part_bytes(uint64_t, uint32_t, int);
+size_t stats_long_scratch_bytes(uint64_t, uint64_t, uint32_t, int);
 void launch_shard_words(hipStream_t, const DevOut *, const DevOut *, uint64_t, uint64_t *);
 void launch_carry_fold(hipStream_t, const uint64_t *, int, int, DevCarry *, DevCarry *, DevOut *);
 void launch_shard_counts(hipStream_t, const DevOut *, const DevOut *, const DevCarry *, uint64_t *);

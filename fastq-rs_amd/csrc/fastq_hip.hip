@@ -1300,7 +1300,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         // 4 GiB), k_stats_long is ahead from there (500 bp: 1.98 / 1.34) and it alone keeps 128 quality bins in LDS: with
         // qualities beyond '`' the passes of k_stats_oct count byte by byte in device memory (300 bp, 80 % '~': 146 ms).
         const bool long_route = passes;
-        const size_t hist_bytes = long_route ? std::max(stats_oct_scratch_bytes(lmax, ctx->n_cu), stats_long_part_bytes(n - skip, max_line, ctx->n_cu))
+        const size_t hist_bytes = long_route ? std::max(stats_oct_scratch_bytes(lmax, ctx->n_cu), stats_long_scratch_bytes(n - skip, len, max_line, ctx->n_cu))
                                              : stats_oct_scratch_bytes(lmax, ctx->n_cu);
         const uint64_t flag_words = passes ? (n - skip + 31) / 32 + 1 : 0;
         const size_t need = hist_bytes + ((size_t)flag_words * 2 + 1) * sizeof(uint32_t);

@@ -449,7 +449,8 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
 // reads took 20 passes, 557 GB/s).  The reference treats every record up to BUFSIZE alike (src/lib.rs:276-283,
 // src/records.rs:75-90); so does this: the work item is (record, block of 256 columns), found by plain arithmetic on the
 // IdxRecord-style index (fqh_idx_record: start + the four newline offsets) — no tile lists, no line-start search.
-//   * a block of 1024 threads owns one column block cb = blockIdx.x % n_cb and a slice of the records; its LDS holds the
+//   * a block of 1024 threads owns one work item: a column block cb and a range of the records that reach it (the plan is
+//     made on the device from the reads' lengths: k_long_plan below); its LDS holds the
 //     bank-scheduled histogram of those 256 columns (stats_dev.h: 8 KiB sequence + 128 KiB quality: 128 bins per column,
 //     '!' .. 0xA0 — HiFi reads are mostly '~' (Q93), and a 64-bin window sent every such byte to the caller's arrays);
 //   * eight lanes walk a line's 256 columns, eight records per wavefront and round.  A lane loads EIGHT contiguous bytes four
@@ -463,14 +464,29 @@ hipError_t launch_stats_oct(hipStream_t s, StatsArgs a, int n_cu) {
 //     outside ACGTN" is ORed over a line's column blocks through one bit per record and flag in scratch (atomicOr: the
 //     block that sets a bit first counts the record), sequence columns beyond lmax included;
 //   * every input byte of a sequence / quality line is read once; algorithmic bytes: the buffer's length.
+// The plan of one launch, made ON THE DEVICE from the lengths of the records at hand (k_long_census / k_long_plan below): the
+// work items (column block, range of records), slice-major.
+struct LongItem {
+    uint32_t cb, pad;
+    uint64_t r_lo, r_hi;           // positions in the column block's LIST of records (LongPlan::listed), or records
+};
+struct LongPlan {
+    uint32_t n_items;              // work items in use (<= the launch's blocks)
+    uint32_t listed;               // 1: records of several length classes: every column block walks the list of the records that reach it
+    uint32_t q_max;                // slices of column block 0 (the most any column block has)
+    uint32_t w;                    // records per item
+};
 struct LongArgs {
     const uint8_t *buf;            // chunk-relative: the byte at file offset o is buf[o - base_offset]
     uint64_t len, base_offset;
     const fqh_idx_record *idx;     // the records that count: idx[0 .. n)
+    const uint32_t *lists;         // per column block, the records that reach it (LongPlan::listed): list cb starts at lists[list_off[cb]]
+    const uint64_t *list_off;
     uint64_t n;
-    uint32_t lmax, n_cb, n_slices;
-    uint32_t per_xcd;              // blocks per XCD: block (xcd, j) is work item xcd * per_xcd + j of the n_cb * n_slices
-    uint32_t *part;                // [n_cb * n_slices][SO_LWORDS]: every block's rows as it leaves them (k_stats_long_reduce adds them up)
+    uint32_t lmax;
+    const LongPlan *plan;
+    const LongItem *items;
+    uint32_t *part;                // [items][SO_LWORDS]: every block's rows as it leaves them (k_stats_long_reduce adds them up)
     uint32_t *flagmap;             // 2 x flag_words words, zeroed: [has N or worse | has a byte outside ACGTN]
     uint64_t flag_words;
     unsigned long long *qual_hist, *base_hist, *scalars;
@@ -480,11 +496,15 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     // Workgroups go to the eight XCDs round-robin (blockIdx % 8), and every XCD has an L2 of its own.  The column blocks of ONE
     // slice of the records read neighbouring 256-byte pieces of the same lines — pieces that are not aligned to the 128-byte
     // cache lines, so that neighbours share the line at either edge — at about the same time: the work items (slice-major:
-    // item = slice * n_cb + cb) are dealt out in eight CONTIGUOUS runs, one per XCD, so that a slice's column blocks sit on
-    // one XCD (two at a run's edge) and the shared lines are fetched once.  (Numbered across the XCDs, every column block of a
-    // slice pulled its edge lines through another L2: 1.7 x the input's bytes from memory, PMC FETCH_SIZE.)
-    const uint32_t xcd = blockIdx.x & 7u, item = xcd * a.per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= a.per_xcd || item >= a.n_cb * a.n_slices) return;   // (the grid is padded to whole runs)
+    // slice s of every column block that has one, then slice s + 1; every item holds LongPlan::w records, so slice s of two
+    // column blocks is the same records) are dealt out in eight CONTIGUOUS runs, one per XCD, so that a slice's column blocks
+    // sit on one XCD (two at a run's edge) and the shared lines are fetched once.  (Numbered across the XCDs, every column
+    // block of a slice pulled its edge lines through another L2: 1.7 x the input's bytes from memory, PMC FETCH_SIZE.)
+    const uint32_t n_items = a.plan->n_items, per_xcd = (n_items + 7u) / 8u;
+    const uint32_t xcd = blockIdx.x & 7u, item = xcd * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || item >= n_items) return;   // (the grid is the most items a plan may use)
+    const LongItem it = a.items[item];
+    const uint32_t *const lst = a.plan->listed ? a.lists + a.list_off[it.cb] : nullptr;   // (block-uniform)
     for (uint32_t i = threadIdx.x; i < SO_LWORDS; i += SO_THREADS) hist[i] = 0;
     __syncthreads();
     if ((uint32_t)(uintptr_t)hist != 0) __builtin_trap();  // the address registers assume the histogram starts at LDS address 0
@@ -498,7 +518,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         c.sel[k] = 0x0C0C0004u + k + (j << 8);
         c.slots |= ((m + 8u * j) * 4u) << (8u * k);
     }
-    const uint32_t cb = item % a.n_cb, slice = item / a.n_cb;
+    const uint32_t cb = it.cb;
     const uint32_t col0 = cb * SO_LC_MAX;
     const uint32_t lc = a.lmax > col0 ? (a.lmax - col0 < SO_LC_MAX ? a.lmax - col0 : SO_LC_MAX) : 0u;  // rows of this block that the caller has
     StatsArgs sa = {};           // what so_exact_step wants to know
@@ -506,8 +526,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     sa.col0 = col0;
     sa.qual_hist = a.qual_hist;
     sa.base_hist = a.base_hist;
-    const uint64_t per = (a.n + a.n_slices - 1) / a.n_slices;
-    const uint64_t r_lo = (uint64_t)slice * per, r_hi = r_lo + per < a.n ? r_lo + per : a.n;
+    const uint64_t r_lo = it.r_lo, r_hi = it.r_hi;
     unsigned long long recs = 0, bases = 0, quals = 0, over_s = 0, over_q = 0;   // per lane (lane m == 0 of a record's group adds)
     uint32_t newn = 0, newi = 0;
     const uint8_t *const bend = a.buf + a.len;
@@ -518,17 +537,19 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
     //   * the three dependent loads of a round — the record's index entry, the byte in front of each line's '\n'
     //     (trim_winline), the lines' words — are spread over three rounds: the entry of round k + 2 is fetched at the top of
     //     round k, its two probe bytes between the counts of round k's two lines (the entry has arrived by then), its words at
-    //     the top of round k + 1.
+    //     the top of round k + 1.  Behind a plan with lists (LongPlan::listed) there is a fourth in front of them: the record's
+    //     number, read from the column block's list three rounds ahead.
     constexpr uint64_t STEP = (uint64_t)SO_WAVES * 8;
-    const uint64_t r_first = r_lo + (uint64_t)wv * 8 + g8;   // this lane group's record of the first round
+    const uint64_t p_first = r_lo + (uint64_t)wv * 8 + g8;   // this lane group's position (in the list, or in the index) in the first round
     struct Round {               // a round whose words are in flight / loaded
-        uint64_t r;
+        uint32_t id;             // the record's number if the plan has lists (else it is the position)
         bool has;
         uint32_t segs[2], ws[2][8];
     };
-    auto entry_of = [&](uint64_t r) {
+    auto id_of = [&](uint64_t p) { return (lst && p < r_hi) ? lst[p] : 0u; };
+    auto entry_of = [&](uint64_t p, uint32_t id) {
         fqh_idx_record ir = {};
-        if (r < r_hi) ir = a.idx[r];
+        if (p < r_hi) ir = a.idx[lst ? (uint64_t)id : p];
         return ir;
     };
     auto probe = [&](const fqh_idx_record &ir, uint64_t r, uint32_t cr[2]) {   // the byte in front of each line's '\n'
@@ -542,8 +563,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         }
     };
     // geometry of record r's two lines in this column block, the record's totals (column block 0), and the loads of its words
-    auto issue = [&](Round &R, uint64_t r, const fqh_idx_record &ir, const uint32_t cr[2]) {
-        R.r = r;
+    auto issue = [&](Round &R, uint64_t r, uint32_t id, const fqh_idx_record &ir, const uint32_t cr[2]) {
+        R.id = id;
         R.has = r < r_hi;
 #pragma unroll
         for (int kind = 0; kind < 2; ++kind) {
@@ -603,58 +624,85 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
             for (int k = 0; k < 4; ++k)
                 (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off), f,
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__ballot(lim_any > C && !f) != 0) {   // (rare) a partial dword, a byte outside, or columns beyond the caller's rows
-                if (lim_any > C && !f) {
-                    const uint32_t pos = (uint32_t)C + m8;
-                    uint32_t an = 0, ai = 0;
-                    if (kind == 0) so_exact_step<true, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
-                    else so_exact_step<false, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
-                    any_n |= an ? 0x08u : 0u;   // (flags() looks at bit 3 of each byte)
-                    any_inv |= ai;
+            bool exact = lim_any > C && !f;           // bytes of the line that the four atomics above did not count
+            if (__ballot(exact) != 0) {
+                // The line's last, partial dword (a line has one unless its length is a multiple of four — and in reads of many
+                // lengths every record's sits in another step): its one to three bytes, inside the caller's rows and inside the
+                // alphabet / window, are counted as the whole dwords are, under a mask per byte.  (Until round 5 they took the
+                // exact statement below, a loop per byte: unseen in the benchmarks, whose reads were 600 .. 20 000 bases long,
+                // all multiples of four — reads of 250 .. 1000 bases ran at HALF the speed per piece.)
+                const int t = lim_any - C;            // bytes of the line in this dword (if in 1 .. 3)
+                if (exact && t < 4 && lim_whole >= lim_any) {
+                    const uint32_t sh = 32u - 8u * (uint32_t)t;
+                    if ((chk << sh) == 0) {
+                        if (kind == 0) any_n |= wu << sh;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            (void)__hip_atomic_fetch_sub((so_lds_u32 *)(uintptr_t)(__builtin_amdgcn_perm(c.slots, pb, c.sel[k]) + off),
+                                                         (int)((uint32_t)k ^ (g8 & 3u)) < t ? 0xFFFFFFFFu : 0u, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                        exact = false;
+                    }
+                }
+                if (__ballot(exact) != 0) {           // (rare) a byte outside, or columns beyond the caller's rows
+                    if (exact) {
+                        const uint32_t pos = (uint32_t)C + m8;
+                        uint32_t an = 0, ai = 0;
+                        if (kind == 0) so_exact_step<true, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
+                        else so_exact_step<false, SO_LQBITS, true>(sa, wu, pos, seg, lc, hist, an, ai);
+                        any_n |= an ? 0x08u : 0u;   // (flags() looks at bit 3 of each byte)
+                        any_inv |= ai;
+                    }
                 }
             }
         }
     };
     // a record's alphabet flags: ORed over the 8 lanes of its group here, over its column blocks through the flag maps
-    auto flags = [&](const Round &R, uint32_t any_n, uint32_t any_inv) {
+    auto flags = [&](const Round &R, uint64_t p, uint32_t any_n, uint32_t any_inv) {
         const unsigned long long bi = __ballot(any_inv != 0), bn = __ballot((any_n & 0x08080808u) != 0) | bi;
         if (bn) {
             const uint32_t sh = lane & 56u;
             const bool gn = ((bn >> sh) & 0xFFull) != 0, gi = ((bi >> sh) & 0xFFull) != 0;
             if (m == 0 && gn && R.has) {
-                const uint32_t bit = 1u << (R.r & 31u);
-                if (!(atomicOr(&a.flagmap[R.r >> 5], bit) & bit)) ++newn;
-                if (gi && !(atomicOr(&a.flagmap[a.flag_words + (R.r >> 5)], bit) & bit)) ++newi;
+                const uint64_t rid = lst ? (uint64_t)R.id : p;   // the record's number among those that count
+                const uint32_t bit = 1u << (rid & 31u);
+                if (!(atomicOr(&a.flagmap[rid >> 5], bit) & bit)) ++newn;
+                if (gi && !(atomicOr(&a.flagmap[a.flag_words + (rid >> 5)], bit) & bit)) ++newi;
             }
         }
     };
     // one round: the NEXT round's words into `N`, then the words of `R` (loaded a round ago) are counted; q: the entry two rounds
     // ahead, fetched here; e1 / cr1: the next round's entry and probe bytes (ready), replaced by the ones after them
     Round A, B;
-    fqh_idx_record e1 = entry_of(r_first + STEP), e2;
+    uint32_t id1 = id_of(p_first + STEP), id2 = id_of(p_first + 2 * STEP), id3;
+    fqh_idx_record e1 = entry_of(p_first + STEP, id1), e2;
     uint32_t cr1[2], cr2[2];
     {
-        const fqh_idx_record e0 = entry_of(r_first);
+        const uint32_t id0 = id_of(p_first);
+        const fqh_idx_record e0 = entry_of(p_first, id0);
         uint32_t cr0[2];
-        probe(e0, r_first, cr0);
-        probe(e1, r_first + STEP, cr1);
-        issue(A, r_first, e0, cr0);
+        probe(e0, p_first, cr0);
+        probe(e1, p_first + STEP, cr1);
+        issue(A, p_first, id0, e0, cr0);
     }
-    auto round = [&](Round &R, Round &N) {
-        issue(N, R.r + STEP, e1, cr1);
-        e2 = entry_of(R.r + 2 * STEP);
+    auto round = [&](Round &R, Round &N, uint64_t p) {   // p: the position R's record was taken from
+        issue(N, p + STEP, id1, e1, cr1);
+        e2 = entry_of(p + 2 * STEP, id2);
+        id3 = id_of(p + 3 * STEP);
         uint32_t any_n = 0, any_inv = 0;
         count_line(R, 0, any_n, any_inv);
-        probe(e2, R.r + 2 * STEP, cr2);
+        probe(e2, p + 2 * STEP, cr2);
         count_line(R, 1, any_n, any_inv);
-        flags(R, any_n, any_inv);
+        flags(R, p, any_n, any_inv);
         e1 = e2;
         cr1[0] = cr2[0];
         cr1[1] = cr2[1];
+        id1 = id2;
+        id2 = id3;
     };
     for (uint64_t r0 = r_lo + (uint64_t)wv * 8; r0 < r_hi; r0 += 2 * STEP) {   // (wave-uniform bounds; two rounds per trip: the buffers swap roles)
-        round(A, B);
-        if (r0 + STEP < r_hi) round(B, A);
+        round(A, B, r0 + g8);
+        if (r0 + STEP < r_hi) round(B, A, r0 + STEP + g8);
         else break;
     }
     // ---- the block's rows -> scratch, as they are (the S slices of a column block adding ~26 000 counters each to the caller's
@@ -684,13 +732,16 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         if (t[4]) atomicAdd(&a.scalars[6], t[4]);
     }
 }
-// the rows of every slice of a column block, summed and added to the caller's arrays (one thread per counter: no atomics)
-__global__ __launch_bounds__(256) void k_stats_long_reduce(const uint32_t *__restrict__ part, uint32_t n_cb, uint32_t n_slices, uint32_t lmax,
+// the rows of every slice of a column block, summed and added to the caller's arrays (one thread per counter: no atomics).
+// Slice s of column block cb is work item slice_start[s] + cb.
+__global__ __launch_bounds__(256) void k_stats_long_reduce(const uint32_t *__restrict__ part, const uint32_t *__restrict__ qs,
+                                                           const uint32_t *__restrict__ slice_start, uint32_t lmax,
                                                            unsigned long long *__restrict__ qual_hist, unsigned long long *__restrict__ base_hist) {
     const uint32_t id = blockIdx.x * 256 + threadIdx.x, cb = blockIdx.y;
     if (id >= SO_LWORDS) return;
     unsigned long long v = 0;
-    for (uint32_t sl = 0; sl < n_slices; ++sl) v += part[((uint64_t)sl * n_cb + cb) * SO_LWORDS + id];
+    const uint32_t n_slices = qs[cb];
+    for (uint32_t sl = 0; sl < n_slices; ++sl) v += part[(uint64_t)(slice_start[sl] + cb) * SO_LWORDS + id];
     if (!v) return;
     const uint32_t col0 = cb * SO_LC_MAX;
     const uint32_t lc = lmax > col0 ? (lmax - col0 < SO_LC_MAX ? lmax - col0 : SO_LC_MAX) : 0u;
@@ -705,16 +756,244 @@ __global__ __launch_bounds__(256) void k_stats_long_reduce(const uint32_t *__res
     else atomicAdd(&base_hist[(uint64_t)(col0 + row) * 8 + bin_to_class(bin)], v);
 }
 
-// One block is resident per CU (its histogram fills the LDS), so the launch runs in ROUNDS of `cus` blocks, and a block
-// costs ~0.2 ms beyond its share of the records (zeroing and storing 136 KiB of counters, the drain of its wavefronts):
-// measured per 4 GiB, 1 kbp reads in 256 blocks 1.37 ms, in 1024 blocks 1.97; a round that is not full wastes CUs for a
-// whole block time.  So: R rounds of as many slices as fill them, R = the cheapest of 1 .. 4 under
-// time ~ R * (cus / blocks + 0.23)  (units: the records' work spread evenly over the CUs).
-static void stats_long_plan(uint64_t n, uint32_t max_line, int n_cu, uint32_t *n_cb, uint32_t *n_slices) {
+// ---- the plan of a launch, made on the device ---------------------------------------------------------------------
+// Reads of ONE length fill every column block alike, and "the records in equal slices per column block" is a balanced plan.
+// Real long reads are not of one length (a nanopore or HiFi run spreads over a decade), and then the column blocks towards
+// the ends of the longest reads hold few bytes: with equal slices their CUs idle for most of the one round the launch runs in
+// (round 4: 1.89 against 1.22 ms per 4 GiB for lengths uniform in 4 .. 16 kbp; a log-normal spread 3.6 ms), and slices in
+// proportion to the bytes do not help as long as a block WALKS every record of its slice to find the few that reach its
+// columns (round 4: a block's time follows the records it walks, 14 ms).  So, before the walk, on the stream and without the
+// host:
+//   * k_long_census counts the records by CLASS = the number of column blocks they reach (ceil(raw line length / 256), at
+//     least 1: column block 0 sees every record — it counts them);
+//   * k_long_plan turns that into cnt[cb] = records that reach column block cb (a suffix sum) and cuts every column block's
+//     records into items of w, w the smallest for which the items fit the launch's blocks (a binary search over
+//     sum ceil(cnt[cb] / w)); the items are numbered slice-major: slice s = the s-th item of every column block that has one;
+//   * k_long_lists writes, per column block, the LIST of the records that reach it, in the file's order (up to the order in
+//     which blocks of 4096 records reserve their share) — what an item is a range of.  Skipped when every record is of one
+//     class: every list would be 0, 1, 2, ...
+// Every item then holds the same number of 256-byte pieces, whatever the lengths, and reads them in the file's order.  (First
+// built as ONE order for all column blocks — the index sorted by class, longest first, column block cb's records a prefix
+// of it: balanced as well, and 2.2 x faster than equal slices on a log-normal spread around 5 kbp, but SLOWER than equal
+// slices on reads of 250 .. 1000 bp, 2.59 against 2.51 ms per 4 GiB: in class-major order neighbouring pieces are far apart
+// in the file; the same data with the FILE sorted by length ran in 1.58 ms, which is what told the two effects apart.)
+constexpr uint32_t LONG_PLAN_MAX = 4096;       // column blocks and items the planner's LDS arrays hold; beyond: equal slices, no census
+constexpr uint32_t LONG_W_MIN = 8 * SO_WAVES;  // records a block's wavefronts take per round: no item is cut smaller
+constexpr uint32_t LONG_SORT_PER_BLOCK = 4096; // records per block of the census / the lists (four per thread)
+__device__ __forceinline__ uint32_t long_class(const fqh_idx_record *idx, uint64_t r, uint32_t n_cb) {
+    uint2 hs;                                  // head, seq: the line's raw length is the distance of the two newlines
+    __builtin_memcpy(&hs, reinterpret_cast<const uint8_t *>(idx + r) + 8, 8);
+    const uint32_t raw = hs.y - hs.x - 1u, k = raw ? (raw - 1u) / SO_LC_MAX + 1u : 1u;
+    return k < n_cb ? k : n_cb;
+}
+// the block's records per class -> lh[1 .. n_cb] (zeroed by the caller); a wavefront whose records are of one class (reads of
+// one length) adds once
+__device__ __forceinline__ void long_count(uint32_t *lh, uint32_t k, bool has) {
+    const unsigned long long hm = __ballot(has);
+    if (!hm) return;
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)(__ffsll((long long)hm) - 1));
+    if (__ballot(has && k != k0) == 0) {
+        if (__lane_id() == (uint32_t)(__ffsll((long long)hm) - 1)) atomicAdd(&lh[k0], (uint32_t)__popcll(hm));
+    } else if (has) {
+        atomicAdd(&lh[k], 1u);
+    }
+}
+__global__ __launch_bounds__(1024) void k_long_census(const fqh_idx_record *__restrict__ idx, uint64_t n, uint32_t n_cb, uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t lh[];           // [n_cb + 1]
+    for (uint32_t i = threadIdx.x; i <= n_cb; i += 1024) lh[i] = 0;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * LONG_SORT_PER_BLOCK + threadIdx.x;
+#pragma unroll
+    for (uint32_t t = 0; t < LONG_SORT_PER_BLOCK / 1024; ++t) {
+        const uint64_t r = r0 + t * 1024u;
+        const bool has = r < n;
+        long_count(lh, has ? long_class(idx, r, n_cb) : 0u, has);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= n_cb; i += 1024)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+struct LongPlanArgs {
+    uint64_t n;
+    uint32_t n_cb, nb;             // column blocks; items the launch has blocks (and rows in `part`) for, >= n_cb
+    uint32_t nb_one_length;        // ... of which reads of ONE class use this many (the host's plan for them: one round of blocks)
+    uint32_t census;               // 0: no census was taken (more column blocks / items than the planner holds): every record reaches every column block
+    const uint32_t *hist;          // [n_cb + 1] records per class (census)
+    uint64_t *list_off;            // [n_cb + 1] -> where column block cb's list starts
+    uint32_t *q;                   // [n_cb] -> slices per column block
+    uint32_t *slice_start;         // [nb + 1] -> first item of slice s
+    LongItem *items;               // [nb]
+    LongPlan *plan;
+};
+__global__ __launch_bounds__(1024) void k_long_plan(LongPlanArgs a) {
+    extern __shared__ uint32_t lp[];           // cnt[n_cb + 1], then start[nb + 1] (census); nothing otherwise
+    __shared__ uint32_t sh_w, sh_qmax, sh_listed;
+    const uint32_t tid = threadIdx.x, n_cb = a.n_cb;
+    uint32_t *const cnt = lp, *const start = lp + n_cb + 1;
+    if (!a.census) {
+        // equal slices, closed form (what the host's plan assumed): nb / n_cb slices of every column block
+        const uint32_t S = a.nb_one_length / n_cb;
+        const uint64_t w = (a.n + S - 1) / S;
+        for (uint32_t i = tid; i < n_cb; i += 1024) a.q[i] = S;
+        for (uint32_t i = tid; i <= S; i += 1024) a.slice_start[i] = i * n_cb;
+        for (uint32_t i = tid; i < S * n_cb; i += 1024) {
+            const uint32_t sl = i / n_cb;
+            const uint64_t lo = (uint64_t)sl * w, hi = lo + w < a.n ? lo + w : a.n;
+            a.items[i] = LongItem{i % n_cb, 0u, lo < a.n ? lo : a.n, hi};
+        }
+        if (tid == 0) *a.plan = LongPlan{S * n_cb, 0u, S, (uint32_t)(w < 0xFFFFFFFFu ? w : 0xFFFFFFFFu)};
+        return;
+    }
+    for (uint32_t i = tid; i <= n_cb; i += 1024) cnt[i] = a.hist[i];
+    __syncthreads();
+    if (tid == 0) {   // cnt[cb] = records of a class above cb (classes 1 .. n_cb)
+        uint32_t run = 0, classes = 0;
+        for (uint32_t k = n_cb; k >= 1; --k) {
+            const uint32_t h = cnt[k];
+            cnt[k] = run;
+            run += h;
+            classes += h ? 1u : 0u;
+        }
+        cnt[0] = run;                          // (== n)
+        sh_listed = classes > 1 ? 1u : 0u;
+        unsigned long long off = 0;            // the lists, one behind the other
+        for (uint32_t cb = 0; cb <= n_cb; ++cb) {
+            a.list_off[cb] = off;
+            off += cnt[cb];
+        }
+    }
+    __syncthreads();
+    // Reads of one class fill one round of blocks evenly, and a second round costs them 3 % (20 kbp: 1.142 / 1.177 / 1.221 ms per
+    // 4 GiB in one / two / three rounds).  Reads of many lengths leave column blocks with a few records each, which take an
+    // item (a block, a CU for that round) all the same: the launch has blocks for a finer cut, and the blocks that finish early
+    // make room for the rest (log-normal around 5 kbp, 118 column blocks: 1.95 / 1.71 / 1.69 ms).
+    const uint32_t nb = sh_listed ? a.nb : a.nb_one_length;
+    // the smallest w with sum over cb of ceil(cnt[cb] / w) <= nb (one wavefront; the sum does not grow with w)
+    if (tid < 64) {
+        const uint32_t n32 = cnt[0];
+        auto items_at = [&](uint32_t w) {
+            unsigned long long t = 0;
+            for (uint32_t cb = tid; cb < n_cb; cb += 64) t += ((unsigned long long)cnt[cb] + w - 1) / w;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+            return t;
+        };
+        uint32_t lo = n32 < LONG_W_MIN ? (n32 ? n32 : 1u) : LONG_W_MIN, hi = n32 ? n32 : 1u;
+        if (items_at(lo) <= nb) hi = lo;
+        while (lo < hi) {                      // invariant: items_at(hi) <= nb (at w = n every column block in use has one item, and nb >= n_cb)
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (items_at(mid) <= nb) hi = mid;
+            else lo = mid + 1;
+        }
+        if (tid == 0) {
+            sh_w = hi;
+            sh_qmax = (uint32_t)(((unsigned long long)n32 + hi - 1) / hi);
+        }
+    }
+    __syncthreads();
+    const uint32_t w = sh_w, q_max = sh_qmax;
+    auto q_of = [&](uint32_t cb) { return cb < n_cb ? (uint32_t)(((unsigned long long)cnt[cb] + w - 1) / w) : 0u; };
+    // column blocks per slice: q_of does not grow with cb, so the column blocks that have a slice s are a prefix — slice s
+    // has cb + 1 of them for s in [q_of(cb + 1), q_of(cb))
+    for (uint32_t cb = tid; cb < n_cb; cb += 1024) {
+        const uint32_t qc = q_of(cb);
+        a.q[cb] = qc;
+        for (uint32_t sl = q_of(cb + 1); sl < qc; ++sl) start[sl + 1] = cb + 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        start[0] = 0;
+        for (uint32_t sl = 0; sl < q_max; ++sl) start[sl + 1] += start[sl];
+    }
+    __syncthreads();
+    const uint32_t n_items = start[q_max];
+    for (uint32_t i = tid; i <= q_max; i += 1024) a.slice_start[i] = start[i];
+    for (uint32_t i = tid; i < n_items; i += 1024) {
+        uint32_t lo = 0, hi = q_max;           // the slice of item i: start[sl] <= i < start[sl + 1]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (start[mid] <= i) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t cb = i - start[lo];
+        const uint64_t r_lo = (uint64_t)lo * w, r_hi = r_lo + w < cnt[cb] ? r_lo + w : cnt[cb];
+        a.items[i] = LongItem{cb, 0u, r_lo, r_hi};
+    }
+    if (tid == 0) *a.plan = LongPlan{n_items, sh_listed, q_max, w};
+}
+// The lists: a block takes 4096 consecutive records, counts them by class (as the census did), turns that into its records
+// per column block, reserves that many places at the end of every list it adds to (one atomic per list and block), and its
+// wavefronts write their records' numbers: for column block cb the lanes whose record reaches it, in lane order, behind what
+// the block's wavefronts have written there so far (one LDS atomic per wavefront, 64 records and column block).
+__global__ __launch_bounds__(1024) void k_long_lists(const fqh_idx_record *__restrict__ idx, uint64_t n, uint32_t n_cb, const LongPlan *__restrict__ plan,
+                                                     const uint64_t *__restrict__ list_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ lists) {
+    extern __shared__ uint32_t lh[];           // [n_cb + 1] the block's records per class -> per column block -> written so far; [n_cb] its place in each list
+    if (!plan->listed) return;
+    uint32_t *const lbase = lh + n_cb + 1;
+    for (uint32_t i = threadIdx.x; i <= n_cb; i += 1024) lh[i] = 0;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * LONG_SORT_PER_BLOCK + threadIdx.x;
+    uint32_t k[LONG_SORT_PER_BLOCK / 1024];
+#pragma unroll
+    for (uint32_t t = 0; t < LONG_SORT_PER_BLOCK / 1024; ++t) {
+        const uint64_t r = r0 + t * 1024u;
+        k[t] = r < n ? long_class(idx, r, n_cb) : 0u;
+        long_count(lh, k[t], r < n);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                    // lh[cb] = the block's records of a class above cb: a suffix sum, 64 entries at a time from the top
+        uint32_t carry = 0;
+        for (int hi = (int)n_cb; hi >= 1; hi -= 64) {
+            const int kk = hi - (int)threadIdx.x;   // class of this lane (descending)
+            uint32_t v = kk >= 1 ? lh[kk] : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(v, d);
+                if ((int)threadIdx.x >= d) v += u;
+            }
+            const uint32_t total = __shfl(v, 63);
+            if (kk >= 1) lbase[kk - 1] = carry + v; // classes kk .. n_cb reach column block kk - 1 (not written over lh: the next 64 are still to be read)
+            carry += total;
+        }
+    }
+    __syncthreads();
+    for (uint32_t cb = threadIdx.x; cb < n_cb; cb += 1024) {
+        const uint32_t c = lbase[cb];
+        lbase[cb] = c ? atomicAdd(&cursor[cb], c) : 0u;
+        lh[cb] = 0;                            // -> written so far
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t t = 0; t < LONG_SORT_PER_BLOCK / 1024; ++t) {
+        const uint32_t kt = k[t];
+        uint32_t kmax = kt;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
+        kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmax);
+        const uint32_t rid = (uint32_t)(r0 + t * 1024u);
+        for (uint32_t cb = 0; cb < kmax; ++cb) {
+            const unsigned long long reach = __ballot(kt > cb);
+            uint32_t base = 0;
+            if (__lane_id() == 0) base = atomicAdd(&lh[cb], (uint32_t)__popcll(reach));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (kt > cb) lists[list_off[cb] + lbase[cb] + base + (uint32_t)__popcll(reach & ((1ull << __lane_id()) - 1ull))] = rid;
+        }
+    }
+}
+
+// One block is resident per CU (its histogram fills the LDS), so the launch runs in ROUNDS of `cus` blocks, and a round
+// costs ~3.5 % beyond its share of the records (zeroing and storing 136 KiB of counters, the start and the drain of its
+// wavefronts' pipelines: 20 kbp reads, per 4 GiB, in one / two / three rounds 1.142 / 1.177 / 1.221 ms; before the rounds
+// were software-pipelined the same cost 0.2 ms a round); a round that is not full wastes CUs for a whole block time.  So: R
+// rounds of as many slices as fill them, R = the cheapest of 1 .. 4 under time ~ R * (cus / blocks + 0.05)  (units: the
+// records' work spread evenly over the CUs).  This is the host's half of the
+// plan — how many items the launch has blocks for — made as if every read reached every column block; the device deals them
+// out by what the reads' lengths are (above).
+static void stats_long_plan(uint64_t n, uint32_t max_line, int n_cu, uint32_t *n_cb, uint32_t *n_slices, uint32_t *n_slices_varied) {
     *n_cb = (max_line + SO_LC_MAX - 1) / SO_LC_MAX;
     if (*n_cb == 0) *n_cb = 1;
     const uint32_t cus = stats_blocks(n_cu);
-    const uint64_t max_slices = std::max<uint64_t>(1, (n + 8 * SO_WAVES - 1) / (8 * SO_WAVES));
+    const uint64_t max_slices = std::max<uint64_t>(1, (n + LONG_W_MIN - 1) / LONG_W_MIN);
     uint32_t rounds_lo = 1, rounds_hi = 4;
 #ifdef FQH_TUNING
     if (getenv("FQH_LONG_ROUNDS") && atoi(getenv("FQH_LONG_ROUNDS")) > 0) rounds_lo = rounds_hi = (uint32_t)atoi(getenv("FQH_LONG_ROUNDS"));
@@ -725,35 +1004,103 @@ static void stats_long_plan(uint64_t n, uint32_t max_line, int n_cu, uint32_t *n
         uint64_t S = std::max<uint64_t>(1, (uint64_t)R * cus / *n_cb);
         if (S > max_slices) S = max_slices;
         const uint64_t blocks = S * *n_cb, r = (blocks + cus - 1) / cus;
-        const double cost = (double)r * ((double)cus / (double)blocks + 0.23);
+        const double cost = (double)r * ((double)cus / (double)blocks + 0.05);
         if (cost < best) {
             best = cost;
             *n_slices = (uint32_t)S;
         }
     }
+    // reads of many lengths (the device finds out): items for at least two rounds once the column blocks are many — most of them
+    // then hold a few records each
+    *n_slices_varied = *n_slices;
+    if (*n_cb > cus / 8) {
+        const uint64_t S2 = std::min<uint64_t>(std::max<uint64_t>(1, (uint64_t)2 * cus / *n_cb), max_slices);
+        if (S2 > *n_slices_varied) *n_slices_varied = (uint32_t)S2;
+    }
+#ifdef FQH_TUNING
+    if (getenv("FQH_LONG_ROUNDS")) *n_slices_varied = *n_slices;
+#endif
 }
-// bytes of scratch launch_stats_long wants for its blocks' rows
-size_t stats_long_part_bytes(uint64_t n, uint32_t max_line, int n_cu) {
-    uint32_t n_cb, n_slices;
-    stats_long_plan(n, max_line, n_cu, &n_cb, &n_slices);
-    return (size_t)n_cb * n_slices * SO_LWORDS * sizeof(uint32_t);
+// the scratch of one launch: every item's rows, the plan's arrays, the column blocks' lists
+struct LongScratch {
+    uint32_t n_cb, nb, nb_one_length;
+    bool census;
+    size_t part, hist, cursor, list_off, q, slice_start, items, plan, lists, bytes;   // byte offsets
+};
+static LongScratch stats_long_scratch(uint64_t n, uint64_t len, uint32_t max_line, int n_cu) {
+    LongScratch L = {};
+    uint32_t n_slices, n_slices_varied;
+    stats_long_plan(n, max_line, n_cu, &L.n_cb, &n_slices, &n_slices_varied);
+    L.nb_one_length = L.n_cb * n_slices;
+    L.nb = L.n_cb * n_slices_varied;
+    L.census = L.n_cb <= LONG_PLAN_MAX && L.nb <= LONG_PLAN_MAX && n < 0xFFFF0000ull;
+#ifdef FQH_TUNING
+    if (getenv("FQH_LONG_CENSUS") && atoi(getenv("FQH_LONG_CENSUS")) == 0) L.census = false;
+#endif
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o += (bytes + 15) & ~(size_t)15;
+        return at;
+    };
+    L.part = take((size_t)L.nb * SO_LWORDS * sizeof(uint32_t));
+    L.hist = take(((size_t)L.n_cb + 1) * sizeof(uint32_t));      // (hist and cursor: zeroed by one memset)
+    L.cursor = take(((size_t)L.n_cb + 1) * sizeof(uint32_t));
+    L.list_off = take(((size_t)L.n_cb + 1) * sizeof(uint64_t));
+    L.q = take((size_t)L.n_cb * sizeof(uint32_t));
+    L.slice_start = take(((size_t)L.nb + 1) * sizeof(uint32_t));
+    L.items = take((size_t)L.nb * sizeof(LongItem));
+    L.plan = take(sizeof(LongPlan));
+    // a record is on max(1, ceil(line / 256)) lists, and the sequence lines of all records are at most half of the input
+    L.lists = take(L.census ? (size_t)(len / (2 * SO_LC_MAX) + n + 1) * sizeof(uint32_t) : 0);
+    L.bytes = o;
+    return L;
 }
+// bytes of scratch launch_stats_long wants (a multiple of 16)
+size_t stats_long_scratch_bytes(uint64_t n, uint64_t len, uint32_t max_line, int n_cu) { return stats_long_scratch(n, len, max_line, n_cu).bytes; }
 // records [0, n) of idx; max_line: no sequence / quality line is longer (bounds the column blocks); flagmap: 2 * flag_words zeroed words;
-// part: stats_long_part_bytes() of scratch
+// scratch: stats_long_scratch_bytes()
 hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, uint64_t base_offset, const fqh_idx_record *idx, uint64_t n,
                              uint32_t lmax, uint32_t max_line, uint32_t *flagmap, uint64_t flag_words, unsigned long long *qual_hist,
-                             unsigned long long *base_hist, unsigned long long *scalars, int n_cu, uint32_t *part) {
+                             unsigned long long *base_hist, unsigned long long *scalars, int n_cu, uint32_t *scratch) {
     if (!n) return hipSuccess;
+    const LongScratch L = stats_long_scratch(n, len, max_line, n_cu);
+    uint8_t *const sc = reinterpret_cast<uint8_t *>(scratch);
+    LongPlanArgs pa = {};
+    pa.n = n;
+    pa.n_cb = L.n_cb;
+    pa.nb = L.nb;
+    pa.nb_one_length = L.nb_one_length;
+    pa.census = L.census ? 1u : 0u;
+    pa.hist = reinterpret_cast<uint32_t *>(sc + L.hist);
+    pa.list_off = reinterpret_cast<uint64_t *>(sc + L.list_off);
+    pa.q = reinterpret_cast<uint32_t *>(sc + L.q);
+    pa.slice_start = reinterpret_cast<uint32_t *>(sc + L.slice_start);
+    pa.items = reinterpret_cast<LongItem *>(sc + L.items);
+    pa.plan = reinterpret_cast<LongPlan *>(sc + L.plan);
+    uint32_t *const lists = reinterpret_cast<uint32_t *>(sc + L.lists);
+    const uint32_t sort_blocks = (uint32_t)((n + LONG_SORT_PER_BLOCK - 1) / LONG_SORT_PER_BLOCK);
+    const size_t class_lds = ((size_t)L.n_cb + 1) * sizeof(uint32_t);
+    if (L.census) {
+        if (hipError_t e = hipMemsetAsync(sc + L.hist, 0, L.list_off - L.hist, s); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_long_census, dim3(sort_blocks), dim3(1024), class_lds, s, idx, n, L.n_cb, reinterpret_cast<uint32_t *>(sc + L.hist));
+    }
+    hipLaunchKernelGGL(k_long_plan, dim3(1), dim3(1024), L.census ? ((size_t)L.n_cb + L.nb + 2) * sizeof(uint32_t) : 0, s, pa);
+    if (L.census)
+        hipLaunchKernelGGL(k_long_lists, dim3(sort_blocks), dim3(1024), 2 * class_lds, s, idx, n, L.n_cb, pa.plan, pa.list_off,
+                           reinterpret_cast<uint32_t *>(sc + L.cursor), lists);
     LongArgs a = {};
     a.buf = buf;
     a.len = len;
     a.base_offset = base_offset;
     a.idx = idx;
+    a.lists = lists;
+    a.list_off = pa.list_off;
     a.n = n;
     a.lmax = lmax;
-    stats_long_plan(n, max_line, n_cu, &a.n_cb, &a.n_slices);
-    a.part = part;
-    a.per_xcd = (a.n_cb * a.n_slices + 7u) / 8u;
+    a.plan = pa.plan;
+    a.items = pa.items;
+    a.part = reinterpret_cast<uint32_t *>(sc + L.part);
     a.flagmap = flagmap;
     a.flag_words = flag_words;
     a.qual_hist = qual_hist;
@@ -762,8 +1109,8 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
     const size_t lds = SO_LADDR_SPAN;  // (a lane without a whole dword subtracts 0 wherever its bytes point: all of that is allocated)
     static LdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void *>(k_stats_long), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stats_long, dim3(8u * a.per_xcd), dim3(SO_THREADS), lds, s, a);
-    hipLaunchKernelGGL(k_stats_long_reduce, dim3((SO_LWORDS + 255) / 256, a.n_cb), dim3(256), 0, s, part, a.n_cb, a.n_slices, lmax, qual_hist,
+    hipLaunchKernelGGL(k_stats_long, dim3(8u * ((L.nb + 7u) / 8u)), dim3(SO_THREADS), lds, s, a);
+    hipLaunchKernelGGL(k_stats_long_reduce, dim3((SO_LWORDS + 255) / 256, L.n_cb), dim3(256), 0, s, a.part, pa.q, pa.slice_start, lmax, qual_hist,
                        base_hist);
     return hipGetLastError();
 }

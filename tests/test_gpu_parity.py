@@ -276,6 +276,46 @@ def test_stats_kilobase_reads(fqref, gpu, shape):
         assert np.array_equal(gq, qh), (shape, lmax, np.argwhere(gq != qh)[:5])
 
 
+@pytest.mark.parametrize("shape", ["tail", "two_classes", "one_class", "few", "empty_lines"])
+def test_stats_long_reads_of_many_lengths(fqref, gpu, shape):
+    """k_stats_long's plan is made on the device from the reads' lengths (k_long_census / k_long_plan / k_long_scatter): records
+    ordered by the number of 256-column blocks they reach, every column block's prefix cut into items of equal size.  Enough
+    records for several items per column block, lengths with a long tail (classes 1 .. 36), two classes only, one class (no
+    sorted copy), fewer records than one item holds, and reads of length 0 among long ones; CRLF lines and bytes outside the
+    alphabets on the way.  (src/lib.rs:276-283 and src/records.rs:75-90 treat every record up to BUFSIZE alike.)"""
+    rng = np.random.default_rng({"tail": 11, "two_classes": 12, "one_class": 13, "few": 14, "empty_lines": 15}[shape])
+    n_rec = {"tail": 5000, "two_classes": 3000, "one_class": 3000, "few": 70, "empty_lines": 1500}[shape]
+    recs = []
+    for i in range(n_rec):
+        if shape == "tail":
+            n = int(min(9000, rng.geometric(1 / 900.0)))
+        elif shape == "two_classes":
+            n = 700 if i % 5 else 2100
+        elif shape == "one_class":
+            n = int(rng.integers(513, 769))
+        elif shape == "few":
+            n = int(rng.integers(1, 4000))
+        else:
+            n = 0 if i % 3 == 0 else int(rng.integers(1, 1500))
+        seq = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes())
+        qual = bytearray(rng.choice(np.frombuffer(b"~!5I", dtype=np.uint8), n).tobytes() if i % 2 else rng.integers(33, 75, n).astype(np.uint8).tobytes())
+        if n and i % 7 == 0:
+            seq[n - 1] = ord("N")                       # in the record's last column block
+        if n > 300 and i % 11 == 0:
+            seq[int(rng.integers(0, n))] = ord("x")
+            qual[int(rng.integers(0, n))] = 0xF0         # outside the 128-bin window
+        e = b"\r\n" if i % 13 == 0 else b"\n"
+        recs.append(b"@r%d" % i + e + bytes(seq) + e + b"+" + e + bytes(qual) + e)
+    data = b"".join(recs)
+    for lmax in (9000, 1000, 600):
+        r, qh, bh, sc = fqref.stats(data, lmax)
+        s, gq, gb, gs = gpu.stats(data, lmax)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (0, n_rec)
+        assert np.array_equal(gs, sc), (shape, lmax, gs, sc)
+        assert np.array_equal(gb, bh), (shape, lmax, np.argwhere(gb != bh)[:5])
+        assert np.array_equal(gq, qh), (shape, lmax, np.argwhere(gq != qh)[:5])
+
+
 @pytest.mark.parametrize("shape", ["fixed150", "fixed36", "ragged", "binned", "crlf", "dirty", "len4k"])
 def test_stats_fast_path_shapes(fqref, torch, pkg, shape):
     """Multi-tile buffers (so that the whole-dword LDS path runs, not only the exact one): fixed and

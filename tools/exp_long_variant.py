@@ -18,10 +18,17 @@ if os.environ.get("QUAL_ILLUMINA") == "1":   # '#'..'I' only: inside every kerne
     qual = rng.integers(35, 74, (nrec, read_len)).astype(np.uint8)
 # READ_LEN_VAR=1: lengths uniform in [READ_LEN / 4, READ_LEN] (the column blocks do not hold equal shares of the bytes any more)
 lens = rng.integers(read_len // 4, read_len + 1, nrec) if os.environ.get("READ_LEN_VAR") == "1" else np.full(nrec, read_len)
+if os.environ.get("READ_LEN_VAR") == "2":   # a long tail (nanopore-like): log-normal, median READ_LEN / 4, clipped to [100, READ_LEN]
+    lens = np.clip(rng.lognormal(np.log(read_len / 4), 0.8, nrec), 100, read_len).astype(np.int64)
 block = b"".join(b"@m%06d/ccs\n" % i + seq[i, :lens[i]].tobytes() + b"\n+\n" + qual[i, :lens[i]].tobytes() + b"\n" for i in range(nrec))
 reps = (4 << 30) // len(block)
 n = reps * len(block)
-d = torch.cat([torch.from_numpy(np.frombuffer(block, dtype=np.uint8).copy()).to(dev).repeat(reps), torch.zeros(16, dtype=torch.uint8, device=dev)])
+if os.environ.get("FILE_SORTED") == "1":   # the file's records ordered by length, longest first (every record `reps` times in a row)
+    order = np.argsort(-lens, kind="stable")
+    one = [b"@m%06d/ccs\n" % i + seq[i, :lens[i]].tobytes() + b"\n+\n" + qual[i, :lens[i]].tobytes() + b"\n" for i in order]
+    d = torch.cat([torch.from_numpy(np.frombuffer(r, dtype=np.uint8).copy()).to(dev).repeat(reps) for r in one] + [torch.zeros(16, dtype=torch.uint8, device=dev)])
+else:
+    d = torch.cat([torch.from_numpy(np.frombuffer(block, dtype=np.uint8).copy()).to(dev).repeat(reps), torch.zeros(16, dtype=torch.uint8, device=dev)])
 qh = torch.zeros(read_len * 256, dtype=torch.int64, device=dev); bh = torch.zeros(read_len * 8, dtype=torch.int64, device=dev); sc = torch.zeros(8, dtype=torch.int64, device=dev)
 best = 1e9
 for _ in range(4):

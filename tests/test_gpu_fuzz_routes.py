@@ -1,5 +1,5 @@
 """Differential fuzz of the ROUTES behind fqh_scan / fqh_stats / fqh_scan_stats: random multi-segment files (read lengths
-from 0 to 600 bp, id lengths from 1 to 120, CRLF, '+id' lines, damage, truncation, random capacities of the offsets array,
+from 0 to 2500 bp — one length per segment, or ragged by up to 2000 —, id lengths from 1 to 120, CRLF, '+id' lines, damage, truncation, random capacities of the offsets array,
 random lmax) against the oracle: offsets, counts, status, maximum record length, histograms.  Drives every loop of
 k_emit_fast (one line / two lines / list area / generic), the single pass (k_scan_stats) and its fall-backs.  The idea is the
 reference's fuzz targets (fuzz/fuzz_targets/fuzz_target_1.rs:11-18), made differential.  tools/fuzz_routes.py runs the
@@ -42,10 +42,10 @@ def fuzz_routes(torch, pkg, fqref, seed, budget_s, max_cases=None):
             ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
         segs = []
         for _ in range(int(rng.integers(1, 5))):
-            L = int(rng.choice([0, 1, 20, 36, 50, 75, 100, 125, 150, 151, 170, 200, 250, 257, 300, 320, 384, 400, 500, 511, 512, 600]))
+            L = int(rng.choice([0, 1, 20, 36, 50, 75, 100, 125, 150, 151, 170, 200, 250, 257, 300, 320, 384, 400, 500, 511, 512, 600, 1000, 2500]))
             rec = 2 * L + 12
             segs.append(segment(int(rng.integers(200, 1 + (3 << 20) // max(rec, 40))), L, int(rng.choice([1, 8, 30, 60, 120])),
-                                bool(rng.random() < 0.15), bool(rng.random() < 0.2), int(rng.choice([0, 0, 0, 3, 40]))))
+                                bool(rng.random() < 0.15), bool(rng.random() < 0.2), int(rng.choice([0, 0, 0, 3, 40, 2000]))))
         data = b"".join(segs)
         if rng.random() < 0.25:   # bytes the single pass does not count itself (lower-case bases, qualities above '`'): dumps, in every instance
             b = bytearray(data)
@@ -82,7 +82,7 @@ def fuzz_routes(torch, pkg, fqref, seed, budget_s, max_cases=None):
             ends = np.concatenate([starts[1:], [len(data)]]).astype(np.int64)
             assert s.max_record_len == int(np.max(ends - starts.astype(np.int64))), ("maxlen", seed, cases)
         fast += bool(ctx.last_scan_fast())
-        lmax = int(rng.choice([36, 50, 64, 96, 100, 128, 150, 152, 170, 192, 200, 256, 300, 320, 384, 401, 500, 511, 512, 600]))
+        lmax = int(rng.choice([36, 50, 64, 96, 100, 128, 150, 152, 170, 192, 200, 256, 300, 320, 384, 401, 500, 511, 512, 600, 1000, 2600]))
         qh = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
         bh = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
         sc = torch.zeros(8, dtype=torch.int64, device=dev)

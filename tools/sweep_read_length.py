@@ -17,6 +17,9 @@ for L in LENS:
     qual = rng.choice(np.frombuffer(b"#,5:F", dtype=np.uint8), (nrec, L))
     lo = int(os.environ.get("RAGGED", "0"))
     lens = rng.integers(min(lo, L), L + 1, nrec) if lo else np.full(nrec, L)
+    if os.environ.get("RAGGED_SET"):   # lengths drawn from a set (<= L), e.g. RAGGED_SET=144,148
+        lens = rng.choice(np.array([int(x) for x in os.environ["RAGGED_SET"].split(",")]), nrec)
+        lo = int(lens.min())
     if lo:   # (columns beyond a record's length do not count)
         seq[np.arange(L)[None, :] >= lens[:, None]] = 0
     block = b"".join(b"@A00123:45:HXXXXXXXX:1:%04d:%05d:%05d 1:N:0:ATCACG\n" % (1101 + i % 400, 1000 + 7 * i, 2000 + 3 * i) + seq[i, :lens[i]].tobytes() + b"\n+\n" +

@@ -316,6 +316,32 @@ def test_stats_long_reads_of_many_lengths(fqref, gpu, shape):
         assert np.array_equal(gq, qh), (shape, lmax, np.argwhere(gq != qh)[:5])
 
 
+@pytest.mark.parametrize("huge", [1_000_000, 1_250_000])
+def test_stats_one_huge_read_among_short_ones(fqref, gpu, huge):
+    """A Buffer of 4 MiB (Parser::new takes any reader, src/lib.rs:208; the Buffer's size is the crate's constant, a caller's
+    choice here) and one read of a million bases among reads of a few hundred: 3 907 column blocks — the planner's arrays hold
+    4 096, k_long_census / k_long_plan / k_long_lists run with nearly all of them in use by ONE record — and 4 883, beyond
+    what the planner holds: equal slices, no census."""
+    rng = np.random.default_rng(huge)
+    recs = []
+    for i in range(60):
+        n = huge if i == 17 else int(rng.integers(0, 900))
+        seq = bytearray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes())
+        qual = rng.choice(np.frombuffer(b"~!5I", dtype=np.uint8), n).tobytes()
+        if n:
+            seq[n - 1] = ord("N")
+        e = b"\r\n" if i % 9 == 0 else b"\n"
+        recs.append(b"@r%d\n" % i + bytes(seq) + e + b"+\n" + qual + e)
+    data = b"".join(recs)
+    B = 4 << 20
+    for lmax in (2000, 700):
+        r, qh, bh, sc = fqref.stats(data, lmax, bufsize=B)
+        s, gq, gb, gs = gpu.stats(data, lmax, bufsize=B)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (0, 60)
+        assert np.array_equal(gs, sc), (huge, lmax, gs, sc)
+        assert np.array_equal(gb, bh) and np.array_equal(gq, qh), (huge, lmax)
+
+
 @pytest.mark.parametrize("shape", ["fixed150", "fixed36", "ragged", "binned", "crlf", "dirty", "len4k"])
 def test_stats_fast_path_shapes(fqref, torch, pkg, shape):
     """Multi-tile buffers (so that the whole-dword LDS path runs, not only the exact one): fixed and

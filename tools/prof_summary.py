@@ -16,7 +16,7 @@ out, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "round4")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 os.makedirs(PROF, exist_ok=True)
-HOT = ("k_index_fast", "k_scan_stats", "k_emit_fast", "k_prefix", "k_finalize", "k_stats_commit", "k_stats_declined", "k_stats_edge", "k_stats_long", "k_index_t", "k_stats_oct",
+HOT = ("k_index_fast", "k_scan_stats", "k_emit_fast", "k_prefix", "k_finalize", "k_stats_commit", "k_stats_declined", "k_stats_edge", "k_stats_long_reduce", "k_stats_long", "k_long_census", "k_long_plan", "k_long_lists", "k_index_t", "k_stats_oct",
        "k_emit(", "k_read_ceiling", "k_stats_reduce")
 txt = []
 

@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void k_stats_long_reduce(const uint32_t *__res
 // in the file; the same data with the FILE sorted by length ran in 1.58 ms, which is what told the two effects apart.)
 constexpr uint32_t LONG_PLAN_MAX = 4096;       // column blocks and items the planner's LDS arrays hold; beyond: equal slices, no census
 constexpr uint32_t LONG_W_MIN = 8 * SO_WAVES;  // records a block's wavefronts take per round: no item is cut smaller
-constexpr uint32_t LONG_SORT_PER_BLOCK = 4096; // records per block of the census / the lists (four per thread)
+constexpr uint32_t LONG_SORT_PER_BLOCK = 4096; // records per block of the census (four per thread)
 __device__ __forceinline__ uint32_t long_class(const fqh_idx_record *idx, uint64_t r, uint32_t n_cb) {
     uint2 hs;                                  // head, seq: the line's raw length is the distance of the two newlines
     __builtin_memcpy(&hs, reinterpret_cast<const uint8_t *>(idx + r) + 8, 8);
@@ -921,27 +921,25 @@ __global__ __launch_bounds__(1024) void k_long_plan(LongPlanArgs a) {
     }
     if (tid == 0) *a.plan = LongPlan{n_items, sh_listed, q_max, w};
 }
-// The lists: a block takes 4096 consecutive records, counts them by class (as the census did), turns that into its records
-// per column block, reserves that many places at the end of every list it adds to (one atomic per list and block), and its
-// wavefronts write their records' numbers: for column block cb the lanes whose record reaches it, in lane order, behind what
-// the block's wavefronts have written there so far (one LDS atomic per wavefront, 64 records and column block).
+// The lists: a block takes 1024 consecutive records (one per thread), counts them by class (as the census did), turns that
+// into its records per column block, reserves that many places at the end of every list it adds to (one atomic per list and
+// block), and its wavefronts write their records' numbers: for column block cb the lanes whose record reaches it, in lane
+// order, behind what the block's wavefronts have written there so far (one LDS atomic per wavefront and column block, four
+// column blocks in flight).  (4096 records per block, one column block at a time: 125 us for 300 000 reads of 370 .. 30 000
+// bases — 74 blocks, each wavefront 4 x 118 dependent LDS round trips — of the 1.5 ms the walk behind it takes.)
+constexpr uint32_t LONG_LIST_PER_BLOCK = 1024;
 __global__ __launch_bounds__(1024) void k_long_lists(const fqh_idx_record *__restrict__ idx, uint64_t n, uint32_t n_cb, const LongPlan *__restrict__ plan,
                                                      const uint64_t *__restrict__ list_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ lists) {
-    extern __shared__ uint32_t lh[];           // [n_cb + 1] the block's records per class -> per column block -> written so far; [n_cb] its place in each list
+    extern __shared__ uint32_t lh[];           // [n_cb + 1] the block's records per class -> written so far per column block; [n_cb] -> its place in each list
     if (!plan->listed) return;
     uint32_t *const lbase = lh + n_cb + 1;
     for (uint32_t i = threadIdx.x; i <= n_cb; i += 1024) lh[i] = 0;
     __syncthreads();
-    const uint64_t r0 = (uint64_t)blockIdx.x * LONG_SORT_PER_BLOCK + threadIdx.x;
-    uint32_t k[LONG_SORT_PER_BLOCK / 1024];
-#pragma unroll
-    for (uint32_t t = 0; t < LONG_SORT_PER_BLOCK / 1024; ++t) {
-        const uint64_t r = r0 + t * 1024u;
-        k[t] = r < n ? long_class(idx, r, n_cb) : 0u;
-        long_count(lh, k[t], r < n);
-    }
+    const uint64_t r = (uint64_t)blockIdx.x * LONG_LIST_PER_BLOCK + threadIdx.x;
+    const uint32_t kt = r < n ? long_class(idx, r, n_cb) : 0u;
+    long_count(lh, kt, r < n);
     __syncthreads();
-    if (threadIdx.x < 64) {                    // lh[cb] = the block's records of a class above cb: a suffix sum, 64 entries at a time from the top
+    if (threadIdx.x < 64) {                    // lbase[cb] = the block's records of a class above cb: a suffix sum, 64 entries at a time from the top
         uint32_t carry = 0;
         for (int hi = (int)n_cb; hi >= 1; hi -= 64) {
             const int kk = hi - (int)threadIdx.x;   // class of this lane (descending)
@@ -963,20 +961,25 @@ __global__ __launch_bounds__(1024) void k_long_lists(const fqh_idx_record *__res
         lh[cb] = 0;                            // -> written so far
     }
     __syncthreads();
+    uint32_t kmax = kt;
 #pragma unroll
-    for (uint32_t t = 0; t < LONG_SORT_PER_BLOCK / 1024; ++t) {
-        const uint32_t kt = k[t];
-        uint32_t kmax = kt;
+    for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
+    kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmax);
+    const uint32_t rid = (uint32_t)r;
+    const unsigned long long below = (1ull << __lane_id()) - 1ull;
+    for (uint32_t cb0 = 0; cb0 < kmax; cb0 += 4) {
+        unsigned long long reach[4];
+        uint32_t base[4];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
-        kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmax);
-        const uint32_t rid = (uint32_t)(r0 + t * 1024u);
-        for (uint32_t cb = 0; cb < kmax; ++cb) {
-            const unsigned long long reach = __ballot(kt > cb);
-            uint32_t base = 0;
-            if (__lane_id() == 0) base = atomicAdd(&lh[cb], (uint32_t)__popcll(reach));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (kt > cb) lists[list_off[cb] + lbase[cb] + base + (uint32_t)__popcll(reach & ((1ull << __lane_id()) - 1ull))] = rid;
+        for (uint32_t j = 0; j < 4; ++j) {
+            reach[j] = __ballot(kt > cb0 + j);     // (0 beyond kmax)
+            base[j] = 0;
+            if (__lane_id() == 0 && reach[j]) base[j] = atomicAdd(&lh[cb0 + j], (uint32_t)__popcll(reach[j]));
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)base[j]);
+            if (kt > cb0 + j) lists[list_off[cb0 + j] + lbase[cb0 + j] + b + (uint32_t)__popcll(reach[j] & below)] = rid;
         }
     }
 }
@@ -1087,7 +1090,7 @@ hipError_t launch_stats_long(hipStream_t s, const uint8_t *buf, uint64_t len, ui
     }
     hipLaunchKernelGGL(k_long_plan, dim3(1), dim3(1024), L.census ? ((size_t)L.n_cb + L.nb + 2) * sizeof(uint32_t) : 0, s, pa);
     if (L.census)
-        hipLaunchKernelGGL(k_long_lists, dim3(sort_blocks), dim3(1024), 2 * class_lds, s, idx, n, L.n_cb, pa.plan, pa.list_off,
+        hipLaunchKernelGGL(k_long_lists, dim3((uint32_t)((n + LONG_LIST_PER_BLOCK - 1) / LONG_LIST_PER_BLOCK)), dim3(1024), 2 * class_lds, s, idx, n, L.n_cb, pa.plan, pa.list_off,
                            reinterpret_cast<uint32_t *>(sc + L.cursor), lists);
     LongArgs a = {};
     a.buf = buf;

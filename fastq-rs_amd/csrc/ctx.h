@@ -122,6 +122,8 @@ struct fqh_ctx {
     // fast path: prove validity with a quarter of the list traffic; any doubt -> exact rerun
     bool spec_enabled = true;   // false: exact path only (callers that need full line lists, FQH_SPEC=0)
     uint32_t exact_holds = 0;   // live fqh_streams that need complete line lists for every chunk: no fast path while > 0
+    uint32_t fused_skip = 0, fused_backoff = 0;  // statistics calls left on the two-pass route after a single pass that had to be given up
+                                                 // (reads longer than the histogram's rows, more dirty lines than the dump area holds): 1, 2, 4 .. 64
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...
     uint32_t spec_backoff = 0;  // ... 1, 2, 4 .. 64 of them, doubling with every failure in a row
     bool reuse_index = false;   // FQH_OPT_REUSE_INDEX: fqh_stats* may count over the last scan's tile index (the caller vouches for the bytes)

@@ -1052,6 +1052,7 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
         return FQH_OK;
     case FQH_OPT_SINGLE_PASS:
         ctx->fused_enabled = value != 0;
+        ctx->fused_skip = ctx->fused_backoff = 0;
         return FQH_OK;
     case FQH_OPT_PLACE_TRIES:
         ctx->place_tries = value < 0 ? 0 : value > 8 ? 8 : value;
@@ -1161,6 +1162,7 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 static bool fused_eligible(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                            uint32_t lmax, uint64_t lead_len, uint64_t n_limit) {
     if (!ctx->fused_enabled || !ctx->spec_enabled || ctx->exact_holds || ctx->spec_skip || ctx->list_cap != LIST_CAP_DEFAULT) return false;
+    if (ctx->fused_skip) return false;   // backing off after a pass that was given up (fused_finish)
     // (chunks with a carry, chunks that are not the file's last and lead bytes are fine: k_stats_edge settles the records at
     // the chunk's two ends; a record LIMIT is not — the kernel counts every line it meets — except for the streaming ring,
     // which commits only after it knows that the limit does not bite: f_defer_commit)
@@ -1193,6 +1195,15 @@ static fqh_status fused_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_
     // batches than the dump area holds.  The scan's result stands, on the fast path; only the histograms take a second pass,
     // and the fast path's back-off does not hear of it: nothing was wrong with the parse)
     *two_pass = !ctx->used_spec || ctx->h_out->stats_declined != 0;
+    // A pass that was given up cost a whole read of the input for nothing, and the next chunk of the same file will do the same:
+    // the context's next 1, 2, 4 .. 64 statistics calls go straight to the two-pass route (fqh_stats_launch counts them down), a
+    // pass that commits resets the count — the fast path's own rule (do_scan_finish), for the same reason.
+    if (ctx->used_spec && ctx->h_out->stats_declined != 0) {
+        ctx->fused_backoff = ctx->fused_backoff ? (ctx->fused_backoff < 64 ? ctx->fused_backoff * 2 : 64) : 1;
+        ctx->fused_skip = ctx->fused_backoff;
+    } else if (ctx->used_spec) {
+        ctx->fused_backoff = 0;
+    }
     ctx->stats_route = *two_pass ? 0 : (ctx->h_out->decl_batches || ctx->h_out->decl_lines) ? 2 : 1;
     if (ctx->used_spec) ctx->timing.stats_ms = ctx->timing.index_ms;  // the one kernel that read the input
     return st;
@@ -1209,6 +1220,7 @@ fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     ctx->f_defer_commit = true;
     const bool ok = fused_eligible(ctx, d_buf, len, is_final, in, lmax, lead_len, 0);
     if (!ok) {
+        if (ctx->fused_enabled && ctx->fused_skip) --ctx->fused_skip;   // (not the second pass of a call that has just given its single pass up)
         ctx->f_defer_commit = false;
         return FQH_OK;
     }
@@ -1248,6 +1260,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         ctx->stats_pending = true;
         return FQH_OK;
     }
+    if (ctx->fused_enabled && ctx->fused_skip) --ctx->fused_skip;   // (not the second pass of a call that has just given its single pass up)
     if (!same_scan(ctx, d_buf, len, is_final, in)) {
         // the histogram kernel needs complete line lists: scan on the exact path right away instead of
         // taking the fast path and indexing a second time
@@ -1293,7 +1306,10 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         // reads longer than the kernel's 256 LDS rows are counted in several passes, which share one bit per record
         // and alphabet flag (behind the partial histograms in the scratch)
         const uint32_t max_line = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ctx->last_summary.max_record_len / 2, len + ctx->carry_in.back[3]), 0xFFFFFFFFu);
-        const bool passes = std::min(max_line ? max_line : lmax, lmax) > 256;
+        // (by the READS' length, not by the caller's rows: lmax is the caller's choice — the first 150 cycles of 5 kbp reads — and
+        // what lies beyond it is still looked at, for the alphabet flags: k_stats_oct does that byte by byte, 10.9 ms per 4 GiB of
+        // 5 kbp reads with lmax = 150; k_stats_long's column blocks beyond lmax only look, at the speed of their loads, 1.3 ms)
+        const bool passes = (max_line ? max_line : lmax) > 256;
         // Reads beyond the 256 rows: one walk over the record index (k_stats_long; its blocks' rows take the place of k_stats_oct's
         // partial histograms in the scratch).  Round 3 kept two passes of k_stats_oct for reads of up to 512 columns (2340 against
         // 1660 GB/s at 300 bp); since k_stats_long runs in one round of blocks the two are level at 300 bp (1.91 / 1.97 ms per
@@ -1455,6 +1471,7 @@ fqh_status fqh_scan_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
         ctx->stats_pending = true;
         return FQH_OK;
     }
+    if (ctx->fused_enabled && ctx->fused_skip) --ctx->fused_skip;   // (not the second pass of a call that has just given its single pass up)
     // two passes: the exact scan (offsets + full index), then the histogram kernel over that index
     const bool spec = ctx->spec_enabled;
     ctx->spec_enabled = false;

@@ -191,8 +191,16 @@ __device__ __forceinline__ void fz_sub4_at(const uint32_t off, const SoLane &c, 
 // the bytes the file holds; quality dwords are rebased in place, which a dump undoes.
 // A batch that holds a byte outside the alphabet / window: its lanes' line words (bit 31: quality lines) and raw dwords go to
 // the dump area, 64 x (1 + NSL) words per batch; k_stats_declined counts them.  No room left: nothing of this pass is used.
+// Has this pass been given up already (DevOut::stats_declined: nothing of it will be committed)?  Asked before every atomic that
+// lists or dumps something: a pass over reads that are ALL longer than the histogram's rows (the caller's lmax is its own
+// choice) otherwise queues millions of read-modify-writes of one counter — 25 ms per 4 GiB of 300-base reads with lmax = 150,
+// against 3 ms for the same pass with its results thrown away.
+__device__ __forceinline__ bool fz_given_up(const FusedArgs &z) {
+    return __hip_atomic_load(&FZ_KARG(out)->stats_declined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 template <bool IS_SEQ, uint32_t NSL>
 __device__ __forceinline__ void fz_dump(const FzBatch<NSL> &B, const FusedArgs &z) {
+    if (fz_given_up(z)) return;
     uint32_t slot = 0;
     if (__lane_id() == 0) slot = (uint32_t)atomicAdd(&FZ_KARG(out)->decl_batches, 1ull);
     slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
@@ -739,7 +747,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                 l = ((e4 - e3) & 0x3FFFu) - 1u;  // raw line, without its '\n'
                                 const int ys = yc - 1 - (int)l;
                                 if (ys < 0) {
-                                    atomicAdd(&FZ_KARG(out)->stats_declined, 1ull);  // began before the kept tail (longer than ~500 bytes): not counted here
+                                    if (!fz_given_up(z)) atomicAdd(&FZ_KARG(out)->stats_declined, 1ull);  // began before the kept tail (longer than ~500 bytes): not counted here
                                 } else {
                                     if (l && bcr == '\r') --l;  // trim_winline, src/records.rs:66-73
                                     // (longer than the histogram's rows: the span is bad if this turns out to be a sequence or a
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
                                 // (where it starts in the buffer, its length, its kind) for k_stats_declined
                                 const bool listed = toolong && (kd & 1u) && Pent != 0;
                                 const unsigned long long lb = __ballot(listed);
-                                if (lb) {
+                                if (lb && !fz_given_up(z)) {
                                     uint32_t base = 0;
                                     const uint32_t nl_ = (uint32_t)__popcll(lb);
                                     if (lane == 0) base = (uint32_t)atomicAdd(&FZ_KARG(out)->decl_lines, (unsigned long long)nl_);

@@ -577,7 +577,8 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
             }
             // this block's columns of the line: [col0, col0 + 256); sequence lines are LOOKED AT to their end (the alphabet
             // flags cover every base), counted up to the caller's rows
-            const uint32_t seg = len > col0 ? (len - col0 < SO_LC_MAX ? len - col0 : SO_LC_MAX) : 0u;  // columns of the line in this block
+            uint32_t seg = len > col0 ? (len - col0 < SO_LC_MAX ? len - col0 : SO_LC_MAX) : 0u;  // columns of the line in this block
+            if (kind && seg > lc) seg = lc;   // (quality bytes beyond the caller's rows are nobody's business: not loaded, not looked at)
             R.segs[kind] = seg;
             // eight contiguous bytes per lane and load (registers 2 v, 2 v + 1: columns 64 v + 8 m .. + 7)
             const uint8_t *p = line + col0 + m8;
@@ -600,6 +601,23 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
         const uint32_t seg = R.segs[kind];
         if (__ballot(seg != 0) == 0) return;
         constexpr uint32_t RB = SO_LRB;
+        if (lc == 0) {
+            // (block-uniform) a column block beyond the caller's rows — lmax is the caller's choice, the reads' length is not: the
+            // sequence bytes are looked at (the alphabet flags cover every base of a record), nothing is counted.  Until round 5
+            // every such dword took the exact statement below: 5 kbp reads with lmax = 150 ran at a NINTH of the speed of lmax = 5000.
+            const int lim = (int)seg - (int)m8;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t wu = R.ws[kind][u];
+                const int t = lim - (int)(64u * (u >> 1) + 4u * (u & 1u));
+                if (t > 0) {
+                    const uint32_t sh = t < 4 ? 32u - 8u * (uint32_t)t : 0u;
+                    any_n |= wu << sh;
+                    any_inv |= ((wu ^ __builtin_amdgcn_perm(0x474EFF54u, 0x43FF41FFu, wu & 0x07070707u)) << sh) ? 1u : 0u;
+                }
+            }
+            return;
+        }
         // a dword at column C + 8 m (C a constant of the step) is whole iff C + 4 <= min(seg, lc) - 8 m, and holds bytes of the
         // line at all iff C < seg - 8 m: one compare with a constant each (the limits are per line, not per dword)
         const int lim_any = (int)seg - (int)m8, lim_whole = lim_any < lim_rows ? lim_any : lim_rows;
@@ -632,6 +650,12 @@ __global__ __launch_bounds__(SO_THREADS) void k_stats_long(LongArgs a) {
                 // exact statement below, a loop per byte: unseen in the benchmarks, whose reads were 600 .. 20 000 bases long,
                 // all multiples of four — reads of 250 .. 1000 bases ran at HALF the speed per piece.)
                 const int t = lim_any - C;            // bytes of the line in this dword (if in 1 .. 3)
+                if (kind == 0 && exact && lim_rows <= C) {   // a dword of the sequence line beyond the caller's rows: looked at, not counted
+                    const uint32_t sh = t < 4 ? 32u - 8u * (uint32_t)t : 0u;
+                    any_n |= wu << sh;
+                    any_inv |= (chk << sh) ? 1u : 0u;
+                    exact = false;
+                }
                 if (exact && t < 4 && lim_whole >= lim_any) {
                     const uint32_t sh = 32u - 8u * (uint32_t)t;
                     if ((chk << sh) == 0) {

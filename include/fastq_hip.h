@@ -120,7 +120,13 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                            and reruns the exact path on any doubt; 0 = exact path only.  Setting it
  *                           also clears the back-off the context keeps after failed attempts.
  *   FQH_OPT_SINGLE_PASS [1] whole-file fqh_stats / fqh_scan_stats count in the scan's own pass over the input
- *                           (k_scan_stats); 0 = always the exact scan followed by the histogram kernel.
+ *                           (k_scan_stats); 0 = always the exact scan followed by the histogram kernel.  A pass that has to
+ *                           be given up (reads longer than lmax by the million, more lines with bytes outside the alphabets
+ *                           than its dump area holds) is counted over the exact index instead, bit-exact, and the context's
+ *                           next 1, 2, 4 .. 64 statistics calls go there directly; setting the option forgets that back-off.
+ *                           lmax is the caller's choice and may be far below the reads' length (the first 150 cycles of
+ *                           kilobase reads): the columns beyond it are looked at (n_valid_dna / n_valid_dnan cover every
+ *                           base), not counted.
  *   FQH_OPT_PLACE_TRIES [0] where the fast path's per-tile lines (1.6 % of the input size) land in device memory can decide
  *                           whether the byte scan runs at 2.65-2.70 or at 2.85-2.95 ms per 16 GiB: the same allocation call
  *                           gives either kind, and the kind stays with the allocation.  With a value of 2..8

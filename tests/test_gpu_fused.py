@@ -58,6 +58,7 @@ def run_ctx(torch, pkg, ctx, fqref, data, lmax, want_fused, offsets, want_route=
     bh += 5
     sc += 7
     ctx.set_spec(True)  # (forget any back-off an earlier case left in the context)
+    ctx.set_single_pass(True)  # (... and the single pass's own, after a pass it gave up)
     rs = None
     if offsets:
         rs = torch.zeros(a.size // 4 + 16, dtype=torch.int64, device=dev)

@@ -88,6 +88,8 @@ def fuzz_routes(torch, pkg, fqref, seed, budget_s, max_cases=None):
         sc = torch.zeros(8, dtype=torch.int64, device=dev)
         ctx.set_spec(True)
         if rng.random() < 0.5:
+            ctx.set_single_pass(True)   # (forgets the back-off of a single pass that was given up; the other half keeps it)
+        if rng.random() < 0.5:
             s2, c2 = ctx.stats(d.data_ptr(), a.size, lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
         else:
             # (every third of these with an offsets array that is too short: FQH_E_CAPACITY on either route, exact histograms)

@@ -316,6 +316,34 @@ def test_stats_long_reads_of_many_lengths(fqref, gpu, shape):
         assert np.array_equal(gq, qh), (shape, lmax, np.argwhere(gq != qh)[:5])
 
 
+def test_single_pass_backs_off_after_a_pass_it_gave_up(fqref, torch, pkg):
+    """Reads longer than the caller's rows by the million (lmax is the caller's choice: the first 100 cycles of 300-base reads)
+    are more than the single pass can list: it gives the pass up (route 0: counted over the exact index, bit-exact) — and the
+    context's next 1, 2, 4, .. statistics calls go straight to that route instead of paying for another attempt; a pass that
+    commits (rows for the whole read) forgets the back-off.  The closure of Parser::each (src/lib.rs:226-237) sees every record
+    whatever the caller does with it: results never depend on the route."""
+    rng = np.random.default_rng(31)
+    nrec = 40000
+    recs = []
+    for i in range(nrec):
+        n = 300
+        recs.append(b"@r%d\n" % i + rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), n, p=[.2475, .2475, .2475, .2475, .01]).tobytes() + b"\n+\n" +
+                    rng.integers(33, 75, n).astype(np.uint8).tobytes() + b"\n")
+    data = b"".join(recs)
+    gpu = Gpu(torch, pkg.Ctx(0), pkg)
+    want = {100: fqref.stats(data, 100), 300: fqref.stats(data, 300)}
+    routes = []
+    for lmax in (100, 100, 100, 100, 300, 300, 300, 300, 300):
+        r, qh, bh, sc = want[lmax]
+        s, gq, gb, gs = gpu.stats(data, lmax)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (0, nrec)
+        assert np.array_equal(gs, sc) and np.array_equal(gq, qh) and np.array_equal(gb, bh), lmax
+        routes.append(gpu.ctx.last_stats_route())
+    # calls 1 and 3 try and give up (back-off 1, then 2); 2, 4 and 5 are skipped; call 6 tries again — rows for the whole read
+    # now — and commits; from there on every call takes the single pass
+    assert routes[:5] == [0, 0, 0, 0, 0] and routes[5:] == [1, 1, 1, 1], routes
+
+
 @pytest.mark.parametrize("huge", [1_000_000, 1_250_000])
 def test_stats_one_huge_read_among_short_ones(fqref, gpu, huge):
     """A Buffer of 4 MiB (Parser::new takes any reader, src/lib.rs:208; the Buffer's size is the crate's constant, a caller's
@@ -381,6 +409,7 @@ def test_stats_fast_path_shapes(fqref, torch, pkg, shape):
               "binned": (150, 300), "crlf": (150, 257), "dirty": (64, 150, 300), "len4k": (148, 152, 256, 260)}[shape]
     gpu = Gpu(torch, pkg.Ctx(0), pkg)   # (a context of its own: the route is pinned, and list sizes / back-offs stick to a context)
     for lmax in lmaxes:
+        gpu.ctx.set_single_pass(True)   # (forgets the back-off a pass that was given up leaves behind: every row count is tried)
         r, qh, bh, sc = fqref.stats(data, lmax)
         s, gq, gb, gs = gpu.stats(data, lmax)
         assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == nrec

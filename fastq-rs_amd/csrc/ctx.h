@@ -22,15 +22,17 @@ size_t stats_long_scratch_bytes(uint64_t, uint64_t, uint32_t, int);
 void launch_shard_words(hipStream_t, const DevOut *, const DevOut *, uint64_t, uint64_t *);
 void launch_carry_fold(hipStream_t, const uint64_t *, int, int, DevCarry *, DevCarry *, DevOut *);
 void launch_shard_counts(hipStream_t, const DevOut *, const DevOut *, const DevCarry *, uint64_t *);
-bool scan_stats_supports(uint32_t lmax);
+bool scan_stats_supports(uint32_t lmax, uint32_t hint);
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu);
 size_t scan_stats_scratch_bytes(int n_cu);
 hipError_t launch_scan_stats(hipStream_t, FusedArgs, int);
 void launch_stats_commit(hipStream_t, const DevOut *, const FusedArgs &, uint32_t, unsigned long long *, unsigned long long *,
                          unsigned long long *);
-hipError_t prepare_stats_declined(uint32_t lmax);
+hipError_t prepare_stats_declined(uint32_t rows);
 void launch_stats_declined(hipStream_t, const DevOut *, const FusedArgs &, unsigned long long *, unsigned long long *, unsigned long long *);
-uint32_t scan_stats_nsl(uint32_t lmax);
+uint32_t scan_stats_nsl(uint32_t rows);
+uint32_t scan_stats_rows(uint32_t lmax, uint32_t hint);
+void launch_peek_lines(hipStream_t, const uint8_t *, uint64_t, unsigned long long *);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_stats_edge(hipStream_t, const DevOut *, const uint8_t *, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
                        unsigned long long *, unsigned long long *);
@@ -122,6 +124,9 @@ struct fqh_ctx {
     // fast path: prove validity with a quarter of the list traffic; any doubt -> exact rerun
     bool spec_enabled = true;   // false: exact path only (callers that need full line lists, FQH_SPEC=0)
     uint32_t exact_holds = 0;   // live fqh_streams that need complete line lists for every chunk: no fast path while > 0
+    uint32_t rows_hint = 0;     // the longest sequence / quality line this context knows of in the kind of input it is given (0: nothing yet):
+                                // what the single pass sizes its rows by (scan_stats_rows)
+    uint32_t f_rows = 0;        // ... the rows of the single pass in flight
     uint32_t fused_skip = 0, fused_backoff = 0;  // statistics calls left on the two-pass route after a single pass that had to be given up
                                                  // (reads longer than the histogram's rows, more dirty lines than the dump area holds): 1, 2, 4 .. 64
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...

@@ -477,7 +477,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         if (!ctx->side) HIPCHK(ctx, hipMalloc((void **)&ctx->side, 2 * FQH_NSCALARS * sizeof(unsigned long long)));
         {   // where the kernel puts what it will not count itself: a slot per 512 KiB of input + 1024 (1.5 KiB per slot: 0.3 % of the input)
             const uint64_t cap = a.len / (512u << 10) + 1024;
-            const size_t bb = (size_t)cap * (1 + scan_stats_nsl(ctx->f_lmax)) * 64 * sizeof(uint32_t);
+            const size_t bb = (size_t)cap * (1 + scan_stats_nsl(ctx->f_rows)) * 64 * sizeof(uint32_t);
             if (cap > ctx->decl_cap || bb > ctx->decl_b_bytes) {
                 (void)hipFree(ctx->decl_b);
                 (void)hipFree(ctx->decl_l);
@@ -501,6 +501,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.fast_rs = lines_in_use(ctx);
         fz.out = &ctx->d_out[0];
         fz.lmax = ctx->f_lmax;
+        fz.rows = ctx->f_rows;
         fz.scratch = ctx->stats_scratch;
         fz.scalars = ctx->side;
         fz.skip_head = a.back[a.nl_count & 3] != 0 ? 1u : 0u;  // the chunk begins inside a record: that one is k_stats_edge's
@@ -508,7 +509,7 @@ static fqh_status enqueue_scan(fqh_ctx *ctx, bool reuse_index, bool fast) {
         fz.decl_l = ctx->decl_l;
         fz.decl_cap = ctx->decl_cap;
         ctx->f_args = fz;
-        HIPCHK(ctx, prepare_stats_declined(fz.lmax));  // (may fail; nothing of this call is enqueued yet that could commit without it)
+        HIPCHK(ctx, prepare_stats_declined(fz.rows));  // (may fail; nothing of this call is enqueued yet that could commit without it)
         if (a.n_tiles) HIPCHK(ctx, launch_scan_stats(s, fz, ctx->n_cu));
 #ifdef FQH_TUNING
         if (getenv("FQH_FZ_WHY")) {
@@ -658,6 +659,9 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
     }
     ctx->last_summary = s;
     ctx->last_carry_out = c;
+    // (what every scan says about the reads' length: no sequence / quality line of a delivered record is longer than half the
+    // longest record — the single pass's rows may come DOWN to that, whichever route found it; they go up in update_rows_hint)
+    if (s.n_records && s.max_record_len / 2 && s.max_record_len / 2 < ctx->rows_hint) ctx->rows_hint = (uint32_t)(s.max_record_len / 2);
     if (out) *out = s;
     if (carry_out) *carry_out = c;
     // (whatever the parse status: the emit kernels clamp their writes to cap, so a caller that walks
@@ -1053,6 +1057,7 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
     case FQH_OPT_SINGLE_PASS:
         ctx->fused_enabled = value != 0;
         ctx->fused_skip = ctx->fused_backoff = 0;
+        ctx->rows_hint = 0;
         return FQH_OK;
     case FQH_OPT_PLACE_TRIES:
         ctx->place_tries = value < 0 ? 0 : value > 8 ? 8 : value;
@@ -1159,6 +1164,41 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 // out the sequence line of the partial record at the end of a chunk that is not the file's last.  So whole files AND chunks
 // take it, as long as the histogram fits the kernel's LDS rows and the context is not backing off from the fast path.  Anything
 // else takes the two-pass route (exact index + k_stats_oct), which knows about record limits.
+// What the context knows about the length of the reads it is given (fqh_ctx::rows_hint; scan_stats_rows says what it is for).
+// Nothing yet: a look at the input's first 64 KiB (one small kernel and a wait of some tens of microseconds, once per context).
+// Afterwards the calls themselves say: a pass that met lines beyond its rows (listed, or given up) takes the scan's longest
+// record as the new bound; a pass that met none lets the bound come down to it.
+static fqh_status ensure_rows_hint(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t lmax) {
+    // (64 rows are the smallest instance anyway.  A context that knows something looks again only at inputs of a GiB and more —
+    // a look is some twenty microseconds, a pass over the wrong rows a whole read of the input — and keeps the larger answer:
+    // the calls' own findings let it come down again, update_rows_hint)
+    if (!ctx->fused_enabled || lmax <= 64 || !len || !d_buf) return FQH_OK;
+    if (ctx->rows_hint && (len < (1ull << 30) || scan_stats_rows(lmax, ctx->rows_hint) >= lmax)) return FQH_OK;   // (nothing a look could change)
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    unsigned long long longest = 0;
+    launch_peek_lines(ctx->stream, d_buf, len, (unsigned long long *)ctx->d_misc);
+    HIPCHK(ctx, hipMemcpyAsync(&longest, ctx->d_misc, sizeof longest, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t seen = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(longest, 1), 0x7FFFFFFFull);
+    if (seen > ctx->rows_hint) ctx->rows_hint = seen;
+    return FQH_OK;
+}
+static void update_rows_hint(fqh_ctx *ctx) {   // after a single pass whose scan stands (fused_finish)
+    const uint64_t bound = ctx->last_summary.max_record_len / 2;   // no sequence / quality line of a delivered record is longer
+    if (!bound) return;
+    const bool beyond = ctx->h_out->stats_declined != 0 || ctx->h_out->decl_lines != 0;
+    if (beyond && bound > ctx->rows_hint) ctx->rows_hint = (uint32_t)std::min<uint64_t>(bound, 0x7FFFFFFFull);   // (down: resolve())
+}
+// A statistics call that does not take the single pass — it is backing off, or the fast path is — counts both back-offs down: the
+// scan it runs instead has the fast path switched off (it needs complete line lists) and so never reaches the count-down in
+// do_scan_launch.  (Until round 5 a context whose fast path had failed once — one file of kilobase reads — and which was then given
+// nothing but fqh_stats calls never tried the fast path, or the single pass, again.)  Not for the second pass of a call that has
+// just given its single pass up (fused_enabled is off for that one).
+static void count_down_backoffs(fqh_ctx *ctx) {
+    if (!ctx->fused_enabled) return;
+    if (ctx->fused_skip) --ctx->fused_skip;
+    if (ctx->spec_enabled && ctx->spec_skip) --ctx->spec_skip;
+}
 static bool fused_eligible(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final, const fqh_carry *in,
                            uint32_t lmax, uint64_t lead_len, uint64_t n_limit) {
     if (!ctx->fused_enabled || !ctx->spec_enabled || ctx->exact_holds || ctx->spec_skip || ctx->list_cap != LIST_CAP_DEFAULT) return false;
@@ -1166,7 +1206,7 @@ static bool fused_eligible(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     // (chunks with a carry, chunks that are not the file's last and lead bytes are fine: k_stats_edge settles the records at
     // the chunk's two ends; a record LIMIT is not — the kernel counts every line it meets — except for the streaming ring,
     // which commits only after it knows that the limit does not bite: f_defer_commit)
-    if ((n_limit != UINT64_MAX && !ctx->f_defer_commit) || !scan_stats_supports(lmax) || !len) return false;
+    if ((n_limit != UINT64_MAX && !ctx->f_defer_commit) || !scan_stats_supports(lmax, ctx->rows_hint) || !len) return false;
     if (in && in->back[in->nl_count & 3] > in->base_offset) return false;
     (void)lead_len;
     (void)is_final;
@@ -1179,6 +1219,7 @@ static fqh_status fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     ctx->fused = true;
     ctx->f_lead = lead_len;
     ctx->f_lmax = lmax;
+    ctx->f_rows = scan_stats_rows(lmax, ctx->rows_hint);
     ctx->f_qual = d_qual_hist;
     ctx->f_base = d_base_hist;
     ctx->f_scalars = d_scalars;
@@ -1198,6 +1239,7 @@ static fqh_status fused_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_
     // A pass that was given up cost a whole read of the input for nothing, and the next chunk of the same file will do the same:
     // the context's next 1, 2, 4 .. 64 statistics calls go straight to the two-pass route (fqh_stats_launch counts them down), a
     // pass that commits resets the count — the fast path's own rule (do_scan_finish), for the same reason.
+    if (ctx->used_spec) update_rows_hint(ctx);
     if (ctx->used_spec && ctx->h_out->stats_declined != 0) {
         ctx->fused_backoff = ctx->fused_backoff ? (ctx->fused_backoff < 64 ? ctx->fused_backoff * 2 : 64) : 1;
         ctx->fused_skip = ctx->fused_backoff;
@@ -1217,10 +1259,11 @@ fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
                                      uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t lead_len, bool *fused) {
     *fused = false;
     if (!ctx || ctx->pending || ctx->stats_pending) return FQH_E_ARG;
+    if (fqh_status hs = ensure_rows_hint(ctx, d_buf, len, lmax); hs != FQH_OK) return hs;
     ctx->f_defer_commit = true;
     const bool ok = fused_eligible(ctx, d_buf, len, is_final, in, lmax, lead_len, 0);
     if (!ok) {
-        if (ctx->fused_enabled && ctx->fused_skip) --ctx->fused_skip;   // (not the second pass of a call that has just given its single pass up)
+        count_down_backoffs(ctx);
         ctx->f_defer_commit = false;
         return FQH_OK;
     }
@@ -1251,6 +1294,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
     fqh_status st;
+    if (st = ensure_rows_hint(ctx, d_buf, len, lmax); st != FQH_OK) return st;
     if (fused_eligible(ctx, d_buf, len, is_final, in, lmax, lead_len, n_limit)) {
         // one read of the input: scan + histograms in k_scan_stats (src/lib.rs:226-237 hands each record to the
         // closure that reads seq()/qual(): one pass).  fqh_stats_finish falls back to the two-pass route if
@@ -1260,7 +1304,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
         ctx->stats_pending = true;
         return FQH_OK;
     }
-    if (ctx->fused_enabled && ctx->fused_skip) --ctx->fused_skip;   // (not the second pass of a call that has just given its single pass up)
+    count_down_backoffs(ctx);
     if (!same_scan(ctx, d_buf, len, is_final, in)) {
         // the histogram kernel needs complete line lists: scan on the exact path right away instead of
         // taking the fast path and indexing a second time
@@ -1465,13 +1509,14 @@ fqh_status fqh_scan_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
     ctx->last_valid = false;  // never a reuse of an earlier scan: the offsets are wanted as well
+    if (fqh_status hs = ensure_rows_hint(ctx, d_buf, len, lmax); hs != FQH_OK) return hs;
     if (fused_eligible(ctx, d_buf, len, is_final, in, lmax, 0, UINT64_MAX)) {
         fqh_status st = fused_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap, lmax, d_qual_hist, d_base_hist, d_scalars);
         if (st != FQH_OK) return st;
         ctx->stats_pending = true;
         return FQH_OK;
     }
-    if (ctx->fused_enabled && ctx->fused_skip) --ctx->fused_skip;   // (not the second pass of a call that has just given its single pass up)
+    count_down_backoffs(ctx);
     // two passes: the exact scan (offsets + full index), then the histogram kernel over that index
     const bool spec = ctx->spec_enabled;
     ctx->spec_enabled = false;

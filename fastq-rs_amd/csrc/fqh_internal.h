@@ -140,6 +140,7 @@ struct FusedArgs {
     uint16_t *fast_rs;    // per tile one 128-byte line (+ a second one), as k_index_fast writes them
     DevOut *out;          // spec_fail
     uint32_t lmax, lc;    // the caller's lmax; lc = rows of the LDS histogram in use (set by the launcher)
+    uint32_t rows;        // rows the single pass is to keep (scan_stats_rows: <= lmax, by what is known about the reads' length)
     uint32_t *scratch;    // [gridDim.x][SO_WORDS] per-block partial histograms
     unsigned long long *scalars;  // FQH_NSCALARS totals (a zeroed side array: k_stats_commit adds them to the caller's)
     uint32_t skip_head;   // the chunk begins inside a record (carry-in): the lines of that record are k_stats_edge's, not this kernel's

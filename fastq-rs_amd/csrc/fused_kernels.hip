@@ -1189,18 +1189,18 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
 #define FQH_FZ_WIDE_FROM 160   // rows above this take a wide instance (sixteen lanes per line, packed counters); 256: rows 161 .. 256 through <8,12>
 #endif
 constexpr uint32_t FZ_LC_MAX = 511;   // rows of the packed instance: a line's length travels in nine bits, and the kept tail holds 511 bytes
-static uint32_t fz_lc(uint32_t lmax) { return lmax < FZ_LC_MAX ? lmax : FZ_LC_MAX; }
+static uint32_t fz_lc(uint32_t rows) { return rows < FZ_LC_MAX ? rows : FZ_LC_MAX; }   // rows: FusedArgs::rows (scan_stats_rows)
 // which rows take a wide (packed, sixteen lanes per line) instance
 static bool fz_is_wide(uint32_t lc) { return lc > FQH_FZ_WIDE_FROM; }
-static size_t stats_declined_lds(uint32_t lmax) { return (size_t)std::min<uint32_t>(fz_lc(lmax), SO_LC_MAX) * DECL_BINS * 2; }
+static size_t stats_declined_lds(uint32_t rows) { return (size_t)std::min<uint32_t>(fz_lc(rows), SO_LC_MAX) * DECL_BINS * 2; }
 // The one thing about k_stats_declined that can fail, done BEFORE the single pass is enqueued: an error behind k_stats_commit
 // would leave the dumped batches and listed lines uncounted in a result that says it is complete.
-hipError_t prepare_stats_declined(uint32_t lmax) {
+hipError_t prepare_stats_declined(uint32_t rows) {
     static LdsAttr attr;
-    return attr.ensure(reinterpret_cast<const void *>(k_stats_declined), stats_declined_lds(lmax));
+    return attr.ensure(reinterpret_cast<const void *>(k_stats_declined), stats_declined_lds(rows));
 }
-uint32_t scan_stats_nsl(uint32_t lmax) {
-    const uint32_t lc = fz_lc(lmax), steps = (lc + 31) / 32;
+uint32_t scan_stats_nsl(uint32_t rows) {
+    const uint32_t lc = fz_lc(rows), steps = (lc + 31) / 32;
     if (fz_is_wide(lc)) {   // the wide instances' steps of 64 columns
         const uint32_t ws = (lc + 63) / 64;
         return ws <= 3 ? 3u : ws <= 6 ? ws : (FQH_FZ_W7 && ws == 7) ? 7u : 8u;
@@ -1210,8 +1210,8 @@ uint32_t scan_stats_nsl(uint32_t lmax) {
 void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z, unsigned long long *qual_hist,
                            unsigned long long *base_hist, unsigned long long *scalars) {
     if (!z.decl_cap) return;
-    const uint32_t lc = fz_lc(z.lmax);   // (the rows the caller's arrays and the single pass share)
-    const uint32_t nsl = scan_stats_nsl(z.lmax);
+    const uint32_t lc = fz_lc(z.rows);   // (the rows the caller's arrays and the single pass share)
+    const uint32_t nsl = scan_stats_nsl(z.rows);
     // a block's 16-bit counters hold the lines of its share of the slots: 8 lines per dumped batch, 1 per listed line
     const uint64_t per_block = DECL_LINES_PER_BLOCK / 9;
     const uint32_t blocks = (uint32_t)std::max<uint64_t>(512, ((uint64_t)z.decl_cap + per_block - 1) / per_block);
@@ -1224,9 +1224,22 @@ void launch_stats_declined(hipStream_t s, const DevOut *out, const FusedArgs &z,
 
 uint32_t stats_blocks(int n_cu);
 
-// can the single-pass kernel take this call's lmax?  (up to 160 / 256 rows of 32-bit counters, up to 512 of packed 16-bit ones;
-// a line of 512 columns or more is listed or declined like any line beyond the rows)
-bool scan_stats_supports(uint32_t lmax) { return lmax >= 1 && lmax <= 512; }
+// The rows the single pass keeps.  An instance issues all its steps for every batch of lines, so it should fit the READS, not the
+// caller's arrays: lmax is the caller's choice and may be far above the reads' length (one tool, lmax = 1000, whatever comes) —
+// 150-base reads with lmax = 512 ran through the eight-step wide instance at 1 186 GB/s, with lmax = 1000 through two passes at
+// 1 491, against 2 233 with lmax = 150.  hint: the longest line the caller of this function knows of in this kind of input
+// (fqh_ctx::rows_hint: a look at the input's first 64 KiB, then what the context's calls found), 0: nothing known.  The rows
+// are the capacity of the instance that holds the hint, at most lmax; a line beyond them is listed and counted behind the pass
+// like any line beyond lmax (k_stats_declined adds its columns below lmax to the caller's arrays), so a hint that is too small
+// costs time, never a count.
+uint32_t scan_stats_rows(uint32_t lmax, uint32_t hint) {
+    if (!hint || hint >= lmax) return lmax;
+    const uint32_t cap = hint <= FQH_FZ_WIDE_FROM ? (hint <= 64 ? 64u : (hint + 31u) / 32u * 32u) : (hint <= 192 ? 192u : (hint + 63u) / 64u * 64u);
+    return cap < lmax ? cap : lmax;
+}
+// can the single-pass kernel take this call?  (up to 160 rows of 32-bit counters, up to 511 of packed 16-bit ones; a line beyond
+// the rows is listed or declined.  More rows than that in the caller's arrays are fine if the reads are known to be shorter.)
+bool scan_stats_supports(uint32_t lmax, uint32_t hint) { return lmax >= 1 && (lmax <= 512 || (hint != 0 && hint <= FZ_LC_MAX)); }
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu) {
     const uint64_t want = ((n_tiles + FZ_SPAN - 1) / FZ_SPAN + FZ_WAVES_MAX - 1) / FZ_WAVES_MAX;
     const uint32_t cus = stats_blocks(n_cu);
@@ -1257,7 +1270,8 @@ static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t block
 // z: buf, len, n_tiles, the fast path's outputs, lmax, scratch (scan_stats_scratch_bytes), scalars = ZEROED side
 // array of FQH_NSCALARS u64 (not the caller's: see k_stats_commit)
 hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
-    z.lc = fz_lc(z.lmax);
+    if (!z.rows || z.rows > z.lmax) z.rows = z.lmax;
+    z.lc = fz_lc(z.rows);
 #ifdef FQH_TUNING  // knock-out flags of the timing experiments (tools/exp_fzdbg.py); not part of the product library
     z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
 #else
@@ -1296,15 +1310,60 @@ hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
 }
 void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, uint32_t blocks,
                          unsigned long long *qual_hist, unsigned long long *base_hist, unsigned long long *scalars) {
-    const uint32_t lc = fz_lc(z.lmax);
+    const uint32_t lc = fz_lc(z.rows);
     if (fz_is_wide(lc)) {
         hipLaunchKernelGGL(k_stats_commit_packed, dim3((2 * SO_WORDS + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
                            z.scratch, blocks, lc, z.scalars, qual_hist, base_hist, scalars);
         return;
     }
-    const uint32_t words = (SO_SBYTES + (scan_stats_nsl(z.lmax) + 1) / 2 * 16384u) / 4;
+    const uint32_t words = (SO_SBYTES + (scan_stats_nsl(z.rows) + 1) / 2 * 16384u) / 4;
     hipLaunchKernelGGL(k_stats_commit, dim3((words + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
                        z.scratch, blocks, lc, words, z.scalars, qual_hist, base_hist, scalars);
+}
+
+
+// k_peek_lines — the longest line among the first bytes of an input (one block; n <= 64 KiB): what the single pass sizes its rows
+// by when the context knows nothing yet about the reads (scan_stats_rows).  A guess, not a promise: whatever it says, the pass
+// counts exactly.  A line that is still open at the end of the window counts with what the window holds of it.
+__global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__ buf, uint32_t n, unsigned long long *__restrict__ out) {
+    __shared__ int last_nl[1024];      // -> the last newline at or before the end of segment t (a running maximum), -1: none
+    __shared__ int best_w[16];
+    const uint32_t t = threadIdx.x, lo = t * 64u;
+    int f = -1, l = -1, g = 0;         // this segment's first / last newline, its longest line between two of its own newlines
+    for (uint32_t i = lo; i < lo + 64u && i < n; ++i) {
+        if (buf[i] == '\n') {
+            if (f < 0) f = (int)i;
+            else if ((int)i - l - 1 > g) g = (int)i - l - 1;
+            l = (int)i;
+        }
+    }
+    last_nl[t] = l;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive maximum scan
+        const int v = t >= d ? last_nl[t - d] : -1;
+        __syncthreads();
+        if (v > last_nl[t]) last_nl[t] = v;
+        __syncthreads();
+    }
+    const int before = t ? last_nl[t - 1] : -1;          // the last newline in front of this segment
+    if (f >= 0 && f - before - 1 > g) g = f - before - 1;
+    if (lo < n && lo + 64u >= n) {                        // the segment that holds the window's end: the line still open there
+        const int open = (int)n - last_nl[t] - 1;
+        if (open > g) g = open;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) g = max(g, __shfl_xor(g, d));
+    if ((t & 63u) == 0) best_w[t >> 6] = g;
+    __syncthreads();
+    if (t == 0) {
+        int best = 0;
+        for (int k = 0; k < 16; ++k) best = max(best, best_w[k]);
+        out[0] = (unsigned long long)best;
+    }
+}
+void launch_peek_lines(hipStream_t s, const uint8_t *buf, uint64_t len, unsigned long long *d_out) {
+    const uint32_t n = (uint32_t)(len < 65536 ? len : 65536);
+    hipLaunchKernelGGL(k_peek_lines, dim3(1), dim3(1024), 0, s, buf, n, d_out);
 }
 
 }  // namespace fqh

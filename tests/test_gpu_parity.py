@@ -316,6 +316,47 @@ def test_stats_long_reads_of_many_lengths(fqref, gpu, shape):
         assert np.array_equal(gq, qh), (shape, lmax, np.argwhere(gq != qh)[:5])
 
 
+@pytest.mark.parametrize("case", ["short_reads_many_rows", "hint_too_small", "second_file_longer", "header_longer_than_reads"])
+def test_single_pass_rows_follow_the_reads(fqref, torch, pkg, case):
+    """lmax is the caller's choice; the reference's closure has none (src/lib.rs:226-237).  The single pass sizes its rows by the
+    reads (the first 64 KiB of the first input a context sees, then what its calls find), at most lmax: rows of 1000 over reads
+    of 150 bases are one pass; a first window that holds only short reads in front of longer ones lists the longer lines (counted
+    behind the pass, columns beyond its rows included) or gives the pass up — bit-exact either way — and the next call knows."""
+    rng = np.random.default_rng({"short_reads_many_rows": 1, "hint_too_small": 2, "second_file_longer": 3, "header_longer_than_reads": 4}[case])
+    def reads(n, lo, hi, hdr=8):
+        out = []
+        for i in range(n):
+            L = int(rng.integers(lo, hi + 1))
+            out.append(b"@" + bytes(rng.integers(97, 123, hdr).astype(np.uint8).tolist()) + b"\n" +
+                       rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L, p=[.2475, .2475, .2475, .2475, .01]).tobytes() + b"\n+\n" +
+                       rng.integers(33, 75, L).astype(np.uint8).tobytes() + b"\n")
+        return b"".join(out)
+    gpu = Gpu(torch, pkg.Ctx(0), pkg)
+    if case == "short_reads_many_rows":
+        files = [(reads(30000, 150, 150), 1000, {1}), (reads(30000, 150, 150), 512, {1}), (reads(30000, 36, 150), 2000, {1})]
+    elif case == "hint_too_small":
+        # 800 reads of 50 bases fill the first 64 KiB; then a few of 300 (listed: route 2), then a file where most are (given up or listed)
+        files = [(reads(800, 50, 50) + reads(20, 300, 300) + reads(20000, 50, 50), 1000, {2}),
+                 (reads(800, 50, 50) + reads(20000, 50, 300), 1000, {0, 1, 2}), (reads(20000, 50, 300), 1000, {1})]
+    elif case == "second_file_longer":
+        # (a pass that is given up also makes the context skip its next attempt: the third file may go either way, the fourth may not;
+        # kilobase reads fail the scan's fast path and with it the single pass, whose back-off the next statistics call counts
+        # down — fqh_stats calls alone used to leave it where it was, for good — so the file after the next is one pass again)
+        files = [(reads(20000, 100, 100), 700, {1}), (reads(20000, 250, 250), 700, {0, 2}), (reads(20000, 250, 250), 700, {0, 1}),
+                 (reads(20000, 250, 250), 700, {1}), (reads(3000, 2000, 2500), 3000, {0}), (reads(20000, 100, 100), 700, {0, 1}),
+                 (reads(20000, 100, 100), 700, {1}), (reads(20000, 100, 100), 700, {1})]
+    else:
+        files = [(reads(20000, 36, 36, hdr=200), 600, {1})]
+    for data, lmax, routes in files:
+        r, qh, bh, sc = fqref.stats(data, lmax)
+        s, gq, gb, gs = gpu.stats(data, lmax)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.status == 0
+        assert np.array_equal(gs, sc), (case, lmax, gs, sc)
+        assert np.array_equal(gq, qh) and np.array_equal(gb, bh), (case, lmax)
+        assert gpu.ctx.last_stats_route() in routes, (case, lmax, gpu.ctx.last_stats_route(), routes)
+    gpu.ctx.close()
+
+
 def test_single_pass_backs_off_after_a_pass_it_gave_up(fqref, torch, pkg):
     """Reads longer than the caller's rows by the million (lmax is the caller's choice: the first 100 cycles of 300-base reads)
     are more than the single pass can list: it gives the pass up (route 0: counted over the exact index, bit-exact) — and the
@@ -1159,21 +1200,24 @@ def test_own_stream_is_ordered_against_the_null_stream(torch, pkg):
 
 @pytest.mark.parametrize("lmax", [300, 600])
 def test_stats_with_many_rows_over_short_reads(fqref, torch, pkg, lmax):
-    """A caller that asks for more than 256 rows gets the record index written by the scan's own emit step, sized for reads of
-    that length (one entry per 512 bytes of input).  Short reads overflow it: the index is emitted again into an array that is
-    large enough — and which a free + allocation may place at the SAME address, old entries and all (the check for "the scan
-    wrote the whole index" used to be made after that replacement: k_stats_long walked whatever lay behind the old entries)."""
+    """A caller that asks for more than 256 rows and is counted over the exact index gets the record index written by the scan's
+    own emit step, sized for reads of that length (one entry per 512 bytes of input).  Short reads overflow it: the index is
+    emitted again into an array that is large enough — and which a free + allocation may place at the SAME address, old entries
+    and all (the check for "the scan wrote the whole index" used to be made after that replacement: k_stats_long walked whatever
+    lay behind the old entries).  And the route: the rows of the single pass follow the READS (a look at the input's first 64 KiB:
+    scan_stats_rows), not the caller's arrays, so 600 rows over reads of 100 bases are one pass as well."""
     rng = np.random.default_rng(77)
     gpu = Gpu(torch, pkg.Ctx(0), pkg)   # (a context of its own: the route is pinned)
     data = fuzzgen.valid_file(rng, 60000, maxlen=100, crlf=False)     # ~ 8 MB: 60 000 records, room for ~ 16 000 entries
     r, oq, ob, osc = fqref.stats(data, lmax)
-    s, gq, gb, gs = gpu.stats(data, lmax)
-    assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == 60000
-    assert np.array_equal(gs, osc) and np.array_equal(gq, oq) and np.array_equal(gb, ob)
-    # the route: 300 rows over reads of up to 100 bases take the scan's own pass (its wide instance of five
-    # steps) — valid_file's lines hold bytes of every kind, so some batches are counted behind it —; 600 rows are beyond the single pass
-    assert gpu.ctx.last_stats_route() in ((0, 2) if lmax == 300 else (0,)), gpu.ctx.last_stats_route()
-    # ... and clean reads of 100 bases under 300 rows are counted by that pass alone
+    for single_pass in (False, True):
+        gpu.ctx.set_single_pass(single_pass)
+        s, gq, gb, gs = gpu.stats(data, lmax)
+        assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == 60000
+        assert np.array_equal(gs, osc) and np.array_equal(gq, oq) and np.array_equal(gb, ob)
+        # valid_file's lines hold bytes of every kind, so some batches are counted behind the single pass, or it is given up
+        assert gpu.ctx.last_stats_route() in ((0, 2) if single_pass else (0,)), gpu.ctx.last_stats_route()
+    # ... and clean reads of 100 bases are counted by that pass alone, under 300 rows and under 600
     clean = b"".join(b"@r%d\n" % i + bytes(rng.choice(fuzzgen.ALPH, 100).tolist()) + b"\n+\n" + bytes(rng.integers(33, 75, 100).astype(np.uint8).tolist()) + b"\n"
                      for i in range(20000))
     r, oq, ob, osc = fqref.stats(clean, lmax)
@@ -1181,5 +1225,5 @@ def test_stats_with_many_rows_over_short_reads(fqref, torch, pkg, lmax):
     gpu = Gpu(torch, pkg.Ctx(0), pkg)   # (the file above has tiles of more than 512 line starts: its context keeps the longer lists — and the exact path)
     s, gq, gb, gs = gpu.stats(clean, lmax)
     assert np.array_equal(gs, osc) and np.array_equal(gq, oq) and np.array_equal(gb, ob)
-    assert gpu.ctx.last_stats_route() == (1 if lmax == 300 else 0), gpu.ctx.last_stats_route()
+    assert gpu.ctx.last_stats_route() == 1, gpu.ctx.last_stats_route()
     gpu.ctx.close()

@@ -126,7 +126,9 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           next 1, 2, 4 .. 64 statistics calls go there directly; setting the option forgets that back-off.
  *                           lmax is the caller's choice and may be far below the reads' length (the first 150 cycles of
  *                           kilobase reads): the columns beyond it are looked at (n_valid_dna / n_valid_dnan cover every
- *                           base), not counted.
+ *                           base), not counted.  It may as well be far above it (1000 rows, whatever comes): the pass keeps
+ *                           the rows the READS need — a look at the first 64 KiB of a context's first input, then what its
+ *                           calls find; setting the option forgets that as well — and any lmax is counted exactly.
  *   FQH_OPT_PLACE_TRIES [0] where the fast path's per-tile lines (1.6 % of the input size) land in device memory can decide
  *                           whether the byte scan runs at 2.65-2.70 or at 2.85-2.95 ms per 16 GiB: the same allocation call
  *                           gives either kind, and the kind stays with the allocation.  With a value of 2..8

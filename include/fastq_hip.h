@@ -359,7 +359,10 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
  * (classes A0 C1 G2 T3 N4 other5), d_scalars as above.  All are u64 device arrays that are ADDED
  * to (zero them first).  Reads its input itself; only with FQH_OPT_REUSE_INDEX set (the caller vouches
  * that the bytes are unchanged) does a call on the (d_buf, len, carry) of the last finished fqh_scan count over that
- * scan's tile index. */
+ * scan's tile index.  The *_launch forms return without waiting for the device — with one exception: the first statistics
+ * call of a context with lmax > 64 (and a later one over a GiB or more whose rows might be too few) looks at the input's
+ * first 64 KiB to size the pass by the reads (FQH_OPT_SINGLE_PASS above) and waits for that look, i.e. for what the
+ * context's stream holds in front of it, once. */
 fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
                      const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                      uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out,

@@ -22,7 +22,7 @@ size_t stats_long_scratch_bytes(uint64_t, uint64_t, uint32_t, int);
 void launch_shard_words(hipStream_t, const DevOut *, const DevOut *, uint64_t, uint64_t *);
 void launch_carry_fold(hipStream_t, const uint64_t *, int, int, DevCarry *, DevCarry *, DevOut *);
 void launch_shard_counts(hipStream_t, const DevOut *, const DevOut *, const DevCarry *, uint64_t *);
-bool scan_stats_supports(uint32_t lmax, uint32_t hint);
+bool scan_stats_supports(uint32_t lmax, uint32_t hint, bool mostly_long);
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu);
 size_t scan_stats_scratch_bytes(int n_cu);
 hipError_t launch_scan_stats(hipStream_t, FusedArgs, int);
@@ -127,6 +127,7 @@ struct fqh_ctx {
     uint32_t rows_hint = 0;     // the longest sequence / quality line this context knows of in the kind of input it is given (0: nothing yet):
                                 // what the single pass sizes its rows by (scan_stats_rows)
     uint32_t f_rows = 0;        // ... the rows of the single pass in flight
+    bool lines_long = false;    // ... and whether most of its lines are longer than the single pass takes (511 bytes): kilobase reads
     uint32_t fused_skip = 0, fused_backoff = 0;  // statistics calls left on the two-pass route after a single pass that had to be given up
                                                  // (reads longer than the histogram's rows, more dirty lines than the dump area holds): 1, 2, 4 .. 64
     uint32_t spec_skip = 0;     // scans left on the exact path after the fast path failed ...

@@ -662,6 +662,7 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
     // (what every scan says about the reads' length: no sequence / quality line of a delivered record is longer than half the
     // longest record — the single pass's rows may come DOWN to that, whichever route found it; they go up in update_rows_hint)
     if (s.n_records && s.max_record_len / 2 && s.max_record_len / 2 < ctx->rows_hint) ctx->rows_hint = (uint32_t)(s.max_record_len / 2);
+    if (s.n_records && s.max_record_len / 2 <= 511) ctx->lines_long = false;
     if (out) *out = s;
     if (carry_out) *carry_out = c;
     // (whatever the parse status: the emit kernels clamp their writes to cap, so a caller that walks
@@ -1058,6 +1059,7 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
         ctx->fused_enabled = value != 0;
         ctx->fused_skip = ctx->fused_backoff = 0;
         ctx->rows_hint = 0;
+        ctx->lines_long = false;
         return FQH_OK;
     case FQH_OPT_PLACE_TRIES:
         ctx->place_tries = value < 0 ? 0 : value > 8 ? 8 : value;
@@ -1170,17 +1172,20 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 // record as the new bound; a pass that met none lets the bound come down to it.
 static fqh_status ensure_rows_hint(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t lmax) {
     // (64 rows are the smallest instance anyway.  A context that knows something looks again only at inputs of a GiB and more —
-    // a look is some twenty microseconds, a pass over the wrong rows a whole read of the input — and keeps the larger answer:
-    // the calls' own findings let it come down again, update_rows_hint)
+    // a look is some tens of microseconds, a pass over the wrong rows a whole read of the input — and only if the answer could
+    // change something: rows below lmax that might be too few, or a belief in kilobase reads that keeps the pass away)
     if (!ctx->fused_enabled || lmax <= 64 || !len || !d_buf) return FQH_OK;
-    if (ctx->rows_hint && (len < (1ull << 30) || scan_stats_rows(lmax, ctx->rows_hint) >= lmax)) return FQH_OK;   // (nothing a look could change)
+    if (ctx->rows_hint && (len < (1ull << 30) || (!ctx->lines_long && scan_stats_rows(lmax, ctx->rows_hint) >= lmax))) return FQH_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    unsigned long long longest = 0;
+    unsigned long long peek[3] = {0, 0, 0};
     launch_peek_lines(ctx->stream, d_buf, len, (unsigned long long *)ctx->d_misc);
-    HIPCHK(ctx, hipMemcpyAsync(&longest, ctx->d_misc, sizeof longest, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(peek, ctx->d_misc, sizeof peek, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t seen = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(longest, 1), 0x7FFFFFFFull);
-    if (seen > ctx->rows_hint) ctx->rows_hint = seen;
+    const uint32_t seen = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(peek[0], 1), 0x7FFFFFFFull);
+    // the rows go up with what a look finds, down with what the scans find (resolve()); whether MOST lines are too long for the
+    // pass is what the look says (64 KiB of kilobase reads: every other line)
+    if (seen > ctx->rows_hint || !ctx->rows_hint) ctx->rows_hint = seen;
+    ctx->lines_long = peek[2] * 4 > peek[1] || (peek[1] == 0 && seen > 511);
     return FQH_OK;
 }
 static void update_rows_hint(fqh_ctx *ctx) {   // after a single pass whose scan stands (fused_finish)
@@ -1188,6 +1193,7 @@ static void update_rows_hint(fqh_ctx *ctx) {   // after a single pass whose scan
     if (!bound) return;
     const bool beyond = ctx->h_out->stats_declined != 0 || ctx->h_out->decl_lines != 0;
     if (beyond && bound > ctx->rows_hint) ctx->rows_hint = (uint32_t)std::min<uint64_t>(bound, 0x7FFFFFFFull);   // (down: resolve())
+    if (ctx->h_out->stats_declined != 0 && bound > 2 * 511) ctx->lines_long = true;   // (given up, and over records that hold such lines)
 }
 // A statistics call that does not take the single pass — it is backing off, or the fast path is — counts both back-offs down: the
 // scan it runs instead has the fast path switched off (it needs complete line lists) and so never reaches the count-down in
@@ -1206,7 +1212,7 @@ static bool fused_eligible(const fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     // (chunks with a carry, chunks that are not the file's last and lead bytes are fine: k_stats_edge settles the records at
     // the chunk's two ends; a record LIMIT is not — the kernel counts every line it meets — except for the streaming ring,
     // which commits only after it knows that the limit does not bite: f_defer_commit)
-    if ((n_limit != UINT64_MAX && !ctx->f_defer_commit) || !scan_stats_supports(lmax, ctx->rows_hint) || !len) return false;
+    if ((n_limit != UINT64_MAX && !ctx->f_defer_commit) || !scan_stats_supports(lmax, ctx->rows_hint, ctx->lines_long) || !len) return false;
     if (in && in->back[in->nl_count & 3] > in->base_offset) return false;
     (void)lead_len;
     (void)is_final;

@@ -1238,8 +1238,14 @@ uint32_t scan_stats_rows(uint32_t lmax, uint32_t hint) {
     return cap < lmax ? cap : lmax;
 }
 // can the single-pass kernel take this call?  (up to 160 rows of 32-bit counters, up to 511 of packed 16-bit ones; a line beyond
-// the rows is listed or declined.  More rows than that in the caller's arrays are fine if the reads are known to be shorter.)
-bool scan_stats_supports(uint32_t lmax, uint32_t hint) { return lmax >= 1 && (lmax <= 512 || (hint != 0 && hint <= FZ_LC_MAX)); }
+// the rows is listed or declined.)  By what is known of the reads: if no line is longer than 511 bytes the pass fits whatever lmax
+// is (more rows than that in the caller's arrays are fine: nothing will be counted there); if MOST lines are (mostly_long:
+// kilobase reads — a line that began before the 512 bytes a wavefront keeps of the previous group gives the pass up) it never
+// does, and the call goes to the two-pass route without an attempt; otherwise, and with nothing known, by lmax (a few lines
+// beyond the rows are listed and counted behind the pass).
+bool scan_stats_supports(uint32_t lmax, uint32_t hint, bool mostly_long) {
+    return lmax >= 1 && !mostly_long && ((hint && hint <= FZ_LC_MAX) || lmax <= 512);
+}
 uint32_t scan_stats_blocks(uint64_t n_tiles, int n_cu) {
     const uint64_t want = ((n_tiles + FZ_SPAN - 1) / FZ_SPAN + FZ_WAVES_MAX - 1) / FZ_WAVES_MAX;
     const uint32_t cus = stats_blocks(n_cu);
@@ -1326,15 +1332,17 @@ void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, u
 // by when the context knows nothing yet about the reads (scan_stats_rows).  A guess, not a promise: whatever it says, the pass
 // counts exactly.  A line that is still open at the end of the window counts with what the window holds of it.
 __global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__ buf, uint32_t n, unsigned long long *__restrict__ out) {
+    // out[0]: the longest line, out[1]: lines that end in the window, out[2]: ... of them longer than the single pass takes (511 bytes)
     __shared__ int last_nl[1024];      // -> the last newline at or before the end of segment t (a running maximum), -1: none
-    __shared__ int best_w[16];
+    __shared__ int best_w[16], lines_w[16], long_w[16];
     const uint32_t t = threadIdx.x, lo = t * 64u;
-    int f = -1, l = -1, g = 0;         // this segment's first / last newline, its longest line between two of its own newlines
+    int f = -1, l = -1, g = 0, nl = 0;  // this segment's first / last newline, its longest line between two of its own newlines, its newlines
     for (uint32_t i = lo; i < lo + 64u && i < n; ++i) {
         if (buf[i] == '\n') {
             if (f < 0) f = (int)i;
             else if ((int)i - l - 1 > g) g = (int)i - l - 1;
             l = (int)i;
+            ++nl;
         }
     }
     last_nl[t] = l;
@@ -1346,19 +1354,35 @@ __global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__
         __syncthreads();
     }
     const int before = t ? last_nl[t - 1] : -1;          // the last newline in front of this segment
+    // (a line of more than 511 bytes spans segments: it is the line this segment's FIRST newline closes, or none of this segment's)
+    int nlong = (f >= 0 && f - before - 1 > (int)FZ_LC_MAX) ? 1 : 0;
     if (f >= 0 && f - before - 1 > g) g = f - before - 1;
     if (lo < n && lo + 64u >= n) {                        // the segment that holds the window's end: the line still open there
         const int open = (int)n - last_nl[t] - 1;
         if (open > g) g = open;
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) g = max(g, __shfl_xor(g, d));
-    if ((t & 63u) == 0) best_w[t >> 6] = g;
+    for (int d = 32; d >= 1; d >>= 1) {
+        g = max(g, __shfl_xor(g, d));
+        nl += __shfl_xor(nl, d);
+        nlong += __shfl_xor(nlong, d);
+    }
+    if ((t & 63u) == 0) {
+        best_w[t >> 6] = g;
+        lines_w[t >> 6] = nl;
+        long_w[t >> 6] = nlong;
+    }
     __syncthreads();
     if (t == 0) {
-        int best = 0;
-        for (int k = 0; k < 16; ++k) best = max(best, best_w[k]);
+        int best = 0, lines = 0, longs = 0;
+        for (int k = 0; k < 16; ++k) {
+            best = max(best, best_w[k]);
+            lines += lines_w[k];
+            longs += long_w[k];
+        }
         out[0] = (unsigned long long)best;
+        out[1] = (unsigned long long)lines;
+        out[2] = (unsigned long long)longs;
     }
 }
 void launch_peek_lines(hipStream_t s, const uint8_t *buf, uint64_t len, unsigned long long *d_out) {

@@ -440,6 +440,24 @@ def main():
             one = timed(lambda: ctx.stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()))
             both = timed(lambda: ctx.scan_stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr(),
                                                 d_rec_start=rec_start.data_ptr(), cap=cap))
+            # the same call from a host that sizes its arrays for whatever may come (1000 rows over 150-base reads): the pass keeps
+            # the rows the READS need (a look at the input's first 64 KiB), lmax only says where the caller's arrays end
+            qh_k = torch.zeros(1000 * 256, dtype=torch.int64, device=dev)
+            bh_k = torch.zeros(1000 * 8, dtype=torch.int64, device=dev)
+            rows_k = None
+            for _ in range(3):
+                qh_k.zero_(); bh_k.zero_(); sc.zero_()
+                ctx.invalidate()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.stats(buf.data_ptr(), nbytes, 1000, qh_k.data_ptr(), bh_k.data_ptr(), sc.data_ptr())
+                torch.cuda.synchronize()
+                w = (time.perf_counter() - t1) * 1e3
+                rows_k = w if rows_k is None else min(rows_k, w)
+                assert int(sc[0].item()) == total_records and int(qh_k.sum().item()) == total_records * 150
+                assert int(qh_k.view(1000, 256)[150:].sum().item()) == 0 and int(bh_k.sum().item()) == total_records * 150
+            rows_k_route = ctx.last_stats_route()
+            del qh_k, bh_k
             ctx.set_single_pass(False)
             two = timed(lambda: ctx.stats(buf.data_ptr(), nbytes, 150, qh.data_ptr(), bh.data_ptr(), sc.data_ptr()), reps=2)
             ctx.set_single_pass(True)
@@ -476,6 +494,7 @@ def main():
                 "frac_of_hbm_peak_end_to_end": round(nbytes / 1e6 / one[0] / HBM_PEAK_GBS, 4),
                 "scan_offsets_and_histograms_end_to_end_ms": round(both[0], 3),
                 "two_pass_route_end_to_end_ms": round(two[0], 3),
+                "lmax_1000_end_to_end_ms": round(rows_k, 3), "lmax_1000_stats_route": rows_k_route,
                 "dirty_input": {"what": "the same cold call with 1e-6 of the bases lower-cased and 1e-6 of the qualities '~' (%d + %d bytes)"
                                         % (pos_s.numel(), pos_q.numel()),
                                 "end_to_end_ms": round(dirty[0], 3), "stats_route": dirty_route,

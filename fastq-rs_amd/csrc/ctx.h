@@ -32,7 +32,7 @@ hipError_t prepare_stats_declined(uint32_t rows);
 void launch_stats_declined(hipStream_t, const DevOut *, const FusedArgs &, unsigned long long *, unsigned long long *, unsigned long long *);
 uint32_t scan_stats_nsl(uint32_t rows);
 uint32_t scan_stats_rows(uint32_t lmax, uint32_t hint);
-void launch_peek_lines(hipStream_t, const uint8_t *, uint64_t, unsigned long long *);
+void launch_peek_lines(hipStream_t, const uint8_t *, uint64_t, uint32_t, unsigned long long *);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_stats_edge(hipStream_t, const DevOut *, const uint8_t *, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
                        unsigned long long *, unsigned long long *);

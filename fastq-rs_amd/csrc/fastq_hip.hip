@@ -1170,22 +1170,23 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
 // Nothing yet: a look at the input's first 64 KiB (one small kernel and a wait of some tens of microseconds, once per context).
 // Afterwards the calls themselves say: a pass that met lines beyond its rows (listed, or given up) takes the scan's longest
 // record as the new bound; a pass that met none lets the bound come down to it.
-static fqh_status ensure_rows_hint(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t lmax) {
-    // (64 rows are the smallest instance anyway.  A context that knows something looks again only at inputs of a GiB and more —
+constexpr uint32_t FZ_ROWS_MAX = 511;   // the most rows the single pass keeps (fused_kernels.hip: FZ_LC_MAX)
+static fqh_status ensure_rows_hint(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, const fqh_carry *in, uint32_t lmax) {
+    // (A context that knows something looks again only at inputs of a GiB and more —
     // a look is some tens of microseconds, a pass over the wrong rows a whole read of the input — and only if the answer could
     // change something: rows below lmax that might be too few, or a belief in kilobase reads that keeps the pass away)
-    if (!ctx->fused_enabled || lmax <= 64 || !len || !d_buf) return FQH_OK;
-    if (ctx->rows_hint && (len < (1ull << 30) || (!ctx->lines_long && scan_stats_rows(lmax, ctx->rows_hint) >= lmax))) return FQH_OK;
+    if (!ctx->fused_enabled || !lmax || !len || !d_buf) return FQH_OK;
+    if (ctx->rows_hint && (len < (1ull << 30) || (!ctx->lines_long && scan_stats_rows(lmax, ctx->rows_hint) >= std::min(lmax, FZ_ROWS_MAX)))) return FQH_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     unsigned long long peek[3] = {0, 0, 0};
-    launch_peek_lines(ctx->stream, d_buf, len, (unsigned long long *)ctx->d_misc);
+    launch_peek_lines(ctx->stream, d_buf, len, in ? (uint32_t)(in->nl_count & 3u) : 0u, (unsigned long long *)ctx->d_misc);
     HIPCHK(ctx, hipMemcpyAsync(peek, ctx->d_misc, sizeof peek, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t seen = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(peek[0], 1), 0x7FFFFFFFull);
     // the rows go up with what a look finds, down with what the scans find (resolve()); whether MOST lines are too long for the
     // pass is what the look says (64 KiB of kilobase reads: every other line)
     if (seen > ctx->rows_hint || !ctx->rows_hint) ctx->rows_hint = seen;
-    ctx->lines_long = peek[2] * 4 > peek[1] || (peek[1] == 0 && seen > 511);
+    ctx->lines_long = peek[2] * 4 > peek[1] || (peek[1] == 0 && len >= 65536);   // (no newline in 64 KiB)
     return FQH_OK;
 }
 static void update_rows_hint(fqh_ctx *ctx) {   // after a single pass whose scan stands (fused_finish)
@@ -1265,7 +1266,7 @@ fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
                                      uint64_t *d_base_hist, uint64_t *d_scalars, uint64_t lead_len, bool *fused) {
     *fused = false;
     if (!ctx || ctx->pending || ctx->stats_pending) return FQH_E_ARG;
-    if (fqh_status hs = ensure_rows_hint(ctx, d_buf, len, lmax); hs != FQH_OK) return hs;
+    if (fqh_status hs = ensure_rows_hint(ctx, d_buf, len, in, lmax); hs != FQH_OK) return hs;
     ctx->f_defer_commit = true;
     const bool ok = fused_eligible(ctx, d_buf, len, is_final, in, lmax, lead_len, 0);
     if (!ok) {
@@ -1300,7 +1301,7 @@ fqh_status fqh_internal_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
     if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
     fqh_status st;
-    if (st = ensure_rows_hint(ctx, d_buf, len, lmax); st != FQH_OK) return st;
+    if (st = ensure_rows_hint(ctx, d_buf, len, in, lmax); st != FQH_OK) return st;
     if (fused_eligible(ctx, d_buf, len, is_final, in, lmax, lead_len, n_limit)) {
         // one read of the input: scan + histograms in k_scan_stats (src/lib.rs:226-237 hands each record to the
         // closure that reads seq()/qual(): one pass).  fqh_stats_finish falls back to the two-pass route if
@@ -1515,7 +1516,7 @@ fqh_status fqh_scan_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t le
     if (!d_qual_hist || !d_base_hist || !d_scalars || lmax == 0) return fail(ctx, FQH_E_ARG, "NULL histogram or lmax == 0");
     if (ctx->pending || ctx->stats_pending) return fail(ctx, FQH_E_ARG, "a launch is already pending");
     ctx->last_valid = false;  // never a reuse of an earlier scan: the offsets are wanted as well
-    if (fqh_status hs = ensure_rows_hint(ctx, d_buf, len, lmax); hs != FQH_OK) return hs;
+    if (fqh_status hs = ensure_rows_hint(ctx, d_buf, len, in, lmax); hs != FQH_OK) return hs;
     if (fused_eligible(ctx, d_buf, len, is_final, in, lmax, 0, UINT64_MAX)) {
         fqh_status st = fused_launch(ctx, d_buf, len, is_final, in, d_rec_start, cap, lmax, d_qual_hist, d_base_hist, d_scalars);
         if (st != FQH_OK) return st;

@@ -931,8 +931,21 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_scan_stats(FusedArgs z) {
 // k_stats_commit: adds what k_scan_stats left in scratch — per-block partial histograms (bank-scheduled layout)
 // and the totals — to the caller's arrays if and only if the scan's finalize kernel kept the fast path's result
 // (DevOut::stats_commit).
+// (lc: the rows the pass kept; lmax: the rows the caller has.  The pass may keep MORE than the caller has — reads longer than lmax:
+// what it counted in rows lmax .. lc - 1 are the columns beyond lmax, scalars[5] / [6])
+__device__ __forceinline__ void commit_overflow(unsigned long long over_s, unsigned long long over_q, unsigned long long *__restrict__ scalars) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        over_s += __shfl_xor(over_s, d);
+        over_q += __shfl_xor(over_q, d);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (over_s) atomicAdd(&scalars[5], over_s);
+        if (over_q) atomicAdd(&scalars[6], over_q);
+    }
+}
 __global__ __launch_bounds__(256) void k_stats_commit(const DevOut *__restrict__ out, const uint32_t *__restrict__ scratch,
-                                                      uint32_t n_blocks, uint32_t lc, uint32_t words,
+                                                      uint32_t n_blocks, uint32_t lc, uint32_t lmax, uint32_t words,
                                                       const unsigned long long *__restrict__ src_scalars,
                                                       unsigned long long *__restrict__ qual_hist,
                                                       unsigned long long *__restrict__ base_hist,
@@ -940,33 +953,35 @@ __global__ __launch_bounds__(256) void k_stats_commit(const DevOut *__restrict__
     if (!out->stats_commit) return;
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.y == 0 && id < FQH_NSCALARS && src_scalars[id]) atomicAdd(&scalars[id], src_scalars[id]);
-    if (id >= words) return;
     const bool isq = id >= SO_SBYTES / 4;
     const uint32_t r = isq ? id - SO_SBYTES / 4 : id;
     const uint32_t rb = isq ? r >> 12 : r >> 9;
     const uint32_t bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
     const uint32_t row = rb * 64 + so_row6(r & 63u);
-    if (row >= lc) return;
-    const uint32_t b0 = blockIdx.y * RED_GROUP;
-    const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
     unsigned long long s = 0;
-    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * SO_WORDS + id];
-    if (!s) return;
-    if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
-    else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+    if (id < words && row < lc) {
+        const uint32_t b0 = blockIdx.y * RED_GROUP;
+        const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
+        for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * SO_WORDS + id];
+    }
+    if (s && row < lmax) {
+        if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
+        else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+        s = 0;
+    }
+    if (lc > lmax) commit_overflow(isq ? 0ull : s, isq ? s : 0ull, scalars);   // (launch-uniform; every lane is here)
 }
 
 // ... and the wide instance's rows: the blocks' 32-bit rows in scratch, [2 i + h] = half h of LDS word i (k_scan_stats<8, 12, true>:
 // step u of a line — 64 columns — counts in half u & 1 of row block u >> 1, slot m + 16 j for row 64 u + 4 m + j)
 __global__ __launch_bounds__(256) void k_stats_commit_packed(const DevOut *__restrict__ out, const uint32_t *__restrict__ scratch,
-                                                             uint32_t n_blocks, uint32_t lc, const unsigned long long *__restrict__ src_scalars,
+                                                             uint32_t n_blocks, uint32_t lc, uint32_t lmax, const unsigned long long *__restrict__ src_scalars,
                                                              unsigned long long *__restrict__ qual_hist,
                                                              unsigned long long *__restrict__ base_hist,
                                                              unsigned long long *__restrict__ scalars) {
     if (!out->stats_commit) return;
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.y == 0 && id < FQH_NSCALARS && src_scalars[id]) atomicAdd(&scalars[id], src_scalars[id]);
-    if (id >= 2u * SO_WORDS) return;
     const uint32_t w = id >> 1, half = id & 1u;
     const bool isq = w >= SO_SBYTES / 4;
     const uint32_t r = isq ? w - SO_SBYTES / 4 : w;
@@ -974,14 +989,18 @@ __global__ __launch_bounds__(256) void k_stats_commit_packed(const DevOut *__res
     const uint32_t bin = isq ? (r >> 6) & 63u : (r >> 6) & 7u;
     const uint32_t slot = r & 63u;
     const uint32_t row = rb * 128u + half * 64u + (slot & 15u) * 4u + (slot >> 4);
-    if (row >= lc) return;
-    const uint32_t b0 = blockIdx.y * RED_GROUP;
-    const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
     unsigned long long s = 0;
-    for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * (2u * SO_WORDS) + id];
-    if (!s) return;
-    if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
-    else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+    if (id < 2u * SO_WORDS && row < lc) {
+        const uint32_t b0 = blockIdx.y * RED_GROUP;
+        const uint32_t b1 = b0 + RED_GROUP < n_blocks ? b0 + RED_GROUP : n_blocks;
+        for (uint32_t b = b0; b < b1; ++b) s += scratch[(uint64_t)b * (2u * SO_WORDS) + id];
+    }
+    if (s && row < lmax) {
+        if (isq) atomicAdd(&qual_hist[(uint64_t)row * 256 + 33 + bin], s);
+        else atomicAdd(&base_hist[(uint64_t)row * 8 + bin_to_class(bin)], s);  // bins 0,2,5 share class 5
+        s = 0;
+    }
+    if (lc > lmax) commit_overflow(isq ? 0ull : s, isq ? s : 0ull, scalars);   // (launch-uniform; every lane is here)
 }
 
 // k_stats_edge — the two records at the edges of a CHUNK that the single pass cannot count by itself (one wavefront, runs
@@ -1163,6 +1182,7 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
         }
     }
     __syncthreads();
+    unsigned long long over_s = 0, over_q = 0;   // (rows the pass kept beyond the caller's: dumped batches of reads longer than lmax)
     for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
         const uint32_t v = dh[i];
         if (!v) continue;
@@ -1171,10 +1191,15 @@ __global__ __launch_bounds__(1024) void k_stats_declined(const DevOut *__restric
             const uint32_t c = (v >> (16u * h)) & 0xFFFFu;
             if (!c) continue;
             const uint32_t k = 2u * i + h, rw = k / DECL_BINS, bin = k - rw * DECL_BINS, row = row0 + rw;
-            if (bin < 8) atomicAdd(&base_hist[(uint64_t)row * 8 + bin], (unsigned long long)c);
+            if (row >= lmax) {
+                if (bin < 8) over_s += c;
+                else over_q += c;
+            } else if (bin < 8) atomicAdd(&base_hist[(uint64_t)row * 8 + bin], (unsigned long long)c);
             else atomicAdd(&qual_hist[(uint64_t)row * 256 + (bin - 8)], (unsigned long long)c);
         }
     }
+    if (over_s) atomicAdd(&scalars[5], over_s);
+    if (over_q) atomicAdd(&scalars[6], over_q);
 }
 #ifndef FQH_FZ_WP
 #define FQH_FZ_WP 12
@@ -1233,9 +1258,11 @@ uint32_t stats_blocks(int n_cu);
 // like any line beyond lmax (k_stats_declined adds its columns below lmax to the caller's arrays), so a hint that is too small
 // costs time, never a count.
 uint32_t scan_stats_rows(uint32_t lmax, uint32_t hint) {
-    if (!hint || hint >= lmax) return lmax;
-    const uint32_t cap = hint <= FQH_FZ_WIDE_FROM ? (hint <= 64 ? 64u : (hint + 31u) / 32u * 32u) : (hint <= 192 ? 192u : (hint + 63u) / 64u * 64u);
-    return cap < lmax ? cap : lmax;
+    if (!hint || hint > FZ_LC_MAX) return lmax < FZ_LC_MAX ? lmax : FZ_LC_MAX;
+    // (the capacity of the instance that holds the hint — also when that is MORE than lmax: reads longer than the caller's rows are
+    // counted in rows of their own and k_stats_commit turns what lies beyond lmax into the overflow counters, instead of every
+    // line being listed for k_stats_declined until the pass is given up)
+    return hint <= FQH_FZ_WIDE_FROM ? (hint <= 64 ? 64u : (hint + 31u) / 32u * 32u) : std::min<uint32_t>(hint <= 192 ? 192u : (hint + 63u) / 64u * 64u, FZ_LC_MAX);
 }
 // can the single-pass kernel take this call?  (up to 160 rows of 32-bit counters, up to 511 of packed 16-bit ones; a line beyond
 // the rows is listed or declined.)  By what is known of the reads: if no line is longer than 511 bytes the pass fits whatever lmax
@@ -1276,7 +1303,7 @@ static hipError_t launch_scan_stats_n(hipStream_t s, FusedArgs z, uint32_t block
 // z: buf, len, n_tiles, the fast path's outputs, lmax, scratch (scan_stats_scratch_bytes), scalars = ZEROED side
 // array of FQH_NSCALARS u64 (not the caller's: see k_stats_commit)
 hipError_t launch_scan_stats(hipStream_t s, FusedArgs z, int n_cu) {
-    if (!z.rows || z.rows > z.lmax) z.rows = z.lmax;
+    if (!z.rows) z.rows = z.lmax;
     z.lc = fz_lc(z.rows);
 #ifdef FQH_TUNING  // knock-out flags of the timing experiments (tools/exp_fzdbg.py); not part of the product library
     z.dbg = getenv("FQH_FZ_DBG") ? (uint32_t)atoi(getenv("FQH_FZ_DBG")) : 0u;
@@ -1319,47 +1346,55 @@ void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, u
     const uint32_t lc = fz_lc(z.rows);
     if (fz_is_wide(lc)) {
         hipLaunchKernelGGL(k_stats_commit_packed, dim3((2 * SO_WORDS + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
-                           z.scratch, blocks, lc, z.scalars, qual_hist, base_hist, scalars);
+                           z.scratch, blocks, lc, z.lmax, z.scalars, qual_hist, base_hist, scalars);
         return;
     }
     const uint32_t words = (SO_SBYTES + (scan_stats_nsl(z.rows) + 1) / 2 * 16384u) / 4;
     hipLaunchKernelGGL(k_stats_commit, dim3((words + 255) / 256, (blocks + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, s, out,
-                       z.scratch, blocks, lc, words, z.scalars, qual_hist, base_hist, scalars);
+                       z.scratch, blocks, lc, z.lmax, words, z.scalars, qual_hist, base_hist, scalars);
 }
 
 
-// k_peek_lines — the longest line among the first bytes of an input (one block; n <= 64 KiB): what the single pass sizes its rows
-// by when the context knows nothing yet about the reads (scan_stats_rows).  A guess, not a promise: whatever it says, the pass
-// counts exactly.  A line that is still open at the end of the window counts with what the window holds of it.
-__global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__ buf, uint32_t n, unsigned long long *__restrict__ out) {
-    // out[0]: the longest line, out[1]: lines that end in the window, out[2]: ... of them longer than the single pass takes (511 bytes)
+// k_peek_lines — a look at the first bytes of an input (one block; n <= 64 KiB): the longest SEQUENCE / QUALITY line — what the
+// single pass sizes its rows by when the context knows nothing yet about the reads (scan_stats_rows) — and how many of all lines
+// are longer than the pass takes.  phase0: the place in its record (0 header .. 3 quality) of the line the window begins in (the
+// carry's newline count & 3: a chunk may begin anywhere), so line i of the window is line (phase0 + i) & 3 of a record — header
+// lines may be several times the reads' length and say nothing about the rows.  A guess, not a promise: whatever it says, the
+// pass counts exactly.  A line that is still open at the end of the window counts with what the window holds of it.
+__global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__ buf, uint32_t n, uint32_t phase0, unsigned long long *__restrict__ out) {
+    // out[0]: the longest sequence / quality line, out[1]: lines that end in the window, out[2]: ... of them longer than 511 bytes
     __shared__ int last_nl[1024];      // -> the last newline at or before the end of segment t (a running maximum), -1: none
+    __shared__ int nl_before[1024];    // -> newlines up to and including segment t (a running sum)
     __shared__ int best_w[16], lines_w[16], long_w[16];
     const uint32_t t = threadIdx.x, lo = t * 64u;
-    int f = -1, l = -1, g = 0, nl = 0;  // this segment's first / last newline, its longest line between two of its own newlines, its newlines
-    for (uint32_t i = lo; i < lo + 64u && i < n; ++i) {
-        if (buf[i] == '\n') {
-            if (f < 0) f = (int)i;
-            else if ((int)i - l - 1 > g) g = (int)i - l - 1;
-            l = (int)i;
-            ++nl;
-        }
-    }
+    int l = -1, nl = 0;
+    for (uint32_t i = lo; i < lo + 64u && i < n; ++i)
+        if (buf[i] == '\n') { l = (int)i; ++nl; }
     last_nl[t] = l;
+    nl_before[t] = nl;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive maximum scan
-        const int v = t >= d ? last_nl[t - d] : -1;
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // inclusive scans: maximum of the last newline, sum of the newlines
+        const int v = t >= d ? last_nl[t - d] : -1, c = t >= d ? nl_before[t - d] : 0;
         __syncthreads();
         if (v > last_nl[t]) last_nl[t] = v;
+        nl_before[t] += c;
         __syncthreads();
     }
-    const int before = t ? last_nl[t - 1] : -1;          // the last newline in front of this segment
-    // (a line of more than 511 bytes spans segments: it is the line this segment's FIRST newline closes, or none of this segment's)
-    int nlong = (f >= 0 && f - before - 1 > (int)FZ_LC_MAX) ? 1 : 0;
-    if (f >= 0 && f - before - 1 > g) g = f - before - 1;
+    // the lines this segment's newlines close: the first one began at `prev + 1` (in an earlier segment, perhaps), it is line
+    // number `idx` of the window
+    int prev = t ? last_nl[t - 1] : -1, idx = t ? nl_before[t - 1] : 0, g = 0, nlong = 0;
+    for (uint32_t i = lo; i < lo + 64u && i < n; ++i) {
+        if (buf[i] == '\n') {
+            const int len = (int)i - prev - 1;
+            if (((phase0 + (uint32_t)idx) & 1u) && len > g) g = len;   // (line 1 of a record: sequence, line 3: quality)
+            nlong += len > (int)FZ_LC_MAX ? 1 : 0;
+            prev = (int)i;
+            ++idx;
+        }
+    }
     if (lo < n && lo + 64u >= n) {                        // the segment that holds the window's end: the line still open there
-        const int open = (int)n - last_nl[t] - 1;
-        if (open > g) g = open;
+        const int open = (int)n - prev - 1;
+        if (((phase0 + (uint32_t)idx) & 1u) && open > g) g = open;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1385,9 +1420,9 @@ __global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__
         out[2] = (unsigned long long)longs;
     }
 }
-void launch_peek_lines(hipStream_t s, const uint8_t *buf, uint64_t len, unsigned long long *d_out) {
+void launch_peek_lines(hipStream_t s, const uint8_t *buf, uint64_t len, uint32_t phase0, unsigned long long *d_out) {
     const uint32_t n = (uint32_t)(len < 65536 ? len : 65536);
-    hipLaunchKernelGGL(k_peek_lines, dim3(1), dim3(1024), 0, s, buf, n, d_out);
+    hipLaunchKernelGGL(k_peek_lines, dim3(1), dim3(1024), 0, s, buf, n, phase0 & 3u, d_out);
 }
 
 }  // namespace fqh

@@ -358,31 +358,43 @@ def test_single_pass_rows_follow_the_reads(fqref, torch, pkg, case):
 
 
 def test_single_pass_backs_off_after_a_pass_it_gave_up(fqref, torch, pkg):
-    """Reads longer than the caller's rows by the million (lmax is the caller's choice: the first 100 cycles of 300-base reads)
-    are more than the single pass can list: it gives the pass up (route 0: counted over the exact index, bit-exact) — and the
-    context's next 1, 2, 4, .. statistics calls go straight to that route instead of paying for another attempt; a pass that
-    commits (rows for the whole read) forgets the back-off.  The closure of Parser::each (src/lib.rs:226-237) sees every record
-    whatever the caller does with it: results never depend on the route."""
+    """A file whose reads are soft-masked by the thousand (any byte may stand in seq(), src/records.rs:75-90) has more batches with
+    a byte outside ACGTN than the single pass can dump: it gives the pass up (route 0: counted over the exact index, bit-exact) —
+    and the context's next 1, 2, 4, .. statistics calls go straight to that route instead of paying for another attempt (an
+    attempt leaves the scan's result on the fast path, a skipped one is the exact path's); a pass that commits forgets the
+    back-off.  The closure of Parser::each (src/lib.rs:226-237) sees every record whatever the caller does with it: results
+    never depend on the route."""
     rng = np.random.default_rng(31)
     nrec = 40000
-    recs = []
-    for i in range(nrec):
-        n = 300
-        recs.append(b"@r%d\n" % i + rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), n, p=[.2475, .2475, .2475, .2475, .01]).tobytes() + b"\n+\n" +
-                    rng.integers(33, 75, n).astype(np.uint8).tobytes() + b"\n")
-    data = b"".join(recs)
+    def reads(masked):
+        recs = []
+        for i in range(nrec):
+            sq = bytearray(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), 150, p=[.2475, .2475, .2475, .2475, .01]).tobytes())
+            if masked and i % 10 == 3:
+                sq[20:60] = bytes(sq[20:60]).lower()
+            recs.append(b"@r%d\n" % i + bytes(sq) + b"\n+\n" + rng.integers(33, 75, 150).astype(np.uint8).tobytes() + b"\n")
+        return b"".join(recs)
+    dirty, clean = reads(True), reads(False)
     gpu = Gpu(torch, pkg.Ctx(0), pkg)
-    want = {100: fqref.stats(data, 100), 300: fqref.stats(data, 300)}
-    routes = []
-    for lmax in (100, 100, 100, 100, 300, 300, 300, 300, 300):
-        r, qh, bh, sc = want[lmax]
-        s, gq, gb, gs = gpu.stats(data, lmax)
+    want = {id(dirty): fqref.stats(dirty, 150), id(clean): fqref.stats(clean, 150)}
+    seen = []
+    for data in (dirty,) * 7 + (clean,) * 2:
+        r, qh, bh, sc = want[id(data)]
+        s, gq, gb, gs = gpu.stats(data, 150)
         assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (0, nrec)
-        assert np.array_equal(gs, sc) and np.array_equal(gq, qh) and np.array_equal(gb, bh), lmax
-        routes.append(gpu.ctx.last_stats_route())
-    # calls 1 and 3 try and give up (back-off 1, then 2); 2, 4 and 5 are skipped; call 6 tries again — rows for the whole read
-    # now — and commits; from there on every call takes the single pass
-    assert routes[:5] == [0, 0, 0, 0, 0] and routes[5:] == [1, 1, 1, 1], routes
+        assert np.array_equal(gs, sc) and np.array_equal(gq, qh) and np.array_equal(gb, bh)
+        seen.append((gpu.ctx.last_stats_route(), bool(gpu.ctx.last_scan_fast())))
+    # calls 1, 3 and 6 try and give up (back-off 1, 2, 4), calls 2, 4, 5 and 7 are skipped; call 8 would be skipped as well
+    # (three more to go) — the clean file is counted over the exact index once or twice more — ...
+    assert seen[:7] == [(0, True), (0, False), (0, True), (0, False), (0, False), (0, True), (0, False)], seen
+    assert all(rt == 0 and not fast for rt, fast in seen[7:]), seen
+    # ... until the count-down is over: then its pass commits and the back-off is forgotten
+    for _ in range(2):
+        gpu.stats(clean, 150)
+    r, qh, bh, sc = want[id(clean)]
+    s, gq, gb, gs = gpu.stats(clean, 150)
+    assert gpu.ctx.last_stats_route() == 1 and np.array_equal(gq, qh) and np.array_equal(gs, sc)
+    gpu.ctx.close()
 
 
 @pytest.mark.parametrize("huge", [1_000_000, 1_250_000])
@@ -456,10 +468,10 @@ def test_stats_fast_path_shapes(fqref, torch, pkg, shape):
         assert (s.parse_status, s.n_records) == (r.status, r.n_records) and r.n_records == nrec
         assert np.array_equal(gs, sc), (shape, lmax, gs, sc)
         assert np.array_equal(gq, qh) and np.array_equal(gb, bh), (shape, lmax)
-        # the route: every row count up to 512 takes the scan's own pass (1; 2 where lines hold bytes outside the alphabets or are
-        # longer than lmax: counted behind it) unless the lines it cannot count itself outnumber its list (one per 512 KiB)
-        longest = {"fixed150": 150, "fixed36": 36, "len4k": 260}.get(shape, 300)
-        want = {1} if (shape != "dirty" and longest <= lmax) else {0, 2}
+        # the route: every row count takes the scan's own pass (1) — also rows fewer than the reads are long: the pass keeps the
+        # rows the READS need and what it counts beyond lmax becomes the overflow counters —; 2 where lines hold bytes outside the
+        # alphabets (counted behind it), 0 where those outnumber its dump area (one slot per 512 KiB)
+        want = {1} if shape != "dirty" else {0, 2}
         assert gpu.ctx.last_stats_route() in want, (shape, lmax, gpu.ctx.last_stats_route())
     gpu.ctx.close()
 

@@ -121,8 +121,8 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           also clears the back-off the context keeps after failed attempts.
  *   FQH_OPT_SINGLE_PASS [1] whole-file fqh_stats / fqh_scan_stats count in the scan's own pass over the input
  *                           (k_scan_stats); 0 = always the exact scan followed by the histogram kernel.  A pass that has to
- *                           be given up (reads longer than lmax by the million, more lines with bytes outside the alphabets
- *                           than its dump area holds) is counted over the exact index instead, bit-exact, and the context's
+ *                           be given up (lines of 512 bytes and more among shorter ones, more lines with bytes outside the
+ *                           alphabets than its dump area holds) is counted over the exact index instead, bit-exact, and the context's
  *                           next 1, 2, 4 .. 64 statistics calls go there directly; setting the option forgets that back-off.
  *                           lmax is the caller's choice and may be far below the reads' length (the first 150 cycles of
  *                           kilobase reads): the columns beyond it are looked at (n_valid_dna / n_valid_dnan cover every

@@ -82,7 +82,7 @@ const char *fqh_strerror(fqh_status s) {
     return "unknown";
 }
 
-static std::string g_create_err = "no context";
+static thread_local std::string g_create_err = "no context";   // (fqh_last_error(NULL): why THIS thread's last fqh_create failed)
 const char *fqh_last_error(fqh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 fqh_status fqh_create(int device, fqh_ctx **out) {

@@ -11,6 +11,8 @@
 //   index        fqh_idx_record [n_records]       optional (stats / RecordSet hand-back)
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 
 #include "../../include/fastq_hip.h"
@@ -153,13 +155,17 @@ struct FusedArgs {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize of one kernel: set per DEVICE (a process may hold contexts on several), raised
 // when a launch asks for more than the device's function was last given, and an error is the caller's to report.
+// (Contexts are single-threaded, a PROCESS is not: two host threads with a context each may launch the same kernel at once —
+// the function-local statics that hold these are shared, so the bookkeeping is under a lock.)
 struct LdsAttr {
     size_t set[64] = {};
+    std::mutex mu;
     hipError_t ensure(const void *fn, size_t lds) {
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lock(mu);
         if (lds <= set[dev]) return hipSuccess;
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) set[dev] = lds;

@@ -10,6 +10,8 @@
 //   k_finalize  EOF rule (src/lib.rs:264-294), carry-out, summary.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -1389,16 +1391,18 @@ void launch_index(hipStream_t s, const uint8_t *buf, uint64_t len, uint16_t *lis
     if (!n_tiles) return;
     // persistent grid = exactly the blocks that are resident at once: a static round-robin of tiles over
     // a grid with one non-resident block per CU would run that block as a tail
-    static int occ[2] = {0, 0};
-    if (!occ[fast]) {
+    static std::atomic<int> occ[2];   // (zero-initialised; two host threads with a context each may be here at once: both find the same answer)
+    int oc = occ[fast].load(std::memory_order_relaxed);
+    if (!oc) {
         int o = 0;
         const hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_fast, 256, 0)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_index_t, 256, 0);
         if (e != hipSuccess || o < 1) o = 4;
-        occ[fast] = o > 8 ? 8 : o;
+        oc = o > 8 ? 8 : o;
+        occ[fast].store(oc, std::memory_order_relaxed);
     }
     uint64_t blocks = (n_tiles + 3) / 4;
-    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ[fast];
+    const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * oc;
     if (blocks > maxb) blocks = maxb;
     if (fast)  // (the entry count travels in the tile's line: the prefix scan leaves the dense copy)
         hipLaunchKernelGGL(k_index_fast, dim3((uint32_t)blocks), dim3(256), 0, s, buf, len, list, list_cap,
@@ -1441,11 +1445,13 @@ void launch_prefix(hipStream_t s, uint32_t *tile_count, const uint16_t *fast_rs,
 }
 void launch_emit(hipStream_t s, const ScanArgs &a, DevOut *out, int n_cu) {
     if (!a.n_tiles) return;
-    static int occ = 0;
+    static std::atomic<int> occ_a;
+    int occ = occ_a.load(std::memory_order_relaxed);
     if (!occ) {
         int o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_emit<false>, 256, 0) != hipSuccess || o < 1) o = 4;
         occ = o > 8 ? 8 : o;
+        occ_a.store(occ, std::memory_order_relaxed);
     }
     uint64_t blocks = ((a.n_tiles + EMIT_G - 1) / EMIT_G + 3) / 4;
     const uint64_t maxb = (uint64_t)(n_cu > 0 ? n_cu : 256) * occ;

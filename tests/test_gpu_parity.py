@@ -357,6 +357,40 @@ def test_single_pass_rows_follow_the_reads(fqref, torch, pkg, case):
     gpu.ctx.close()
 
 
+def test_two_contexts_on_two_host_threads(fqref, torch, pkg):
+    """A context is single-threaded, a process is not (parallel_each's workers, src/lib.rs:521-559, are threads of ONE process):
+    two host threads with a context and a stream each, first calls at the same time — the process-wide bookkeeping behind the
+    launches (LDS attributes per kernel and device, occupancy look-ups) is shared — on inputs that take different kernels."""
+    import threading
+    rng = np.random.default_rng(5)
+    def reads(n, L):
+        return b"".join(b"@r%d\n" % i + rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L, p=[.2475, .2475, .2475, .2475, .01]).tobytes() + b"\n+\n" +
+                        rng.integers(33, 75, L).astype(np.uint8).tobytes() + b"\n" for i in range(n))
+    jobs = [(reads(20000, 150), 150), (reads(3000, 1200), 1200), (reads(20000, 300), 300), (reads(20000, 36), 36)]
+    want = [fqref.stats(d, lmax) for d, lmax in jobs]
+    errors = []
+    def work(which):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                gpu = Gpu(torch, pkg.Ctx(0, stream=stream.cuda_stream), pkg)
+                for rep in range(6):
+                    for k in (which, which + 2):
+                        (data, lmax), (r, qh, bh, sc) = jobs[k], want[k]
+                        s, gq, gb, gs = gpu.stats(data, lmax)
+                        assert (s.parse_status, s.n_records) == (r.status, r.n_records)
+                        assert np.array_equal(gs, sc) and np.array_equal(gq, qh) and np.array_equal(gb, bh), (which, k, rep)
+                gpu.ctx.close()
+        except Exception as e:   # (an assertion in a thread is nobody's unless it is carried out)
+            errors.append((which, repr(e)))
+    threads = [threading.Thread(target=work, args=(w,)) for w in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_single_pass_backs_off_after_a_pass_it_gave_up(fqref, torch, pkg):
     """A file whose reads are soft-masked by the thousand (any byte may stand in seq(), src/records.rs:75-90) has more batches with
     a byte outside ACGTN than the single pass can dump: it gives the pass up (route 0: counted over the exact index, bit-exact) —

@@ -907,12 +907,30 @@ class Coll:
         # node that ever gives it more than one rank must not cost that node's whole record; and no rank may enter a collective
         # of a communicator that another rank has given up).
         ok, why = 1, None
+        # (a communicator that never comes up — ncclCommInitRank waiting for a rank that is not coming — must not hold the node
+        # until somebody's limit ends the job without a word: after FQH_BENCH_COMM_TIMEOUT seconds, default 300, this rank says what
+        # it was waiting for and ends the process; --comm torch is the way around)
+        import threading
+        limit = float(os.environ.get("FQH_BENCH_COMM_TIMEOUT", "300"))
+
+        def stuck():
+            sys.stderr.write("bench.py: rank %d of %d: the library's RCCL binding (fqh_comm_create / its start-up collectives) did not "
+                             "finish within %.0f s; giving the job up (run with --comm torch to keep torch.distributed's collectives)\n"
+                             % (rank, world, limit))
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(limit, stuck) if (world > 1 and not local and limit > 0) else None
+        if watchdog:
+            watchdog.daemon = True
+            watchdog.start()
         try:
             self.comm = pkg.Comm(ctx, world, rank, uid)
         except Exception as e:   # FqhError, or anything the runtime throws
             ok, why = 0, "%s: %s" % (type(e).__name__, e)
         bad = agree(ok, why)
         if bad:
+            if watchdog:
+                watchdog.cancel()
             return give_up(bad)
         if world > 1 and not local:
             try:
@@ -931,7 +949,11 @@ class Coll:
                 ok, why = 0, "%s: %s" % (type(e).__name__, e)
             bad = agree(ok, why)
             if bad:
+                if watchdog:
+                    watchdog.cancel()
                 return give_up(bad)
+        if watchdog:
+            watchdog.cancel()
         self.via_text = "fqh_comm (libfastq_hip.so's own RCCL binding, %d rank%s%s)" % (
             world, "" if world == 1 else "s", "" if world == 1 or local else "; its three collectives checked on known values at start-up")
 

@@ -131,3 +131,26 @@ def test_packed_rows_do_not_wrap_12gib(env):
     assert sc.cpu().tolist()[:5] == [nrec, nrec * L, nrec * L, nrec, nrec]
     ctx.synth_fill(buf.data_ptr(), 0, NBYTES)               # (leave the buffer as the fixture made it)
     ctx.invalidate()
+
+
+@pytest.mark.parametrize("varied", [False, True])
+def test_kilobase_reads_12gib(varied):
+    """configs[2]'s per-read statistics loop over KILOBASE reads at full size (12 GiB; the 16 GiB buffer of this module is
+    somebody else's): reads of 5 kbp, and reads of log-normal length around 5 kbp (370 .. 30 000 bases: 118 column blocks,
+    k_stats_long's work items cut on the device from a census of the lengths, per-column-block record lists), against the
+    per-position count numpy makes of the repeated block — every (position, quality value) counter and the base total,
+    bit-exact (src/records.rs:75-90; src/lib.rs:276-283 treats every record up to the Buffer alike).  bench.py's own leg, at
+    three times its size."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    import bench
+    pkg = g.load_package()
+    dev = torch.device("cuda:0")
+    ctx = pkg.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        r = bench.long_read_leg(pkg, torch, dev, ctx, gib=12.0, varied=varied)   # (asserts the counts itself)
+        assert r["gbs_end_to_end"] > 0
+    finally:
+        ctx.close()

@@ -102,6 +102,30 @@ def test_histograms_16gib_properties(env, fqref):
     assert np.array_equal(s3.cpu().numpy().astype(np.uint64), osc)
 
 
+def test_rows_on_either_side_of_the_reads_16gib(env):
+    """lmax is the caller's choice (the closure of Parser::each has none, src/lib.rs:226-237): 1000 rows over the 150-base reads,
+    and 100.  One pass either way (the pass keeps the rows the READS need); the first 100 / 150 rows equal those of the call
+    with 150 rows, rows beyond the reads stay zero, and the columns beyond 100 rows are the overflow counters."""
+    torch, pkg, ctx, buf, dev = env
+    q0, b0, s0 = hists(torch, dev)
+    ctx.invalidate()
+    ctx.stats(buf.data_ptr(), NBYTES, 150, q0.data_ptr(), b0.data_ptr(), s0.data_ptr())
+    assert ctx.last_stats_route() == 1 and int(s0[0]) == NREC
+    for lmax in (1000, 100):
+        q = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+        b = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+        sc = torch.zeros(8, dtype=torch.int64, device=dev)
+        ctx.invalidate()
+        s, c = ctx.stats(buf.data_ptr(), NBYTES, lmax, q.data_ptr(), b.data_ptr(), sc.data_ptr())
+        assert (s.parse_status, s.n_records) == (pkg.OK, NREC) and ctx.last_stats_route() == 1, (lmax, ctx.last_stats_route())
+        k = min(lmax, 150)
+        assert torch.equal(q.view(lmax, 256)[:k], q0.view(150, 256)[:k]) and torch.equal(b.view(lmax, 8)[:k], b0.view(150, 8)[:k])
+        assert int(q.view(lmax, 256)[k:].sum()) == 0 and int(b.view(lmax, 8)[k:].sum()) == 0
+        want = s0.clone()
+        want[5] = want[6] = NREC * (150 - k)
+        assert torch.equal(sc, want), (lmax, sc.cpu().tolist(), want.cpu().tolist())
+
+
 def test_packed_rows_do_not_wrap_12gib(env):
     """Reads of 300 columns at full size through the packed instance of the single pass (two rows per LDS word, 16-bit halves,
     flushed every few spans): 12 GiB of ONE record repeated — every quality byte 'I', every base 'A' — puts ~ 76 000 counts per

@@ -11,7 +11,7 @@ L, nrec = 150, 4096
 seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), (nrec, L), p=[0.2495, 0.2495, 0.2495, 0.2495, 0.002])
 qual = rng.choice(np.frombuffer(b"#,5:F", dtype=np.uint8), (nrec, L))
 block = b"".join(b"@A00123:45:HXXXXXXXX:1:%04d:%05d:%05d 1:N:0:ATCACG\n" % (1101 + i % 400, 1000 + 7 * i, 2000 + 3 * i) + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n" for i in range(nrec))
-slot = 255 << 20
+slot = int(os.environ.get("SLOT_MIB", "255")) << 20
 reps = slot // len(block)
 fill = np.frombuffer(block * reps, dtype=np.uint8)
 for lmax in [int(x) for x in sys.argv[1:]] or [150, 1000]:

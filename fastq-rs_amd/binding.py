@@ -9,13 +9,13 @@ LIB_PATH = os.environ.get("FQH_LIB_PATH") or os.path.join(_HERE, "libfastq_hip.s
 
 __all__ = ["LIB_PATH", "lib", "Ctx", "Stream", "Comm", "COMM_ID_BYTES", "Chunk", "ShardResult", "READ_FN", "SHARD_STREAM_WORDS", "NO_ERROR_KEY", "shard_stream_outcome", "shard_failed_words", "shard_failure_key", "SHARD_EMPTY", "SHARD_PASS", "SHARD_DEFER", "STREAM_INDEX", "STREAM_STATS", "STREAM_TIMING", "StreamTimes", "Carry", "Summary", "Timing", "IdxRecord", "FqhError",
            "strerror", "carry_combine", "OK", "E_HEADER", "E_SEP", "E_LEN_MISMATCH", "E_TRUNCATED", "E_TOO_LONG",
-           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "OPT_REUSE_INDEX", "OPT_ADAPT_LINES", "OPT_OWN_STREAM_NONBLOCKING", "EXPORTS"]
+           "E_IO", "E_DEVICE", "E_ARG", "E_CAPACITY", "E_AGAIN", "SHARD_WORDS", "BUFSIZE", "NSCALARS", "OPT_FAST_PATH", "OPT_SINGLE_PASS", "OPT_PLACE_TRIES", "OPT_SPIN_WAIT", "OPT_REUSE_INDEX", "OPT_ADAPT_LINES", "OPT_OWN_STREAM_NONBLOCKING", "OPT_KEEP_RING", "STREAM_EXTERNAL", "MAP_FN", "EXPORTS"]
 
 OK, E_HEADER, E_SEP, E_LEN_MISMATCH, E_TRUNCATED, E_TOO_LONG, E_IO, E_DEVICE, E_ARG, E_CAPACITY, E_AGAIN = range(11)
 SHARD_WORDS = 8
 BUFSIZE = 68 * 1024
 NSCALARS = 8
-OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT, OPT_REUSE_INDEX, OPT_ADAPT_LINES, OPT_OWN_STREAM_NONBLOCKING = 1, 2, 3, 4, 5, 6, 7
+OPT_FAST_PATH, OPT_SINGLE_PASS, OPT_PLACE_TRIES, OPT_SPIN_WAIT, OPT_REUSE_INDEX, OPT_ADAPT_LINES, OPT_OWN_STREAM_NONBLOCKING, OPT_KEEP_RING = 1, 2, 3, 4, 5, 6, 7, 8
 
 # every symbol include/fastq_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -28,7 +28,8 @@ EXPORTS = [
     "fqh_allreduce_u64", "fqh_allreduce_min_u64", "fqh_sync", "fqh_shard_stream_run", "fqh_shard_result_words",
     "fqh_shard_failed_words", "fqh_shard_failure_key",
     "fqh_shard_stream_finish", "fqh_shard_stream_outcome", "fqh_stream_set_origin", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
-    "fqh_memcpy_d2h", "fqh_memset",
+    "fqh_memcpy_d2h", "fqh_memset", "fqh_stream_submit_external", "fqh_host_register", "fqh_host_unregister",
+    "fqh_shard_stream_run_mapped",
 ]
 
 
@@ -69,12 +70,14 @@ class ShardResult(C.Structure):
 
 
 READ_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64)   # fqh_read_fn
+MAP_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64))   # fqh_map_fn
 SHARD_STREAM_WORDS = 10
 SHARD_EMPTY, SHARD_PASS, SHARD_DEFER = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFD
 NO_ERROR_KEY = (1 << 64) - 1
 STREAM_INDEX = 1
 STREAM_STATS = 2
 STREAM_TIMING = 4
+STREAM_EXTERNAL = 8
 
 
 class StreamTimes(C.Structure):
@@ -156,6 +159,9 @@ def lib():
         L.fqh_stream_destroy.restype = None
         L.fqh_stream_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.fqh_stream_submit.argtypes = [vp, u64, i32]
+        L.fqh_stream_submit_external.argtypes = [vp, vp, u64, i32]
+        L.fqh_host_register.argtypes = [vp, vp, u64]
+        L.fqh_host_unregister.argtypes = [vp, vp]
         L.fqh_stream_collect.argtypes = [vp, C.POINTER(Chunk)]
         L.fqh_stream_release.argtypes = [vp]
         L.fqh_stream_timing.argtypes = [vp, C.POINTER(StreamTimes)]
@@ -167,6 +173,7 @@ def lib():
         L.fqh_allreduce_u64.argtypes = [vp, vp, vp, u64]
         L.fqh_allreduce_min_u64.argtypes = [vp, vp, vp, u64]
         L.fqh_shard_stream_run.argtypes = [vp, READ_FN, vp, u64, u64, u64, u64, u32, u32, vp, vp, vp, C.POINTER(ShardResult)]
+        L.fqh_shard_stream_run_mapped.argtypes = [vp, READ_FN, MAP_FN, vp, u64, u64, u64, u64, u32, u32, vp, vp, vp, C.POINTER(ShardResult)]
         L.fqh_shard_result_words.argtypes = [C.POINTER(ShardResult), u64, u64, C.POINTER(u64 * SHARD_STREAM_WORDS)]
         L.fqh_shard_result_words.restype = None
         L.fqh_shard_failed_words.argtypes = [i32, u64, u64, C.POINTER(u64 * SHARD_STREAM_WORDS)]
@@ -404,6 +411,17 @@ class Ctx:
         """Let fqh_stats* count over the last scan's tile index when buffer, length and carry match (the caller vouches for the bytes)."""
         self._chk(self._L.fqh_set_option(self._h, OPT_REUSE_INDEX, 1 if on else 0))
 
+    def set_keep_ring(self, on):
+        """A destroyed ring's pinned slots stay with the context for the next ring of the same geometry (FQH_OPT_KEEP_RING)."""
+        self._chk(self._L.fqh_set_option(self._h, OPT_KEEP_RING, 1 if on else 0))
+
+    def host_register(self, addr, nbytes):
+        """Page-locks the caller's own host memory (a source of Stream.submit_external / a mapped shard run)."""
+        self._chk(self._L.fqh_host_register(self._h, addr, nbytes))
+
+    def host_unregister(self, addr):
+        self._chk(self._L.fqh_host_unregister(self._h, addr))
+
     def set_spin_wait(self, usec):
         """Microseconds *_finish polls the stream before sleeping on it (default 0: sleeps at once)."""
         self._chk(self._L.fqh_set_option(self._h, OPT_SPIN_WAIT, int(usec)))
@@ -505,12 +523,28 @@ class Stream:
         self.ctx._chk(st)
         return p.value, cap.value
 
+    def acquire_status(self):
+        """The raw status of fqh_stream_acquire (for tests of its error paths); a slot it hands out is given back empty."""
+        p, cap = C.c_void_p(), C.c_uint64()
+        st = self._L.fqh_stream_acquire(self._h, C.byref(p), C.byref(cap))
+        if st == OK:
+            self.ctx._chk(self._L.fqh_stream_submit(self._h, 0, 0))
+        return st
+
     def note_read(self, got, asked):
         """One read() of the host's reader into the acquired slot: got of asked bytes (a reader that may come back short)."""
         self.ctx._chk(self._L.fqh_stream_note_read(self._h, got, asked))
 
     def submit(self, nbytes, is_final):
         self.ctx._chk(self._L.fqh_stream_submit(self._h, nbytes, 1 if is_final else 0))
+
+    def submit_external(self, host_addr, nbytes, is_final):
+        """The next slot's bytes straight from the caller's (page-locked) memory -> True, or False when the ring is full."""
+        st = self._L.fqh_stream_submit_external(self._h, host_addr, nbytes, 1 if is_final else 0)
+        if st == E_CAPACITY:
+            return False
+        self.ctx._chk(st)
+        return True
 
     def collect(self):
         c = Chunk()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "fqh_internal.h"
 #include "replay.h"
@@ -158,6 +159,19 @@ struct fqh_ctx {
     uint32_t decl_cap = 0;
     size_t decl_b_bytes = 0;
     int stats_route = 0;          // fqh_last_stats_route: how the last finished statistics call counted
+    // FQH_OPT_KEEP_RING: the pinned / device buffers of destroyed rings, parked for the next fqh_stream_create of the same
+    // geometry (pinning hundreds of MiB takes tens of ms: a host that opens one ring per file, or per fqh_shard_stream_run,
+    // pays it once per context instead)
+    struct ParkedSlot {
+        uint8_t *h = nullptr, *d_base = nullptr;
+        uint64_t h_bytes = 0, d_bytes = 0;
+        uint64_t *d_rec = nullptr, *h_rec = nullptr;
+        uint64_t rec_cap = 0;
+        fqh_idx_record *d_idx = nullptr, *h_idx = nullptr;
+        uint64_t idx_cap = 0;
+    };
+    std::vector<ParkedSlot> parked;
+    bool keep_ring = false;
     bool fused_enabled = true;    // FQH_FUSED=0: histograms always as a second pass over a full index
 };
 
@@ -185,5 +199,7 @@ fqh_status fqh_internal_fused_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_
 bool fqh_internal_fused_owed(const fqh_ctx *ctx);
 void fqh_internal_fused_commit(fqh_ctx *ctx);
 void fqh_internal_fused_drop(fqh_ctx *ctx);
+// frees the ring buffers a context has parked (FQH_OPT_KEEP_RING)
+void fqh_internal_free_parked(fqh_ctx *ctx);
 // error visibility of the failing record of the last finished scan (BufferReplay::step's `need`)
 uint64_t fqh_internal_last_need(const fqh_ctx *ctx);

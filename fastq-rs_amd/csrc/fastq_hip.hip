@@ -138,6 +138,7 @@ void fqh_destroy(fqh_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    fqh_internal_free_parked(ctx);
     (void)hipFree(ctx->list);
     (void)hipFree(ctx->tile_count);
     (void)hipFree(ctx->tile_prefix);
@@ -1072,6 +1073,10 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
         return FQH_OK;
     case FQH_OPT_SPIN_WAIT:
         ctx->spin_wait_us = value < 0 ? 0 : value > 1000000 ? 1000000 : value;
+        return FQH_OK;
+    case FQH_OPT_KEEP_RING:
+        ctx->keep_ring = value != 0;
+        if (!ctx->keep_ring) fqh_internal_free_parked(ctx);
         return FQH_OK;
     case FQH_OPT_OWN_STREAM_NONBLOCKING: {
         // the context's own stream again, blocking (ordered against the legacy null stream: the safe default) or not (no

@@ -78,8 +78,10 @@ struct Span {
 // Parses the file's bytes [from, to) — `from` is a record start — through a pinned ring, exactly as a file of its own that
 // begins at file offset `from` (fqh_stream_set_origin: offsets in the result are file offsets, and so is what "too long" is
 // judged on).  is_final: `to` is the end of the file (EOF rule, src/lib.rs:264-294).
-fqh_status stream_span(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t from, uint64_t to, bool is_final, uint64_t slot_bytes,
-                       uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars, Span *out) {
+// map != NULL: the bytes are taken in place from the caller's page-locked memory (fqh_stream_submit_external), no pinned slots.
+fqh_status stream_span(fqh_ctx *ctx, fqh_read_fn read, fqh_map_fn map, void *user, uint64_t from, uint64_t to, bool is_final,
+                       uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist, uint64_t *d_base_hist,
+                       uint64_t *d_scalars, Span *out) {
     *out = Span{};
     out->end_of_records = out->seen_to = from;
     if (to <= from && !is_final) return FQH_OK;
@@ -88,7 +90,7 @@ fqh_status stream_span(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t from
     const uint64_t sb = std::min<uint64_t>(slot_bytes, want);
     fqh_stream *sp = nullptr;
     const bool stats = lmax != 0;
-    fqh_status st = fqh_stream_create(ctx, sb, n_slots, stats ? FQH_STREAM_STATS : 0u, &sp);
+    fqh_status st = fqh_stream_create(ctx, sb, n_slots, (stats ? FQH_STREAM_STATS : 0u) | (map ? FQH_STREAM_EXTERNAL : 0u), &sp);
     if (st != FQH_OK) return st;
     struct Closer {
         fqh_stream *s;
@@ -104,7 +106,22 @@ fqh_status stream_span(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t from
     bool done_reading = false, io_failed = false;
     uint64_t submitted = 0, collected = 0;
     for (;;) {
-        while (!done_reading && !io_failed) {
+        while (!done_reading && !io_failed && map) {
+            if (submitted - collected >= n_slots) break;  // the ring is full: collect first
+            uint64_t n = std::min<uint64_t>(sb, to - pos), avail = 0;
+            const uint8_t *src = n ? map(user, pos, n, &avail) : nullptr;
+            if (n && (!src || !avail)) {
+                io_failed = true;  // (file order: see below)
+                break;
+            }
+            n = std::min<uint64_t>(n, avail);
+            done_reading = pos + n >= to;
+            st = fqh_stream_submit_external(sp, src, n, (done_reading && is_final) ? 1 : 0);
+            if (st != FQH_OK) return st;
+            pos += n;
+            ++submitted;
+        }
+        while (!done_reading && !io_failed && !map) {
             uint8_t *dst = nullptr;
             uint64_t cap = 0;
             st = fqh_stream_acquire(sp, &dst, &cap);
@@ -273,6 +290,13 @@ fqh_status fqh_shard_stream_outcome(uint64_t key, const uint64_t *records_per_ra
 fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t lo, uint64_t hi, uint64_t file_len,
                                 uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist,
                                 uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res) {
+    return fqh_shard_stream_run_mapped(ctx, read, nullptr, user, lo, hi, file_len, slot_bytes, n_slots, lmax, d_qual_hist, d_base_hist,
+                                       d_scalars, res);
+}
+
+fqh_status fqh_shard_stream_run_mapped(fqh_ctx *ctx, fqh_read_fn read, fqh_map_fn map, void *user, uint64_t lo, uint64_t hi,
+                                       uint64_t file_len, uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax,
+                                       uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res) {
     if (!ctx || !read || !res || hi < lo || hi > file_len || n_slots < 2) return FQH_E_ARG;
     const bool stats = lmax != 0;
     if (stats && (!d_qual_hist || !d_base_hist || !d_scalars)) return FQH_E_ARG;
@@ -355,7 +379,7 @@ fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint
     }
     // ---- an anchor: [lo + R, hi) as a file of its own
     Span sp;
-    fqh_status st = stream_span(ctx, read, user, lo + R, hi, hi >= file_len, slot_bytes, n_slots, lmax, d_qual_hist, d_base_hist,
+    fqh_status st = stream_span(ctx, read, map, user, lo + R, hi, hi >= file_len, slot_bytes, n_slots, lmax, d_qual_hist, d_base_hist,
                                 d_scalars, &sp);
     if (st == FQH_E_IO) {  // (no parse error in what could be read: see FLAG_IO_FAILED)
         *res = fqh_shard_result{};
@@ -413,7 +437,7 @@ fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, fqh_read_fn read, void *user, u
     if (job.gap) {
         if (!ctx || !read || n_slots < 2 || (lmax && (!d_qual_hist || !d_base_hist || !d_scalars))) return FQH_E_ARG;
         Span g;
-        fqh_status st = stream_span(ctx, read, user, job.gap_from, job.gap_to, job.gap_final, slot_bytes, n_slots, lmax, d_qual_hist,
+        fqh_status st = stream_span(ctx, read, nullptr, user, job.gap_from, job.gap_to, job.gap_final, slot_bytes, n_slots, lmax, d_qual_hist,
                                     d_base_hist, d_scalars, &g);
         if (st != FQH_OK) return st;
         out[0] += g.n_records;

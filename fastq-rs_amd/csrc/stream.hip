@@ -16,8 +16,10 @@ struct fqh_stream {
     uint64_t slot_bytes = 0, reserve = 0;
     hipStream_t copy_stream = nullptr;
     struct Slot {
-        uint8_t *h = nullptr;   // pinned: [reserve][slot_bytes]
+        uint8_t *h = nullptr;   // pinned: [reserve][slot_bytes] ([reserve] only in a ring of FQH_STREAM_EXTERNAL)
         uint8_t *d_base = nullptr, *d = nullptr;  // device: [reserve][slot_bytes + 16], d = d_base + reserve
+        uint64_t h_bytes = 0, d_bytes = 0;
+        const uint8_t *ext = nullptr;  // fqh_stream_submit_external: the caller's (registered) memory the slot's bytes came from
         uint64_t *d_rec = nullptr, *h_rec = nullptr;
         uint64_t rec_cap = 0;
         fqh_idx_record *d_idx = nullptr, *h_idx = nullptr;
@@ -74,6 +76,20 @@ static fqh_status grow_idx(fqh_stream *st, fqh_stream::Slot &s, uint64_t need) {
     return FQH_OK;
 }
 
+void fqh_internal_free_parked(fqh_ctx *ctx) {
+    if (!ctx || ctx->parked.empty()) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto &k : ctx->parked) {
+        if (k.h) (void)hipHostFree(k.h);
+        (void)hipFree(k.d_base);
+        (void)hipFree(k.d_rec);
+        if (k.h_rec) (void)hipHostFree(k.h_rec);
+        (void)hipFree(k.d_idx);
+        if (k.h_idx) (void)hipHostFree(k.h_idx);
+    }
+    ctx->parked.clear();
+}
+
 extern "C" {
 
 void fqh_stream_destroy(fqh_stream *st) {
@@ -87,13 +103,31 @@ void fqh_stream_destroy(fqh_stream *st) {
             s.launched = false;
         }
     (void)hipStreamSynchronize(st->ctx->stream);
+    fqh_ctx *const ctx = st->ctx;
+    // FQH_OPT_KEEP_RING: the buffers of ONE geometry stay with the context — the biggest seen (a gap of a few hundred bytes
+    // opens a ring of 64 KiB slots next to the range's 255 MiB ones: those are not worth keeping)
+    bool park = ctx->keep_ring && !st->slots.empty() && st->slots[0].h && st->slots[0].d_base;
+    if (park && !ctx->parked.empty()) {
+        const uint64_t have = ctx->parked[0].h_bytes + ctx->parked[0].d_bytes, mine = st->slots[0].h_bytes + st->slots[0].d_bytes;
+        const bool same = ctx->parked[0].h_bytes == st->slots[0].h_bytes && ctx->parked[0].d_bytes == st->slots[0].d_bytes;
+        if (!same && mine > have) fqh_internal_free_parked(ctx);
+        else if (!same) park = false;
+    }
     for (auto &s : st->slots) {
-        if (s.h) (void)hipHostFree(s.h);
-        (void)hipFree(s.d_base);
-        (void)hipFree(s.d_rec);
-        if (s.h_rec) (void)hipHostFree(s.h_rec);
-        (void)hipFree(s.d_idx);
-        if (s.h_idx) (void)hipHostFree(s.h_idx);
+        if (park && s.h && s.d_base && ctx->parked.size() < 16) {
+            fqh_ctx::ParkedSlot k;
+            k.h = s.h; k.d_base = s.d_base; k.h_bytes = s.h_bytes; k.d_bytes = s.d_bytes;
+            k.d_rec = s.d_rec; k.h_rec = s.h_rec; k.rec_cap = s.rec_cap;
+            k.d_idx = s.d_idx; k.h_idx = s.h_idx; k.idx_cap = s.idx_cap;
+            ctx->parked.push_back(k);
+        } else {
+            if (s.h) (void)hipHostFree(s.h);
+            (void)hipFree(s.d_base);
+            (void)hipFree(s.d_rec);
+            if (s.h_rec) (void)hipHostFree(s.h_rec);
+            (void)hipFree(s.d_idx);
+            if (s.h_idx) (void)hipHostFree(s.h_idx);
+        }
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.got) (void)hipEventDestroy(s.got);
         if (s.idle) (void)hipEventDestroy(s.idle);
@@ -108,7 +142,8 @@ void fqh_stream_destroy(fqh_stream *st) {
 
 fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots, uint32_t flags,
                              fqh_stream **out) {
-    if (!ctx || !out || n_slots < 2 || slot_bytes < 4096) return FQH_E_ARG;
+    if (!ctx || !out || n_slots < 2 || slot_bytes < 4096 || (flags & ~(FQH_STREAM_INDEX | FQH_STREAM_STATS | FQH_STREAM_TIMING | FQH_STREAM_EXTERNAL)))
+        return FQH_E_ARG;
     *out = nullptr;
     fqh_stream *st = new (std::nothrow) fqh_stream();
     if (!st) return FQH_E_DEVICE;
@@ -132,10 +167,20 @@ fqh_status fqh_stream_create(fqh_ctx *ctx, uint64_t slot_bytes, uint32_t n_slots
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = FQH_E_DEVICE; break; }
         if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) { rc = FQH_E_DEVICE; break; }
         if ((flags & FQH_STREAM_TIMING) && (hipEventCreate(&st->t_base) != hipSuccess || hipEventRecord(st->t_base, ctx->stream) != hipSuccess)) { rc = FQH_E_DEVICE; break; }
+        const uint64_t h_bytes = st->reserve + ((flags & FQH_STREAM_EXTERNAL) ? 0 : st->slot_bytes);
+        const uint64_t d_bytes = st->reserve + st->slot_bytes + 16;
         for (auto &s : st->slots) {
-            if (hipHostMalloc((void **)&s.h, st->reserve + st->slot_bytes, hipHostMallocDefault) != hipSuccess ||
-                hipMalloc((void **)&s.d_base, st->reserve + st->slot_bytes + 16) != hipSuccess ||
-                hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+            s.h_bytes = h_bytes;
+            s.d_bytes = d_bytes;
+            if (!ctx->parked.empty() && ctx->parked.back().h_bytes == h_bytes && ctx->parked.back().d_bytes == d_bytes) {
+                const fqh_ctx::ParkedSlot k = ctx->parked.back();   // (FQH_OPT_KEEP_RING: a ring of this geometry lived before)
+                ctx->parked.pop_back();
+                s.h = k.h; s.d_base = k.d_base;
+                s.d_rec = k.d_rec; s.h_rec = k.h_rec; s.rec_cap = k.rec_cap;
+                s.d_idx = k.d_idx; s.h_idx = k.h_idx; s.idx_cap = k.idx_cap;
+            } else if (hipHostMalloc((void **)&s.h, h_bytes, hipHostMallocDefault) != hipSuccess ||
+                       hipMalloc((void **)&s.d_base, d_bytes) != hipSuccess) { rc = FQH_E_DEVICE; break; }
+            if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s.got, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s.idle, hipEventDisableTiming) != hipSuccess) { rc = FQH_E_DEVICE; break; }
             if ((flags & FQH_STREAM_TIMING) && (hipEventCreate(&s.tc0) != hipSuccess || hipEventCreate(&s.tc1) != hipSuccess ||
@@ -166,6 +211,7 @@ fqh_status fqh_stream_set_stats(fqh_stream *st, uint32_t lmax, uint64_t *d_qual_
 
 fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap) {
     if (!st || !h_dst || !cap) return FQH_E_ARG;
+    if (st->flags & FQH_STREAM_EXTERNAL) return FQH_E_ARG;  // (its slots have no pinned data area)
     fqh_stream::Slot &s = st->slots[st->head % st->n_slots];
     if (st->head != st->sub || s.state != 0) return FQH_E_CAPACITY;  // previous acquire not submitted, or ring full
     s.state = 1;
@@ -175,6 +221,24 @@ fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap) {
     return FQH_OK;
 }
 
+fqh_status fqh_stream_submit_external(fqh_stream *st, const uint8_t *h_src, uint64_t nbytes, int is_final) {
+    if (!st || (!h_src && nbytes)) return FQH_E_ARG;
+    fqh_stream::Slot &s = st->slots[st->head % st->n_slots];
+    if (st->head != st->sub) return FQH_E_ARG;      // an acquired slot has not been submitted
+    if (s.state != 0) return FQH_E_CAPACITY;        // ring full: collect / release first
+    if (nbytes > st->slot_bytes) return FQH_E_ARG;
+    s.state = 1;
+    s.ext = h_src ? h_src : s.h + st->reserve;  // (nbytes == 0: nothing is read; the slot's own lead area stays in front)
+    ++st->head;
+    const fqh_status rc = fqh_stream_submit(st, nbytes, is_final);
+    if (rc != FQH_OK) {  // (the slot goes back: nothing of it is in flight)
+        s.state = 0;
+        s.ext = nullptr;
+        --st->head;
+    }
+    return rc;
+}
+
 fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final) {
     if (!st) return FQH_E_ARG;
     if (st->sub + 1 != st->head) return FQH_E_ARG;  // nothing acquired
@@ -182,13 +246,14 @@ fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final) {
     if (s.state != 1 || nbytes > st->slot_bytes) return FQH_E_ARG;
     fqh_ctx *ctx = st->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint8_t *const src = s.ext ? s.ext : s.h + st->reserve;
     s.n_new = nbytes;
     s.is_final = is_final ? 1 : 0;
     // (the copy may not overtake what the context's stream still has to do on this slot's previous contents: commit kernels
     // that read its bytes, the move of its partial trailing record — enqueued by the collect that handed the slot back)
     if (s.idle_set) HIPCHK(ctx, hipStreamWaitEvent(st->copy_stream, s.idle, 0));
     if (s.tc0) HIPCHK(ctx, hipEventRecord(s.tc0, st->copy_stream));
-    if (nbytes) HIPCHK(ctx, hipMemcpyAsync(s.d, s.h + st->reserve, nbytes, hipMemcpyHostToDevice, st->copy_stream));
+    if (nbytes) HIPCHK(ctx, hipMemcpyAsync(s.d, src, nbytes, hipMemcpyHostToDevice, st->copy_stream));
     if (s.tc1) HIPCHK(ctx, hipEventRecord(s.tc1, st->copy_stream));
     HIPCHK(ctx, hipEventRecord(s.copied, st->copy_stream));
     s.state = 2;
@@ -327,8 +392,10 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     c.n_records = n;
     c.base_offset = base_offset;
     c.data_len = s.n_new;
-    c.lead_len = s.lead;
-    c.h_data = s.h + st->reserve;
+    // (a slot whose bytes came from the caller's own memory: that memory is the chunk's host view; the beginning of the record
+    // in progress at its start lies at the END of the chunk before it, not in front of h_data — d_data has it in front)
+    c.lead_len = s.ext ? 0 : s.lead;
+    c.h_data = s.ext ? s.ext : s.h + st->reserve;
     c.h_index = (st->flags & FQH_STREAM_INDEX) ? s.h_idx : nullptr;
     c.h_rec_start = s.h_rec;
     c.d_data = s.d;
@@ -390,7 +457,16 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
             c.err_need = tail;
         } else {
             fqh_stream::Slot &nx = st->slots[(st->col + 1) % st->n_slots];
-            if (tail) memcpy(nx.h + st->reserve - tail, s.h + st->reserve + s.n_new - tail, tail);
+            if (tail) {
+                uint8_t *const dst = nx.h + st->reserve - tail;
+                if (!s.ext || tail <= s.n_new) {
+                    memcpy(dst, (s.ext ? s.ext : s.h + st->reserve) + s.n_new - tail, tail);
+                } else {  // no record ended in a slot of the caller's memory: the record in progress began in the slot's own lead area
+                    const uint64_t old = tail - s.n_new;
+                    memcpy(dst, s.h + st->reserve - old, old);
+                    memcpy(dst + old, s.ext, s.n_new);
+                }
+            }
             if (tail && want_stats && !dev_tail_done) {  // device twin of the same move (may reach into s's own lead)
                 HIPCHK(ctx, hipMemcpyAsync(nx.d - tail, s.d + s.n_new - tail, tail, hipMemcpyDeviceToDevice, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -463,6 +539,21 @@ fqh_status fqh_stream_release(fqh_stream *st) {
     s.state = 0;
     s.lead = 0;
     s.launched = false;
+    s.ext = nullptr;
+    return FQH_OK;
+}
+
+fqh_status fqh_host_register(fqh_ctx *ctx, void *h_ptr, uint64_t bytes) {
+    if (!ctx || !h_ptr || !bytes) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    return FQH_OK;
+}
+
+fqh_status fqh_host_unregister(fqh_ctx *ctx, void *h_ptr) {
+    if (!ctx || !h_ptr) return FQH_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostUnregister(h_ptr));
     return FQH_OK;
 }
 

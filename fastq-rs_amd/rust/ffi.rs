@@ -47,6 +47,9 @@ pub struct fqh_summary {
     pub max_record_len: u64, pub n_line_starts: u64,
 }
 
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct fqh_timing { pub total_ms: f32, pub index_ms: f32, pub prefix_ms: f32, pub emit_ms: f32, pub stats_ms: f32 }
+
 #[repr(C)] pub struct fqh_comm { _p: [u8; 0] }
 pub const FQH_COMM_ID_BYTES: usize = 128;
 pub const FQH_OPT_FAST_PATH: c_int = 1;
@@ -63,6 +66,18 @@ pub const FQH_NO_ERROR_KEY: u64 = u64::MAX;
 pub const FQH_SHARD_EMPTY: u32 = 0xFFFF_FFFF;  // fqh_shard_result.phase of an empty byte range
 pub const FQH_SHARD_PASS: u32 = 0xFFFF_FFFE;   // ... of a byte range without a record start
 pub const FQH_SHARD_DEFER: u32 = 0xFFFF_FFFD;  // ... of a byte range whose window does not single out a line phase
+pub const FQH_OPT_KEEP_RING: c_int = 8;         // default 0: a destroyed ring's pinned slots are freed, not kept for the next ring
+pub const FQH_ABI_VERSION: c_int = 1;
+pub const FQH_NSCALARS: usize = 8;
+// fqh_status (the five parse errors carry the crate's own messages: fqh_strerror)
+pub const FQH_E_HEADER: c_int = 1;        // src/records.rs:143-146
+pub const FQH_E_SEP: c_int = 2;           // src/records.rs:157-160
+pub const FQH_E_LEN_MISMATCH: c_int = 3;  // src/records.rs:234-237
+pub const FQH_E_TRUNCATED: c_int = 4;     // src/lib.rs:287-290
+pub const FQH_E_TOO_LONG: c_int = 5;      // src/lib.rs:279-282
+pub const FQH_E_IO: c_int = 6;
+pub const FQH_E_DEVICE: c_int = 7;
+pub const FQH_E_ARG: c_int = 8;
 pub const FQH_E_AGAIN: c_int = 10;
 
 #[link(name = "fastq_hip")]
@@ -132,6 +147,10 @@ extern "C" {
     pub fn fqh_shard_stream_run(ctx: *mut fqh_ctx, read: extern "C" fn(*mut c_void, *mut u8, u64, u64) -> c_int, user: *mut c_void,
                                 lo: u64, hi: u64, file_len: u64, slot_bytes: u64, n_slots: u32, lmax: u32,
                                 d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64, res: *mut fqh_shard_result) -> c_int;
+    pub fn fqh_shard_stream_run_mapped(ctx: *mut fqh_ctx, read: extern "C" fn(*mut c_void, *mut u8, u64, u64) -> c_int,
+                                       map: extern "C" fn(*mut c_void, u64, u64, *mut u64) -> *const u8, user: *mut c_void,
+                                       lo: u64, hi: u64, file_len: u64, slot_bytes: u64, n_slots: u32, lmax: u32,
+                                       d_qual_hist: *mut u64, d_base_hist: *mut u64, d_scalars: *mut u64, res: *mut fqh_shard_result) -> c_int;
     pub fn fqh_shard_result_words(res: *const fqh_shard_result, lo: u64, hi: u64, words: *mut u64);
     pub fn fqh_shard_failed_words(why: c_int, lo: u64, hi: u64, words: *mut u64);
     pub fn fqh_shard_stream_finish(ctx: *mut fqh_ctx, read: extern "C" fn(*mut c_void, *mut u8, u64, u64) -> c_int, user: *mut c_void,
@@ -147,6 +166,11 @@ extern "C" {
     pub fn fqh_stream_destroy(st: *mut fqh_stream);
     pub fn fqh_stream_acquire(st: *mut fqh_stream, h_dst: *mut *mut u8, cap: *mut u64) -> c_int;
     pub fn fqh_stream_submit(st: *mut fqh_stream, nbytes: u64, is_final: c_int) -> c_int;
+    // the slot's bytes straight from the host's own page-locked memory (an mmap'ed file registered once): no staging copy — the
+    // copy src/thread_reader.rs:90-97 makes
+    pub fn fqh_stream_submit_external(st: *mut fqh_stream, h_src: *const u8, nbytes: u64, is_final: c_int) -> c_int;
+    pub fn fqh_host_register(ctx: *mut fqh_ctx, h_ptr: *mut c_void, bytes: u64) -> c_int;
+    pub fn fqh_host_unregister(ctx: *mut fqh_ctx, h_ptr: *mut c_void) -> c_int;
     pub fn fqh_stream_collect(st: *mut fqh_stream, out: *mut fqh_chunk) -> c_int;
     pub fn fqh_stream_release(st: *mut fqh_stream) -> c_int;
     pub fn fqh_stream_carry(st: *mut fqh_stream, out: *mut fqh_carry) -> c_int;
@@ -164,6 +188,11 @@ extern "C" {
                               d_index: *const fqh_idx_record, n: u64, d_flags: *const u8, mask: u8, want: u8,
                               d_out: *mut u8, out_cap: u64, n_selected: *mut u64, out_bytes: *mut u64) -> c_int;
 
+    // ---- benchmarks: kernel times of the last launch, the synthetic file of SURVEY 8(d), the bare streaming read
+    pub fn fqh_last_timing(ctx: *mut fqh_ctx, out: *mut fqh_timing) -> c_int;
+    pub fn fqh_synth_fill(ctx: *mut fqh_ctx, d_out: *mut u8, byte_off: u64, len: u64, seed: u64) -> c_int;
+    pub fn fqh_read_ceiling(ctx: *mut fqh_ctx, d_buf: *const u8, len: u64, checksum: *mut u64, ms: *mut f32) -> c_int;
+
     // ---- device memory for hosts without a HIP binding of their own
     pub fn fqh_dev_alloc(ctx: *mut fqh_ctx, bytes: u64, d_ptr: *mut *mut c_void) -> c_int;
     pub fn fqh_dev_free(ctx: *mut fqh_ctx, d_ptr: *mut c_void) -> c_int;
@@ -180,6 +209,8 @@ const FQH_STREAM_INDEX: u32 = 1;
 const FQH_STREAM_STATS: u32 = 2;
 #[allow(dead_code)]
 const FQH_STREAM_TIMING: u32 = 4;
+#[allow(dead_code)]
+const FQH_STREAM_EXTERNAL: u32 = 8;
 
 /// What `Parser` holds instead of `buffer::Buffer`.
 pub struct GpuScanner<R: Read> {

@@ -36,17 +36,36 @@ class Shard:
         return [int(x) for x in w]
 
 
-def stream_shard(ctx, read_into, lo, hi, file_len, slot_bytes, n_slots=3, stats=None):
+def _map_callback(map_at):
+    def cb(user, off, want, avail):
+        try:
+            r = map_at(off, want)
+            if not r:
+                return None
+            avail[0] = int(r[1])
+            return int(r[0])
+        except Exception:
+            return None
+    return B.MAP_FN(cb)
+
+
+def stream_shard(ctx, read_into, lo, hi, file_len, slot_bytes, n_slots=3, stats=None, map_at=None):
     """Streams bytes [lo, hi) of a file of file_len bytes through a pinned ring on ctx's device (fqh_shard_stream_run).
     read_into(host_addr, file_offset, nbytes) fills pinned memory (a file read, a memcpy, nothing at all for a pre-filled
     benchmark ring).  stats = (lmax, d_qual, d_base, d_scalars) adds every record the rank delivers to the histograms (the
     rank's own arrays, zeroed).  A failure of the run (the callback raised, a device error) is kept in Shard.failed, not raised:
-    the other ranks wait in the exchange."""
+    the other ranks wait in the exchange.  map_at(file_offset, want) -> (host_addr, avail) or None: the streamed bytes are taken in
+    place from page-locked host memory instead (fqh_shard_stream_run_mapped; read_into still serves the alignment window)."""
     fn = _callback(read_into)
     sh = Shard()
     sh.res, sh.lo, sh.hi, sh.failed = B.ShardResult(), lo, hi, 0
     lmax, dq, db, ds = stats if stats else (0, None, None, None)
-    st = ctx._L.fqh_shard_stream_run(ctx._h, fn, None, lo, hi, file_len, slot_bytes, n_slots, lmax, dq, db, ds, C.byref(sh.res))
+    if map_at is not None:
+        mfn = _map_callback(map_at)
+        st = ctx._L.fqh_shard_stream_run_mapped(ctx._h, fn, mfn, None, lo, hi, file_len, slot_bytes, n_slots, lmax, dq, db, ds,
+                                                C.byref(sh.res))
+    else:
+        st = ctx._L.fqh_shard_stream_run(ctx._h, fn, None, lo, hi, file_len, slot_bytes, n_slots, lmax, dq, db, ds, C.byref(sh.res))
     if st != B.OK:
         sh.failed = st
     return sh

@@ -157,6 +157,11 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           null-stream work in either direction — for hosts that overlap other null-stream work with their
  *                           scans and order what they hand in with events.  0: the blocking stream of fqh_create.  Not while a
  *                           launch is pending.
+ *   FQH_OPT_KEEP_RING [0]   1: fqh_stream_destroy leaves the ring's pinned slots and their device twins with the context, and the
+ *                           next fqh_stream_create of the same geometry (slot_bytes, flags' slot layout) takes them instead of
+ *                           pinning memory again (3 x 255 MiB: 70 ms) — for hosts that open one ring per file, and for
+ *                           fqh_shard_stream_run, which opens one per call (the reference recycles its two 4 MiB boxes the same
+ *                           way, src/thread_reader.rs:60-75).  One geometry is kept, the biggest; 0 (or fqh_destroy) frees it.
  *   FQH_OPT_SPIN_WAIT [0]   microseconds fqh_*_finish polls the stream before it sleeps on it (hipStreamSynchronize wakes up
  *                           ~15 us after the last kernel); a host core spinning inside a library call is the caller's choice.
  * fqh_last_scan_fast: did the last finished scan (or single-pass statistics call) keep the fast path's result (1), or
@@ -168,6 +173,7 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
 #define FQH_OPT_REUSE_INDEX 5
 #define FQH_OPT_ADAPT_LINES 6
 #define FQH_OPT_OWN_STREAM_NONBLOCKING 7
+#define FQH_OPT_KEEP_RING 8
 fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
 int fqh_last_scan_fast(fqh_ctx *ctx);
 /* How the last finished statistics call (fqh_stats*, fqh_scan_stats*) counted: 1 = in the scan's own pass over the input
@@ -335,6 +341,16 @@ typedef struct {
 fqh_status fqh_shard_stream_run(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t lo, uint64_t hi, uint64_t file_len,
                                 uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax, uint64_t *d_qual_hist,
                                 uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res);
+/* The same with the range's bytes taken IN PLACE from page-locked host memory (fqh_stream_submit_external): for the bytes it
+ * streams, the run asks `map(user, file_offset, want, &avail)` for a pointer to the file's bytes [file_offset, file_offset +
+ * avail), 1 <= avail (more or less than `want` — a slot takes min(slot_bytes, avail)); NULL = these bytes cannot be had (as a
+ * failing read).  The ring then has no pinned data slots at all (FQH_STREAM_EXTERNAL).  `read` still serves the 4 MiB alignment
+ * window, newline counts of ranges that stream nothing, and the gap parse of fqh_shard_stream_finish.  map == NULL: exactly
+ * fqh_shard_stream_run. */
+typedef const uint8_t *(*fqh_map_fn)(void *user, uint64_t file_offset, uint64_t want, uint64_t *avail);
+fqh_status fqh_shard_stream_run_mapped(fqh_ctx *ctx, fqh_read_fn read, fqh_map_fn map, void *user, uint64_t lo, uint64_t hi,
+                                       uint64_t file_len, uint64_t slot_bytes, uint32_t n_slots, uint32_t lmax,
+                                       uint64_t *d_qual_hist, uint64_t *d_base_hist, uint64_t *d_scalars, fqh_shard_result *res);
 void fqh_shard_result_words(const fqh_shard_result *res, uint64_t lo, uint64_t hi, uint64_t words[FQH_SHARD_STREAM_WORDS]);
 void fqh_shard_failed_words(fqh_status why, uint64_t lo, uint64_t hi, uint64_t words[FQH_SHARD_STREAM_WORDS]);
 fqh_status fqh_shard_stream_finish(fqh_ctx *ctx, fqh_read_fn read, void *user, uint64_t file_len, const uint64_t *h_all_words,
@@ -458,6 +474,8 @@ typedef struct {
 #define FQH_STREAM_INDEX 1u /* also build + download the IdxRecord-style index per chunk */
 #define FQH_STREAM_STATS 2u /* also add every delivered record to the histograms of fqh_stream_set_stats */
 #define FQH_STREAM_TIMING 4u /* HIP events around every slot's copy and scan: fqh_stream_timing */
+#define FQH_STREAM_EXTERNAL 8u /* every slot is fed by fqh_stream_submit_external: no pinned data area per slot (only the lead
+                                  area for the record in progress), fqh_stream_acquire is FQH_E_ARG */
 /* (slot_bytes: a slot costs about 0.2 ms of device-side launches whatever it holds, and a host-to-device copy of a few MiB does
  * not fill the link — measured with the slots filled once and submitted again and again: 255 MiB slots 52 GB/s, 32 MiB 39 GB/s,
  * 4 MiB 11 GB/s; slots of 64 MiB and more keep the copy engine the bound) */
@@ -473,6 +491,18 @@ fqh_status fqh_stream_set_stats(fqh_stream *st, uint32_t lmax, uint64_t *d_qual_
  * is submitted or held by the caller. */
 fqh_status fqh_stream_acquire(fqh_stream *st, uint8_t **h_dst, uint64_t *cap);
 fqh_status fqh_stream_submit(fqh_stream *st, uint64_t nbytes, int is_final);
+/* The slot's bytes straight from the CALLER's memory, no staging copy: h_src[0..nbytes) is page-locked host memory
+ * (fqh_host_register, hipHostRegister / hipHostMalloc of the host's own, an mmap'ed file registered once) and the DMA engine
+ * reads it directly — the host moves 1 byte of DRAM traffic per input byte instead of 3 (read source + write pinned slot + DMA
+ * read), which is what bounds eight rings on one host.  The reference's thread_reader makes the same copy
+ * this removes (src/thread_reader.rs:90-97).  Takes the next free slot by itself (no fqh_stream_acquire; FQH_E_CAPACITY when the
+ * ring is full); nbytes <= slot_bytes; h_src must stay unchanged until the chunk's fqh_stream_release.  The chunk's h_data is
+ * h_src itself and its lead_len is 0: the beginning of the record in progress lies at the end of the previous chunk's memory
+ * (d_data keeps it in front, as always).  Pageable h_src works too, at the speed of the driver's own staging. */
+fqh_status fqh_stream_submit_external(fqh_stream *st, const uint8_t *h_src, uint64_t nbytes, int is_final);
+/* Page-lock / release a range of the host's own memory for fqh_stream_submit_external (hipHostRegister / hipHostUnregister). */
+fqh_status fqh_host_register(fqh_ctx *ctx, void *h_ptr, uint64_t bytes);
+fqh_status fqh_host_unregister(fqh_ctx *ctx, void *h_ptr);
 fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out);
 fqh_status fqh_stream_release(fqh_stream *st); /* done with the chunk of the last collect */
 /* FQH_STREAM_TIMING: how the ingest overlapped the scan, measured with HIP events on the two streams over the slots collected

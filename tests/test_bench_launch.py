@@ -76,7 +76,7 @@ def test_eight_ranks_hbm_resident_on_one_gpu():
     blk = (32 << 20) // 2640 * 2640
     assert ss["ranks"] == 8 and ss["bytes_per_gpu"] == max(blk, (256 << 20) // blk * blk) + 997 and len(ss["numa"]) == 8
     assert len(ss["ring_setup_seconds"]) == 8 and all(x > 0 for x in ss["ring_setup_seconds"])
-    for name in ("producer", "pinned_replay"):
+    for name in ("producer", "registered", "pinned_replay"):
         r = ss[name]
         assert r["check"]["phases_ok"] and r["check"]["histograms_ok"] and r["records"] == r["check"]["records_expected"]
         assert len(r["gbs_per_rank"]) == 8 and len(r["finish_seconds"]) == 8 and r["gbs_aggregate"] > 0
@@ -103,7 +103,7 @@ def test_eight_ranks_sharded_and_streamed_on_one_gpu():
     Then a broken separator line in rank 5's range: the first-error key comes from rank 5 and names the oracle's record."""
     j = _bench(["--gpus", "8", "--stream-gib", "4", "--slot-mib", "32"])
     assert j["mode"] == "sharded-stream" and j["n_gpus"] == 8 and len(j["numa"]) == 8
-    for name in ("producer", "pinned_replay"):
+    for name in ("producer", "registered", "pinned_replay"):
         assert j[name]["check"]["phases_ok"] and j[name]["check"]["histograms_ok"]
         assert j[name]["records"] == j[name]["check"]["records_expected"]
     blk = (32 << 20) // 2640 * 2640
@@ -129,5 +129,5 @@ def test_one_rank_through_the_library_rccl_binding():
     assert j["n_gpus"] == 1 and j["rccl"]["via"].startswith("fqh_comm") and "protocol_check" in j["rccl"]
     ss = j["sharded_stream"]
     assert ss["comm"].startswith("fqh_comm") and ss["ranks"] == 1 and ss["ratio_vs_n1"] == 1.0 and ss["n1"] == "this run"
-    for name in ("producer", "pinned_replay"):
+    for name in ("producer", "registered", "pinned_replay"):
         assert ss[name]["check"]["histograms_ok"] and ss[name]["records"] == ss[name]["check"]["records_expected"]

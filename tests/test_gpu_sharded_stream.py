@@ -31,12 +31,14 @@ def env():
     return torch, pkg, sharded
 
 
-def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, bufsize=None, fail_rank=None, fail_from=None):
+def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, bufsize=None, fail_rank=None, fail_from=None, mapped=None):
     """Every "rank" streams its byte range (fqh_shard_stream_run), the exchange is a list of words, every rank finishes
     (fqh_shard_stream_finish: true-phase check, the parse of the gap in front of it, packed first-error key); the per-rank record
     slots, the sum of the histograms and the MINIMUM of the keys are what the all-reduces deliver, fqh_shard_stream_outcome
     turns them into Parser::each's result.  Every rank has histogram arrays of its own.  fail_rank: that rank's read callback
     raises; fail_from: every rank's read callback raises for bytes at or behind that file offset.
+    mapped = the most bytes one map call hands out: the ranks stream their ranges IN PLACE from the (registered) host copy
+    (fqh_shard_stream_run_mapped), the read callback only serves windows and gaps.
     -> (status, n_records, histograms, shards)"""
     torch, pkg, sharded = env
     dev = torch.device("cuda:0")
@@ -68,7 +70,18 @@ def run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, bufsize=None, fail_ra
     shards = []
     for r in range(world):  # every "rank" has a context (a GPU) of its own
         ctx = ctx_of()
-        shards.append(sharded.stream_shard(ctx, reader(r), bounds[r], bounds[r + 1], n, slot_bytes, stats=stats_of(r)))
+        map_at = None
+        if mapped:
+            ctx.host_register(C.addressof(host), max(1, n))
+
+            def map_at(off, want, r=r):
+                if r == fail_rank or (fail_from is not None and off >= fail_from):
+                    return None
+                assert off < n
+                return C.addressof(host) + off, min(n - off, mapped, (fail_from - off) if fail_from is not None else n)
+        shards.append(sharded.stream_shard(ctx, reader(r), bounds[r], bounds[r + 1], n, slot_bytes, stats=stats_of(r), map_at=map_at))
+        if mapped:
+            ctx.host_unregister(C.addressof(host))
         ctx.close()
     # ---- the exchange (a list instead of an all_gather), then every rank's finish; sums and minimum instead of all_reduces
     words = [sh.words() for sh in shards]
@@ -169,7 +182,7 @@ def test_bench_sharded_streamed_three_ranks_one_gpu():
     assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-2000:]
     j = json.loads(lines[-1])
     assert j["mode"] == "sharded-stream" and j["n_gpus"] == 3 and j["ranks"] == 3
-    for name in ("producer", "pinned_replay"):   # (real producer threads / one pinned block replayed: both sub-runs, same function)
+    for name in ("producer", "registered", "pinned_replay"):   # (real producer threads / one pinned block replayed: both sub-runs, same function)
         assert j[name]["check"]["phases_ok"] and j[name]["check"]["histograms_ok"]
         assert j[name]["records"] == j[name]["check"]["records_expected"]
 
@@ -413,3 +426,31 @@ def test_byte_ranges_without_a_record_start_are_stitched_across(env, fqref, shap
 def test_fuzz_sharded(env, fqref, seed):
     cases, errs = fuzz_sharded(env, fqref, seed, 15.0, max_cases=100)
     assert cases >= 20 and errs >= 1, (cases, errs)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_sharded_streamed_in_place_from_registered_memory(env, fqref, seed):
+    """fqh_shard_stream_run_mapped: every rank's range is DMA'd from the caller's page-locked memory where it lies (no pinned
+    staging slots, no host copy) — same outcome and histograms as the oracle over the whole file; map calls that hand out less
+    than a slot (seeds 1, 3), a parse error (seed 2), bytes the map cannot deliver from some offset on (seed 3: the sequential
+    reader's FQH_E_IO, or a parse error in front of it)."""
+    torch, pkg, sharded = env
+    rng = np.random.default_rng(4100 + seed)
+    lmax = 150
+    data = fuzzgen.valid_file(rng, 9000, maxlen=150)
+    if seed == 2:
+        data = fuzzgen.mutate(rng, data, 1)
+    cuts = cut_points(rng, data, 3)
+    fail_from = len(data) * 2 // 3 if seed == 3 else None
+    status, n_records, hist, results = run_sharded(env, data, cuts, lmax, slot_bytes=1 << 16, mapped=(1 << 30) if seed % 2 == 0 else 30011,
+                                                   fail_from=fail_from)
+    if fail_from is None:
+        r, oq, ob, osc = fqref.stats(data, lmax)
+        assert (status, n_records) == (r.status, r.n_records)
+        if r.status == pkg.OK:
+            assert np.array_equal(hist[:8], osc)
+            assert np.array_equal(hist[8: 8 + lmax * 256].reshape(lmax, 256), oq)
+            assert np.array_equal(hist[8 + lmax * 256:].reshape(lmax, 8), ob)
+    else:
+        # the bytes from fail_from on cannot be had by anybody: the reader's error, as for a failing read callback
+        assert status == pkg.E_IO

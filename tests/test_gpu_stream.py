@@ -445,3 +445,132 @@ def test_filter_between_collects_takes_a_second_context(fqref, env):
     ctx.close()
     side.close()
     assert n_rec == r.n_records == 30000 and flagged >= 5 and refused >= 1
+
+
+def stream_external(torch, pkg, data, slot_bytes, lmax, mode, seed, n_slots=3, registered=True):
+    """As stream_stats, but the slots' bytes come straight from the caller's memory (fqh_stream_submit_external).
+    mode "external": a ring of FQH_STREAM_EXTERNAL (no pinned data slots); "mixed": an ordinary ring whose slots are fed either
+    way at random.  Pieces of random size (a few bytes to a slot), so records straddle chunks of either kind.
+    -> (status, n_records, qual, base, scalars, boundaries)"""
+    dev = torch.device("cuda:0")
+    ctx = pkg.Ctx(0)
+    flags = pkg.STREAM_STATS | (pkg.STREAM_EXTERNAL if mode == "external" else 0)
+    st = pkg.Stream(ctx, slot_bytes, n_slots, flags)
+    qh = torch.zeros(lmax * 256, dtype=torch.int64, device=dev)
+    bh = torch.zeros(lmax * 8, dtype=torch.int64, device=dev)
+    sc = torch.zeros(8, dtype=torch.int64, device=dev)
+    st.set_stats(lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+    src = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, np.uint8)
+    if registered:
+        ctx.host_register(src.ctypes.data, max(1, len(data)))
+    if mode == "external":
+        assert st.acquire_status() == pkg.E_ARG     # no pinned data area to hand out
+    pos, total = 0, len(data)
+    status, nrec, bounds = pkg.OK, 0, [0]
+    in_flight = 0
+    done_reading = False
+    rng = np.random.default_rng(seed)
+    while True:
+        while not done_reading and in_flight < n_slots:
+            n = min(slot_bytes, total - pos, int(rng.integers(1, slot_bytes + 1)) if rng.integers(0, 3) else slot_bytes)
+            last = pos + n >= total
+            if mode == "mixed" and rng.integers(0, 2):
+                a = st.acquire()
+                assert a is not None
+                C.memmove(a[0], src.ctypes.data + pos, n)
+                st.submit(n, last)
+            else:
+                assert st.submit_external(src.ctypes.data + pos, n, last)
+            pos += n
+            done_reading = last
+            in_flight += 1
+        if mode == "external" and not done_reading:
+            assert not st.submit_external(src.ctypes.data + pos, 1, False)   # the ring is full: FQH_E_CAPACITY, nothing taken
+        if in_flight == 0:
+            break
+        c = st.collect()
+        in_flight -= 1
+        nrec += c.n_records
+        rs = np.ctypeslib.as_array(C.cast(c.h_rec_start, C.POINTER(C.c_uint64)), shape=(c.n_records + 1,)).copy()
+        bounds += [int(x) for x in rs[1:]]
+        st.release()
+        if c.parse_status != pkg.OK:
+            status = c.parse_status
+            break
+        if c.is_final:
+            break
+    torch.cuda.synchronize()
+    out = (status, nrec, qh.cpu().numpy().astype(np.uint64).reshape(lmax, 256),
+           bh.cpu().numpy().astype(np.uint64).reshape(lmax, 8), sc.cpu().numpy().astype(np.uint64), bounds)
+    st.close()
+    if registered:
+        ctx.host_unregister(src.ctypes.data)
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("mode", ["external", "mixed"])
+@pytest.mark.parametrize("seed", range(4))
+def test_stream_external_source_equals_oracle(fqref, env, mode, seed):
+    """fqh_stream_submit_external: the DMA engine reads the caller's registered memory, no staging copy (the copy
+    src/thread_reader.rs:90-97 makes).  Boundaries, status and histograms are the oracle's whatever the pieces; records in
+    progress cross chunks of the caller's memory and ring slots alike (seed 3: a mutated file; seed 2: pageable memory)."""
+    torch, pkg = env
+    rng = np.random.default_rng(900 + seed)
+    data = fuzzgen.valid_file(rng, 4000, maxlen=150)
+    if seed == 3:
+        data = fuzzgen.mutate(rng, data, 1)
+    res, idx = fqref.index(data)
+    r, oq, ob, osc = fqref.stats(data, 150)
+    for slot in (4096, 1 << 16, 1 << 20):
+        status, nrec, q, b, sc, bounds = stream_external(torch, pkg, data, slot, 150, mode, seed * 7 + slot, registered=seed != 2)
+        assert (status, nrec) == (res.status, res.n_records)
+        assert bounds[: res.n_records + 1][:-1] == [int(x) for x in idx[:, 0]]
+        if res.status == pkg.OK:
+            assert np.array_equal(q, oq) and np.array_equal(b, ob) and np.array_equal(sc, osc)
+
+
+def test_keep_ring_hands_the_pinned_slots_to_the_next_ring(fqref, env):
+    """FQH_OPT_KEEP_RING: a destroyed ring's pinned slots stay with the context; the next ring of the same geometry gets the
+    same memory (nothing is pinned again), a ring of another geometry gets its own, and results do not care."""
+    torch, pkg = env
+    rng = np.random.default_rng(5)
+    data = fuzzgen.valid_file(rng, 2000, maxlen=100)
+    res = fqref.count(data)
+    ctx = pkg.Ctx(0)
+    ctx.set_keep_ring(True)
+
+    def run(slot_bytes):
+        st = pkg.Stream(ctx, slot_bytes, 3, 0)
+        addrs, pos, n_rec, done = [], 0, 0, False
+        sub = col = 0
+        while True:
+            while not done:
+                a = st.acquire()
+                if a is None:
+                    break
+                addrs.append(a[0])
+                n = min(a[1], len(data) - pos)
+                C.memmove(a[0], data[pos: pos + n], n)
+                pos += n
+                done = pos >= len(data)
+                st.submit(n, done)
+                sub += 1
+            if col == sub:
+                break
+            c = st.collect()
+            col += 1
+            n_rec += c.n_records
+            st.release()
+            assert c.parse_status == pkg.OK
+        st.close()
+        return set(addrs[:3]), n_rec
+
+    a1, n1 = run(1 << 16)
+    a2, n2 = run(1 << 16)
+    a3, n3 = run(1 << 15)       # another geometry: memory of its own (and the parked ring stays: it is the bigger one)
+    a4, n4 = run(1 << 16)
+    assert n1 == n2 == n3 == n4 == res.n_records
+    assert a1 == a2 == a4 and not (a1 & a3)
+    ctx.set_keep_ring(False)    # frees what is parked
+    ctx.close()

@@ -29,7 +29,7 @@ EXPORTS = [
     "fqh_shard_failed_words", "fqh_shard_failure_key",
     "fqh_shard_stream_finish", "fqh_shard_stream_outcome", "fqh_stream_set_origin", "fqh_synth_fill", "fqh_read_ceiling", "fqh_dev_alloc", "fqh_dev_free", "fqh_memcpy_h2d",
     "fqh_memcpy_d2h", "fqh_memset", "fqh_stream_submit_external", "fqh_host_register", "fqh_host_unregister",
-    "fqh_shard_stream_run_mapped",
+    "fqh_shard_stream_run_mapped", "fqh_stream_release_chunk",
 ]
 
 
@@ -160,6 +160,7 @@ def lib():
         L.fqh_stream_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.fqh_stream_submit.argtypes = [vp, u64, i32]
         L.fqh_stream_submit_external.argtypes = [vp, vp, u64, i32]
+        L.fqh_stream_release_chunk.argtypes = [vp, C.POINTER(Chunk)]
         L.fqh_host_register.argtypes = [vp, vp, u64]
         L.fqh_host_unregister.argtypes = [vp, vp]
         L.fqh_stream_collect.argtypes = [vp, C.POINTER(Chunk)]
@@ -547,12 +548,20 @@ class Stream:
         return True
 
     def collect(self):
+        """-> the next chunk, or None while the slot behind it is still held (FQH_E_AGAIN: release that chunk, call again)."""
         c = Chunk()
-        self.ctx._chk(self._L.fqh_stream_collect(self._h, C.byref(c)))
+        st = self._L.fqh_stream_collect(self._h, C.byref(c))
+        if st == E_AGAIN:
+            return None
+        self.ctx._chk(st)
         return c
 
     def release(self):
         self.ctx._chk(self._L.fqh_stream_release(self._h))
+
+    def release_chunk(self, chunk):
+        """Done with THIS chunk (several may be held at once, given back in any order)."""
+        self.ctx._chk(self._L.fqh_stream_release_chunk(self._h, C.byref(chunk)))
 
     def carry(self):
         c = Carry()

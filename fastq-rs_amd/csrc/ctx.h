@@ -127,6 +127,9 @@ struct fqh_ctx {
     uint32_t exact_holds = 0;   // live fqh_streams that need complete line lists for every chunk: no fast path while > 0
     uint32_t rows_hint = 0;     // the longest sequence / quality line this context knows of in the kind of input it is given (0: nothing yet):
                                 // what the single pass sizes its rows by (scan_stats_rows)
+    const uint8_t *hint_buf = nullptr;   // ... and the input that belief is about: buffer, length, file offset of the last statistics call
+    uint64_t hint_len = 0, hint_base = 0;
+    bool hint_valid = false;
     uint32_t f_rows = 0;        // ... the rows of the single pass in flight
     bool lines_long = false;    // ... and whether most of its lines are longer than the single pass takes (511 bytes): kilobase reads
     uint32_t fused_skip = 0, fused_backoff = 0;  // statistics calls left on the two-pass route after a single pass that had to be given up

@@ -662,8 +662,10 @@ static fqh_status resolve(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out) 
     ctx->last_carry_out = c;
     // (what every scan says about the reads' length: no sequence / quality line of a delivered record is longer than half the
     // longest record — the single pass's rows may come DOWN to that, whichever route found it; they go up in update_rows_hint)
-    if (s.n_records && s.max_record_len / 2 && s.max_record_len / 2 < ctx->rows_hint) ctx->rows_hint = (uint32_t)(s.max_record_len / 2);
-    if (s.n_records && s.max_record_len / 2 <= 511) ctx->lines_long = false;
+    // ... of the input the belief is about (a plain scan of ANOTHER buffer in between says nothing about it)
+    const bool hinted = ctx->hint_valid && a.buf == ctx->hint_buf && a.len == ctx->hint_len && a.base_offset == ctx->hint_base;
+    if (hinted && s.n_records && s.max_record_len / 2 && s.max_record_len / 2 < ctx->rows_hint) ctx->rows_hint = (uint32_t)(s.max_record_len / 2);
+    if (hinted && s.n_records && s.max_record_len / 2 <= 511) ctx->lines_long = false;
     if (out) *out = s;
     if (carry_out) *carry_out = c;
     // (whatever the parse status: the emit kernels clamp their writes to cap, so a caller that walks
@@ -1061,6 +1063,7 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value) {
         ctx->fused_skip = ctx->fused_backoff = 0;
         ctx->rows_hint = 0;
         ctx->lines_long = false;
+        ctx->hint_valid = false;
         return FQH_OK;
     case FQH_OPT_PLACE_TRIES:
         ctx->place_tries = value < 0 ? 0 : value > 8 ? 8 : value;
@@ -1181,6 +1184,24 @@ static fqh_status ensure_rows_hint(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t 
     // a look is some tens of microseconds, a pass over the wrong rows a whole read of the input — and only if the answer could
     // change something: rows below lmax that might be too few, or a belief in kilobase reads that keeps the pass away)
     if (!ctx->fused_enabled || !lmax || !len || !d_buf) return FQH_OK;
+    // What the context believes about the reads' length, and its back-off from the single pass, belong to ONE input: the same
+    // buffer again (a benchmark's steps, a resident file counted twice) or the next chunk of the same file (ring slots, a host's
+    // own chunking: the carry's file offset continues).  Anything else is another input — a 300 bp file behind a 100 bp one —
+    // and starts from a look of its own, with no back-off it has not earned.
+    {
+        const uint64_t base = in ? in->base_offset : 0;
+        const bool same = ctx->hint_valid && ctx->hint_buf == d_buf && ctx->hint_len == len && ctx->hint_base == base;
+        const bool next = ctx->hint_valid && base != 0 && base == ctx->hint_base + ctx->hint_len;
+        if (!same && !next) {
+            ctx->rows_hint = 0;
+            ctx->lines_long = false;
+            ctx->fused_skip = ctx->fused_backoff = 0;
+        }
+        ctx->hint_buf = d_buf;
+        ctx->hint_len = len;
+        ctx->hint_base = base;
+        ctx->hint_valid = true;
+    }
     if (ctx->rows_hint && (len < (1ull << 30) || (!ctx->lines_long && scan_stats_rows(lmax, ctx->rows_hint) >= std::min(lmax, FZ_ROWS_MAX)))) return FQH_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     unsigned long long peek[3] = {0, 0, 0};

@@ -296,6 +296,9 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     if (st->ended) return FQH_E_ARG;
     fqh_stream::Slot &s = st->slots[st->col % st->n_slots];
     if (s.state != 2) return FQH_E_ARG;
+    // (a host that holds several chunks at once — fqh_stream_release_chunk — may still hold the chunk that lives in the NEXT slot
+    // of the ring: this collect would write its partial trailing record in front of that slot's data, under the holder's eyes)
+    if (!s.is_final && st->slots[(st->col + 1) % st->n_slots].state == 3) return FQH_E_AGAIN;
     fqh_ctx *ctx = st->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool want_stats = (st->flags & FQH_STREAM_STATS) && st->lmax;
@@ -541,6 +544,20 @@ fqh_status fqh_stream_release(fqh_stream *st) {
     s.launched = false;
     s.ext = nullptr;
     return FQH_OK;
+}
+
+fqh_status fqh_stream_release_chunk(fqh_stream *st, const fqh_chunk *c) {
+    if (!st || !c || !c->d_data) return FQH_E_ARG;
+    for (auto &s : st->slots)
+        if (s.d == c->d_data) {
+            if (s.state != 3) return FQH_E_ARG;
+            s.state = 0;
+            s.lead = 0;
+            s.launched = false;
+            s.ext = nullptr;
+            return FQH_OK;
+        }
+    return FQH_E_ARG;
 }
 
 fqh_status fqh_host_register(fqh_ctx *ctx, void *h_ptr, uint64_t bytes) {

@@ -25,7 +25,10 @@
 // at end of input (std::io::Read); it may throw.
 #pragma once
 #include <dlfcn.h>
+#include <errno.h>
 #include <stdint.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -120,15 +123,19 @@ class RefRecord {
     uint32_t head_, seq_, sep_, qual_;
 };
 
-// An owned batch of records (src/lib.rs:306-353): one byte buffer + the index into it.
+// A batch of records (src/lib.rs:306-353).  The reference's RecordSet OWNS its 68 KiB buffer: RecordSetIter::next swaps a fresh
+// buffer into the parser and moves the full one into the set (src/lib.rs:384-385, src/buffer.rs:30-48) — one move, no copy
+// per record.  Here a set CO-OWNS the ring slot its records lie in (pinned host memory, `keep_`): handing a set out costs a
+// reference count, and the slot goes back to the ring when the last set that borrows it is dropped — on whatever thread that
+// happens (Send, like the reference's).  Only a set whose records lie in two slots (at most one per slot) is a copy.
 class RecordSet {
   public:
-    struct Idx { uint64_t start; uint32_t head, seq, sep, qual; };
-    size_t len() const { return idx_.size(); }
-    bool is_empty() const { return idx_.empty(); }
+    RecordSet() = default;
+    size_t len() const { return n_; }
+    bool is_empty() const { return n_ == 0; }
     RefRecord at(size_t i) const {
-        const Idx &r = idx_[i];
-        return RefRecord(buf_.data() + r.start, (size_t)r.qual + 1, r.head, r.seq, r.sep, r.qual);
+        const fqh_idx_record &r = idx_[i];
+        return RefRecord(base_ + (int64_t)(r.start - origin_), (size_t)r.qual + 1, r.head, r.seq, r.sep, r.qual);
     }
     class iterator {
       public:
@@ -141,41 +148,54 @@ class RecordSet {
         size_t i_;
     };
     iterator begin() const { return iterator(this, 0); }
-    iterator end() const { return iterator(this, idx_.size()); }
+    iterator end() const { return iterator(this, n_); }
     const RecordSet &iter() const { return *this; }
-    void push(const uint8_t *rec, const fqh_idx_record &r) {
-        Idx x{buf_.size(), r.head, r.seq, r.sep, r.qual};
-        buf_.insert(buf_.end(), rec, rec + (size_t)r.qual + 1);
-        idx_.push_back(x);
+
+    // records idx[0 .. n) whose bytes lie at base[start - origin ..]; `keep` keeps both arrays alive
+    static RecordSet view(std::shared_ptr<const void> keep, const uint8_t *base, uint64_t origin, const fqh_idx_record *idx, size_t n) {
+        RecordSet s;
+        s.keep_ = std::move(keep);
+        s.base_ = base;
+        s.origin_ = origin;
+        s.idx_ = idx;
+        s.n_ = n;
+        return s;
     }
-    // records [a, b) as a set of their own (their bytes are contiguous in buf_)
-    RecordSet slice(size_t a, size_t b) const {
-        RecordSet out;
-        if (b > a) {
-            const uint64_t lo = idx_[a].start, hi = idx_[b - 1].start + idx_[b - 1].qual + 1;
-            out.buf_.assign(buf_.begin() + (ptrdiff_t)lo, buf_.begin() + (ptrdiff_t)hi);
-            out.idx_.assign(idx_.begin() + (ptrdiff_t)a, idx_.begin() + (ptrdiff_t)b);
-            for (auto &x : out.idx_) x.start -= lo;
+    // an owned copy, for sets whose records come from more than one place
+    struct Block {
+        std::vector<uint8_t> buf;
+        std::vector<fqh_idx_record> idx;   // start = offset into buf
+        void push(const uint8_t *rec, const fqh_idx_record &r) {
+            fqh_idx_record x = r;
+            x.start = buf.size();
+            buf.insert(buf.end(), rec, rec + (size_t)r.qual + 1);
+            idx.push_back(x);
         }
-        return out;
+    };
+    static RecordSet of_block(std::shared_ptr<const Block> b) {
+        const Block *p = b.get();
+        return view(std::move(b), p->buf.data(), 0, p->idx.data(), p->idx.size());
     }
-    void clear() { buf_.clear(); idx_.clear(); }
 
   private:
-    std::vector<uint8_t> buf_;
-    std::vector<Idx> idx_;
+    std::shared_ptr<const void> keep_;
+    const uint8_t *base_ = nullptr;
+    uint64_t origin_ = 0;
+    const fqh_idx_record *idx_ = nullptr;
+    size_t n_ = 0;
 };
 
 struct Options {
     int device = 0;
     uint64_t slot_bytes = 32ull << 20;  // pinned ring slot (the GPU-side "BUFSIZE")
-    uint32_t n_slots = 3;
+    uint32_t n_slots = 3;               // (record_sets / parallel_each open at least 4: their sets hold slots while workers walk them)
     uint64_t bufsize = BUFSIZE;         // the reference's BUFSIZE, for its "too long" rule (64 = cfg(fuzzing))
     // Pipes and sockets: the reference delivers records as soon as a 68 KiB refill holds one (src/lib.rs:255-303); the
     // ring waits for a whole slot.  With low_latency a slot is submitted as it is when the reader comes back with less than
     // was asked for and nothing else is on its way to the GPU (the consumer would only wait).  Results are the same;
     // a chunk then costs a GPU round trip per read() of the pipe, so it is off for files.
     bool low_latency = false;
+    unsigned read_threads = 1;          // parse_path on a regular file: pread()s side by side per slot (FileReader)
 };
 
 namespace detail {
@@ -191,6 +211,27 @@ struct Handles {
     ~Handles() {
         if (st) fqh_stream_destroy(st);
         if (ctx) fqh_destroy(ctx);
+    }
+};
+// The chunks RecordSets have borrowed: a set co-owns a Lease; the last one to go puts the chunk on the list, and the parser's
+// thread — the only one that may talk to the ring — gives the slot back (fqh_stream_release_chunk).
+struct Returns {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<fqh_chunk> back;
+    size_t out = 0;  // leases alive
+};
+struct Lease {
+    std::shared_ptr<Handles> h;  // the ring (and its context) outlive every set, whatever happens to the parser
+    std::shared_ptr<Returns> ret;
+    fqh_chunk c;
+    ~Lease() {
+        {
+            std::lock_guard<std::mutex> lk(ret->m);
+            ret->back.push_back(c);
+            --ret->out;
+        }
+        ret->cv.notify_all();
     }
 };
 }  // namespace detail
@@ -227,25 +268,74 @@ class Parser {
     template <class F>
     void record_sets(F f) {
         open(true);
-        RecordSet pend;       // records scanned but not yet assigned to a set (the replay lags by < BUFSIZE)
-        size_t pend_off = 0;  // records of pend already handed out
+        // Records scanned but not yet assigned to a set (the replay of the reference's refills lags the scan by < BUFSIZE): the
+        // chunks they lie in, each under a lease that the sets cut from it share.
+        struct Pending {
+            std::shared_ptr<const void> lease;   // the slot's lease, or an owned copy of what is left of it (below)
+            const uint8_t *base;
+            uint64_t origin;
+            const fqh_idx_record *idx;
+            uint64_t n, done;
+            bool copied;
+        };
+        std::deque<Pending> pend;
         std::vector<uint64_t> sizes;
         for (;;) {
             Chunk c = next_chunk(&sizes);
-            for (uint64_t i = 0; i < c.n; ++i) pend.push(c.record_ptr(i), c.idx[i]);
             const int status = c.status;
             const bool fin = c.is_final;
-            release();
+            {
+                auto lease = std::make_shared<detail::Lease>();
+                lease->h = h_;
+                lease->ret = returns_;
+                lease->c = c.raw;
+                {
+                    std::lock_guard<std::mutex> lk(returns_->m);
+                    ++returns_->out;
+                }
+                held_ = false;  // (the lease gives the slot back, not release())
+                if (c.n) pend.push_back(Pending{std::move(lease), c.h_data, c.base, c.idx, c.n, 0, false});
+            }
             for (uint64_t want : sizes) {  // one RecordSet per refill of the reference's buffer
-                RecordSet out = pend.slice(pend_off, pend_off + (size_t)want);
-                pend_off += (size_t)want;
+                RecordSet out;
+                while (!pend.empty() && pend.front().done == pend.front().n) pend.pop_front();
+                if (want && !pend.empty() && pend.front().n - pend.front().done >= want) {
+                    Pending &p = pend.front();   // the common case: a view into one slot
+                    out = RecordSet::view(p.lease, p.base, p.origin, p.idx + p.done, (size_t)want);
+                    p.done += want;
+                } else if (want) {               // the set straddles two chunks: copied
+                    auto blk = std::make_shared<RecordSet::Block>();
+                    for (uint64_t left = want; left;) {
+                        while (!pend.empty() && pend.front().done == pend.front().n) pend.pop_front();
+                        if (pend.empty()) throw Error(ErrorKind::Other, "record_sets: the replay asks for records that were not scanned");
+                        Pending &p = pend.front();
+                        const uint64_t k = std::min<uint64_t>(left, p.n - p.done);
+                        for (uint64_t i = 0; i < k; ++i) {
+                            const fqh_idx_record &r = p.idx[p.done + i];
+                            blk->push(p.base + (int64_t)(r.start - p.origin), r);
+                        }
+                        p.done += k;
+                        left -= k;
+                    }
+                    out = RecordSet::of_block(std::move(blk));
+                }
+                while (!pend.empty() && pend.front().done == pend.front().n) pend.pop_front();
                 if (!f(std::move(out))) return;
             }
             sizes.clear();
-            if (pend_off == pend.len()) { pend.clear(); pend_off = 0; }
-            else if (pend_off > 4096) { pend = pend.slice(pend_off, pend.len()); pend_off = 0; }
             if (status != FQH_OK) throw Error(ErrorKind::InvalidData, detail::message(status, true));
             if (fin) return;
+            // The parser itself keeps ONE slot across the next refill (the newest: its last records wait for the replay).  What is
+            // left of older chunks — less than BUFSIZE bytes of records, and only with slots smaller than that — is copied out,
+            // so that the ring never waits for a lease its own consumer holds.
+            for (size_t j = 0; j + 1 < pend.size(); ++j) {
+                Pending &p = pend[j];
+                if (p.copied) continue;
+                auto blk = std::make_shared<RecordSet::Block>();
+                for (uint64_t i = p.done; i < p.n; ++i) blk->push(p.base + (int64_t)(p.idx[i].start - p.origin), p.idx[i]);
+                const RecordSet::Block *q = blk.get();
+                p = Pending{std::move(blk), q->buf.data(), 0, q->idx.data(), (uint64_t)q->idx.size(), 0, true};
+            }
         }
     }
 
@@ -324,6 +414,7 @@ class Parser {
         const uint8_t *h_data = nullptr;
         uint64_t base = 0;
         const fqh_idx_record *idx = nullptr;
+        fqh_chunk raw = {};
         const uint8_t *record_ptr(uint64_t i) const { return h_data + (int64_t)(idx[i].start - base); }
         RefRecord record(uint64_t i) const {
             const fqh_idx_record &r = idx[i];
@@ -332,23 +423,47 @@ class Parser {
     };
 
     void open(bool sets) {
-        if (h_.ctx) throw Error(ErrorKind::Other, "parser already consumed");
-        if (fqh_create(opt_.device, &h_.ctx) != FQH_OK)
+        if (h_->ctx) throw Error(ErrorKind::Other, "parser already consumed");
+        if (fqh_create(opt_.device, &h_->ctx) != FQH_OK)
             throw Error(ErrorKind::Other, std::string("fqh_create: ") + fqh_last_error(nullptr));
-        fqh_set_bufsize(h_.ctx, 0);  // the "too long" rule is replayed here, mode-exact (each vs record sets)
-        if (fqh_stream_create(h_.ctx, opt_.slot_bytes, opt_.n_slots, FQH_STREAM_INDEX, &h_.st) != FQH_OK)
-            throw Error(ErrorKind::Other, std::string("fqh_stream_create: ") + fqh_last_error(h_.ctx));
+        fqh_set_bufsize(h_->ctx, 0);  // the "too long" rule is replayed here, mode-exact (each vs record sets)
+        // (sets borrow slots: one being filled, one being scanned, one or two under the workers' hands)
+        if (fqh_stream_create(h_->ctx, opt_.slot_bytes, sets ? std::max<uint32_t>(opt_.n_slots, 4) : opt_.n_slots, FQH_STREAM_INDEX, &h_->st) != FQH_OK)
+            throw Error(ErrorKind::Other, std::string("fqh_stream_create: ") + fqh_last_error(h_->ctx));
         replay_.reset(opt_.bufsize, sets);
         sets_ = sets;
+    }
+
+    // Slots whose last RecordSet is gone go back to the ring (this thread is the only one that talks to it).  wait: block until
+    // at least one comes back (false: none is out — waiting would be for ever).
+    bool take_back(bool wait) {
+        std::vector<fqh_chunk> back;
+        {
+            std::unique_lock<std::mutex> lk(returns_->m);
+            if (wait) {
+                if (returns_->back.empty() && returns_->out == 0) return false;
+                returns_->cv.wait(lk, [&] { return !returns_->back.empty(); });
+            }
+            back.swap(returns_->back);
+        }
+        for (const fqh_chunk &c : back)
+            if (fqh_stream_release_chunk(h_->st, &c) != FQH_OK) throw Error(ErrorKind::Other, "fqh_stream_release_chunk");
+        return true;
     }
 
     void fill() {  // keep the ring busy: read -> pinned slot -> async H2D
         while (!eof_) {
             uint8_t *dst;
             uint64_t cap;
-            fqh_status st = fqh_stream_acquire(h_.st, &dst, &cap);
+            take_back(false);
+            fqh_status st = fqh_stream_acquire(h_->st, &dst, &cap);
+            if (st == FQH_E_CAPACITY && in_flight_ == 0 && !held_) {
+                // nothing to collect and no slot to fill: every slot is under some RecordSet's lease — wait for one
+                if (!take_back(true)) throw Error(ErrorKind::Other, "fqh_stream_acquire: the ring is full and nothing is held");
+                continue;
+            }
             if (st == FQH_E_CAPACITY) return;
-            if (st != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
+            if (st != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_->ctx));
             // Until the stream has delivered its FIRST record, a chunk ends as soon as the reads so far may hold it — four
             // newlines have come in — or after BUFSIZE bytes, is submitted at once and collected before anything else is read:
             // record 0 reaches the caller after no more input than the reference's refills take to hold it (src/lib.rs:264-275;
@@ -366,7 +481,7 @@ class Parser {
                 if (first && startup_newlines_ >= 4) break;
                 if (opt_.low_latency && got < want && in_flight_ == 0) break;  // what there is, now
             }
-            if (fqh_stream_submit(h_.st, n, eof_ ? 1 : 0) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
+            if (fqh_stream_submit(h_->st, n, eof_ ? 1 : 0) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_->ctx));
             ++in_flight_;
             if (first) return;
         }
@@ -375,7 +490,12 @@ class Parser {
     Chunk next_chunk(std::vector<uint64_t> *set_sizes = nullptr) {
         fill();
         fqh_chunk c;
-        if (fqh_stream_collect(h_.st, &c) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_.ctx));
+        for (;;) {
+            const fqh_status cs = fqh_stream_collect(h_->st, &c);
+            if (cs == FQH_OK) break;
+            // (the slot behind the one to collect is still under a RecordSet's lease: the ring cannot put the record in progress in front of it)
+            if (cs != FQH_E_AGAIN || !take_back(true)) throw Error(ErrorKind::Other, fqh_last_error(h_->ctx));
+        }
         --in_flight_;
         held_ = true;
         if (c.n_records) startup_ = false;
@@ -386,6 +506,7 @@ class Parser {
         out.h_data = c.h_data;
         out.base = c.base_offset;
         out.idx = c.h_index;
+        out.raw = c;
         // the reference's Buffer, replayed over the boundaries: "too long" and (sets) the set cuts
         uint64_t which = 0;
         bool finished = false;
@@ -402,13 +523,14 @@ class Parser {
     }
 
     void release() {
-        if (held_) fqh_stream_release(h_.st);
+        if (held_) fqh_stream_release(h_->st);
         held_ = false;
     }
 
     Reader reader_;
     Options opt_;
-    detail::Handles h_;
+    std::shared_ptr<detail::Handles> h_ = std::make_shared<detail::Handles>();
+    std::shared_ptr<detail::Returns> returns_ = std::make_shared<detail::Returns>();
     fqh::BufferReplay replay_;
     bool sets_ = false, eof_ = false, held_ = false, startup_ = true;
     uint64_t records_done_ = 0, startup_newlines_ = 0;
@@ -585,18 +707,68 @@ class MemReader {  // std::io::Cursor<&[u8]>
 
 class FileReader {  // std::fs::File / stdin
   public:
-    explicit FileReader(FILE *f, bool own) : f_(f), own_(own) {}
-    FileReader(FileReader &&o) noexcept : f_(o.f_), own_(o.own_) { o.f_ = nullptr; }
+    // read_threads > 1: reads of 8 MiB and more from a REGULAR file are split into that many pread()s side by side (one thread's
+    // copy out of the page cache runs at a fraction of what the link to the GPU takes; the reference reads on one thread
+    // because its parser is the slower part, src/lib.rs:186-192).  Pipes, stdin and small reads: one read() per call.
+    explicit FileReader(FILE *f, bool own, unsigned read_threads = 1) : f_(f), own_(own), par_(read_threads ? read_threads : 1) {
+        struct stat sb;
+        const off_t at = ftello(f);
+        if (at >= 0 && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            regular_ = true;   // (from here on the FILE's own buffer is bypassed: pread at a position kept here)
+            pos_ = (uint64_t)at;
+        }
+    }
+    FileReader(FileReader &&o) noexcept : f_(o.f_), own_(o.own_), par_(o.par_), regular_(o.regular_), pos_(o.pos_) { o.f_ = nullptr; }
     FileReader(const FileReader &) = delete;
     ~FileReader() { if (f_ && own_) fclose(f_); }
     size_t read(uint8_t *dst, size_t n) {
-        size_t k = fread(dst, 1, n, f_);
-        if (k == 0 && ferror(f_)) throw Error(ErrorKind::Other, "read error");
-        return k;
+        if (!regular_) {
+            size_t k = fread(dst, 1, n, f_);
+            if (k == 0 && ferror(f_)) throw Error(ErrorKind::Other, "read error");
+            return k;
+        }
+        const int fd = fileno(f_);
+        auto pread_all = [fd](uint8_t *d, size_t want, uint64_t at) -> ssize_t {  // up to `want` bytes, less only at the end of the file
+            size_t got = 0;
+            while (got < want) {
+                const ssize_t k = ::pread(fd, d + got, want - got, (off_t)(at + got));
+                if (k < 0) {
+                    if (errno == EINTR) continue;  // src/buffer.rs:85-97
+                    return -1;
+                }
+                if (k == 0) break;
+                got += (size_t)k;
+            }
+            return (ssize_t)got;
+        };
+        size_t got = 0;
+        if (par_ > 1 && n >= (8u << 20)) {
+            const size_t piece = ((n + par_ - 1) / par_ + 4095) & ~(size_t)4095;
+            std::vector<ssize_t> res((n + piece - 1) / piece, 0);
+            std::vector<std::thread> th;
+            for (size_t j = 1; j < res.size(); ++j)
+                th.emplace_back([&, j] { res[j] = pread_all(dst + j * piece, std::min(piece, n - j * piece), pos_ + j * piece); });
+            res[0] = pread_all(dst, std::min(piece, n), pos_);
+            for (auto &t : th) t.join();
+            for (size_t j = 0; j < res.size(); ++j) {
+                if (res[j] < 0) throw Error(ErrorKind::Other, "read error");
+                got += (size_t)res[j];
+                if ((size_t)res[j] < std::min(piece, n - j * piece)) break;  // the end of the file lies in this piece
+            }
+        } else {
+            const ssize_t k = pread_all(dst, n, pos_);
+            if (k < 0) throw Error(ErrorKind::Other, "read error");
+            got = (size_t)k;
+        }
+        pos_ += got;
+        return got;
     }
   private:
     FILE *f_;
     bool own_;
+    unsigned par_ = 1;
+    bool regular_ = false;
+    uint64_t pos_ = 0;
 };
 
 // thread_reader (src/thread_reader.rs:182-200): `queuelen` recycled buffers of `bufsize` bytes are
@@ -1096,7 +1268,7 @@ class Lz4Reader {
 // lz4 frames are an EXTENSION of the mirror: the crate's docs name lz4 (src/lib.rs:137-141), but niffler >= 2.4 has no lz4
 // format, so the reference as built today would read an .lz4 file as plain bytes and fail on its header.
 template <class F>
-auto with_plain_reader(const std::optional<std::string> &path, F use) {  // use(DynReader &) sees plain bytes
+auto with_plain_reader(const std::optional<std::string> &path, F use, unsigned read_threads = 1) {  // use(DynReader &) sees plain bytes
     FILE *f = stdin;
     bool own = false;
     if (path && *path != "-") {
@@ -1104,7 +1276,7 @@ auto with_plain_reader(const std::optional<std::string> &path, F use) {  // use(
         if (!f) throw Error(ErrorKind::Other, "cannot open " + *path);
         own = true;
     }
-    FileReader file(f, own);
+    FileReader file(f, own, read_threads);
     uint8_t first[5];
     size_t have = 0;
     while (have < 5) {
@@ -1164,7 +1336,7 @@ auto parse_path(const std::optional<std::string> &path, F func, Options opt = Op
     return with_plain_reader(path, [&](DynReader &dyn) {
         Parser<DynReader> p(std::move(dyn), opt);
         return func(p);
-    });
+    }, opt.read_threads);
 }
 
 }  // namespace fastq

@@ -207,6 +207,17 @@ static int pipe_mode(const char *file, size_t cap, uint64_t bufsize, uint64_t sl
     return 0;
 }
 
+// an order-independent digest of the records a consumer saw: sum over the records of FNV-1a(head | 0 | seq | 0 | qual | raw bytes)
+static uint64_t digest(const RefRecord &r) {
+    uint64_t h = 1469598103934665603ull;
+    auto eat = [&](fastq::bytes_view v) {
+        for (uint8_t x : v) h = (h ^ x) * 1099511628211ull;
+        h = (h ^ 0xFF) * 1099511628211ull;
+    };
+    eat(r.head()); eat(r.seq()); eat(r.qual()); eat(r.data());
+    return h;
+}
+
 static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) {
     std::ifstream f(file, std::ios::binary);
     std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -216,10 +227,12 @@ static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) 
     {   // each
         Parser<MemReader> p(MemReader(d), o);
         size_t n = 0, bases = 0;
+        uint64_t sum = 0;
         std::string err = "ok";
-        try { p.each([&](const RefRecord &r) { ++n; bases += r.seq().size(); return true; }); }
+        try { p.each([&](const RefRecord &r) { ++n; bases += r.seq().size(); sum += digest(r); return true; }); }
         catch (const Error &e) { err = e.what(); }
         printf("each %zu %zu %s\n", n, bases, err.c_str());
+        printf("eachsum %llu\n", (unsigned long long)sum);
     }
     {   // each over a pipe, chunks submitted as the reads come in (Options::low_latency): the same records
         Options ol = o;
@@ -231,21 +244,45 @@ static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) 
         catch (const Error &e) { err = e.what(); }
         printf("pipe %zu %zu %s\n", n, bases, err.c_str());
     }
-    {   // record_sets
+    {   // record_sets: the sets are kept until the parse is over (they co-own ring slots: the ring must cope), then walked
         Parser<MemReader> p(MemReader(d), o);
         std::string err = "ok", sizes;
-        try { p.record_sets([&](RecordSet &&s) { sizes += std::to_string(s.len()) + ","; return true; }); }
-        catch (const Error &e) { err = e.what(); }
+        std::vector<RecordSet> kept;
+        uint64_t sum = 0, n = 0;
+        try {
+            p.record_sets([&](RecordSet &&s) {
+                sizes += std::to_string(s.len()) + ",";
+                if (kept.size() >= 40) {  // (at most a few slots' worth held at a time: the oldest are walked and dropped)
+                    for (const RefRecord &r : kept.front()) { sum += digest(r); ++n; }
+                    kept.erase(kept.begin());
+                }
+                kept.push_back(std::move(s));
+                return true;
+            });
+        } catch (const Error &e) { err = e.what(); }
+        for (const RecordSet &s : kept)
+            for (const RefRecord &r : s) { sum += digest(r); ++n; }
         printf("sets %s %s\n", sizes.empty() ? "-" : sizes.c_str(), err.c_str());
+        printf("setsum %llu %llu\n", (unsigned long long)n, (unsigned long long)sum);
     }
     {   // parallel_each
         Parser<MemReader> p(MemReader(d), o);
         std::string err = "ok", counts;
+        uint64_t sum = 0;
         try {
-            auto res = p.parallel_each<size_t>((size_t)threads, [](auto next) { size_t c = 0; while (auto s = next()) c += s->len(); return c; });
-            for (size_t c : res) counts += std::to_string(c) + ",";
+            auto res = p.parallel_each<std::pair<size_t, uint64_t>>((size_t)threads, [](auto next) {
+                size_t c = 0;
+                uint64_t h = 0;
+                while (auto s = next()) {
+                    c += s->len();
+                    for (const RefRecord &r : *s) h += digest(r);
+                }
+                return std::make_pair(c, h);
+            });
+            for (auto &c : res) { counts += std::to_string(c.first) + ","; sum += c.second; }
         } catch (const Error &e) { err = e.what(); }
         printf("workers %s %s\n", counts.empty() ? "-" : counts.c_str(), err.c_str());
+        printf("worksum %llu\n", (unsigned long long)sum);
     }
     return 0;
 }

@@ -173,6 +173,7 @@ extern "C" {
     pub fn fqh_host_unregister(ctx: *mut fqh_ctx, h_ptr: *mut c_void) -> c_int;
     pub fn fqh_stream_collect(st: *mut fqh_stream, out: *mut fqh_chunk) -> c_int;
     pub fn fqh_stream_release(st: *mut fqh_stream) -> c_int;
+    pub fn fqh_stream_release_chunk(st: *mut fqh_stream, c: *const fqh_chunk) -> c_int;   // RecordSets that borrow a slot (src/lib.rs:306-318)
     pub fn fqh_stream_carry(st: *mut fqh_stream, out: *mut fqh_carry) -> c_int;
     pub fn fqh_stream_set_origin(st: *mut fqh_stream, file_offset: u64) -> c_int;
     pub fn fqh_stream_note_read(st: *mut fqh_stream, got: u64, asked: u64) -> c_int;   // a reader that comes back short (src/buffer.rs:74-100)

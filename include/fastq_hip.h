@@ -52,7 +52,8 @@ typedef enum {
     FQH_E_DEVICE = 7,       /* HIP runtime error; fqh_last_error() has the text */
     FQH_E_ARG = 8,
     FQH_E_CAPACITY = 9,     /* rec_start / index capacity too small; summary.n_records is exact */
-    FQH_E_AGAIN = 10        /* fqh_scan_finish after fqh_shard_rescan_launch: some shard left the fast path; take the host recipe */
+    FQH_E_AGAIN = 10        /* fqh_scan_finish after fqh_shard_rescan_launch: some shard left the fast path; take the host recipe.
+                               fqh_stream_collect: the next slot of the ring is still held (fqh_stream_release_chunk), call again */
 } fqh_status;
 
 /* Parser state at a byte boundary of the input: everything a scan of the NEXT chunk needs to be
@@ -505,6 +506,13 @@ fqh_status fqh_host_register(fqh_ctx *ctx, void *h_ptr, uint64_t bytes);
 fqh_status fqh_host_unregister(fqh_ctx *ctx, void *h_ptr);
 fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out);
 fqh_status fqh_stream_release(fqh_stream *st); /* done with the chunk of the last collect */
+/* Done with THIS chunk, whichever collect handed it out: a host may hold several chunks at once (RecordSets that borrow a
+ * slot's pinned memory while worker threads walk them, the way a RecordSet of the reference owns its buffer,
+ * src/lib.rs:306-318, 384-385) and give them back in any order.  The ring still fills its slots in order: a slot that is held
+ * stops the producer when its turn comes (fqh_stream_acquire: FQH_E_CAPACITY), and fqh_stream_collect returns FQH_E_AGAIN —
+ * nothing done — while the slot BEHIND the one it would collect is held (the partial trailing record goes in front of that
+ * slot's data).  Same thread as every other call on the stream. */
+fqh_status fqh_stream_release_chunk(fqh_stream *st, const fqh_chunk *c);
 /* FQH_STREAM_TIMING: how the ingest overlapped the scan, measured with HIP events on the two streams over the slots collected
  * so far — the point of src/thread_reader.rs:131-139 (the producer's read() runs while the consumer parses).  copy_busy_ms /
  * scan_busy_ms: time the side stream spent in host-to-device copies / the context's stream in the slots' kernels;

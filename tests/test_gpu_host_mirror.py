@@ -99,6 +99,76 @@ def test_each_sets_parallel_each_equal_oracle(gpu_ok, fqref, tmp_path, seed):
         assert w_err == want_err
         if rs.status == 0:
             assert w_counts == ",".join(str(int(x)) for x in workers) + ","
+        # what the consumers SAW: the records of each(), of the sets (views into ring slots, kept 40 sets deep) and of the workers
+        want_sum = _digest_sum(fqref, data2, idx)
+        assert int(got["eachsum"]) == want_sum
+        n_in_sets = int(sum(sizes))   # (the two modes may draw the "too long" line at different records: index without it)
+        _, idx_all = fqref.index(data2, bufsize=1 << 24)
+        assert got["setsum"].split() == [str(n_in_sets), str(_digest_sum(fqref, data2, idx_all[:n_in_sets]))], (bufsize, slot)
+        if rs.status == 0:
+            assert int(got["worksum"]) == _digest_sum(fqref, data2, idx_all[:n_in_sets])
+
+
+def _digest_sum(fqref, data, idx):
+    """host_tests.cpp: digest() summed over the records — FNV-1a over head | 0xFF | seq | 0xFF | qual | 0xFF | raw | 0xFF."""
+    M = (1 << 64) - 1
+    total = 0
+    for row in idx:
+        head, seq, qual = fqref.accessors(data, row)
+        start = int(row[0])
+        raw = data[start: start + int(row[4]) + 1]
+        h = 1469598103934665603
+        for part in (head, seq, qual, raw):
+            for x in part:
+                h = ((h ^ x) * 1099511628211) & M
+            h = ((h ^ 0xFF) * 1099511628211) & M
+        total = (total + h) & M
+    return total
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_arbitrary_bytes_through_parallel_each(gpu_ok, fqref, tmp_path, seed):
+    """The reference's second fuzz target (fuzz/fuzz_targets/fuzz_target_2.rs:10-22: arbitrary bytes through parallel_each(3, ..),
+    never a panic), differential: garbage, files with several mutations and truncated files through each, record_sets and
+    parallel_each(3) of the C++ mirror — status, counts, set sizes, per-worker counts and the records' bytes are the oracle's,
+    at BUFSIZE 64 (cfg(fuzzing), src/lib.rs:126-127) and 68 KiB."""
+    rng = np.random.default_rng(6100 + seed)
+    path = tmp_path / "fz.fq"
+    cases = []
+    for i in range(10):
+        k = i % 5
+        if k == 0:
+            cases.append(fuzzgen.garbage(rng, int(rng.integers(0, 3000))))
+        elif k == 1:
+            cases.append(fuzzgen.mutate(rng, fuzzgen.valid_file(rng, int(rng.integers(1, 400)), maxlen=30), int(rng.integers(2, 6))))
+        elif k == 2:
+            d = fuzzgen.valid_file(rng, int(rng.integers(1, 300)), maxlen=20)
+            cases.append(d[: int(rng.integers(0, len(d) + 1))])
+        elif k == 3:
+            cases.append(fuzzgen.valid_file(rng, 200, maxlen=12) + fuzzgen.garbage(rng, 100) + fuzzgen.valid_file(rng, 50, maxlen=12))
+        else:
+            cases.append(bytes(rng.integers(0, 256, int(rng.integers(1, 2000))).astype(np.uint8).tolist()))
+    for data in cases:
+        path.write_bytes(data)
+        for bufsize, slot in ((64, 4096), (fqref.BUFSIZE, 1 << 16)):
+            got = run_dump(str(path), 3, bufsize, slot)
+            r = fqref.count(data, bufsize=bufsize)
+            _, idx = fqref.index(data, bufsize=bufsize)
+            each = got["each"].split(" ", 2)
+            assert (int(each[0]), each[2]) == (r.n_records, fqref.strerror(r.status) if r.status else "ok"), (data, bufsize)
+            assert int(got["eachsum"]) == _digest_sum(fqref, data, idx)
+            rs, sizes, workers = fqref.record_sets(data, n_threads=3, bufsize=bufsize)
+            s_sizes, s_err = got["sets"].rsplit(" ", 1) if got["sets"].endswith("ok") else got["sets"].split(" ", 1)
+            want_err = "ok" if rs.status == 0 else SETS_MSG.get(rs.status, fqref.strerror(rs.status))
+            assert (s_sizes, s_err) == (",".join(str(int(x)) for x in sizes) + ",", want_err), (data, bufsize)
+            n_in_sets = int(sum(sizes))
+            _, idx_all = fqref.index(data, bufsize=1 << 24)
+            assert got["setsum"].split() == [str(n_in_sets), str(_digest_sum(fqref, data, idx_all[:n_in_sets]))]
+            w_counts, w_err = got["workers"].rsplit(" ", 1) if got["workers"].endswith("ok") else got["workers"].split(" ", 1)
+            assert w_err == want_err
+            if rs.status == 0:
+                assert w_counts == ",".join(str(int(x)) for x in workers) + ","
+                assert int(got["worksum"]) == _digest_sum(fqref, data, idx_all[:n_in_sets])
 
 
 def _sized_record(rng, total):

@@ -336,13 +336,19 @@ def test_single_pass_rows_follow_the_reads(fqref, torch, pkg, case):
         files = [(reads(30000, 150, 150), 1000, {1}), (reads(30000, 150, 150), 512, {1}), (reads(30000, 36, 150), 2000, {1})]
     elif case == "hint_too_small":
         # 800 reads of 50 bases fill the first 64 KiB; then a few of 300 (listed: route 2), then a file where most are (given up or listed)
+        # (every file is another input: the context looks at each one's first 64 KiB itself — ADVICE r5 — so the third file's rows
+        # are what ITS window shows: reads longer than that further down are listed, or — too many of them — the pass is given up)
         files = [(reads(800, 50, 50) + reads(20, 300, 300) + reads(20000, 50, 50), 1000, {2}),
-                 (reads(800, 50, 50) + reads(20000, 50, 300), 1000, {0, 1, 2}), (reads(20000, 50, 300), 1000, {1})]
+                 (reads(800, 50, 50) + reads(20000, 50, 300), 1000, {0, 1, 2}), (reads(20000, 50, 300), 1000, {0, 1, 2})]
     elif case == "second_file_longer":
         # (a pass that is given up also makes the context skip its next attempt: the third file may go either way, the fourth may not;
         # kilobase reads fail the scan's fast path and with it the single pass, whose back-off the next statistics call counts
         # down — fqh_stats calls alone used to leave it where it was, for good — so the file after the next is one pass again)
-        files = [(reads(20000, 100, 100), 700, {1}), (reads(20000, 250, 250), 700, {0, 2}), (reads(20000, 250, 250), 700, {0, 1}),
+        # what a context believes about the reads' length belongs to ONE input.  A 250 bp file behind a 100 bp one is
+        # looked at itself and takes the single pass at once (until round 5 it was sized by the 100 bp file, listed every line,
+        # gave the pass up and sent the NEXT call to two passes as well); kilobase reads take two passes without an attempt, and
+        # the 100 bp file behind them is one pass again
+        files = [(reads(20000, 100, 100), 700, {1}), (reads(20000, 250, 250), 700, {1}), (reads(20000, 250, 250), 700, {1}),
                  (reads(20000, 250, 250), 700, {1}), (reads(3000, 2000, 2500), 3000, {0}), (reads(20000, 100, 100), 700, {0, 1}),
                  (reads(20000, 100, 100), 700, {1}), (reads(20000, 100, 100), 700, {1})]
     else:
@@ -411,23 +417,34 @@ def test_single_pass_backs_off_after_a_pass_it_gave_up(fqref, torch, pkg):
     dirty, clean = reads(True), reads(False)
     gpu = Gpu(torch, pkg.Ctx(0), pkg)
     want = {id(dirty): fqref.stats(dirty, 150), id(clean): fqref.stats(clean, 150)}
+    dev = {id(dirty): gpu.upload(dirty), id(clean): gpu.upload(clean)}   # two resident inputs (two buffers)
     seen = []
-    for data in (dirty,) * 7 + (clean,) * 2:
+
+    def count(data):
         r, qh, bh, sc = want[id(data)]
-        s, gq, gb, gs = gpu.stats(data, 150)
+        d, n = dev[id(data)]
+        gq = torch.zeros(150 * 256, dtype=torch.int64, device=gpu.dev)
+        gb = torch.zeros(150 * 8, dtype=torch.int64, device=gpu.dev)
+        gs = torch.zeros(8, dtype=torch.int64, device=gpu.dev)
+        s, _ = gpu.ctx.stats(d.data_ptr(), n, 150, gq.data_ptr(), gb.data_ptr(), gs.data_ptr())
         assert (s.parse_status, s.n_records) == (r.status, r.n_records) == (0, nrec)
-        assert np.array_equal(gs, sc) and np.array_equal(gq, qh) and np.array_equal(gb, bh)
+        assert np.array_equal(gs.cpu().numpy().astype(np.uint64), sc)
+        assert np.array_equal(gq.cpu().numpy().astype(np.uint64).reshape(150, 256), qh)
+        assert np.array_equal(gb.cpu().numpy().astype(np.uint64).reshape(150, 8), bh)
         seen.append((gpu.ctx.last_stats_route(), bool(gpu.ctx.last_scan_fast())))
-    # calls 1, 3 and 6 try and give up (back-off 1, 2, 4), calls 2, 4, 5 and 7 are skipped; call 8 would be skipped as well
-    # (three more to go) — the clean file is counted over the exact index once or twice more — ...
+
+    for _ in range(7):
+        count(dirty)
+    # calls 1, 3 and 6 try and give up (back-off 1, 2, 4), calls 2, 4, 5 and 7 are skipped; call 8 on the SAME input would be
+    # skipped as well (three more to go) ...
     assert seen[:7] == [(0, True), (0, False), (0, True), (0, False), (0, False), (0, True), (0, False)], seen
-    assert all(rt == 0 and not fast for rt, fast in seen[7:]), seen
-    # ... until the count-down is over: then its pass commits and the back-off is forgotten
-    for _ in range(2):
-        gpu.stats(clean, 150)
-    r, qh, bh, sc = want[id(clean)]
-    s, gq, gb, gs = gpu.stats(clean, 150)
-    assert gpu.ctx.last_stats_route() == 1 and np.array_equal(gq, qh) and np.array_equal(gs, sc)
+    # ... but the back-off belongs to the input that earned it: another input — the clean file, another buffer — is
+    # looked at itself and takes the single pass at once; and back on the dirty one the count-down starts over
+    count(clean)
+    count(clean)
+    assert seen[7:] == [(1, True), (1, True)], seen
+    count(dirty)
+    assert seen[9] == (0, True), seen
     gpu.ctx.close()
 
 

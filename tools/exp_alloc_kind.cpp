@@ -160,8 +160,25 @@ int main(int argc, char **argv) {
                     fqh_last_timing(ctx, &t);
                     if (pmc || k >= 2) best = std::min(best, t.index_ms);
                 }
-                printf("%-8s round %d instance %d @ %p: bare read %.3f ms, index kernel %.3f ms (fast path %d)\n", m.c_str(), rnd, i,
-                       as[i].p, rd, best, fqh_last_scan_fast(ctx));
+                // the same kernel WITHOUT its line stores, on the first 4 GiB of this input (FQH_OPT_PLACE_TRIES's yardstick: a fresh
+                // context's first scan times it, fqh_placement reports it): is an input of the slow kind slow without the stores too?
+                float nostore = 0, cand0 = 0;
+                if (!pmc && rnd == 0) {
+                    fqh_ctx *c2 = nullptr;
+                    if (fqh_create(0, &c2) == FQH_OK) {
+                        fqh_set_option(c2, FQH_OPT_ADAPT_LINES, 0);
+                        fqh_set_option(c2, FQH_OPT_PLACE_TRIES, 2);
+                        fqh_summary s;
+                        if (fqh_scan(c2, b, n, 1, nullptr, rs, cap, &s, nullptr) == FQH_OK) {
+                            int nc = 0;
+                            float ms[10];
+                            if (fqh_placement(c2, &nc, ms) == FQH_OK && nc) { nostore = ms[9]; cand0 = ms[0]; }
+                        }
+                        fqh_destroy(c2);
+                    }
+                }
+                printf("%-8s round %d instance %d @ %p: bare read %.3f ms, index kernel %.3f ms (fast path %d); first 4 GiB without stores %.3f, with %.3f\n",
+                       m.c_str(), rnd, i, as[i].p, rd, best, fqh_last_scan_fast(ctx), nostore, cand0);
                 fflush(stdout);
             }
         for (auto &a : as) release(a);

@@ -658,8 +658,8 @@ def host_api_leg(path, nbytes, exp_hist):
     C ABI; examples/fastq-count.rs:14-23 and, with --threads, examples/fastq-count-thread.rs — on the configs[0] file the
     cpu_baseline leg wrote to /dev/shm, next to the oracle's fastq-count on one core.  Every variant parses the file three times
     in one process (--repeat 3): pass 0 pays the HIP runtime's start-up, the best later pass is the path.  Variants: Parser::each
-    / parallel_each(8) with the reference's one reader thread, the same with 8 pread()s side by side per ring slot, and the
-    histogram consumer (FQH_STREAM_STATS: the loop over Record::seq()/qual() on the GPU while the file streams)."""
+    / parallel_each(8) with the reference's one reader thread, the same with 8 pread()s side by side per ring slot
+    (Options::read_threads) and with a filler thread of the parser's own on top (Options::read_ahead), and the histogram consumer (FQH_STREAM_STATS: the loop over Record::seq()/qual() on the GPU while the file streams)."""
     import re
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fastq-rs_amd", "host", "bin", "fastq_count")
@@ -667,9 +667,10 @@ def host_api_leg(path, nbytes, exp_hist):
         return {"error": "%s is not built (make -C fastq-rs_amd/host)" % exe}
     n_rec = nbytes // RECLEN
     checksum = int((exp_hist * (1 + __import__("numpy").arange(exp_hist.size, dtype="uint64"))).sum(dtype="uint64"))
-    variants = [("each", []), ("each_read8", ["--read-threads", "8"]), ("parallel_each8", ["--threads", "8"]),
-                ("parallel_each8_read8", ["--threads", "8", "--read-threads", "8"]),
-                ("stats150_read8", ["--stats", "150", "--read-threads", "8"]), ("stats150", ["--stats", "150"])]
+    variants = [("each", []), ("each_read8", ["--read-threads", "8"]), ("each_read8_ahead", ["--read-threads", "8", "--read-ahead"]),
+                ("parallel_each8", ["--threads", "8"]), ("parallel_each8_read8", ["--threads", "8", "--read-threads", "8"]),
+                ("parallel_each8_read8_ahead", ["--threads", "8", "--read-threads", "8", "--read-ahead"]),
+                ("stats150", ["--stats", "150"]), ("stats150_read8", ["--stats", "150", "--read-threads", "8"])]
     res = {"file": "configs[0]: %.2f GiB of the synthetic file on /dev/shm" % (nbytes / 2**30), "binary": "fastq-rs_amd/host/bin/fastq_count",
            "note": "GB/s of the best warm pass of three in one process (pass 0 = cold: HIP start-up, context, ring); one process per "
                    "variant; ring 3-4 x 32 MiB; the oracle's one-core rate is cpu_baseline.value"}

@@ -1,4 +1,4 @@
-// ctx.h — the library-internal definition of fqh_ctx, shared by fastq_hip.hip and stream.hip.
+// ctx.h — the library-internal definition of fqh_ctx, shared by context.hip, scan_dispatch.hip, stats_dispatch.hip and stream.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         // one whole 128-byte line, non-temporal: written once, read once by k_emit_fast.  On the boxes where
         // a plain store costs the kernel 0.45 ms, this one costs 0.2.  (No plain/nt switch here: the
         // optimizer merges two stores to one address and drops the hint.)
-        // (fast_rs == nullptr: the yardstick launch of place_fast_rs, fastq_hip.hip — the same scan without its stores)
+        // (fast_rs == nullptr: the yardstick launch of place_fast_rs, scan_dispatch.hip — the same scan without its stores)
         if (fast_rs) __builtin_nontemporal_store((uint16_t)rv, fast_rs + tile * FR_STRIDE + lane);
         (void)run;
     };
@@ -1348,7 +1348,7 @@ __global__ void k_shard_words(const DevOut *__restrict__ out, const DevOut *__re
     // (the finalize kernel has reset the accumulators behind the copy it published)
     w[7] = (mirror->spec_fail || mirror->overflow) ? 1ull : 0ull;
 }
-// fqh_carry_combine over the rows of the ranks in front of `rank` (src of the host version: fastq_hip.hip)
+// fqh_carry_combine over the rows of the ranks in front of `rank` (src of the host version: scan_dispatch.hip)
 __global__ void k_carry_fold(const unsigned long long *__restrict__ all, int n_ranks, int rank, DevCarry *__restrict__ dc,
                              DevCarry *__restrict__ hc, DevOut *__restrict__ out) {
     __shared__ DevCarry cs[2];  // (in LDS, not in scratch: see FQH_ARGS_WITH_CARRY)

@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -196,6 +197,11 @@ struct Options {
     // a chunk then costs a GPU round trip per read() of the pipe, so it is off for files.
     bool low_latency = false;
     unsigned read_threads = 1;          // parse_path on a regular file: pread()s side by side per slot (FileReader)
+    // A thread of the parser's own keeps the ring's slots filled while the calling thread collects, replays and hands out
+    // (thread_reader's producer, src/thread_reader.rs:131-139, one level down: its destination IS the pinned slot, no copy
+    // in between).  For readers that fill every read (files): the reads are not noted for the replay of the "too long" band
+    // (csrc/replay.h), and record 0 is delivered after its slot, not after its first 68 KiB.  Off: one thread does it all.
+    bool read_ahead = false;
 };
 
 namespace detail {
@@ -243,6 +249,9 @@ template <class Reader>
 class Parser {
   public:
     explicit Parser(Reader reader, Options opt = Options()) : reader_(std::move(reader)), opt_(opt) {}
+    Parser(const Parser &) = delete;
+    Parser &operator=(const Parser &) = delete;
+    ~Parser() { stop_filler(); }
 
     // Parser::each (src/lib.rs:221-239): true if the input was exhausted, false if f stopped it.
     template <class F>
@@ -345,11 +354,18 @@ class Parser {
     // error the results are discarded and the error is thrown after all workers have finished.
     template <class O, class F>
     std::vector<O> parallel_each(size_t n_threads, F func) {
+        // sync_channel(10) per worker (lib.rs:521-532).  A set is 68 KiB of records — microseconds of work for a light closure — so
+        // the hand-off itself is what a count-only run pays for: a consumer that finds its queue empty polls it for a few dozen
+        // microseconds before it sleeps (the producer's notify is then no system call: nobody waits), and a notify goes out
+        // only when somebody does wait.
         struct Queue {
             std::mutex m;
             std::condition_variable cv_put, cv_get;
             std::deque<RecordSet> q;
+            std::atomic<size_t> avail{0};
+            std::atomic<bool> done{false};
             bool closed = false, consumer_gone = false;
+            int get_waiting = 0, put_waiting = 0;
         };
         std::vector<std::unique_ptr<Queue>> qs;
         for (size_t i = 0; i < n_threads; ++i) qs.emplace_back(new Queue());
@@ -360,18 +376,28 @@ class Parser {
             threads.emplace_back([&, i] {
                 Queue &q = *qs[i];
                 auto next = [&q]() -> std::optional<RecordSet> {
+                    if (!q.avail.load(std::memory_order_acquire) && !q.done.load(std::memory_order_acquire)) {
+                        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(50);
+                        while (!q.avail.load(std::memory_order_acquire) && !q.done.load(std::memory_order_acquire) &&
+                               std::chrono::steady_clock::now() < until) {
+                        }
+                    }
                     std::unique_lock<std::mutex> lk(q.m);
+                    ++q.get_waiting;
                     q.cv_get.wait(lk, [&] { return !q.q.empty() || q.closed; });
+                    --q.get_waiting;
                     if (q.q.empty()) return std::nullopt;
                     RecordSet s = std::move(q.q.front());
                     q.q.pop_front();
-                    q.cv_put.notify_one();
+                    q.avail.fetch_sub(1, std::memory_order_release);
+                    if (q.put_waiting) q.cv_put.notify_one();
                     return s;
                 };
                 try { results[i] = func(next); } catch (...) { panics[i] = std::current_exception(); }
                 std::lock_guard<std::mutex> lk(q.m);
                 q.consumer_gone = true;
                 q.q.clear();
+                q.avail.store(0, std::memory_order_release);
                 q.cv_put.notify_all();
             });
         }
@@ -383,10 +409,13 @@ class Parser {
                     Queue &q = *qs[turn % n_threads];  // senders.iter().cycle(), lib.rs:535
                     ++turn;
                     std::unique_lock<std::mutex> lk(q.m);
+                    ++q.put_waiting;
                     q.cv_put.wait(lk, [&] { return q.q.size() < 10 || q.consumer_gone; });  // sync_channel(10)
+                    --q.put_waiting;
                     if (q.consumer_gone) return false;  // send error: stop parsing (lib.rs:538-543)
                     q.q.push_back(std::move(s));
-                    q.cv_get.notify_one();
+                    q.avail.fetch_add(1, std::memory_order_release);
+                    if (q.get_waiting) q.cv_get.notify_one();
                     return true;
                 });
             }
@@ -396,6 +425,7 @@ class Parser {
         for (auto &q : qs) {  // drop(senders)
             std::lock_guard<std::mutex> lk(q->m);
             q->closed = true;
+            q->done.store(true, std::memory_order_release);
             q->cv_get.notify_all();
         }
         for (auto &t : threads) t.join();
@@ -432,6 +462,77 @@ class Parser {
             throw Error(ErrorKind::Other, std::string("fqh_stream_create: ") + fqh_last_error(h_->ctx));
         replay_.reset(opt_.bufsize, sets);
         sets_ = sets;
+        if (opt_.read_ahead) {
+            ahead_ = true;
+            startup_ = false;
+            filler_ = std::thread([this] { fill_ahead(); });
+        }
+    }
+
+    // ---- Options::read_ahead: the filler thread and the calling thread share the ring under ring_mu_ (the ring itself is
+    // single-threaded); the read() into an acquired slot runs outside the lock
+    struct RingLock {
+        std::unique_lock<std::mutex> lk;
+        explicit RingLock(Parser *p) : lk(p->ring_mu_, std::defer_lock) { if (p->ahead_) lk.lock(); }
+    };
+    void fill_ahead() {
+        try {
+            bool eof = false;
+            while (!eof) {
+                uint8_t *dst = nullptr;
+                uint64_t cap = 0;
+                {
+                    std::unique_lock<std::mutex> lk(ring_mu_);
+                    for (;;) {
+                        if (filler_stop_) return;
+                        const fqh_status st = fqh_stream_acquire(h_->st, &dst, &cap);
+                        if (st == FQH_OK) break;
+                        if (st != FQH_E_CAPACITY) throw Error(ErrorKind::Other, fqh_last_error(h_->ctx));
+                        ring_cv_.wait(lk);   // (a release, or a lease that came back, frees a slot)
+                    }
+                }
+                uint64_t n = 0;
+                while (n < cap) {
+                    const size_t got = reader_.read(dst + n, (size_t)(cap - n));
+                    if (got == 0) { eof = true; break; }
+                    n += got;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(ring_mu_);
+                    if (fqh_stream_submit(h_->st, n, eof ? 1 : 0) != FQH_OK) throw Error(ErrorKind::Other, fqh_last_error(h_->ctx));
+                    ++in_flight_;
+                }
+                { std::lock_guard<std::mutex> lk(returns_->m); }
+                returns_->cv.notify_all();   // (the calling thread waits there for chunks and for leases alike)
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(ring_mu_);
+            filler_err_ = std::current_exception();
+        }
+        { std::lock_guard<std::mutex> lk(returns_->m); }
+        returns_->cv.notify_all();
+    }
+    void stop_filler() {
+        if (!filler_.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(ring_mu_);
+            filler_stop_ = true;
+        }
+        ring_cv_.notify_all();
+        filler_.join();
+    }
+    // the calling thread, until the filler has submitted something to collect
+    void wait_ahead() {
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(ring_mu_);
+                if (in_flight_ > 0) return;
+                if (filler_err_) std::rethrow_exception(filler_err_);
+            }
+            take_back(false);   // (slots whose sets are gone: the filler may be waiting for one)
+            std::unique_lock<std::mutex> lk(returns_->m);
+            if (returns_->back.empty()) returns_->cv.wait_for(lk, std::chrono::microseconds(200));
+        }
     }
 
     // Slots whose last RecordSet is gone go back to the ring (this thread is the only one that talks to it).  wait: block until
@@ -446,8 +547,12 @@ class Parser {
             }
             back.swap(returns_->back);
         }
-        for (const fqh_chunk &c : back)
-            if (fqh_stream_release_chunk(h_->st, &c) != FQH_OK) throw Error(ErrorKind::Other, "fqh_stream_release_chunk");
+        {
+            RingLock rl(this);
+            for (const fqh_chunk &c : back)
+                if (fqh_stream_release_chunk(h_->st, &c) != FQH_OK) throw Error(ErrorKind::Other, "fqh_stream_release_chunk");
+        }
+        if (ahead_ && !back.empty()) ring_cv_.notify_all();
         return true;
     }
 
@@ -488,15 +593,19 @@ class Parser {
     }
 
     Chunk next_chunk(std::vector<uint64_t> *set_sizes = nullptr) {
-        fill();
+        if (ahead_) wait_ahead(); else fill();
         fqh_chunk c;
         for (;;) {
-            const fqh_status cs = fqh_stream_collect(h_->st, &c);
+            fqh_status cs;
+            {
+                RingLock rl(this);
+                cs = fqh_stream_collect(h_->st, &c);
+                if (cs == FQH_OK) --in_flight_;
+            }
             if (cs == FQH_OK) break;
             // (the slot behind the one to collect is still under a RecordSet's lease: the ring cannot put the record in progress in front of it)
             if (cs != FQH_E_AGAIN || !take_back(true)) throw Error(ErrorKind::Other, fqh_last_error(h_->ctx));
         }
-        --in_flight_;
         held_ = true;
         if (c.n_records) startup_ = false;
         Chunk out;
@@ -523,7 +632,13 @@ class Parser {
     }
 
     void release() {
-        if (held_) fqh_stream_release(h_->st);
+        if (held_) {
+            {
+                RingLock rl(this);
+                fqh_stream_release(h_->st);
+            }
+            if (ahead_) ring_cv_.notify_all();
+        }
         held_ = false;
     }
 
@@ -533,6 +648,12 @@ class Parser {
     std::shared_ptr<detail::Returns> returns_ = std::make_shared<detail::Returns>();
     fqh::BufferReplay replay_;
     bool sets_ = false, eof_ = false, held_ = false, startup_ = true;
+    // Options::read_ahead
+    bool ahead_ = false, filler_stop_ = false;
+    std::thread filler_;
+    std::mutex ring_mu_;
+    std::condition_variable ring_cv_;
+    std::exception_ptr filler_err_;
     uint64_t records_done_ = 0, startup_newlines_ = 0;
     int in_flight_ = 0;
 };

@@ -4,6 +4,7 @@
 // `.expect("Invalid fastq file")` with the reference's error message.
 //   --threads N       parallel_each with N workers (examples/fastq-count-thread.rs)
 //   --read-threads N  a regular file is read with N pread()s side by side per ring slot (default 1: the reference's one reader)
+//   --read-ahead      a thread of the parser's own fills the ring while the calling thread parses (for files)
 //   --slot-mib M      size of a ring slot (default 32)
 //   --repeat K        parse the file K times in this process and print every pass's seconds to stderr ("pass i: S s"): the
 //                     first pass pays for the HIP runtime's start-up (a few hundred ms), the later ones are the path itself
@@ -89,6 +90,7 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--read-threads") && i + 1 < argc) opt.read_threads = (unsigned)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--read-ahead")) opt.read_ahead = true;
         else if (!strcmp(argv[i], "--slot-mib") && i + 1 < argc) opt.slot_bytes = (uint64_t)atoi(argv[++i]) << 20;
         else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::max(1, atoi(argv[++i]));
         else if (!strcmp(argv[i], "--stats") && i + 1 < argc) stats_lmax = (uint32_t)atoi(argv[++i]);

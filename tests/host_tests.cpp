@@ -224,16 +224,61 @@ static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) 
     Options o;
     o.bufsize = bufsize;
     o.slot_bytes = slot;
-    {   // each
-        Parser<MemReader> p(MemReader(d), o);
-        size_t n = 0, bases = 0;
-        uint64_t sum = 0;
-        std::string err = "ok";
-        try { p.each([&](const RefRecord &r) { ++n; bases += r.seq().size(); sum += digest(r); return true; }); }
-        catch (const Error &e) { err = e.what(); }
-        printf("each %zu %zu %s\n", n, bases, err.c_str());
-        printf("eachsum %llu\n", (unsigned long long)sum);
-    }
+    // each, record_sets and parallel_each; pre = "" for the parser that does everything on the calling thread, "ahead_" for the one
+    // with a filler thread of its own (Options::read_ahead: a MemReader fills every read, as a file does)
+    auto three = [&](Options oo, const char *pre) {
+        {   // each
+            Parser<MemReader> p(MemReader(d), oo);
+            size_t n = 0, bases = 0;
+            uint64_t sum = 0;
+            std::string err = "ok";
+            try { p.each([&](const RefRecord &r) { ++n; bases += r.seq().size(); sum += digest(r); return true; }); }
+            catch (const Error &e) { err = e.what(); }
+            printf("%seach %zu %zu %s\n", pre, n, bases, err.c_str());
+            printf("%seachsum %llu\n", pre, (unsigned long long)sum);
+        }
+        {   // record_sets: the sets are kept until the parse is over (they co-own ring slots: the ring must cope), then walked
+            Parser<MemReader> p(MemReader(d), oo);
+            std::string err = "ok", sizes;
+            std::vector<RecordSet> kept;
+            uint64_t sum = 0, n = 0;
+            try {
+                p.record_sets([&](RecordSet &&s) {
+                    sizes += std::to_string(s.len()) + ",";
+                    if (kept.size() >= 40) {  // (at most a few slots' worth held at a time: the oldest are walked and dropped)
+                        for (const RefRecord &r : kept.front()) { sum += digest(r); ++n; }
+                        kept.erase(kept.begin());
+                    }
+                    kept.push_back(std::move(s));
+                    return true;
+                });
+            } catch (const Error &e) { err = e.what(); }
+            for (const RecordSet &s : kept)
+                for (const RefRecord &r : s) { sum += digest(r); ++n; }
+            printf("%ssets %s %s\n", pre, sizes.empty() ? "-" : sizes.c_str(), err.c_str());
+            printf("%ssetsum %llu %llu\n", pre, (unsigned long long)n, (unsigned long long)sum);
+        }
+        {   // parallel_each
+            Parser<MemReader> p(MemReader(d), oo);
+            std::string err = "ok", counts;
+            uint64_t sum = 0;
+            try {
+                auto res = p.parallel_each<std::pair<size_t, uint64_t>>((size_t)threads, [](auto next) {
+                    size_t c = 0;
+                    uint64_t h = 0;
+                    while (auto s = next()) {
+                        c += s->len();
+                        for (const RefRecord &r : *s) h += digest(r);
+                    }
+                    return std::make_pair(c, h);
+                });
+                for (auto &c : res) { counts += std::to_string(c.first) + ","; sum += c.second; }
+            } catch (const Error &e) { err = e.what(); }
+            printf("%sworkers %s %s\n", pre, counts.empty() ? "-" : counts.c_str(), err.c_str());
+            printf("%sworksum %llu\n", pre, (unsigned long long)sum);
+        }
+    };
+    three(o, "");
     {   // each over a pipe, chunks submitted as the reads come in (Options::low_latency): the same records
         Options ol = o;
         ol.low_latency = true;
@@ -244,46 +289,9 @@ static int dump(const char *file, int threads, uint64_t bufsize, uint64_t slot) 
         catch (const Error &e) { err = e.what(); }
         printf("pipe %zu %zu %s\n", n, bases, err.c_str());
     }
-    {   // record_sets: the sets are kept until the parse is over (they co-own ring slots: the ring must cope), then walked
-        Parser<MemReader> p(MemReader(d), o);
-        std::string err = "ok", sizes;
-        std::vector<RecordSet> kept;
-        uint64_t sum = 0, n = 0;
-        try {
-            p.record_sets([&](RecordSet &&s) {
-                sizes += std::to_string(s.len()) + ",";
-                if (kept.size() >= 40) {  // (at most a few slots' worth held at a time: the oldest are walked and dropped)
-                    for (const RefRecord &r : kept.front()) { sum += digest(r); ++n; }
-                    kept.erase(kept.begin());
-                }
-                kept.push_back(std::move(s));
-                return true;
-            });
-        } catch (const Error &e) { err = e.what(); }
-        for (const RecordSet &s : kept)
-            for (const RefRecord &r : s) { sum += digest(r); ++n; }
-        printf("sets %s %s\n", sizes.empty() ? "-" : sizes.c_str(), err.c_str());
-        printf("setsum %llu %llu\n", (unsigned long long)n, (unsigned long long)sum);
-    }
-    {   // parallel_each
-        Parser<MemReader> p(MemReader(d), o);
-        std::string err = "ok", counts;
-        uint64_t sum = 0;
-        try {
-            auto res = p.parallel_each<std::pair<size_t, uint64_t>>((size_t)threads, [](auto next) {
-                size_t c = 0;
-                uint64_t h = 0;
-                while (auto s = next()) {
-                    c += s->len();
-                    for (const RefRecord &r : *s) h += digest(r);
-                }
-                return std::make_pair(c, h);
-            });
-            for (auto &c : res) { counts += std::to_string(c.first) + ","; sum += c.second; }
-        } catch (const Error &e) { err = e.what(); }
-        printf("workers %s %s\n", counts.empty() ? "-" : counts.c_str(), err.c_str());
-        printf("worksum %llu\n", (unsigned long long)sum);
-    }
+    Options oa = o;
+    oa.read_ahead = true;
+    three(oa, "ahead_");
     return 0;
 }
 

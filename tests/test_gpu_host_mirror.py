@@ -53,6 +53,10 @@ def run_dump(path, threads, bufsize, slot):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in out.stdout.strip().split("\n")}
+    # Options::read_ahead (a filler thread of the parser's own; the reader fills every read): everything the calling thread's
+    # parser delivers, to the byte
+    for k in ("each", "eachsum", "sets", "setsum", "workers", "worksum"):
+        assert lines["ahead_" + k] == lines[k], (k, lines[k], lines["ahead_" + k], bufsize, slot)
     return lines
 
 

@@ -415,18 +415,27 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
     const bool bad_here = sum.parse_status != FQH_OK;
     const uint64_t need = bad_here ? need0 : fqh::TooLong::NO_BAD;
     bool too_long;
+    bool late = false;       // the replay's verdict names a record of an EARLIER chunk (see fqh_stream_note_read in the header)
+    uint64_t late_k = 0, late_off = 0;
     if (st->replay_on) {   // (a reader that comes back short: the reference's reads are replayed, fqh_stream_note_read)
         uint64_t k = 0;
         too_long = st->replay.step(s.h_rec, st->records_done, n, known_end, s.is_final || bad_here, need, &k);
+        if (too_long && k < st->records_done) {
+            // the replay stops where the reference's reader would block, up to BUFSIZE bytes behind the chunk it was given: a
+            // record of the band that ends that close to a chunk's end is judged with the NEXT chunk, after it was handed out
+            late = true;
+            late_k = k;
+            late_off = st->replay.pend.empty() ? 0 : st->replay.pend[0];   // (step() has dropped the boundaries in front of k)
+        }
         which = k >= st->records_done ? std::min<uint64_t>(k - st->records_done, n) : 0;
     } else {
         too_long = fqh::TooLong::first(ctx->bufsize, s.h_rec, n, known_end - s.h_rec[n], need, &which);
     }
     if (too_long) {
         c.parse_status = FQH_E_TOO_LONG;
-        c.err_record = st->records_done + which;
+        c.err_record = late ? late_k : st->records_done + which;
         c.n_records = which;
-        c.err_offset = s.h_rec[which];
+        c.err_offset = late ? late_off : s.h_rec[which];
     }
     // histograms of the records this chunk delivers (the one in progress at its start included: its
     // beginning sits in front of the slot's device data)
@@ -519,6 +528,10 @@ fqh_status fqh_stream_set_origin(fqh_stream *st, uint64_t file_offset) {
 
 fqh_status fqh_stream_note_read(fqh_stream *st, uint64_t got, uint64_t asked) {
     if (!st || got > asked) return FQH_E_ARG;
+    // (the replay asks for up to BUFSIZE bytes at a time: a host whose first ask of a slot could be less cannot say what the
+    // reference's reader would have got; and the BUFSIZE the replay was started with must still be the context's)
+    if (st->ctx->bufsize && st->slot_bytes < st->ctx->bufsize) return FQH_E_ARG;
+    if (st->replay_on && st->replay.B != st->ctx->bufsize) return FQH_E_ARG;
     if (!st->replay_on) {
         // the replay walks the reference's Buffer from the first byte of the file: the notes must begin with the first slot
         if (st->sub || st->col || st->carry.base_offset) return FQH_E_ARG;

@@ -573,8 +573,14 @@ class Parser {
             // newlines have come in — or after BUFSIZE bytes, is submitted at once and collected before anything else is read:
             // record 0 reaches the caller after no more input than the reference's refills take to hold it (src/lib.rs:264-275;
             // a producer on a pipe may be waiting for an answer to it).  Every later chunk fills its slot.
+            // (a chunk without a record — a first record longer than BUFSIZE with bufsize 0, blank lines in front — must not
+            // leave every later chunk of the start-up one read() long: the count starts over per chunk and the chunks double)
             const bool first = startup_;
-            const uint64_t target = first ? std::min<uint64_t>(cap, opt_.bufsize ? opt_.bufsize : BUFSIZE) : cap;
+            if (first) {
+                startup_newlines_ = 0;
+                startup_target_ = startup_target_ ? std::min<uint64_t>(cap, 2 * startup_target_) : std::min<uint64_t>(cap, opt_.bufsize ? opt_.bufsize : BUFSIZE);
+            }
+            const uint64_t target = first ? startup_target_ : cap;
             uint64_t n = 0;
             while (n < target) {
                 const size_t want = (size_t)(target - n);
@@ -654,7 +660,7 @@ class Parser {
     std::mutex ring_mu_;
     std::condition_variable ring_cv_;
     std::exception_ptr filler_err_;
-    uint64_t records_done_ = 0, startup_newlines_ = 0;
+    uint64_t records_done_ = 0, startup_newlines_ = 0, startup_target_ = 0;
     int in_flight_ = 0;
 };
 

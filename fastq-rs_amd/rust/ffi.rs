@@ -219,7 +219,7 @@ pub struct GpuScanner<R: Read> {
     /// a chunk's parse error waits here while the records in front of it are handed out
     pending: Option<Error>,
     /// no record delivered yet: chunks end as soon as four newlines have come in (the first record early, src/lib.rs:264-275)
-    startup: bool, startup_newlines: usize,
+    startup: bool, startup_newlines: usize, startup_target: usize,
 }
 
 impl<R: Read> GpuScanner<R> {
@@ -233,7 +233,7 @@ impl<R: Read> GpuScanner<R> {
                 fqh_destroy(ctx);
                 return Err(Error::new(ErrorKind::Other, "fqh_stream_create"));
             }
-            Ok(GpuScanner { reader, ctx, st, eof: false, pending: None, startup: true, startup_newlines: 0 })
+            Ok(GpuScanner { reader, ctx, st, eof: false, pending: None, startup: true, startup_newlines: 0, startup_target: 0 })
         }
     }
 
@@ -248,7 +248,11 @@ impl<R: Read> GpuScanner<R> {
                     _ => return Err(Error::new(ErrorKind::Other, "fqh_stream_acquire")),
                 }
                 let first = self.startup;
-                let target = if first { (cap as usize).min(FQH_BUFSIZE) } else { cap as usize };
+                if first {   // per chunk: the newline count starts over, the chunks double until a record is out
+                    self.startup_newlines = 0;
+                    self.startup_target = if self.startup_target == 0 { (cap as usize).min(FQH_BUFSIZE) } else { (cap as usize).min(2 * self.startup_target) };
+                }
+                let target = if first { self.startup_target } else { cap as usize };
                 let slot = std::slice::from_raw_parts_mut(dst, target);
                 let mut n = 0usize;
                 while n < slot.len() {
@@ -257,7 +261,9 @@ impl<R: Read> GpuScanner<R> {
                         Ok(0) => { self.eof = true; break; }
                         Ok(k) => {
                             // a reader that comes back short decides the 69 618 .. 69 632-byte band (src/buffer.rs:74-100)
-                            fqh_stream_note_read(self.st, k as u64, asked as u64);
+                            if fqh_stream_note_read(self.st, k as u64, asked as u64) != FQH_OK {
+                                return Err(Error::new(ErrorKind::Other, "fqh_stream_note_read"));
+                            }
                             if first { self.startup_newlines += slot[n..n + k].iter().filter(|&&b| b == b'\n').count(); }
                             n += k;
                             if first && self.startup_newlines >= 4 { break; }

@@ -179,8 +179,8 @@ fqh_status fqh_set_option(fqh_ctx *ctx, int option, int value);
 int fqh_last_scan_fast(fqh_ctx *ctx);
 /* How the last finished statistics call (fqh_stats*, fqh_scan_stats*) counted: 1 = in the scan's own pass over the input
  * (k_scan_stats); 2 = the same, and the lines that pass does not count itself — batches of eight with a byte outside ACGTN
- * or '!'..'`', lines longer than lmax — were counted one by one behind it (a few KiB re-read); 0 = in a second pass over the
- * input (lmax > 512, reads of 512 bases and more, a parse error, or more such lines than one per 512 KiB).  Results are
+ * or '!'..'`', lines longer than the pass's rows — were counted one by one behind it (a few KiB re-read); 0 = in a second pass over the
+ * input (reads of 512 bases and more — whatever lmax is —, a parse error, or more such lines than one per 512 KiB).  Results are
  * identical; for benchmarks and tests.  A count the single pass declines is no doubt about the parse: it neither reruns the
  * scan nor touches the fast path's back-off. */
 int fqh_last_stats_route(fqh_ctx *ctx);
@@ -388,12 +388,12 @@ fqh_status fqh_stats_launch(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, in
                             const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                             uint64_t *d_base_hist, uint64_t *d_scalars);
 fqh_status fqh_stats_finish(fqh_ctx *ctx, fqh_summary *out, fqh_carry *carry_out);
-/* Record scan AND statistics of one buffer in a single call — with lmax <= 512 in a single READ of the input: one kernel scans,
+/* Record scan AND statistics of one buffer in a single call — for reads of up to 511 bases, whatever lmax is, in a single READ of the input: one kernel scans,
  * validates and counts (k_scan_stats), the way the reference's Parser::each hands each record to the closure that reads
  * seq()/qual() (src/lib.rs:226-237); whole files, chunks with a carry and chunks that are not the file's last alike.  Outputs as
  * fqh_scan (d_rec_start may be NULL) plus fqh_stats.  fqh_stats on its own takes the same single-pass route.  Lines with bytes
- * outside ACGTN / '!'..'`' and lines longer than lmax are counted one by one behind that pass (fqh_last_stats_route() == 2).
- * lmax > 512, reads of 512 bases and more, or more such lines than one per 512 KiB send the HISTOGRAMS to a second pass over
+ * outside ACGTN / '!'..'`' and lines longer than the pass's rows are counted one by one behind that pass (fqh_last_stats_route() == 2).
+ * Reads of 512 bases and more, or more such lines than one per 512 KiB, send the HISTOGRAMS to a second pass over
  * the input (the scan's result stands); an input the fast path cannot prove valid (any parse error) runs the exact scan
  * followed by the histogram kernel; results are identical either way.  FQH_E_CAPACITY (d_rec_start shorter than
  * n_records + 1) is reported by the blocking call / the finish on either route, with the summary, the carry-out and the
@@ -534,7 +534,13 @@ fqh_status fqh_stream_set_origin(fqh_stream *st, uint64_t file_offset);
  * or for a stream with an origin); slots of at least BUFSIZE bytes.  "Fastq record is too long" is then decided by the replay of
  * the reference's Buffer under a reader that hands out what the notes say (csrc/replay.h: exact for a reader with one cap per
  * call, tests/replay_fuzz.cpp; for a pipe whose reads depend on timing, the closest statement there is).  Without any note the
- * reader is taken to fill every read — a file — and the rule's closed form is used. */
+ * reader is taken to fill every read — a file — and the rule's closed form is used.  FQH_E_ARG: slots smaller than BUFSIZE, or a
+ * BUFSIZE (fqh_set_bufsize) that is no longer the one the first note was made under.  The replay stops where the reference's reader
+ * would block, up to BUFSIZE bytes behind the chunk it was given; a record of the 15-byte band that ends that close to a chunk's end
+ * is therefore judged with the NEXT chunk, after its chunk has handed it out: that chunk then comes back with FQH_E_TOO_LONG,
+ * n_records 0 and err_record / err_offset naming the record of the EARLIER chunk.  A host that needs the reference's exact
+ * delivery holds a chunk's last records (those that begin in its last BUFSIZE bytes) back until the next collect, as
+ * fastq.hpp's record_sets does. */
 fqh_status fqh_stream_note_read(fqh_stream *st, uint64_t got, uint64_t asked);
 /* Parser state behind the last collected chunk (nl_count = newlines the stream has seen: what the next shard's phase is
  * checked against in the sharded mode). */

@@ -1,6 +1,4 @@
 set -u
-mkdir -p gpurun_out/r6d
-python -m pytest tests -m gpu -x -q > gpurun_out/r6d/pytest.txt 2>&1
-tail -25 gpurun_out/r6d/pytest.txt
-timeout 900 python bench.py > gpurun_out/r6d/bench.json 2> gpurun_out/r6d/bench.err
-tail -c 300 gpurun_out/r6d/bench.err
+bash tools/prof.sh round6 > gpurun_out/prof_run.log 2>&1
+tail -5 gpurun_out/prof_run.log
+du -sh gpurun_out/prof

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --pmc-traffic off --default-stream-gib 32"
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --pmc-traffic off --default-stream-gib 32 --default-shard-stream-gib 16"
 PMC_CMD="$CMD --no-stream --no-shard-stream"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
@@ -18,4 +18,4 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
 done
 # configs[3]: the streamed leg on its own, kernels AND memory copies (no counters in this pass)
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/stream -o stream -- python bench.py --stream-gib 32 --producer-threads 8 > $OUT/stream.log 2>&1
-python3 tools/prof_summary.py $OUT ${1:-round5}
+python3 tools/prof_summary.py $OUT ${1:-round6}

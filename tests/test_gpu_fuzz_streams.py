@@ -50,29 +50,66 @@ def fuzz_streams(torch, pkg, fqref, seed, budget, max_cases=None):
         ctx = pkg.Ctx(0)
         if rng.random() < 0.5:   # ---- the ring
             slot = int(rng.choice([4096, 65536, 300000 // 16 * 16, 1 << 20, 3 << 20]))
-            st = pkg.Stream(ctx, slot, int(rng.integers(2, 5)), pkg.STREAM_STATS)
+            # round 6: slots fed from the caller's own memory (fqh_stream_submit_external; "external": a ring without pinned data
+            # slots, "mixed": either way per slot), chunks HELD and given back out of order (fqh_stream_release_chunk), and rings
+            # made of a parked ring's memory (FQH_OPT_KEEP_RING: the context's second ring of the case)
+            feed = str(rng.choice(["pinned", "pinned", "external", "mixed"]))
+            n_slots = int(rng.integers(2, 5))
+            hold = int(rng.integers(0, n_slots - 1)) if rng.random() < 0.4 else 0   # chunks kept back besides the current one
+            keep = rng.random() < 0.3
+            if keep:
+                ctx.set_keep_ring(True)
+                pkg.Stream(ctx, slot, n_slots, pkg.STREAM_STATS | (pkg.STREAM_EXTERNAL if feed == "external" else 0)).close()
+            st = pkg.Stream(ctx, slot, n_slots, pkg.STREAM_STATS | (pkg.STREAM_EXTERNAL if feed == "external" else 0))
             st.set_stats(lmax, qh.data_ptr(), bh.data_ptr(), sc.data_ptr())
+            src = a.copy() if len(a) else np.zeros(1, np.uint8)
+            if feed != "pinned" and rng.random() < 0.7:
+                ctx.host_register(src.ctypes.data, max(1, len(data)))
+                registered = True
+            else:
+                registered = False
             pos = nrec = sub = col = 0
             status, done = pkg.OK, False
+            held = []
             while True:
-                while not done:
-                    acq = st.acquire()
-                    if acq is None: break
-                    n = min(acq[1], len(data) - pos)
-                    if rng.random() < 0.3: n = min(n, int(rng.integers(1, acq[1] + 1)))
-                    C.memmove(acq[0], data[pos: pos + n], n)
-                    pos += n; done = pos >= len(data)
-                    st.submit(n, done); sub += 1
+                while not done and sub - col + len(held) < n_slots:
+                    ext = feed == "external" or (feed == "mixed" and rng.random() < 0.5)
+                    room = slot
+                    if not ext:
+                        acq = st.acquire()
+                        if acq is None: break
+                        room = acq[1]
+                    n = min(room, len(data) - pos)
+                    if rng.random() < 0.3: n = min(n, int(rng.integers(1, room + 1)))
+                    last = pos + n >= len(data)
+                    if ext:
+                        if not st.submit_external(src.ctypes.data + pos, n, last): break
+                    else:
+                        C.memmove(acq[0], data[pos: pos + n], n)
+                        st.submit(n, last)
+                    pos += n; done = last
+                    sub += 1
                 if col == sub: break
-                c = st.collect(); col += 1
+                c = st.collect()
+                if c is None:            # (FQH_E_AGAIN: the slot behind the one to collect is still held)
+                    assert held, (seed, cases, "E_AGAIN with nothing held")
+                    st.release_chunk(held.pop(int(rng.integers(0, len(held)))))
+                    continue
+                col += 1
                 nrec += c.n_records
                 single += bool(ctx.last_scan_fast())
-                st.release()
+                held.append(c)
+                while len(held) > hold:  # give back in a random order
+                    st.release_chunk(held.pop(int(rng.integers(0, len(held)))))
                 if c.parse_status != pkg.OK: status = c.parse_status; break
                 if c.is_final: break
+            for c in held:
+                st.release_chunk(c)
             torch.cuda.synchronize()
             st.close()
-            what = ("ring", slot)
+            if registered:
+                ctx.host_unregister(src.ctypes.data)
+            what = ("ring", slot, feed, n_slots, hold, keep)
         else:                    # ---- hand-made chunks of one device buffer, with the lead in front of each
             n = len(data)
             d = torch.empty(n + 64, dtype=torch.uint8, device=dev); d[:n].copy_(torch.from_numpy(a.copy()))

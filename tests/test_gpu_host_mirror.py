@@ -45,6 +45,25 @@ def test_cpp_mirror_under_asan_ubsan_and_tsan(gpu_ok):
         assert "Sanitizer" not in out.stderr, out.stderr[-4000:]
 
 
+def test_leases_queues_and_the_filler_thread_under_tsan_and_asan(gpu_ok, tmp_path):
+    """Round 6's threads — RecordSets that give their ring slot back from whatever thread drops them, parallel_each's queues that
+    poll before they sleep, the parser's own filler thread (Options::read_ahead) — through each / record_sets / parallel_each(3)
+    of the sanitizer builds, on slots small enough that sets straddle them and leases pile up: no report, same output as the
+    plain build."""
+    rng = np.random.default_rng(77)
+    path = tmp_path / "san.fq"
+    path.write_bytes(fuzzgen.valid_file(rng, 6000, maxlen=150))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="ignore_noninstrumented_modules=1 report_signal_unsafe=0")
+    want = subprocess.run([os.path.join(BIN, "host_tests"), "--dump", str(path), "3", "69632", "65536"], capture_output=True, text=True, timeout=600)
+    assert want.returncode == 0
+    for exe, pre in (("host_tests_asan", []), ("host_tests_tsan", ["setarch", "x86_64", "-R"])):
+        out = subprocess.run(pre + [os.path.join(BIN, exe), "--dump", str(path), "3", "69632", "65536"], capture_output=True, text=True,
+                             timeout=900, env=env)
+        assert out.returncode == 0, exe + out.stdout[-2000:] + out.stderr[-4000:]
+        assert "Sanitizer" not in out.stderr, out.stderr[-4000:]
+        assert out.stdout == want.stdout
+
+
 SETS_MSG = {4: "Truncated input file.", 5: "Fastq record is too long."}
 
 

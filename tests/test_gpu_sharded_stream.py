@@ -376,7 +376,11 @@ def fuzz_sharded(env, fqref, seed, budget, max_cases=None):
                 assert status == pkg.E_IO or (status, n_records) == (r.status, r.n_records), ctx_
             cases += 1
             continue
-        status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=int(rng.choice([1 << 16, 1 << 18, 1 << 20])))
+        # (a third of the cases streams its ranges IN PLACE from registered memory: fqh_shard_stream_run_mapped, map calls that
+        # hand out a slot's worth or less)
+        how = int(rng.integers(0, 3))
+        status, n_records, hist, shards = run_sharded(env, data, cuts, lmax, slot_bytes=int(rng.choice([1 << 16, 1 << 18, 1 << 20])),
+                                                      mapped=[None, None, int(rng.choice([1 << 30, 70001, 4097]))][how])
         r, oq, ob, osc = fqref.stats(data, lmax)
         # status and the number of records delivered before the first error are the sequential parser's, whatever the cuts
         assert (status, n_records) == (r.status, r.n_records), (seed, cases, cuts, (status, n_records), (r.status, r.n_records))

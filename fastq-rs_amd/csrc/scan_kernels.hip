@@ -780,14 +780,6 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
     const uint64_t per_w = (n_full + nwaves - 1) / nwaves;
     uint64_t tile = wave0 * per_w;
     const uint64_t tend = tile + per_w < n_full ? tile + per_w : n_full;
-#ifdef FQH_RUN_ROT
-    // (experiment: every wavefront begins somewhere else inside its run and wraps around — tiles need nothing from each other —
-    // so that the thousands of streams are not at the same offset of their 4 MiB windows at the same time)
-    const uint64_t t_begin = tile, t_cnt = tile < tend ? tend - tile : 0;
-    uint64_t t_i = 0;
-    if (t_cnt) tile = t_begin + (wave0 * 2654435761ull >> 5) % t_cnt;
-#define FQH_NEXT_TILE(t) (t_begin + ((t) - t_begin + 1) % t_cnt)
-#endif
     if (tile < tend) {
         const uint8_t *p = buf + (tile << WT_SHIFT) + lo;
         uint32_t pb = tile ? buf[(tile << WT_SHIFT) - 1] : 0u;  // the byte before the tile
@@ -796,13 +788,8 @@ __global__ __launch_bounds__(256) void k_index_fast(const uint8_t *__restrict__ 
         bool pending = false;          // the previous tile's two lines are still in registers
         uint64_t ptile = 0;
         uint32_t prv = 0, prun = 0;
-#ifdef FQH_RUN_ROT
-        for (; t_i < t_cnt; ++t_i, tile = FQH_NEXT_TILE(tile)) {
-            const uint64_t nxt = t_i + 1 < t_cnt ? FQH_NEXT_TILE(tile) : tile;
-#else
         for (; tile < tend; tile += 1) {
             const uint64_t nxt = tile + 1 < tend ? tile + 1 : tile;  // clamped: the prefetch is unconditional
-#endif
             uint32_t run = 0, nstaged = 0;
             uint32_t prev = (tile && pb == '\n') ? 1u : 0u;
 #pragma unroll 1

@@ -1,9 +1,15 @@
 set -u
-mkdir -p gpurun_out/r6f
-for rep in 1 2; do
-  tools/bin/exp_alloc_kind malloc 6 16 > gpurun_out/r6f/pol0_$rep.txt 2>&1
-  for v in 1 2 3 4 5; do
-    LD_PRELOAD=tools/bin/pol$v/libfastq_hip.so tools/bin/exp_alloc_kind malloc 6 16 > gpurun_out/r6f/pol${v}_$rep.txt 2>&1
+mkdir -p gpurun_out/r6g
+for lo in 0 149 100 36; do
+  for fused in 1 0; do
+    echo "== RAGGED=$lo FQH_FUSED=$fused" >> gpurun_out/r6g/ragged.txt
+    RAGGED=$lo FQH_FUSED=$fused python tools/sweep_read_length.py 8 150 2>&1 | grep "read length" >> gpurun_out/r6g/ragged.txt
   done
 done
-for v in 0 1 2 3 4 5; do echo "policy $v: $(grep -h 'round 1' gpurun_out/r6f/pol${v}_*.txt | sed 's/.*index kernel \([0-9.]*\) ms.*/\1/' | tr '\n' ' ')"; done
+for lo in 100 36; do
+  for fused in 1 0; do
+    echo "== RAGGED=$lo L=100 FQH_FUSED=$fused" >> gpurun_out/r6g/ragged.txt
+    RAGGED=$lo FQH_FUSED=$fused python tools/sweep_read_length.py 8 100 250 2>&1 | grep "read length" >> gpurun_out/r6g/ragged.txt
+  done
+done
+cat gpurun_out/r6g/ragged.txt | cut -c1-200

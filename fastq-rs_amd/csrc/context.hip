@@ -108,7 +108,7 @@ fqh_status fqh_create(int device, fqh_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }
         ctx->stream = ctx->own_stream;
         if (hipMalloc((void **)&ctx->d_out, 2 * sizeof(DevOut)) != hipSuccess) { st = FQH_E_DEVICE; break; }
-        if (hipMalloc((void **)&ctx->d_misc, 64) != hipSuccess) { st = FQH_E_DEVICE; break; }
+        if (hipMalloc((void **)&ctx->d_misc, 256) != hipSuccess) { st = FQH_E_DEVICE; break; }
         if (hipMalloc((void **)&ctx->list_dummy, 1024) != hipSuccess) { st = FQH_E_DEVICE; break; }
         if (hipHostMalloc((void **)&ctx->h_out, sizeof(DevOut), hipHostMallocDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }
         if (hipHostMalloc((void **)&ctx->h_init, sizeof(DevOut), hipHostMallocDefault) != hipSuccess) { st = FQH_E_DEVICE; break; }

@@ -34,6 +34,7 @@ void launch_stats_declined(hipStream_t, const DevOut *, const FusedArgs &, unsig
 uint32_t scan_stats_nsl(uint32_t rows);
 uint32_t scan_stats_rows(uint32_t lmax, uint32_t hint);
 void launch_peek_lines(hipStream_t, const uint8_t *, uint64_t, uint32_t, unsigned long long *);
+uint32_t peek_windows(uint64_t len);
 void launch_stats_head(hipStream_t, const StatsArgs &, const uint64_t back[4]);
 void launch_stats_edge(hipStream_t, const DevOut *, const uint8_t *, uint64_t, uint64_t, int, uint32_t, unsigned long long *,
                        unsigned long long *, unsigned long long *);
@@ -68,7 +69,7 @@ struct fqh_ctx {
     DevOut *d_out = nullptr;      // [0] the scan's, [1] scratch for index-only emits
     DevOut *h_out = nullptr;      // pinned
     DevOut *h_init = nullptr;     // pinned reset image
-    uint64_t *d_misc = nullptr;   // 8 u64 of scratch
+    uint64_t *d_misc = nullptr;   // 32 u64 of scratch
     bool placed = false;             // the line buffer in use has been through place_fast_rs
     int place_tries = 0;             // candidates of the fast path's per-tile lines the first big scan may allocate and time (FQH_OPT_PLACE_TRIES)
     int spin_wait_us = 0;            // FQH_OPT_SPIN_WAIT: poll the stream this long in fqh_*_finish before sleeping on it

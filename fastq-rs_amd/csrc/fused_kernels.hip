@@ -1355,18 +1355,29 @@ void launch_stats_commit(hipStream_t s, const DevOut *out, const FusedArgs &z, u
 }
 
 
-// k_peek_lines — a look at the first bytes of an input (one block; n <= 64 KiB): the longest SEQUENCE / QUALITY line — what the
-// single pass sizes its rows by when the context knows nothing yet about the reads (scan_stats_rows) — and how many of all lines
-// are longer than the pass takes.  phase0: the place in its record (0 header .. 3 quality) of the line the window begins in (the
-// carry's newline count & 3: a chunk may begin anywhere), so line i of the window is line (phase0 + i) & 3 of a record — header
-// lines may be several times the reads' length and say nothing about the rows.  A guess, not a promise: whatever it says, the
-// pass counts exactly.  A line that is still open at the end of the window counts with what the window holds of it.
-__global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__ buf, uint32_t n, uint32_t phase0, unsigned long long *__restrict__ out) {
-    // out[0]: the longest sequence / quality line, out[1]: lines that end in the window, out[2]: ... of them longer than 511 bytes
+// k_peek_lines — a look at an input before its first single pass: the longest SEQUENCE / QUALITY line — what the pass sizes its
+// rows by when the context knows nothing yet about the reads (scan_stats_rows) — and how many of all lines are longer than the pass
+// takes.  FOUR windows of up to 64 KiB, one block each: the input's first bytes and three more, a quarter of the input apart (a file
+// whose first reads are shorter than the rest — sorted, or trimmed harder at the start of a run — used to cost its first call a
+// whole wasted pass).  Window 0 knows its line phase (phase0: the place in its record, 0 header .. 3 quality, of the line the
+// window begins in — the carry's newline count & 3), so line i of the window is line (phase0 + i) & 3 of a record; the other
+// windows begin anywhere and settle their phase themselves: the one residue (mod 4) whose lines ALL begin with '@' while the lines
+// two further on ALL begin with '+' is the headers' (src/records.rs:141, 155); no such residue, or several: the longest line of any
+// kind (an over-estimate costs speed, never a count).  Header lines may be several times the reads' length and say nothing about
+// the rows.  A guess, not a promise: whatever it says, the pass counts exactly.  A line that is still open at the end of a window
+// counts with what the window holds of it; the line a later window begins in is skipped (its beginning is not in the window).
+// out[3 w + 0]: the longest sequence / quality line of window w, [3 w + 1]: lines that end in it, [3 w + 2]: ... longer than 511 bytes.
+constexpr uint32_t PEEK_WINDOWS = 4, PEEK_BYTES = 65536;
+__global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__ buf0, uint64_t len, uint32_t phase0, unsigned long long *__restrict__ out) {
     __shared__ int last_nl[1024];      // -> the last newline at or before the end of segment t (a running maximum), -1: none
     __shared__ int nl_before[1024];    // -> newlines up to and including segment t (a running sum)
-    __shared__ int best_w[16], lines_w[16], long_w[16];
-    const uint32_t t = threadIdx.x, lo = t * 64u;
+    __shared__ int r_max[4], r_cnt[4], r_at[4], r_plus[4], n_lines, n_long;
+    const uint32_t w = blockIdx.x, t = threadIdx.x, lo = t * 64u;
+    const uint64_t start = w == 0 ? 0 : (len / PEEK_WINDOWS * w) & ~(uint64_t)15;
+    const uint32_t n = (uint32_t)(len - start < PEEK_BYTES ? len - start : PEEK_BYTES);
+    const uint8_t *__restrict__ buf = buf0 + start;
+    if (t < 4) r_max[t] = r_cnt[t] = r_at[t] = r_plus[t] = 0;
+    if (t == 0) n_lines = n_long = 0;
     int l = -1, nl = 0;
     for (uint32_t i = lo; i < lo + 64u && i < n; ++i)
         if (buf[i] == '\n') { l = (int)i; ++nl; }
@@ -1381,48 +1392,56 @@ __global__ __launch_bounds__(1024) void k_peek_lines(const uint8_t *__restrict__
         __syncthreads();
     }
     // the lines this segment's newlines close: the first one began at `prev + 1` (in an earlier segment, perhaps), it is line
-    // number `idx` of the window
-    int prev = t ? last_nl[t - 1] : -1, idx = t ? nl_before[t - 1] : 0, g = 0, nlong = 0;
+    // number `idx` of the window; residue = its place mod 4 (window 0: its place in the record)
+    int prev = t ? last_nl[t - 1] : -1, idx = t ? nl_before[t - 1] : 0;
+    const uint32_t ph = w == 0 ? phase0 : 0u;
+    auto tally = [&](int len_, int first) {   // a line of the window: its length, the position of its first byte (-1: not in the window)
+        const uint32_t r = (ph + (uint32_t)idx) & 3u;
+        if (w != 0 && first < 0) return;      // (began in front of a later window: neither its length nor its first byte is known)
+        atomicMax(&r_max[r], len_);
+        atomicAdd(&r_cnt[r], 1);
+        if (first >= 0 && first < (int)n) {
+            const uint8_t b0 = buf[first];
+            if (b0 == '@') atomicAdd(&r_at[r], 1);
+            if (b0 == '+') atomicAdd(&r_plus[r], 1);
+        }
+    };
     for (uint32_t i = lo; i < lo + 64u && i < n; ++i) {
         if (buf[i] == '\n') {
-            const int len = (int)i - prev - 1;
-            if (((phase0 + (uint32_t)idx) & 1u) && len > g) g = len;   // (line 1 of a record: sequence, line 3: quality)
-            nlong += len > (int)FZ_LC_MAX ? 1 : 0;
+            const int len_ = (int)i - prev - 1;
+            tally(len_, prev < 0 ? (w == 0 ? 0 : -1) : prev + 1);
+            atomicAdd(&n_lines, 1);
+            if (len_ > (int)FZ_LC_MAX) atomicAdd(&n_long, 1);
             prev = (int)i;
             ++idx;
         }
     }
     if (lo < n && lo + 64u >= n) {                        // the segment that holds the window's end: the line still open there
         const int open = (int)n - prev - 1;
-        if (((phase0 + (uint32_t)idx) & 1u) && open > g) g = open;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        g = max(g, __shfl_xor(g, d));
-        nl += __shfl_xor(nl, d);
-        nlong += __shfl_xor(nlong, d);
-    }
-    if ((t & 63u) == 0) {
-        best_w[t >> 6] = g;
-        lines_w[t >> 6] = nl;
-        long_w[t >> 6] = nlong;
+        if (open > 0) tally(open, prev < 0 ? (w == 0 ? 0 : -1) : prev + 1);
     }
     __syncthreads();
     if (t == 0) {
-        int best = 0, lines = 0, longs = 0;
-        for (int k = 0; k < 16; ++k) {
-            best = max(best, best_w[k]);
-            lines += lines_w[k];
-            longs += long_w[k];
+        int best = 0;
+        if (w == 0) {
+            best = max(r_max[1], r_max[3]);               // (line 1 of a record: sequence, line 3: quality)
+        } else {
+            int hdr = -1, cands = 0;
+            for (int r = 0; r < 4; ++r)
+                if (r_cnt[r] > 0 && r_at[r] == r_cnt[r] && r_cnt[(r + 2) & 3] > 0 && r_plus[(r + 2) & 3] == r_cnt[(r + 2) & 3]) { hdr = r; ++cands; }
+            if (cands == 1) best = max(r_max[(hdr + 1) & 3], r_max[(hdr + 3) & 3]);
+            else best = max(max(r_max[0], r_max[1]), max(r_max[2], r_max[3]));
         }
-        out[0] = (unsigned long long)best;
-        out[1] = (unsigned long long)lines;
-        out[2] = (unsigned long long)longs;
+        out[3 * w + 0] = (unsigned long long)best;
+        out[3 * w + 1] = (unsigned long long)n_lines;
+        out[3 * w + 2] = (unsigned long long)n_long;
     }
 }
 void launch_peek_lines(hipStream_t s, const uint8_t *buf, uint64_t len, uint32_t phase0, unsigned long long *d_out) {
-    const uint32_t n = (uint32_t)(len < 65536 ? len : 65536);
-    hipLaunchKernelGGL(k_peek_lines, dim3(1), dim3(1024), 0, s, buf, n, phase0 & 3u, d_out);
+    // (inputs of up to four windows' bytes: the first window is the input)
+    const uint32_t windows = len > (uint64_t)PEEK_WINDOWS * PEEK_BYTES ? PEEK_WINDOWS : 1u;
+    hipLaunchKernelGGL(k_peek_lines, dim3(windows), dim3(1024), 0, s, buf, len, phase0 & 3u, d_out);
 }
+uint32_t peek_windows(uint64_t len) { return len > (uint64_t)PEEK_WINDOWS * PEEK_BYTES ? PEEK_WINDOWS : 1u; }
 
 }  // namespace fqh

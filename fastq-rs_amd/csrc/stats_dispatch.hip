@@ -51,15 +51,22 @@ static fqh_status ensure_rows_hint(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t 
     }
     if (ctx->rows_hint && (len < (1ull << 30) || (!ctx->lines_long && scan_stats_rows(lmax, ctx->rows_hint) >= std::min(lmax, FZ_ROWS_MAX)))) return FQH_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    unsigned long long peek[3] = {0, 0, 0};
+    unsigned long long peek[12] = {};
+    const uint32_t nw = peek_windows(len);
     launch_peek_lines(ctx->stream, d_buf, len, in ? (uint32_t)(in->nl_count & 3u) : 0u, (unsigned long long *)ctx->d_misc);
-    HIPCHK(ctx, hipMemcpyAsync(peek, ctx->d_misc, sizeof peek, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(peek, ctx->d_misc, nw * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t seen = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(peek[0], 1), 0x7FFFFFFFull);
+    unsigned long long longest = 0, lines = 0, longs = 0;   // over the windows (k_peek_lines: the input's first bytes and three more)
+    for (uint32_t w = 0; w < nw; ++w) {
+        longest = std::max(longest, peek[3 * w]);
+        lines += peek[3 * w + 1];
+        longs += peek[3 * w + 2];
+    }
+    const uint32_t seen = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(longest, 1), 0x7FFFFFFFull);
     // the rows go up with what a look finds, down with what the scans find (resolve()); whether MOST lines are too long for the
     // pass is what the look says (64 KiB of kilobase reads: every other line)
     if (seen > ctx->rows_hint || !ctx->rows_hint) ctx->rows_hint = seen;
-    ctx->lines_long = peek[2] * 4 > peek[1] || (peek[1] == 0 && len >= 65536);   // (no newline in 64 KiB)
+    ctx->lines_long = longs * 4 > lines || (lines == 0 && len >= 65536);   // (no newline in 64 KiB)
     return FQH_OK;
 }
 static void update_rows_hint(fqh_ctx *ctx) {   // after a single pass whose scan stands (fused_finish)

@@ -20,6 +20,10 @@
  *   Record::write (filter loops)    src/records.rs:93-96          fqh_gather_records
  *   Buffer                          src/buffer.rs:1-112           fqh_stream_* (pinned ring)
  *   thread_reader                   src/thread_reader.rs:182-200  fqh_stream_* (copy stream)
+ *   ... its copy box -> buffer      src/thread_reader.rs:90-97    removed: fqh_stream_submit_external (DMA from the host's memory)
+ *   ... its recycled boxes          src/thread_reader.rs:60-75    FQH_OPT_KEEP_RING
+ *   RecordSet owning its buffer     src/lib.rs:306-318, 384-385   fqh_stream_release_chunk (sets borrow ring slots)
+ *   parallel_each, one worker / GPU src/lib.rs:509-565            fqh_shard_stream_run[_mapped] / _finish / _outcome
  *   parallel_each gather            src/lib.rs:553-559            fqh_allgather / fqh_allreduce_u64 (RCCL)
  */
 #ifndef FASTQ_HIP_H
@@ -128,8 +132,10 @@ fqh_status fqh_set_bufsize(fqh_ctx *ctx, uint64_t bufsize);
  *                           lmax is the caller's choice and may be far below the reads' length (the first 150 cycles of
  *                           kilobase reads): the columns beyond it are looked at (n_valid_dna / n_valid_dnan cover every
  *                           base), not counted.  It may as well be far above it (1000 rows, whatever comes): the pass keeps
- *                           the rows the READS need — a look at the first 64 KiB of a context's first input, then what its
- *                           calls find; setting the option forgets that as well — and any lmax is counted exactly.
+ *                           the rows the READS need — a look at four 64 KiB windows of every NEW input (its first bytes and three
+ *                           more, a quarter of it apart; the same buffer again and the next chunk of the same file are not
+ *                           new), then what the calls on that input find; setting the option forgets that as well — and any
+ *                           lmax is counted exactly.  The back-off after a pass that was given up belongs to that input too.
  *   FQH_OPT_PLACE_TRIES [0] where the fast path's per-tile lines (1.6 % of the input size) land in device memory can decide
  *                           whether the byte scan runs at 2.65-2.70 or at 2.85-2.95 ms per 16 GiB: the same allocation call
  *                           gives either kind, and the kind stays with the allocation.  With a value of 2..8
@@ -377,9 +383,9 @@ fqh_status fqh_index_records(fqh_ctx *ctx, fqh_idx_record *d_index, uint64_t cap
  * to (zero them first).  Reads its input itself; only with FQH_OPT_REUSE_INDEX set (the caller vouches
  * that the bytes are unchanged) does a call on the (d_buf, len, carry) of the last finished fqh_scan count over that
  * scan's tile index.  The *_launch forms return without waiting for the device — with one exception: the first statistics
- * call of a context with lmax > 64 (and a later one over a GiB or more whose rows might be too few) looks at the input's
- * first 64 KiB to size the pass by the reads (FQH_OPT_SINGLE_PASS above) and waits for that look, i.e. for what the
- * context's stream holds in front of it, once. */
+ * call on a NEW input (another buffer, length or file offset than the context's last statistics call; and a later one over a GiB
+ * or more whose rows might be too few) looks at four 64 KiB windows of the input to size the pass by the reads
+ * (FQH_OPT_SINGLE_PASS above) and waits for that look, i.e. for what the context's stream holds in front of it, once. */
 fqh_status fqh_stats(fqh_ctx *ctx, const uint8_t *d_buf, uint64_t len, int is_final,
                      const fqh_carry *in, uint32_t lmax, uint64_t *d_qual_hist,
                      uint64_t *d_base_hist, uint64_t *d_scalars, fqh_summary *out,

@@ -316,13 +316,15 @@ def test_stats_long_reads_of_many_lengths(fqref, gpu, shape):
         assert np.array_equal(gq, qh), (shape, lmax, np.argwhere(gq != qh)[:5])
 
 
-@pytest.mark.parametrize("case", ["short_reads_many_rows", "hint_too_small", "second_file_longer", "header_longer_than_reads"])
+@pytest.mark.parametrize("case", ["short_reads_many_rows", "hint_too_small", "second_file_longer", "header_longer_than_reads",
+                                  "longer_reads_further_down"])
 def test_single_pass_rows_follow_the_reads(fqref, torch, pkg, case):
     """lmax is the caller's choice; the reference's closure has none (src/lib.rs:226-237).  The single pass sizes its rows by the
     reads (the first 64 KiB of the first input a context sees, then what its calls find), at most lmax: rows of 1000 over reads
     of 150 bases are one pass; a first window that holds only short reads in front of longer ones lists the longer lines (counted
     behind the pass, columns beyond its rows included) or gives the pass up — bit-exact either way — and the next call knows."""
-    rng = np.random.default_rng({"short_reads_many_rows": 1, "hint_too_small": 2, "second_file_longer": 3, "header_longer_than_reads": 4}[case])
+    rng = np.random.default_rng({"short_reads_many_rows": 1, "hint_too_small": 2, "second_file_longer": 3, "header_longer_than_reads": 4,
+                                 "longer_reads_further_down": 5}[case])
     def reads(n, lo, hi, hdr=8):
         out = []
         for i in range(n):
@@ -351,6 +353,14 @@ def test_single_pass_rows_follow_the_reads(fqref, torch, pkg, case):
         files = [(reads(20000, 100, 100), 700, {1}), (reads(20000, 250, 250), 700, {1}), (reads(20000, 250, 250), 700, {1}),
                  (reads(20000, 250, 250), 700, {1}), (reads(3000, 2000, 2500), 3000, {0}), (reads(20000, 100, 100), 700, {0, 1}),
                  (reads(20000, 100, 100), 700, {1}), (reads(20000, 100, 100), 700, {1})]
+    elif case == "longer_reads_further_down":
+        # the look takes four windows, a quarter of the input apart (round 6): half a megabyte of 50-base reads in front of 150-base
+        # ones — a run trimmed harder at its start — is ONE pass sized by the longer reads; the later windows begin inside lines
+        # and settle their line phase themselves ('@' / '+' residues), also with quality lines that begin with '@' or '+' and with
+        # headers longer than the reads
+        files = [(reads(5000, 50, 50) + reads(60000, 150, 150), 1000, {1}),
+                 (reads(5000, 36, 36, hdr=180) + reads(40000, 120, 120, hdr=180), 300, {1}),
+                 (reads(6000, 50, 50) + reads(30000, 250, 250), 250, {1})]
     else:
         files = [(reads(20000, 36, 36, hdr=200), 600, {1})]
     for data, lmax, routes in files:

@@ -1,15 +1,9 @@
 set -u
-mkdir -p gpurun_out/r6g
-for lo in 0 149 100 36; do
-  for fused in 1 0; do
-    echo "== RAGGED=$lo FQH_FUSED=$fused" >> gpurun_out/r6g/ragged.txt
-    RAGGED=$lo FQH_FUSED=$fused python tools/sweep_read_length.py 8 150 2>&1 | grep "read length" >> gpurun_out/r6g/ragged.txt
-  done
-done
-for lo in 100 36; do
-  for fused in 1 0; do
-    echo "== RAGGED=$lo L=100 FQH_FUSED=$fused" >> gpurun_out/r6g/ragged.txt
-    RAGGED=$lo FQH_FUSED=$fused python tools/sweep_read_length.py 8 100 250 2>&1 | grep "read length" >> gpurun_out/r6g/ragged.txt
-  done
-done
-cat gpurun_out/r6g/ragged.txt | cut -c1-200
+mkdir -p gpurun_out/r6i
+python -m pytest tests -m gpu -x -q > gpurun_out/r6i/pytest.txt 2>&1
+tail -12 gpurun_out/r6i/pytest.txt
+python tools/fuzz_routes.py 120 631 2>&1 | tail -1 > gpurun_out/r6i/fuzz.txt
+python tools/fuzz_streams.py 120 632 2>&1 | tail -1 >> gpurun_out/r6i/fuzz.txt
+cat gpurun_out/r6i/fuzz.txt
+timeout 900 python bench.py > gpurun_out/r6i/bench.json 2> gpurun_out/r6i/bench.err
+python tools/bench_summary.py gpurun_out/r6i/bench.json

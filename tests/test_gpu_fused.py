@@ -198,7 +198,9 @@ def test_declined_counts_beyond_256_columns(env, fqref, shape):
                 r[h + 301 + 2 + col] = int(rng.choice([97, 105, 126, 125, 200, 255, 0, 32]))
         data = b"".join(bytes(r) for r in recs)
     elif shape == "few_longer_than_lmax":
-        data = make(rng, 3000, lambda i: 420 if i % 400 == 399 else 300)   # (none in the first 64 KiB: the pass keeps rows for 300 columns)
+        # (none in the four 64 KiB windows the context looks at — the input's first bytes and three more, a quarter of it apart:
+        # the pass keeps rows for 300 columns and LISTS the longer lines)
+        data = make(rng, 3000, lambda i: 420 if i % 400 == 199 else 300)
     else:
         data = make(rng, 3000, lambda i: int(rng.choice([512, 513, 600])) if i % 300 == 11 else 300)
         lmax, route = 512, -1        # (listed or declined, by where the line happens to lie in its 4 KiB group)
@@ -246,7 +248,7 @@ def test_declined_counts_are_no_parse_doubt(env, fqref, shape):
                 r[h + 151 + 2 + col] = int(rng.choice([97, 105, 126, 125, 200, 255, 0, 32]))   # above '`', below '!', NUL, high bit
         data = bytearray(b"".join(bytes(r) for r in recs))
     elif shape == "few_long":                 # a few reads longer than the pass's rows among reads that fit: listed, columns >= lmax go to scalars[5], [6]
-        data = bytearray(make(rng, 4000, lambda i: 190 if i % 500 == 499 else 150))   # (none in the first 64 KiB, by which the pass sizes its rows)
+        data = bytearray(make(rng, 4000, lambda i: 190 if i % 500 == 299 else 150))   # (none in the four 64 KiB windows by which the pass sizes its rows)
     elif shape == "crlf_dirty":
         data = bytearray(make(rng, 4000, 150, crlf=0.5))
         for k in rng.integers(1000, len(data) - 1000, 40):

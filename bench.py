@@ -667,10 +667,12 @@ def host_api_leg(path, nbytes, exp_hist):
         return {"error": "%s is not built (make -C fastq-rs_amd/host)" % exe}
     n_rec = nbytes // RECLEN
     checksum = int((exp_hist * (1 + __import__("numpy").arange(exp_hist.size, dtype="uint64"))).sum(dtype="uint64"))
-    variants = [("each", []), ("each_read8", ["--read-threads", "8"]), ("each_read8_ahead", ["--read-threads", "8", "--read-ahead"]),
-                ("parallel_each8", ["--threads", "8"]), ("parallel_each8_read8", ["--threads", "8", "--read-threads", "8"]),
+    one = ["--read-threads", "1"]   # (the reference's one reader; fastq_count's own default is up to eight pread()s per slot)
+    variants = [("each", one), ("each_read8", ["--read-threads", "8"]), ("each_read8_ahead", ["--read-threads", "8", "--read-ahead"]),
+                ("parallel_each8", ["--threads", "8"] + one), ("parallel_each8_read8", ["--threads", "8", "--read-threads", "8"]),
                 ("parallel_each8_read8_ahead", ["--threads", "8", "--read-threads", "8", "--read-ahead"]),
-                ("stats150", ["--stats", "150"]), ("stats150_read8", ["--stats", "150", "--read-threads", "8"])]
+                ("stats150", ["--stats", "150"] + one), ("stats150_read8", ["--stats", "150", "--read-threads", "8"]),
+                ("each_default_options", [])]
     res = {"file": "configs[0]: %.2f GiB of the synthetic file on /dev/shm" % (nbytes / 2**30), "binary": "fastq-rs_amd/host/bin/fastq_count",
            "note": "GB/s of the best warm pass of three in one process (pass 0 = cold: HIP start-up, context, ring); one process per "
                    "variant; ring 3-4 x 32 MiB; the oracle's one-core rate is cpu_baseline.value"}

@@ -196,7 +196,10 @@ struct Options {
     // was asked for and nothing else is on its way to the GPU (the consumer would only wait).  Results are the same;
     // a chunk then costs a GPU round trip per read() of the pipe, so it is off for files.
     bool low_latency = false;
-    unsigned read_threads = 1;          // parse_path on a regular file: pread()s side by side per slot (FileReader)
+    // parse_path on a regular file: pread()s side by side per slot (FileReader).  0 = as many as an eighth of the host's hardware
+    // threads, at most 8 (one thread's copy out of the page cache feeds the GPU at the oracle's own rate);
+    // 1 = the reference's one reader (src/lib.rs:186-192)
+    unsigned read_threads = 0;
     // A thread of the parser's own keeps the ring's slots filled while the calling thread collects, replays and hands out
     // (thread_reader's producer, src/thread_reader.rs:131-139, one level down: its destination IS the pinned slot, no copy
     // in between).  For readers that fill every read (files): the reads are not noted for the replay of the "too long" band
@@ -1463,7 +1466,7 @@ auto parse_path(const std::optional<std::string> &path, F func, Options opt = Op
     return with_plain_reader(path, [&](DynReader &dyn) {
         Parser<DynReader> p(std::move(dyn), opt);
         return func(p);
-    }, opt.read_threads);
+    }, opt.read_threads ? opt.read_threads : std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 8u)));
 }
 
 }  // namespace fastq

@@ -3,7 +3,8 @@
 // file (path argument, "-" or nothing = stdin); on a malformed file it fails like the reference's
 // `.expect("Invalid fastq file")` with the reference's error message.
 //   --threads N       parallel_each with N workers (examples/fastq-count-thread.rs)
-//   --read-threads N  a regular file is read with N pread()s side by side per ring slot (default 1: the reference's one reader)
+//   --read-threads N  a regular file is read with N pread()s side by side per ring slot (default: an eighth of the host's hardware
+//                     threads, at most 8; 1 = the reference's one reader)
 //   --read-ahead      a thread of the parser's own fills the ring while the calling thread parses (for files)
 //   --slot-mib M      size of a ring slot (default 32)
 //   --repeat K        parse the file K times in this process and print every pass's seconds to stderr ("pass i: S s"): the
@@ -29,7 +30,7 @@ static int run_stats(const std::optional<std::string> &path, uint32_t lmax, cons
         if (!f) { fprintf(stderr, "cannot open %s\n", path->c_str()); return 2; }
         own = true;
     }
-    fastq::FileReader file(f, own, opt.read_threads);
+    fastq::FileReader file(f, own, opt.read_threads ? opt.read_threads : std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 8u)));
     fastq::detail::Handles h;
     auto die = [&](const char *what) { fprintf(stderr, "%s: %s\n", what, fqh_last_error(h.ctx)); return 2; };
     if (fqh_create(opt.device, &h.ctx) != FQH_OK) return die("fqh_create");

@@ -1,11 +1,11 @@
 set -u
-mkdir -p gpurun_out/r6l
+mkdir -p gpurun_out/r6n
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r6n/pytest.txt 2>&1
+tail -6 gpurun_out/r6n/pytest.txt
 for rep in 1 2 3; do
-  tools/bin/exp_alloc_kind malloc 6 16 > gpurun_out/r6l/base_$rep.txt 2>&1
-  FQH_EXP_IGNORE=1 LD_PRELOAD=tools/bin/tr/libfastq_hip.so tools/bin/exp_alloc_kind malloc 6 16 > gpurun_out/r6l/tr_$rep.txt 2>&1
+  FQH_INDEX_WRITER=0 timeout 300 tools/bin/exp_alloc_kind malloc 6 16 > gpurun_out/r6n/w0_$rep.txt 2>&1
+  FQH_INDEX_WRITER=1 timeout 300 tools/bin/exp_alloc_kind malloc 6 16 > gpurun_out/r6n/w1_$rep.txt 2>&1
 done
-echo "base  with-stores (first 4 GiB, fresh line buffer): $(grep -h 'round 0' gpurun_out/r6l/base_*.txt | sed 's/.* with \([0-9.]*\)$/\1/' | tr '\n' ' ')"
-echo "base  without:                                      $(grep -h 'round 0' gpurun_out/r6l/base_*.txt | sed 's/.*without stores \([0-9.]*\),.*/\1/' | tr '\n' ' ')"
-echo "trans with-stores:                                  $(grep -h 'round 0' gpurun_out/r6l/tr_*.txt | sed 's/.* with \([0-9.]*\)$/\1/' | tr '\n' ' ')"
-echo "trans without:                                      $(grep -h 'round 0' gpurun_out/r6l/tr_*.txt | sed 's/.*without stores \([0-9.]*\),.*/\1/' | tr '\n' ' ')"
-tail -2 gpurun_out/r6l/tr_1.txt
+echo "legacy: $(grep -h 'round 1' gpurun_out/r6n/w0_*.txt | sed 's/.*index kernel \([0-9.]*\) ms.*/\1/' | tr '\n' ' ')"
+echo "writer: $(grep -h 'round 1' gpurun_out/r6n/w1_*.txt | sed 's/.*index kernel \([0-9.]*\) ms.*/\1/' | tr '\n' ' ')"
+tail -2 gpurun_out/r6n/w1_1.txt

@@ -421,8 +421,8 @@ fqh_status fqh_stream_collect(fqh_stream *st, fqh_chunk *out) {
         uint64_t k = 0;
         too_long = st->replay.step(s.h_rec, st->records_done, n, known_end, s.is_final || bad_here, need, &k);
         if (too_long && k < st->records_done) {
-            // the replay stops where the reference's reader would block, up to BUFSIZE bytes behind the chunk it was given: a
-            // record of the band that ends that close to a chunk's end is judged with the NEXT chunk, after it was handed out
+            // (defensive: the verdict on a record falls before its last byte is read, so a record is judged with the chunk it ends
+            // in and this is not known to be reachable — tests/test_gpu_stream.py searches for it; if it ever is, name the record)
             late = true;
             late_k = k;
             late_off = st->replay.pend.empty() ? 0 : st->replay.pend[0];   // (step() has dropped the boundaries in front of k)

@@ -541,12 +541,10 @@ fqh_status fqh_stream_set_origin(fqh_stream *st, uint64_t file_offset);
  * the reference's Buffer under a reader that hands out what the notes say (csrc/replay.h: exact for a reader with one cap per
  * call, tests/replay_fuzz.cpp; for a pipe whose reads depend on timing, the closest statement there is).  Without any note the
  * reader is taken to fill every read — a file — and the rule's closed form is used.  FQH_E_ARG: slots smaller than BUFSIZE, or a
- * BUFSIZE (fqh_set_bufsize) that is no longer the one the first note was made under.  The replay stops where the reference's reader
- * would block, up to BUFSIZE bytes behind the chunk it was given; a record of the 15-byte band that ends that close to a chunk's end
- * is therefore judged with the NEXT chunk, after its chunk has handed it out: that chunk then comes back with FQH_E_TOO_LONG,
- * n_records 0 and err_record / err_offset naming the record of the EARLIER chunk.  A host that needs the reference's exact
- * delivery holds a chunk's last records (those that begin in its last BUFSIZE bytes) back until the next collect, as
- * fastq.hpp's record_sets does. */
+ * BUFSIZE (fqh_set_bufsize) that is no longer the one the first note was made under.  (The replay stops where the reference's
+ * reader would block, up to BUFSIZE bytes behind the chunk it was given; the verdict on a record never needs those bytes — it
+ * falls when the reference's buffer is full and the record still open, before the record's last byte is read — so the chunk a
+ * record ends in is also the chunk that judges it: tests/test_gpu_stream.py.) */
 fqh_status fqh_stream_note_read(fqh_stream *st, uint64_t got, uint64_t asked);
 /* Parser state behind the last collected chunk (nl_count = newlines the stream has seen: what the next shard's phase is
  * checked against in the sharded mode). */

@@ -574,3 +574,76 @@ def test_keep_ring_hands_the_pinned_slots_to_the_next_ring(fqref, env):
     assert a1 == a2 == a4 and not (a1 & a3)
     ctx.set_keep_ring(False)    # frees what is parked
     ctx.close()
+
+
+def test_stream_noted_reads_too_long_names_the_record(fqref, env):
+    """fqh_stream_note_read, files of mostly band-sized records (BUFSIZE - 17 .. BUFSIZE) in slots whose ends fall anywhere: the chunk
+    that reports "Fastq record is too long" names the record Parser::each stops at under the same reader (the oracle's max_read) —
+    err_record, err_offset — and delivers exactly the records in front of it.  ADVICE r5 asked whether the replay, which stops
+    where the reference's reader would block, can judge a record only AFTER its chunk has handed it out; it cannot: the
+    reference's verdict falls when its buffer is full and the record still open, i.e. before the record's last byte is read
+    (src/lib.rs:276-283, src/buffer.rs:51-72), so every byte the verdict needs lies in the chunk the record ends in.  300+
+    too-long cases here, none judged late (the ring still reports such a case correctly, should one exist: stream.hip)."""
+    torch, pkg = env
+    B, slot = 256, 4096
+    late = checked = 0
+    for seed in range(400):
+        rng = np.random.default_rng(7000 + seed)
+
+        def sized(total):
+            body = total - 6
+            s = int(rng.integers(0, body // 2 + 1))
+            return b"@" + b"h" * (body - 2 * s) + b"\n" + b"A" * s + b"\n+\n" + b"I" * s + b"\n"
+
+        data = b"".join(sized(int(rng.integers(B - 17, B + 1))) if rng.integers(0, 3) else sized(int(rng.integers(6, 60))) for _ in range(70))
+        cap = int(rng.choice([5, 16, 37, 100, 255]))
+        r = fqref.count(data, bufsize=B, max_read=cap)
+        if r.status != pkg.E_TOO_LONG:
+            continue
+        _, idx = fqref.index(data, bufsize=1 << 20)
+        ctx = pkg.Ctx(0, bufsize=B)
+        st = pkg.Stream(ctx, slot, 3)
+        pos, delivered, done = 0, 0, False
+        submitted = collected = 0
+        verdict = None
+        while verdict is None:
+            while not done:
+                a = st.acquire()
+                if a is None:
+                    break
+                addr, room = a
+                n = 0
+                while n < room and pos < len(data):
+                    asked = room - n
+                    got = min(asked, len(data) - pos, cap)
+                    C.memmove(addr + n, data[pos: pos + got], got)
+                    st.note_read(got, asked)
+                    n += got
+                    pos += got
+                done = pos >= len(data)
+                st.submit(n, done)
+                submitted += 1
+            if collected == submitted:
+                break
+            c = st.collect()
+            collected += 1
+            if c.parse_status != pkg.OK:
+                verdict = (c.parse_status, int(c.n_records), int(c.err_record), int(c.err_offset), delivered)
+            delivered += c.n_records
+            st.release()
+            if c.is_final:
+                break
+        st.close()
+        ctx.close()
+        assert verdict is not None and verdict[0] == pkg.E_TOO_LONG, (seed, cap, verdict, r.n_records)
+        status, n_here, err_record, err_offset, before = verdict
+        checked += 1
+        assert err_record == r.n_records, (seed, cap, verdict, r.n_records)          # the record the reference stops at ...
+        assert err_offset == int(idx[r.n_records][0]), (seed, cap, verdict)            # ... and where it begins
+        if err_record < before:                                                         # judged one chunk late
+            late += 1
+            assert n_here == 0
+        else:
+            assert before + n_here == r.n_records
+    assert checked >= 100, checked
+    assert late == 0, late
